@@ -1,0 +1,75 @@
+"""Pin the CPU oracle against the fixtures derived from the reference.
+
+(i)  196 canonical 31-mers shipped in /root/reference/page/results/**: each must be its own
+     canonical form under the oracle's convention (and 7 of them are NOT canonical under the
+     lexicographic A<C<G<T convention, which is what makes the fixture discriminating).
+(ii) pack / unpack / minimum-uint vectors produced by executing the reference's
+     bin/kover/core/kover/utils.py:117-187 (tests/golden/make_golden.py).
+"""
+import json
+import os
+
+import numpy as np
+
+from oracle import oracle_ctypes as orc
+from oracle import pyoracle
+
+
+def _kmers(golden_dir):
+    return [l.strip() for l in open(os.path.join(golden_dir, "canonical_31mers.txt")) if l.strip() and not l.startswith("#")]
+
+
+def test_reference_kmers_are_canonical_under_gatb_order(golden_dir):
+    kmers = _kmers(golden_dir)
+    assert len(kmers) == 196
+    for km in kmers:
+        can, words = orc.canonical_ascii(km)
+        assert can == km, km
+        assert pyoracle.canonical(km) == km
+        assert words[0] == pyoracle.kmer_value(km)
+        # and the reverse complement canonicalises to the same string
+        assert orc.canonical_ascii(pyoracle.revcomp(km))[0] == km
+
+
+def test_fixture_discriminates_against_lexicographic_order(golden_dir):
+    comp = str.maketrans("ACGT", "TGCA")
+    not_lex = [km for km in _kmers(golden_dir) if km > km.translate(comp)[::-1]]
+    assert len(not_lex) == 7
+    assert "ATGGCGTCGACGTTCTTGACGAAGGCGCGCT" in not_lex
+
+
+def test_pack_vectors(golden_dir):
+    d = json.load(open(os.path.join(golden_dir, "pack_vectors.json")))
+    for case in d["pack_cases"]:
+        bits = np.array(case["bits"], dtype=np.uint8)
+        want = np.array([[int(x) for x in row] for row in case["packed"]], dtype=np.uint64)
+        got = orc.pack_bits(bits, case["pack_size"])
+        assert got.shape == want.shape
+        assert (got == want).all()
+
+
+def test_minimum_uint_size(golden_dir):
+    d = json.load(open(os.path.join(golden_dir, "pack_vectors.json")))
+    for e in d["minimum_uint_size"]:
+        assert orc.minimum_uint_bytes(int(e["max_value"])) == np.dtype(e["dtype"]).itemsize
+
+
+def test_matrix_bits_follow_pack_layout():
+    # matrix produced by the merge must equal _pack_binary_bytes_to_ints of the dense matrix
+    rng = np.random.RandomState(5)
+    genomes = []
+    for g in range(70):
+        seq = "".join(rng.choice(list("ACGT"), size=60))
+        genomes.append([(">g%d\n%s\n" % (g, seq)).encode()])
+    # share some content so that columns have several carriers
+    for g in range(1, 70, 3):
+        genomes[g] = genomes[0]
+    m = orc.build_matrix(genomes, k=11)
+    U = m["kmers"].shape[0]
+    dense = np.zeros((70, U), dtype=np.uint8)
+    index = {int(v): i for i, v in enumerate(m["kmers"][:, 0])}
+    for g, (km, _) in enumerate(m["per_genome"]):
+        for v in km[:, 0]:
+            dense[g, index[int(v)]] = 1
+    assert (orc.pack_bits(dense, 64) == m["matrix"]).all()
+    assert (dense.sum(axis=0) == m["n_genomes_with"]).all()
