@@ -1,0 +1,993 @@
+// grm_api.cpp -- C ABI of libgrmkmer.so (include/grm_kmer.h): host orchestration of the
+// gfx950 kernels in grm_kernels.hip.  No CPU fallback: every compute entry point needs a
+// HIP device and fails loudly without one.
+//
+// Reference call sites replaced (the reference has no in-process API for this path):
+//   multidsk  bin/kover/core/kover/dataset/tools/kmer_count.py:28-37,44-53
+//   dsk2kover bin/kover/core/kover/dataset/tools/kmer_pack.py:28-36
+//   dsk       src/app.py:1372           Ray Surveyor  src/app.py:1310
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/grm_kmer.h"
+#include "grm_internal.h"
+
+using namespace grm;
+
+// --------------------------------------------------------------------------------------
+// context
+// --------------------------------------------------------------------------------------
+struct TimingRec {
+    std::string name;
+    hipEvent_t e0, e1;
+    uint64_t units;
+};
+
+struct grm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool timing = false;
+    std::vector<TimingRec> recs;
+    // options (<0: automatic)
+    int opt_groups_per_thread = -1;
+    int opt_bucket_bits = -1;
+    int opt_cap_log2 = -1;
+    int opt_sub_bits = -1;
+};
+
+static int fail(grm_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? GRM_ERR_OOM : GRM_ERR_HIP, "%s: %s (%s:%d)", #call, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                               \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t n)
+    {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        else p = nullptr;
+        return e;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct TimeScope {
+    grm_ctx *c;
+    int idx = -1;
+    TimeScope(grm_ctx *ctx, const char *name, uint64_t units) : c(ctx)
+    {
+        if (!c->timing) return;
+        TimingRec r;
+        r.name = name;
+        r.units = units;
+        if (hipEventCreate(&r.e0) != hipSuccess) return;
+        if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); return; }
+        (void)hipEventRecord(r.e0, c->stream);
+        c->recs.push_back(r);
+        idx = (int)c->recs.size() - 1;
+    }
+    ~TimeScope()
+    {
+        if (idx >= 0) (void)hipEventRecord(c->recs[idx].e1, c->stream);
+    }
+};
+
+extern "C" const char *grm_version(void) { return "grm-kmer-mi355x 0.1 (gfx950)"; }
+
+extern "C" grm_ctx *grm_create(int device_ordinal, int n_streams)
+{
+    (void)n_streams;
+    if (device_ordinal < 0) return nullptr;   // no CPU mode
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_ordinal >= n) return nullptr;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return nullptr;
+    grm_ctx *c = new grm_ctx();
+    c->device = device_ordinal;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    if (set_max_dynamic_lds() != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
+    return c;
+}
+
+extern "C" void grm_destroy(grm_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (auto &r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char *grm_last_error(grm_ctx *c) { return c ? c->err.c_str() : "no context (no HIP device?)"; }
+
+extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
+{
+    if (!c || !name) return GRM_ERR_ARG;
+    std::string n(name);
+    if (n == "groups_per_thread") c->opt_groups_per_thread = value;
+    else if (n == "bucket_bits") c->opt_bucket_bits = value;
+    else if (n == "cap_log2") c->opt_cap_log2 = value;
+    else if (n == "sub_bits") c->opt_sub_bits = value;
+    else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
+    return GRM_OK;
+}
+
+extern "C" int grm_timing_enable(grm_ctx *c, int on)
+{
+    if (!c) return GRM_ERR_ARG;
+    c->timing = on != 0;
+    return GRM_OK;
+}
+extern "C" int grm_timing_reset(grm_ctx *c)
+{
+    if (!c) return GRM_ERR_ARG;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    c->recs.clear();
+    return GRM_OK;
+}
+extern "C" int grm_timing_count(grm_ctx *c) { return c ? (int)c->recs.size() : 0; }
+extern "C" int grm_timing_get(grm_ctx *c, int i, char *name, size_t name_cap, double *ms, uint64_t *units)
+{
+    if (!c || i < 0 || i >= (int)c->recs.size()) return GRM_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float f = 0;
+    HIPCHK(c, hipEventElapsedTime(&f, c->recs[i].e0, c->recs[i].e1));
+    if (name && name_cap) snprintf(name, name_cap, "%s", c->recs[i].name.c_str());
+    if (ms) *ms = f;
+    if (units) *units = c->recs[i].units;
+    return GRM_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// result objects
+// --------------------------------------------------------------------------------------
+struct grm_kmer_set {
+    int k = 0, words = 1;
+    uint64_t occurrences = 0;
+    std::vector<uint64_t> kmers;
+    std::vector<uint32_t> counts;
+};
+
+struct grm_matrix {
+    grm_ctx *ctx = nullptr;
+    int k = 0, words = 1, n_genomes = 0;
+    size_t n_rows = 0, n_kmers = 0;
+    DevBuf d_kmers, d_data;
+    std::vector<uint64_t> h_kmers, h_data;
+    bool have_kmers = false, have_data = false;
+};
+
+extern "C" size_t grm_kmer_set_size(const grm_kmer_set *s) { return s ? s->counts.size() : 0; }
+extern "C" int grm_kmer_set_k(const grm_kmer_set *s) { return s ? s->k : 0; }
+extern "C" int grm_kmer_set_words(const grm_kmer_set *s) { return s ? s->words : 0; }
+extern "C" uint64_t grm_kmer_set_occurrences(const grm_kmer_set *s) { return s ? s->occurrences : 0; }
+extern "C" const uint64_t *grm_kmer_set_kmers(const grm_kmer_set *s) { return s ? s->kmers.data() : nullptr; }
+extern "C" const uint32_t *grm_kmer_set_counts(const grm_kmer_set *s) { return s ? s->counts.data() : nullptr; }
+extern "C" void grm_kmer_set_free(grm_kmer_set *s) { delete s; }
+
+extern "C" int grm_kmer_set_from_host(grm_ctx *c, const uint64_t *kmers, const uint32_t *counts, size_t n, int k,
+                                      grm_kmer_set **out)
+{
+    if (!c || !out || (n && !kmers)) return fail(c, GRM_ERR_ARG, "grm_kmer_set_from_host: bad argument");
+    if (k < 1 || k > 32) return fail(c, k > 32 && k <= 64 ? GRM_ERR_UNSUPPORTED : GRM_ERR_ARG, "k=%d unsupported (1..32 in this build)", k);
+    grm_kmer_set *s = new grm_kmer_set();
+    s->k = k;
+    s->kmers.assign(kmers, kmers + n);
+    if (counts) s->counts.assign(counts, counts + n);
+    else s->counts.assign(n, 1u);
+    *out = s;
+    return GRM_OK;
+}
+
+extern "C" size_t grm_matrix_n_kmers(const grm_matrix *m) { return m ? m->n_kmers : 0; }
+extern "C" size_t grm_matrix_n_rows(const grm_matrix *m) { return m ? m->n_rows : 0; }
+extern "C" int grm_matrix_n_genomes(const grm_matrix *m) { return m ? m->n_genomes : 0; }
+extern "C" int grm_matrix_k(const grm_matrix *m) { return m ? m->k : 0; }
+extern "C" int grm_matrix_words(const grm_matrix *m) { return m ? m->words : 0; }
+extern "C" const void *grm_matrix_dev_kmers(const grm_matrix *m) { return m ? m->d_kmers.p : nullptr; }
+extern "C" const void *grm_matrix_dev_data(const grm_matrix *m) { return m ? m->d_data.p : nullptr; }
+
+extern "C" const uint64_t *grm_matrix_kmers(grm_matrix *m)
+{
+    if (!m) return nullptr;
+    if (!m->have_kmers) {
+        m->h_kmers.resize(m->n_kmers * m->words + 1);
+        if (m->n_kmers) {
+            (void)hipSetDevice(m->ctx->device);
+            if (hipMemcpy(m->h_kmers.data(), m->d_kmers.p, m->n_kmers * m->words * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                fail(m->ctx, GRM_ERR_HIP, "D2H of dictionary failed");
+                return nullptr;
+            }
+        }
+        m->have_kmers = true;
+    }
+    return m->h_kmers.data();
+}
+extern "C" const uint64_t *grm_matrix_data(grm_matrix *m)
+{
+    if (!m) return nullptr;
+    if (!m->have_data) {
+        m->h_data.resize(m->n_kmers * m->n_rows + 1);
+        if (m->n_kmers && m->n_rows) {
+            (void)hipSetDevice(m->ctx->device);
+            if (hipMemcpy(m->h_data.data(), m->d_data.p, m->n_kmers * m->n_rows * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                fail(m->ctx, GRM_ERR_HIP, "D2H of matrix failed");
+                return nullptr;
+            }
+        }
+        m->have_data = true;
+    }
+    return m->h_data.data();
+}
+extern "C" int grm_matrix_column_counts(grm_matrix *m, uint32_t *out)
+{
+    if (!m || !out) return GRM_ERR_ARG;
+    grm_ctx *c = m->ctx;
+    if (!m->n_kmers) return GRM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf d;
+    HIPCHK(c, d.alloc(m->n_kmers * 4));
+    {
+        TimeScope t(c, "column_popcount", m->n_kmers * m->n_rows);
+        launch_column_popcount(c->stream, m->d_data.as<uint64_t>(), m->n_rows, m->n_kmers, nullptr, d.as<uint32_t>());
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, d.p, m->n_kmers * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GRM_OK;
+}
+extern "C" void grm_matrix_free(grm_matrix *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    delete m;
+}
+
+// --------------------------------------------------------------------------------------
+// batch
+// --------------------------------------------------------------------------------------
+struct HostFile {
+    int genome;
+    std::vector<uint8_t> bytes;
+};
+
+struct grm_batch {
+    grm_ctx *ctx = nullptr;
+    int n_genomes = 0;
+    std::vector<HostFile> files;
+    bool uploaded = false, partitioned = false, have_local = false, have_global = false;
+    // inputs
+    uint64_t input_bytes = 0;
+    uint64_t raw_bytes = 0;   // tile-aligned image size (without front pad)
+    uint32_t n_tiles = 0;
+    DevBuf d_raw_alloc;       // front pad + image
+    DevBuf d_genome_tile_off; // u32[n_genomes+1]
+    // parse products
+    DevBuf d_sums, d_tile_off, d_tile_state, d_sym2, d_inv, d_genome_sym_off;
+    uint64_t total_syms = 0;
+    std::vector<uint64_t> h_genome_sym_off;
+    // partition products
+    int k = 0, bb = 0;
+    uint32_t abundance_min = 1;
+    uint64_t total_keys = 0;       // k-mer occurrences
+    DevBuf d_counts, d_off, d_cursor, d_keys, d_len, d_kcnt;
+    bool deduped = false;
+    // dictionary
+    int sb_dict = 0, sb_fill = 0;
+    uint32_t cap_log2 = 12;
+    DevBuf d_local_keys, d_local_flags;
+    uint64_t n_local = 0;
+    DevBuf d_dict;                 // sorted, filtered global dictionary (U)
+    uint64_t n_dict = 0;
+    DevBuf d_dkeys, d_dcol, d_seg_start;   // bucketised view for matrix_fill
+    int filter_singleton = 0;
+};
+
+extern "C" int grm_batch_create(grm_ctx *c, int n_genomes, grm_batch **out)
+{
+    if (!c) return GRM_ERR_NO_DEVICE;
+    if (!out || n_genomes < 0) return fail(c, GRM_ERR_ARG, "grm_batch_create: bad argument");
+    grm_batch *b = new grm_batch();
+    b->ctx = c;
+    b->n_genomes = n_genomes;
+    *out = b;
+    return GRM_OK;
+}
+
+extern "C" void grm_batch_free(grm_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    delete b;
+}
+
+extern "C" int grm_batch_add(grm_batch *b, int genome_index, const void *buf, size_t len)
+{
+    if (!b) return GRM_ERR_ARG;
+    if (genome_index < 0 || genome_index >= b->n_genomes || (len && !buf))
+        return fail(b->ctx, GRM_ERR_ARG, "grm_batch_add: bad genome index %d / buffer", genome_index);
+    if (b->uploaded) return fail(b->ctx, GRM_ERR_STATE, "grm_batch_add after upload");
+    HostFile f;
+    f.genome = genome_index;
+    f.bytes.assign((const uint8_t *)buf, (const uint8_t *)buf + len);
+    b->files.push_back(std::move(f));
+    return GRM_OK;
+}
+
+extern "C" int grm_batch_add_file(grm_batch *b, int genome_index, const char *path)
+{
+    if (!b || !path) return GRM_ERR_ARG;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(b->ctx, GRM_ERR_IO, "cannot open %s", path);
+    std::vector<uint8_t> bytes;
+    uint8_t tmp[1 << 16];
+    size_t got;
+    while ((got = fread(tmp, 1, sizeof tmp, f)) > 0) bytes.insert(bytes.end(), tmp, tmp + got);
+    fclose(f);
+    return grm_batch_add(b, genome_index, bytes.data(), bytes.size());
+}
+
+static inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+extern "C" int grm_batch_upload(grm_batch *b)
+{
+    if (!b) return GRM_ERR_ARG;
+    grm_ctx *c = b->ctx;
+    if (b->uploaded) return fail(c, GRM_ERR_STATE, "batch already uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    // genome-major, stable in insertion order
+    std::stable_sort(b->files.begin(), b->files.end(), [](const HostFile &x, const HostFile &y) { return x.genome < y.genome; });
+    // layout: every file = ">\n" + bytes + "\n", padded with '\n' to a tile boundary.  The
+    // synthetic header guarantees a separator in front of every file's first base and the
+    // trailing newline terminates an unterminated last line.
+    std::vector<uint32_t> genome_tile_off(b->n_genomes + 1, 0);
+    uint64_t pos = 0;
+    std::vector<uint64_t> file_pos(b->files.size());
+    size_t fi = 0;
+    b->input_bytes = 0;
+    for (int g = 0; g < b->n_genomes; g++) {
+        genome_tile_off[g] = (uint32_t)(pos / TILE_BYTES);
+        bool any = false;
+        while (fi < b->files.size() && b->files[fi].genome == g) {
+            file_pos[fi] = pos;
+            pos = round_up(pos + 2 + b->files[fi].bytes.size() + 1, TILE_BYTES);
+            b->input_bytes += b->files[fi].bytes.size();
+            fi++;
+            any = true;
+        }
+        if (!any) pos += TILE_BYTES;   // an empty genome still owns one (all-newline) tile
+    }
+    genome_tile_off[b->n_genomes] = (uint32_t)(pos / TILE_BYTES);
+    if (pos / TILE_BYTES >= 0xffffffffull) return fail(c, GRM_ERR_ARG, "batch too large (%llu bytes)", (unsigned long long)pos);
+    b->raw_bytes = pos;
+    b->n_tiles = (uint32_t)(pos / TILE_BYTES);
+
+    HIPCHK(c, b->d_raw_alloc.alloc(RAW_FRONT_PAD + pos + 64));
+    uint8_t *d_raw = b->d_raw_alloc.as<uint8_t>();
+    HIPCHK(c, hipMemsetAsync(d_raw, '\n', RAW_FRONT_PAD + pos + 64, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint8_t> img;
+    for (size_t i = 0; i < b->files.size(); i++) {
+        img.resize(b->files[i].bytes.size() + 3);
+        img[0] = '>';
+        img[1] = '\n';
+        if (!b->files[i].bytes.empty()) memcpy(img.data() + 2, b->files[i].bytes.data(), b->files[i].bytes.size());
+        img[img.size() - 1] = '\n';
+        HIPCHK(c, hipMemcpy(d_raw + RAW_FRONT_PAD + file_pos[i], img.data(), img.size(), hipMemcpyHostToDevice));
+        std::vector<uint8_t>().swap(b->files[i].bytes);
+    }
+    HIPCHK(c, b->d_genome_tile_off.alloc((b->n_genomes + 1) * 4));
+    HIPCHK(c, hipMemcpy(b->d_genome_tile_off.p, genome_tile_off.data(), (b->n_genomes + 1) * 4, hipMemcpyHostToDevice));
+    b->uploaded = true;
+    return GRM_OK;
+}
+
+static int pick_bucket_bits(grm_ctx *c, uint64_t max_genome_syms)
+{
+    if (c->opt_bucket_bits >= 0) return std::min(c->opt_bucket_bits, MAX_BUCKET_BITS);
+    // aim at ~512 k-mer occurrences per (genome, bucket)
+    int bb = 0;
+    while (bb < MAX_BUCKET_BITS && (max_genome_syms >> bb) > 512) bb++;
+    return bb;
+}
+
+// parse + histogram + scan + scatter (+ dedup when abundance_min > 1)
+static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, bool want_counts)
+{
+    grm_ctx *c = b->ctx;
+    if (!b->uploaded) return fail(c, GRM_ERR_STATE, "grm_batch_partition before grm_batch_upload");
+    if (k < 1 || k > 64) return fail(c, GRM_ERR_ARG, "k=%d out of range", k);
+    if (k > 32) return fail(c, GRM_ERR_UNSUPPORTED, "k=%d: two-word k-mers (33..64) are not built yet", k);
+    if (abundance_min < 1) abundance_min = 1;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint8_t *raw = b->d_raw_alloc.as<uint8_t>() + RAW_FRONT_PAD;
+    const uint32_t G = (uint32_t)b->n_genomes;
+    b->partitioned = b->have_local = b->have_global = false;
+    b->k = k;
+    b->abundance_min = abundance_min;
+    b->deduped = false;
+
+    if (b->n_tiles == 0 || G == 0) {
+        b->total_syms = b->total_keys = 0;
+        b->bb = 0;
+        b->h_genome_sym_off.assign(G + 1, 0);
+        HIPCHK(c, b->d_off.alloc((G + 2) * 8));
+        HIPCHK(c, hipMemsetAsync(b->d_off.p, 0, (G + 2) * 8, s));
+        HIPCHK(c, b->d_keys.alloc(16));
+        HIPCHK(c, hipStreamSynchronize(s));
+        b->partitioned = true;
+        return GRM_OK;
+    }
+
+    // ---- stage 0: parse ----
+    const uint64_t max_groups = b->raw_bytes / 64 + 8;
+    if (!b->d_sums.p) {
+        HIPCHK(c, b->d_sums.alloc((size_t)b->n_tiles * sizeof(TileSummary)));
+        HIPCHK(c, b->d_tile_off.alloc(((size_t)b->n_tiles + 1) * 8));
+        HIPCHK(c, b->d_tile_state.alloc((size_t)b->n_tiles + 16));
+        HIPCHK(c, b->d_sym2.alloc(max_groups * 16));
+        HIPCHK(c, b->d_inv.alloc(max_groups * 8));
+        HIPCHK(c, b->d_genome_sym_off.alloc(((size_t)G + 1) * 8));
+    }
+    HIPCHK(c, hipMemsetAsync(b->d_sym2.p, 0, max_groups * 16, s));
+    HIPCHK(c, hipMemsetAsync(b->d_inv.p, 0, max_groups * 8, s));
+    {
+        TimeScope t(c, "parse_summarize", b->raw_bytes);
+        launch_parse_summarize(s, raw, b->n_tiles, b->d_sums.as<TileSummary>());
+    }
+    {
+        TimeScope t(c, "parse_scan", b->n_tiles);
+        launch_parse_scan(s, b->d_sums.as<TileSummary>(), b->n_tiles, b->d_tile_off.as<uint64_t>(),
+                          b->d_tile_state.as<uint8_t>(), b->d_genome_tile_off.as<uint32_t>(), G,
+                          b->d_genome_sym_off.as<uint64_t>());
+    }
+    {
+        TimeScope t(c, "parse_pack", b->raw_bytes);
+        launch_parse_pack(s, raw, b->n_tiles, b->d_tile_off.as<uint64_t>(), b->d_tile_state.as<uint8_t>(),
+                          b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>());
+    }
+    HIPCHK(c, hipGetLastError());
+    b->h_genome_sym_off.resize(G + 1);
+    HIPCHK(c, hipMemcpyAsync(b->h_genome_sym_off.data(), b->d_genome_sym_off.p, ((size_t)G + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    b->total_syms = b->h_genome_sym_off[G];
+    uint64_t max_g = 0;
+    for (uint32_t g = 0; g < G; g++) max_g = std::max(max_g, b->h_genome_sym_off[g + 1] - b->h_genome_sym_off[g]);
+    if (max_g >= 0xffffffffull) return fail(c, GRM_ERR_ARG, "a genome has %llu symbols (limit 2^32-1)", (unsigned long long)max_g);
+    if (b->total_syms > max_groups * 64 - 256) return fail(c, GRM_ERR_HIP, "internal: symbol count exceeds the packed buffers");
+    b->bb = pick_bucket_bits(c, max_g);
+    const uint64_t B = 1ull << b->bb;
+    const uint64_t n_seg = (uint64_t)G * B;
+
+    // ---- stage 1: histogram, scan, scatter ----
+    KmerLaunch L;
+    L.sym2 = b->d_sym2.as<uint64_t>();
+    L.inv = b->d_inv.as<uint64_t>();
+    L.total_syms = b->total_syms;
+    L.genome_sym_off = b->d_genome_sym_off.as<uint64_t>();
+    L.n_genomes = G;
+    L.k = k;
+    L.bb = b->bb;
+    L.groups_per_thread = c->opt_groups_per_thread > 0 ? (uint32_t)c->opt_groups_per_thread : 16u;
+
+    HIPCHK(c, b->d_counts.alloc(n_seg * 4));
+    HIPCHK(c, b->d_cursor.alloc(n_seg * 4));
+    HIPCHK(c, b->d_off.alloc((n_seg + 1) * 8));
+    HIPCHK(c, hipMemsetAsync(b->d_counts.p, 0, n_seg * 4, s));
+    HIPCHK(c, hipMemsetAsync(b->d_cursor.p, 0, n_seg * 4, s));
+    {
+        TimeScope t(c, "kmer_hist", b->total_syms);
+        launch_kmer_hist(s, L, b->d_counts.as<uint32_t>());
+    }
+    {
+        TimeScope t(c, "bucket_scan", n_seg);
+        launch_scan_u32(s, b->d_counts.as<uint32_t>(), n_seg, b->d_off.as<uint64_t>());
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&b->total_keys, b->d_off.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, b->d_keys.alloc((b->total_keys + 2) * 8));
+    {
+        TimeScope t(c, "kmer_scatter", b->total_keys);
+        launch_kmer_scatter(s, L, b->d_off.as<uint64_t>(), b->d_cursor.as<uint32_t>(), b->d_keys.as<uint64_t>());
+    }
+    HIPCHK(c, hipGetLastError());
+
+    // ---- stage 2 (optional): per-bucket dedup / count / abundance filter ----
+    b->cap_log2 = c->opt_cap_log2 > 0 ? (uint32_t)c->opt_cap_log2 : 12u;
+    if (abundance_min > 1 || want_counts) {
+        DevBuf d_flag;
+        HIPCHK(c, d_flag.alloc(4));
+        HIPCHK(c, hipMemsetAsync(d_flag.p, 0, 4, s));
+        HIPCHK(c, b->d_len.alloc(n_seg * 4));
+        if (want_counts) HIPCHK(c, b->d_kcnt.alloc((b->total_keys + 2) * 4));
+        {
+            TimeScope t(c, "bucket_dedup", b->total_keys);
+            launch_bucket_dedup(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), n_seg, b->cap_log2, abundance_min,
+                                b->d_len.as<uint32_t>(), want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, d_flag.as<int>());
+        }
+        HIPCHK(c, hipGetLastError());
+        int ov = 0;
+        HIPCHK(c, hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (ov) return fail(c, GRM_ERR_OVERFLOW, "bucket_dedup: a (genome,bucket) segment holds more distinct k-mers than the LDS table (cap 2^%u); raise bucket_bits", b->cap_log2);
+        b->deduped = true;
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    b->partitioned = true;
+    return GRM_OK;
+}
+
+extern "C" int grm_batch_partition(grm_batch *b, int k, uint32_t abundance_min)
+{
+    if (!b) return GRM_ERR_ARG;
+    return batch_partition_impl(b, k, abundance_min, false);
+}
+
+extern "C" uint64_t grm_batch_n_symbols(const grm_batch *b) { return b ? b->total_syms : 0; }
+extern "C" uint64_t grm_batch_n_occurrences(const grm_batch *b) { return b ? b->total_keys : 0; }
+extern "C" uint64_t grm_batch_input_bytes(const grm_batch *b) { return b ? b->input_bytes : 0; }
+
+// ---- dictionary of the local genomes ------------------------------------------------------
+extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
+{
+    if (!b) return GRM_ERR_ARG;
+    grm_ctx *c = b->ctx;
+    if (!b->partitioned) return fail(c, GRM_ERR_STATE, "grm_batch_local_dict before grm_batch_partition");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    b->have_local = b->have_global = false;
+    const uint32_t G = (uint32_t)b->n_genomes;
+    if (b->total_keys == 0) {
+        b->n_local = 0;
+        HIPCHK(c, b->d_local_keys.alloc(16));
+        HIPCHK(c, b->d_local_flags.alloc(16));
+        b->have_local = true;
+        if (n_local) *n_local = 0;
+        return GRM_OK;
+    }
+    const uint32_t cap = 1u << b->cap_log2;
+    int sb = c->opt_sub_bits >= 0 ? c->opt_sub_bits : 0;
+    DevBuf d_flag, d_stage_keys, d_stage_flags, d_stage_cnt, d_stage_off;
+    HIPCHK(c, d_flag.alloc(4));
+    for (;; sb++) {
+        if (b->bb + sb > 24) return fail(c, GRM_ERR_OVERFLOW, "dict_build: bucket union does not fit the LDS table even with 2^%d sub-buckets", sb);
+        const uint32_t n_wg = 1u << (b->bb + sb);
+        HIPCHK(c, d_stage_keys.alloc((size_t)n_wg * cap * 8));
+        HIPCHK(c, d_stage_flags.alloc((size_t)n_wg * cap));
+        HIPCHK(c, d_stage_cnt.alloc((size_t)n_wg * 4));
+        HIPCHK(c, d_stage_off.alloc(((size_t)n_wg + 1) * 8));
+        HIPCHK(c, hipMemsetAsync(d_flag.p, 0, 4, s));
+        {
+            TimeScope t(c, "dict_build", b->total_keys);
+            launch_dict_build(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(),
+                              b->deduped ? b->d_len.as<uint32_t>() : nullptr, G, b->bb, sb, b->cap_log2,
+                              d_stage_keys.as<uint64_t>(), d_stage_flags.as<uint8_t>(), d_stage_cnt.as<uint32_t>(),
+                              d_flag.as<int>());
+        }
+        HIPCHK(c, hipGetLastError());
+        int ov = 0;
+        HIPCHK(c, hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (!ov) {
+            launch_scan_u32(s, d_stage_cnt.as<uint32_t>(), n_wg, d_stage_off.as<uint64_t>());
+            HIPCHK(c, hipMemcpyAsync(&b->n_local, d_stage_off.as<uint64_t>() + n_wg, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, b->d_local_keys.alloc((b->n_local + 2) * 8));
+            HIPCHK(c, b->d_local_flags.alloc(b->n_local + 16));
+            {
+                TimeScope t(c, "dict_gather", b->n_local);
+                launch_dict_gather(s, d_stage_keys.as<uint64_t>(), d_stage_flags.as<uint8_t>(), d_stage_off.as<uint64_t>(),
+                                   n_wg, cap, b->d_local_keys.as<uint64_t>(), b->d_local_flags.as<uint8_t>());
+            }
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(s));
+            break;
+        }
+        if (c->opt_sub_bits >= 0 && sb >= c->opt_sub_bits + 8)
+            return fail(c, GRM_ERR_OVERFLOW, "dict_build: overflow persists");
+    }
+    b->sb_dict = sb;
+    b->have_local = true;
+    if (n_local) *n_local = b->n_local;
+    return GRM_OK;
+}
+
+extern "C" int grm_batch_export_dict(grm_batch *b, void *dev_keys_out, void *dev_flags_out)
+{
+    if (!b) return GRM_ERR_ARG;
+    grm_ctx *c = b->ctx;
+    if (!b->have_local) return fail(c, GRM_ERR_STATE, "grm_batch_export_dict before grm_batch_local_dict");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->n_local) {
+        HIPCHK(c, hipMemcpyAsync(dev_keys_out, b->d_local_keys.p, b->n_local * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dev_flags_out, b->d_local_flags.p, b->n_local, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GRM_OK;
+}
+
+// bucketise the global dictionary for matrix_fill with 2^sb sub-buckets
+static int bucketise_dict(grm_batch *b, int sb)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    const uint64_t U = b->n_dict;
+    const uint32_t n_wg = 1u << (b->bb + sb);
+    HIPCHK(c, b->d_seg_start.alloc(((size_t)n_wg + 2) * 8));
+    HIPCHK(c, b->d_dkeys.alloc((U + 2) * 8));
+    HIPCHK(c, b->d_dcol.alloc((U + 2) * 4));
+    if (U == 0) {
+        HIPCHK(c, hipMemsetAsync(b->d_seg_start.p, 0, ((size_t)n_wg + 2) * 8, s));
+        b->sb_fill = sb;
+        return GRM_OK;
+    }
+    DevBuf d_bid, d_col, d_bid_sorted, d_tmp;
+    HIPCHK(c, d_bid.alloc(U * 4));
+    HIPCHK(c, d_col.alloc(U * 4));
+    HIPCHK(c, d_bid_sorted.alloc(U * 4));
+    TimeScope t(c, "dict_bucketise", U);
+    launch_dict_bucket_ids(s, b->d_dict.as<uint64_t>(), U, b->bb, sb, d_bid.as<uint32_t>(), d_col.as<uint32_t>());
+    size_t tmp_bytes = 0;
+    HIPCHK(c, sort_pairs_u32_u32(s, d_bid.as<uint32_t>(), d_bid_sorted.as<uint32_t>(), d_col.as<uint32_t>(),
+                                 b->d_dcol.as<uint32_t>(), U, b->bb + sb, nullptr, tmp_bytes));
+    HIPCHK(c, d_tmp.alloc(tmp_bytes));
+    HIPCHK(c, sort_pairs_u32_u32(s, d_bid.as<uint32_t>(), d_bid_sorted.as<uint32_t>(), d_col.as<uint32_t>(),
+                                 b->d_dcol.as<uint32_t>(), U, b->bb + sb, d_tmp.p, tmp_bytes));
+    launch_gather_u64(s, b->d_dict.as<uint64_t>(), b->d_dcol.as<uint32_t>(), U, b->d_dkeys.as<uint64_t>());
+    launch_segment_starts(s, d_bid_sorted.as<uint32_t>(), U, n_wg, b->d_seg_start.as<uint64_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    b->sb_fill = sb;
+    return GRM_OK;
+}
+
+extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, const void *dev_flags, uint64_t n,
+                                         int filter_singleton, uint64_t *n_kmers)
+{
+    if (!b) return GRM_ERR_ARG;
+    grm_ctx *c = b->ctx;
+    if (!b->partitioned) return fail(c, GRM_ERR_STATE, "grm_batch_set_global_dict before grm_batch_partition");
+    if (n && (!dev_keys || !dev_flags)) return fail(c, GRM_ERR_ARG, "grm_batch_set_global_dict: NULL buffers");
+    if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "dictionary of %llu k-mers exceeds 2^32-1 columns", (unsigned long long)n);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    b->have_global = false;
+    b->filter_singleton = filter_singleton;
+    b->n_dict = 0;
+    if (n) {
+        DevBuf d_sk, d_sf, d_keep, d_pos, d_tmp;
+        HIPCHK(c, d_sk.alloc(n * 8));
+        HIPCHK(c, d_sf.alloc(n));
+        HIPCHK(c, d_keep.alloc((n + 1) * 4));
+        HIPCHK(c, d_pos.alloc((n + 1) * 8));
+        {
+            TimeScope t(c, "dict_sort", n);
+            size_t tmp_bytes = 0;
+            HIPCHK(c, sort_pairs_u64_u8(s, (const uint64_t *)dev_keys, d_sk.as<uint64_t>(), (const uint8_t *)dev_flags,
+                                        d_sf.as<uint8_t>(), n, nullptr, tmp_bytes));
+            HIPCHK(c, d_tmp.alloc(tmp_bytes));
+            HIPCHK(c, sort_pairs_u64_u8(s, (const uint64_t *)dev_keys, d_sk.as<uint64_t>(), (const uint8_t *)dev_flags,
+                                        d_sf.as<uint8_t>(), n, d_tmp.p, tmp_bytes));
+            HIPCHK(c, hipMemsetAsync(d_keep.as<uint32_t>() + n, 0, 4, s));
+            launch_dict_mark(s, d_sk.as<uint64_t>(), d_sf.as<uint8_t>(), n, filter_singleton, d_keep.as<uint32_t>());
+            size_t tmp2 = 0;
+            HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, nullptr, tmp2));
+            if (tmp2 > d_tmp.bytes) HIPCHK(c, d_tmp.alloc(tmp2));
+            HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, d_tmp.p, tmp2));
+            HIPCHK(c, hipMemcpyAsync(&b->n_dict, d_pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, b->d_dict.alloc((b->n_dict + 2) * 8));
+            launch_dict_select(s, d_sk.as<uint64_t>(), d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n, b->d_dict.as<uint64_t>());
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(s));
+    } else {
+        HIPCHK(c, b->d_dict.alloc(16));
+    }
+    // sub-bucket count for the fill: keep the mean dictionary slice under 1/4 of the table
+    int sb = c->opt_sub_bits >= 0 ? c->opt_sub_bits : 0;
+    const uint64_t cap = 1ull << b->cap_log2;
+    while (b->bb + sb < 24 && (b->n_dict >> (b->bb + sb)) > cap / 4) sb++;
+    int rc = bucketise_dict(b, sb);
+    if (rc) return rc;
+    b->have_global = true;
+    if (n_kmers) *n_kmers = b->n_dict;
+    return GRM_OK;
+}
+
+extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
+{
+    if (!b || !out) return GRM_ERR_ARG;
+    grm_ctx *c = b->ctx;
+    if (!b->have_global) return fail(c, GRM_ERR_STATE, "grm_batch_fill before grm_batch_set_global_dict");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    grm_matrix *m = new grm_matrix();
+    m->ctx = c;
+    m->k = b->k;
+    m->words = 1;
+    m->n_genomes = b->n_genomes;
+    m->n_rows = ((size_t)b->n_genomes + 63) / 64;
+    m->n_kmers = b->n_dict;
+    const size_t cells = m->n_rows * m->n_kmers;
+    hipError_t e = m->d_data.alloc(cells * 8);
+    if (e == hipSuccess) e = m->d_kmers.alloc((m->n_kmers + 2) * 8);
+    if (e != hipSuccess) { delete m; return fail(c, GRM_ERR_OOM, "matrix allocation failed (%zu cells)", cells); }
+    int rc = GRM_OK;
+    DevBuf d_flag;
+    if (d_flag.alloc(4) != hipSuccess) { delete m; return fail(c, GRM_ERR_OOM, "alloc"); }
+    for (;;) {
+        if (cells) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
+        (void)hipMemsetAsync(d_flag.p, 0, 4, s);
+        if (cells && b->total_keys) {
+            TimeScope t(c, "matrix_fill", b->total_keys);
+            launch_matrix_fill(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), b->deduped ? b->d_len.as<uint32_t>() : nullptr,
+                               (uint32_t)b->n_genomes, b->bb, b->sb_fill, b->cap_log2, b->d_dkeys.as<uint64_t>(),
+                               b->d_dcol.as<uint32_t>(), b->d_seg_start.as<uint64_t>(), m->d_data.as<uint64_t>(), m->n_kmers,
+                               d_flag.as<int>());
+        }
+        int ov = 0;
+        hipError_t e2 = hipGetLastError();
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, s);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
+        if (e2 != hipSuccess) { rc = fail(c, GRM_ERR_HIP, "matrix_fill: %s", hipGetErrorString(e2)); break; }
+        if (!ov) break;
+        if (b->bb + b->sb_fill >= 24) { rc = fail(c, GRM_ERR_OVERFLOW, "matrix_fill: dictionary slice does not fit the LDS table"); break; }
+        rc = bucketise_dict(b, b->sb_fill + 1);
+        if (rc) break;
+    }
+    if (rc == GRM_OK && m->n_kmers) {
+        hipError_t e3 = hipMemcpyAsync(m->d_kmers.p, b->d_dict.p, m->n_kmers * 8, hipMemcpyDeviceToDevice, s);
+        if (e3 == hipSuccess) e3 = hipStreamSynchronize(s);
+        if (e3 != hipSuccess) rc = fail(c, GRM_ERR_HIP, "dictionary copy: %s", hipGetErrorString(e3));
+    }
+    if (rc != GRM_OK) { delete m; return rc; }
+    *out = m;
+    return GRM_OK;
+}
+
+extern "C" int grm_batch_run(grm_batch *b, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out)
+{
+    if (!b || !out) return GRM_ERR_ARG;
+    int rc = batch_partition_impl(b, k, abundance_min, false);
+    if (rc) return rc;
+    uint64_t n_local = 0, n_kmers = 0;
+    rc = grm_batch_local_dict(b, &n_local);
+    if (rc) return rc;
+    rc = grm_batch_set_global_dict(b, b->d_local_keys.p, b->d_local_flags.p, n_local, filter_singleton, &n_kmers);
+    if (rc) return rc;
+    return grm_batch_fill(b, out);
+}
+
+// sorted (k-mer, count) list of one genome after partition(+dedup)
+static int genome_set_impl(grm_batch *b, int g, bool have_counts, grm_kmer_set **out)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    const uint64_t B = 1ull << b->bb;
+    grm_kmer_set *set = new grm_kmer_set();
+    set->k = b->k;
+    set->words = 1;
+    *out = set;
+    if (b->total_keys == 0) return GRM_OK;
+    std::vector<uint64_t> off(B + 1), dst(B + 1);
+    std::vector<uint32_t> len(B);
+    HIPCHK(c, hipMemcpy(off.data(), b->d_off.as<uint64_t>() + (uint64_t)g * B, (B + 1) * 8, hipMemcpyDeviceToHost));
+    set->occurrences = off[B] - off[0];
+    if (b->deduped) HIPCHK(c, hipMemcpy(len.data(), b->d_len.as<uint32_t>() + (uint64_t)g * B, B * 4, hipMemcpyDeviceToHost));
+    else for (uint64_t i = 0; i < B; i++) len[i] = (uint32_t)(off[i + 1] - off[i]);
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < B; i++) { dst[i] = n; n += len[i]; }
+    if (n == 0) return GRM_OK;
+    DevBuf d_dst_off, d_len, d_k, d_c, d_k2, d_c2, d_tmp;
+    HIPCHK(c, d_dst_off.alloc(B * 8));
+    HIPCHK(c, d_len.alloc(B * 4));
+    HIPCHK(c, d_k.alloc(n * 8)); HIPCHK(c, d_c.alloc(n * 4));
+    HIPCHK(c, d_k2.alloc(n * 8)); HIPCHK(c, d_c2.alloc(n * 4));
+    HIPCHK(c, hipMemcpy(d_dst_off.p, dst.data(), B * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_len.p, len.data(), B * 4, hipMemcpyHostToDevice));
+    launch_segments_compact(s, b->d_keys.as<uint64_t>(), have_counts ? b->d_kcnt.as<uint32_t>() : nullptr,
+                            b->d_off.as<uint64_t>() + (uint64_t)g * B, d_len.as<uint32_t>(), d_dst_off.as<uint64_t>(),
+                            (uint32_t)B, d_k.as<uint64_t>(), d_c.as<uint32_t>());
+    size_t tb = 0;
+    HIPCHK(c, sort_pairs_u64_u32(s, d_k.as<uint64_t>(), d_k2.as<uint64_t>(), d_c.as<uint32_t>(), d_c2.as<uint32_t>(), n, nullptr, tb));
+    HIPCHK(c, d_tmp.alloc(tb));
+    HIPCHK(c, sort_pairs_u64_u32(s, d_k.as<uint64_t>(), d_k2.as<uint64_t>(), d_c.as<uint32_t>(), d_c2.as<uint32_t>(), n, d_tmp.p, tb));
+    HIPCHK(c, hipGetLastError());
+    set->kmers.resize(n);
+    set->counts.resize(n);
+    HIPCHK(c, hipMemcpyAsync(set->kmers.data(), d_k2.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(set->counts.data(), d_c2.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return GRM_OK;
+}
+
+extern "C" int grm_batch_genome_set(grm_batch *b, int genome_index, grm_kmer_set **out)
+{
+    if (!b || !out) return GRM_ERR_ARG;
+    grm_ctx *c = b->ctx;
+    if (!b->partitioned) return fail(c, GRM_ERR_STATE, "grm_batch_genome_set before partition");
+    if (genome_index < 0 || genome_index >= b->n_genomes) return fail(c, GRM_ERR_ARG, "bad genome index");
+    if (!b->deduped || !b->d_kcnt.p) return fail(c, GRM_ERR_STATE, "grm_batch_genome_set needs a counting partition (use grm_count_genome)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = genome_set_impl(b, genome_index, true, out);
+    if (rc) { grm_kmer_set_free(*out); *out = nullptr; }
+    return rc;
+}
+
+extern "C" int grm_count_genome_buffers(grm_ctx *c, const void *const *bufs, const size_t *lens, int n_bufs, int k,
+                                        uint32_t abundance_min, grm_kmer_set **out)
+{
+    if (!c) return GRM_ERR_NO_DEVICE;
+    if (!out || n_bufs < 0) return fail(c, GRM_ERR_ARG, "grm_count_genome_buffers: bad argument");
+    grm_batch *b = nullptr;
+    int rc = grm_batch_create(c, 1, &b);
+    if (rc) return rc;
+    for (int i = 0; i < n_bufs && !rc; i++) rc = grm_batch_add(b, 0, bufs[i], lens[i]);
+    if (!rc) rc = grm_batch_upload(b);
+    if (!rc) rc = batch_partition_impl(b, k, abundance_min, true);
+    if (!rc) rc = genome_set_impl(b, 0, true, out);
+    if (rc && *out) { grm_kmer_set_free(*out); *out = nullptr; }
+    grm_batch_free(b);
+    return rc;
+}
+
+extern "C" int grm_count_genome(grm_ctx *c, const char *const *paths, int n_paths, int k, uint32_t abundance_min,
+                                grm_kmer_set **out)
+{
+    if (!c) return GRM_ERR_NO_DEVICE;
+    if (!out || n_paths < 0 || (n_paths && !paths)) return fail(c, GRM_ERR_ARG, "grm_count_genome: bad argument");
+    *out = nullptr;
+    grm_batch *b = nullptr;
+    int rc = grm_batch_create(c, 1, &b);
+    if (rc) return rc;
+    for (int i = 0; i < n_paths && !rc; i++) rc = grm_batch_add_file(b, 0, paths[i]);
+    if (!rc) rc = grm_batch_upload(b);
+    if (!rc) rc = batch_partition_impl(b, k, abundance_min, true);
+    if (!rc) rc = genome_set_impl(b, 0, true, out);
+    if (rc && *out) { grm_kmer_set_free(*out); *out = nullptr; }
+    grm_batch_free(b);
+    return rc;
+}
+
+// dsk2kover's merge: per-genome sets (host) -> partition the explicit key lists -> same
+// dictionary / fill kernels as the fused path.
+extern "C" int grm_build_matrix(grm_ctx *c, grm_kmer_set *const *sets, int n_genomes, int filter_singleton,
+                                grm_matrix **out)
+{
+    if (!c) return GRM_ERR_NO_DEVICE;
+    if (!out || n_genomes < 0 || (n_genomes && !sets)) return fail(c, GRM_ERR_ARG, "grm_build_matrix: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int k = n_genomes ? sets[0]->k : 1;
+    std::vector<uint64_t> gko(n_genomes + 1, 0);
+    uint64_t max_g = 0;
+    for (int g = 0; g < n_genomes; g++) {
+        if (!sets[g] || sets[g]->k != k) return fail(c, GRM_ERR_ARG, "grm_build_matrix: sets with different k");
+        gko[g + 1] = gko[g] + sets[g]->counts.size();
+        max_g = std::max<uint64_t>(max_g, sets[g]->counts.size());
+    }
+    const uint64_t n = gko[n_genomes];
+    grm_batch *b = nullptr;
+    int rc = grm_batch_create(c, n_genomes, &b);
+    if (rc) return rc;
+    auto body = [&]() -> int {
+        b->uploaded = true;
+        b->k = k;
+        b->abundance_min = 1;
+        b->total_keys = n;
+        b->total_syms = n;
+        b->bb = pick_bucket_bits(c, max_g);
+        b->cap_log2 = c->opt_cap_log2 > 0 ? (uint32_t)c->opt_cap_log2 : 12u;
+        const uint64_t B = 1ull << b->bb, n_seg = (uint64_t)n_genomes * B;
+        DevBuf d_in, d_gko;
+        HIPCHK(c, d_in.alloc((n + 2) * 8));
+        HIPCHK(c, d_gko.alloc((n_genomes + 1) * 8));
+        for (int g = 0; g < n_genomes; g++)
+            if (!sets[g]->kmers.empty())
+                HIPCHK(c, hipMemcpy(d_in.as<uint64_t>() + gko[g], sets[g]->kmers.data(), sets[g]->kmers.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_gko.p, gko.data(), (n_genomes + 1) * 8, hipMemcpyHostToDevice));
+        HIPCHK(c, b->d_counts.alloc((n_seg + 1) * 4));
+        HIPCHK(c, b->d_cursor.alloc((n_seg + 1) * 4));
+        HIPCHK(c, b->d_off.alloc((n_seg + 2) * 8));
+        HIPCHK(c, b->d_keys.alloc((n + 2) * 8));
+        HIPCHK(c, hipMemsetAsync(b->d_counts.p, 0, (n_seg + 1) * 4, s));
+        HIPCHK(c, hipMemsetAsync(b->d_cursor.p, 0, (n_seg + 1) * 4, s));
+        launch_keys_partition_hist(s, d_in.as<uint64_t>(), n, d_gko.as<uint64_t>(), (uint32_t)n_genomes, b->bb, b->d_counts.as<uint32_t>());
+        launch_scan_u32(s, b->d_counts.as<uint32_t>(), n_seg, b->d_off.as<uint64_t>());
+        launch_keys_partition_scatter(s, d_in.as<uint64_t>(), n, d_gko.as<uint64_t>(), (uint32_t)n_genomes, b->bb,
+                                      b->d_off.as<uint64_t>(), b->d_cursor.as<uint32_t>(), b->d_keys.as<uint64_t>());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(s));
+        b->partitioned = true;
+        uint64_t n_local = 0, n_kmers = 0;
+        int r = grm_batch_local_dict(b, &n_local);
+        if (r) return r;
+        r = grm_batch_set_global_dict(b, b->d_local_keys.p, b->d_local_flags.p, n_local, filter_singleton, &n_kmers);
+        if (r) return r;
+        return grm_batch_fill(b, out);
+    };
+    rc = body();
+    grm_batch_free(b);
+    return rc;
+}
+
+// --------------------------------------------------------------------------------------
+// writers
+// --------------------------------------------------------------------------------------
+static inline void decode_kmer(uint64_t v, int k, char *out)
+{
+    static const char L[4] = {'A', 'C', 'T', 'G'};
+    for (int i = 0; i < k; i++) out[i] = L[(v >> (2 * (k - 1 - i))) & 3];
+}
+
+extern "C" int grm_write_tsv(grm_matrix *m, const char *const *genome_ids, const char *path)
+{
+    if (!m || !path || (m->n_genomes && !genome_ids)) return GRM_ERR_ARG;
+    grm_ctx *c = m->ctx;
+    const uint64_t *kmers = grm_matrix_kmers(m);
+    const uint64_t *data = grm_matrix_data(m);
+    if (!kmers || !data) return GRM_ERR_HIP;
+    std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(c, GRM_ERR_IO, "cannot create %s", tmp.c_str());
+    std::vector<char> obuf(1 << 22);
+    setvbuf(f, obuf.data(), _IOFBF, obuf.size());
+    fputs("kmers", f);   // first header cell is forced by dataset/create.py:241
+    for (int g = 0; g < m->n_genomes; g++) { fputc('\t', f); fputs(genome_ids[g], f); }
+    fputc('\n', f);
+    const size_t line_len = (size_t)m->k + 2 * (size_t)m->n_genomes + 1;
+    std::vector<char> line(line_len);
+    for (size_t col = 0; col < m->n_kmers; col++) {
+        decode_kmer(kmers[col], m->k, line.data());
+        size_t p = (size_t)m->k;
+        for (int g = 0; g < m->n_genomes; g++) {
+            line[p++] = '\t';
+            line[p++] = ((data[(size_t)(g >> 6) * m->n_kmers + col] >> (63 - (g & 63))) & 1) ? '1' : '0';
+        }
+        line[p++] = '\n';
+        if (fwrite(line.data(), 1, p, f) != p) { fclose(f); remove(tmp.c_str()); return fail(c, GRM_ERR_IO, "short write to %s", tmp.c_str()); }
+    }
+    if (fclose(f) != 0) { remove(tmp.c_str()); return fail(c, GRM_ERR_IO, "close failed on %s", tmp.c_str()); }
+    if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return fail(c, GRM_ERR_IO, "rename to %s failed", path); }
+    return GRM_OK;
+}

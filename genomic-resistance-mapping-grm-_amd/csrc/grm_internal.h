@@ -1,0 +1,91 @@
+// grm_internal.h -- shared between grm_kernels.hip (device side) and grm_api.cpp (host side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace grm {
+
+// ---- parse geometry ----
+constexpr int PARSE_THREADS = 256;
+constexpr int ROUND_BYTES = PARSE_THREADS * 16;            // one 16-B load per thread
+constexpr int ROUNDS_PER_TILE = 4;
+constexpr int TILE_BYTES = ROUND_BYTES * ROUNDS_PER_TILE;  // 16 KiB; every file starts on a tile boundary
+constexpr int STAGE_BYTES = ROUND_BYTES + 64;              // <=63 lead symbols + one round
+constexpr int RAW_FRONT_PAD = 64;                          // '\n' bytes in front of raw[0]
+
+// ---- k-mer kernels ----
+constexpr int KMER_THREADS = 256;
+constexpr int MAX_BUCKET_BITS = 13;                        // LDS: 8 B per bucket in the scatter kernel
+
+// ---- LDS table kernels ----
+constexpr int TABLE_THREADS = 512;                         // 8 waves: one genome per wave at a time
+constexpr int TABLE_SCRATCH_BYTES = 128;
+
+struct TileSummary {
+    uint32_t known;       // symbols whose emission does not depend on the incoming line type
+    uint32_t unknown;     // symbols emitted only if the line running into the tile is a sequence line
+    uint32_t last_event;  // T_SEQ / T_HDR of the last line starting inside the tile, 0 if none
+};
+
+struct KmerLaunch {
+    const uint64_t *sym2;
+    const uint64_t *inv;
+    uint64_t total_syms;
+    const uint64_t *genome_sym_off;   // device, n_genomes + 1
+    uint32_t n_genomes;
+    int k;
+    int bb;
+    uint32_t groups_per_thread;
+};
+
+void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, TileSummary *sums);
+void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles, uint64_t *tile_off,
+                       uint8_t *tile_state, const uint32_t *genome_tile_off, uint32_t n_genomes,
+                       uint64_t *genome_sym_off);
+void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint64_t *tile_off,
+                       const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv);
+void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
+void launch_kmer_scatter(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor, uint64_t *keys);
+void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
+                                uint32_t n_genomes, int bb, uint32_t *counts);
+void launch_keys_partition_scatter(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
+                                   uint32_t n_genomes, int bb, const uint64_t *off, uint32_t *cursor, uint64_t *keys);
+void launch_scan_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *out);
+void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const uint64_t *off, uint64_t n_segments, uint32_t cap_log2,
+                         uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow);
+void launch_dict_build(hipStream_t s, const uint64_t *keys, const uint64_t *off, const uint32_t *len,
+                       uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, uint64_t *stage_keys,
+                       uint8_t *stage_flags, uint32_t *stage_cnt, int *overflow);
+void launch_dict_gather(hipStream_t s, const uint64_t *stage_keys, const uint8_t *stage_flags, const uint64_t *stage_off,
+                        uint32_t n_wg, uint32_t cap, uint64_t *out_keys, uint8_t *out_flags);
+void launch_dict_mark(hipStream_t s, const uint64_t *skeys, const uint8_t *sflags, uint64_t n, int filter_singleton,
+                      uint32_t *keep);
+void launch_dict_select(hipStream_t s, const uint64_t *skeys, const uint32_t *keep, const uint64_t *pos, uint64_t n,
+                        uint64_t *dict);
+void launch_dict_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int bb, int sb, uint32_t *bucket_of,
+                            uint32_t *col_of);
+void launch_segments_compact(hipStream_t s, const uint64_t *src, const uint32_t *src_cnt, const uint64_t *src_off,
+                             const uint32_t *len, const uint64_t *dst_off, uint32_t n_seg, uint64_t *dst,
+                             uint32_t *dst_cnt);
+void launch_segment_starts(hipStream_t s, const uint32_t *ids, uint64_t n, uint32_t n_ids, uint64_t *start);
+void launch_gather_u64(hipStream_t s, const uint64_t *src, const uint32_t *index, uint64_t n, uint64_t *dst);
+void launch_matrix_fill(hipStream_t s, const uint64_t *keys, const uint64_t *off, const uint32_t *len,
+                        uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint64_t *dkeys,
+                        const uint32_t *dcol, const uint64_t *seg_start, uint64_t *matrix, uint64_t n_cols,
+                        int *overflow);
+void launch_column_popcount(hipStream_t s, const uint64_t *matrix, uint64_t n_rows, uint64_t n_cols,
+                            const uint64_t *row_mask, uint32_t *out);
+void launch_iota_u32(hipStream_t s, uint32_t *p, uint64_t n);
+hipError_t set_max_dynamic_lds();
+
+// rocPRIM-backed plumbing for the (small) dictionary: radix sort of pairs, exclusive scan
+hipError_t sort_pairs_u64_u8(hipStream_t s, const uint64_t *kin, uint64_t *kout, const uint8_t *vin, uint8_t *vout,
+                             uint64_t n, void *tmp, size_t &tmp_bytes);
+hipError_t sort_pairs_u32_u32(hipStream_t s, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                              uint64_t n, int end_bit, void *tmp, size_t &tmp_bytes);
+hipError_t sort_pairs_u64_u32(hipStream_t s, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,
+                              uint64_t n, void *tmp, size_t &tmp_bytes);
+hipError_t exclusive_scan_u32_u64(hipStream_t s, const uint32_t *in, uint64_t *out, uint64_t n, void *tmp,
+                                  size_t &tmp_bytes);
+
+}  // namespace grm

@@ -1,0 +1,987 @@
+// grm_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the k-mer-matrix engine.
+//
+// Replaces the compute inside the reference's absent native tools:
+//   DSK / multidsk  (call sites bin/kover/core/kover/dataset/tools/kmer_count.py:28-53,
+//                    src/app.py:1372)                     -> parse_*, kmer_hist, kmer_scatter,
+//                                                             bucket_dedup
+//   dsk2kover       (call site .../tools/kmer_pack.py:28-36) -> dict_build, dict_*, matrix_fill
+//
+// All work is integer / byte work bounded by HBM bandwidth: no MFMA.  Design notes in
+// DESIGN.md ("Kernels").  Wave width is hard-coded to 64.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "grm_device_fns.h"
+#include "grm_internal.h"
+
+namespace grm {
+
+// ------------------------------------------------------------------------------------
+// small cooperative helpers (256- or 1024-thread blocks, wave64)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// exclusive "rightmost non-zero" scan over the block, in thread order.
+// returns the carry for this thread (0 if no non-zero value precedes it in the block);
+// *block_last receives the rightmost non-zero value of the whole block (0 if none).
+// scratch: >= 16 ints of LDS.  Contains two __syncthreads().
+__device__ __forceinline__ int block_scan_last_nonzero(int v, int *scratch, int *block_last)
+{
+    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(inc, d);
+        if (lane >= d && inc == 0) inc = o;
+    }
+    int exc = __shfl_up(inc, 1);
+    if (lane == 0) exc = 0;
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    int prefix = 0, last = 0;
+    for (int w = 0; w < nw; w++) {
+        int t = scratch[w];
+        if (w < wave && t) prefix = t;
+        if (t) last = t;
+    }
+    __syncthreads();
+    *block_last = last;
+    return exc ? exc : prefix;
+}
+
+// exclusive sum scan over the block (uint32); *block_total = sum of all.
+__device__ __forceinline__ uint32_t block_scan_sum(uint32_t v, uint32_t *scratch, uint32_t *block_total)
+{
+    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    uint32_t prefix = 0, total = 0;
+    for (int w = 0; w < nw; w++) {
+        uint32_t t = scratch[w];
+        if (w < wave) prefix += t;
+        total += t;
+    }
+    __syncthreads();
+    *block_total = total;
+    return prefix + inc - v;
+}
+
+__device__ __forceinline__ uint64_t block_scan_sum64(uint64_t v, uint64_t *scratch, uint64_t *block_total)
+{
+    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    uint64_t prefix = 0, total = 0;
+    for (int w = 0; w < nw; w++) {
+        uint64_t t = scratch[w];
+        if (w < wave) prefix += t;
+        total += t;
+    }
+    __syncthreads();
+    *block_total = total;
+    return prefix + inc - v;
+}
+
+// ------------------------------------------------------------------------------------
+// Stage 0: FASTA -> packed symbol stream
+//
+// raw   : all file images of the batch, each file starting on a TILE_BYTES boundary,
+//         gaps filled with '\n'; raw[-1] exists and is '\n' (front pad), so
+//         "byte i starts a line" == (raw[i-1] == '\n') everywhere.
+// Lines whose first byte is '>' are headers: the '>' emits ONE separator symbol
+// (inv bit set) so that no k-mer spans two records; other header bytes emit nothing.
+// Every other line emits each byte except '\n' / '\r' as a symbol:
+// code (c>>1)&3, inv bit (c>>3)&1  (SURVEY 8(c)(1),(3)).
+// ------------------------------------------------------------------------------------
+struct RoundState {
+    uint32_t nl, gt, cr, ls;
+    uint32_t w[4];
+};
+
+__device__ __forceinline__ void load_round(const uint8_t *raw, uint64_t byte_base, RoundState &rs)
+{
+    const uint4 v = *reinterpret_cast<const uint4 *>(raw + byte_base);
+    rs.w[0] = v.x; rs.w[1] = v.y; rs.w[2] = v.z; rs.w[3] = v.w;
+    chunk_masks(rs.w, rs.nl, rs.gt, rs.cr);
+    const uint32_t prev_nl = raw[(int64_t)byte_base - 1] == '\n';
+    rs.ls = ((rs.nl << 1) | prev_nl) & 0xffffu;
+}
+
+// P1: per tile -> {symbols that depend on the incoming line type, symbols that do not,
+//                  type of the last line that starts inside the tile}
+__global__ __launch_bounds__(PARSE_THREADS) void parse_summarize_kernel(
+    const uint8_t *__restrict__ raw, uint32_t n_tiles, TileSummary *__restrict__ sums)
+{
+    __shared__ int scratch_i[16];
+    __shared__ uint32_t acc[2];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    if (threadIdx.x < 2) acc[threadIdx.x] = 0;
+    __syncthreads();
+    int carry = T_NONE;
+    uint32_t my_unk = 0, my_known = 0;
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        RoundState rs;
+        load_round(raw, (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u, rs);
+        int ev = chunk_last_event(rs.ls, rs.gt);
+        int block_last;
+        int cin = block_scan_last_nonzero(ev, scratch_i, &block_last);
+        if (!cin) cin = carry;
+        uint32_t emit, sep, unk;
+        chunk_classify(rs.nl, rs.gt, rs.cr, rs.ls, cin, emit, sep, unk);
+        my_known += __popc(emit);
+        my_unk += __popc(unk);
+        if (block_last) carry = block_last;
+    }
+    // block reduce through LDS atomics (two counters, once per thread)
+    if (my_known) atomicAdd(&acc[0], my_known);
+    if (my_unk) atomicAdd(&acc[1], my_unk);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TileSummary s;
+        s.known = acc[0];
+        s.unknown = acc[1];
+        s.last_event = (uint32_t)carry;
+        sums[tile] = s;
+    }
+}
+
+// P-scan: ONE workgroup walks all tile summaries: resolves each tile's incoming line type
+// (rightmost-non-zero scan of last_event) and its first symbol index (exclusive sum).
+// Also emits the first symbol index of every genome (genome_tile_off: first tile of
+// genome g; entry [n_genomes] = n_tiles) and the total.
+__global__ __launch_bounds__(1024) void parse_scan_kernel(
+    const TileSummary *__restrict__ sums, uint32_t n_tiles, uint64_t *tile_off,
+    uint8_t *__restrict__ tile_state, const uint32_t *__restrict__ genome_tile_off,
+    uint32_t n_genomes, uint64_t *__restrict__ genome_sym_off /* n_genomes+1 */)
+{
+    __shared__ int scratch_i[16];
+    __shared__ uint64_t scratch_l[16];
+    const uint32_t per = (n_tiles + blockDim.x - 1) / blockDim.x;
+    const uint32_t t0 = min((uint64_t)threadIdx.x * per, (uint64_t)n_tiles);
+    const uint32_t t1 = min((uint64_t)t0 + per, (uint64_t)n_tiles);
+    int last = 0;
+    for (uint32_t t = t0; t < t1; t++) {
+        int e = (int)sums[t].last_event;
+        if (e) last = e;
+    }
+    int dummy;
+    int cur = block_scan_last_nonzero(last, scratch_i, &dummy);
+    uint64_t sum = 0;
+    int c = cur;
+    for (uint32_t t = t0; t < t1; t++) {
+        TileSummary s = sums[t];
+        sum += s.known + (c != T_HDR ? s.unknown : 0u);
+        if (s.last_event) c = (int)s.last_event;
+    }
+    uint64_t total;
+    uint64_t off = block_scan_sum64(sum, scratch_l, &total);
+    c = cur;
+    for (uint32_t t = t0; t < t1; t++) {
+        TileSummary s = sums[t];
+        tile_off[t] = off;
+        tile_state[t] = (uint8_t)c;
+        off += s.known + (c != T_HDR ? s.unknown : 0u);
+        if (s.last_event) c = (int)s.last_event;
+    }
+    if (threadIdx.x == 0) tile_off[n_tiles] = total;
+    __syncthreads();   // tile_off written by this block is visible to it after the barrier
+    for (uint32_t g = threadIdx.x; g <= n_genomes; g += blockDim.x)
+        genome_sym_off[g] = tile_off[genome_tile_off[g]];
+}
+
+// P2: re-classify with the known incoming type, compact the symbols of each 4-KiB round
+// in LDS, then pack 64 symbols per wave step with three ballots (wave64):
+// ballot(code bit0), ballot(code bit1), ballot(inv).
+__global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
+    const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint64_t *__restrict__ tile_off,
+    const uint8_t *__restrict__ tile_state, uint64_t *__restrict__ sym2, uint64_t *__restrict__ inv)
+{
+    __shared__ int scratch_i[16];
+    __shared__ uint32_t scratch_u[16];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE_BYTES];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    int carry = (int)tile_state[tile];
+    uint64_t sym_base = tile_off[tile];
+    const int lane = lane_id(), wave = wave_id();
+
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        RoundState rs;
+        load_round(raw, (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u, rs);
+        int ev = chunk_last_event(rs.ls, rs.gt);
+        int block_last;
+        int cin = block_scan_last_nonzero(ev, scratch_i, &block_last);
+        if (!cin) cin = carry;
+        if (cin == T_NONE) cin = T_SEQ;     // only possible before the first line start of the buffer
+        uint32_t emit, sep, unk;
+        chunk_classify(rs.nl, rs.gt, rs.cr, rs.ls, cin, emit, sep, unk);
+        uint32_t round_total;
+        uint32_t local = block_scan_sum((uint32_t)__popc(emit), scratch_u, &round_total);
+
+        // zero the staging area (bytes outside [lead, lead+round_total) must read as 0)
+        for (int i = threadIdx.x; i < STAGE_BYTES / 4; i += PARSE_THREADS)
+            reinterpret_cast<uint32_t *>(stage)[i] = 0;
+        __syncthreads();
+        const uint32_t lead = (uint32_t)(sym_base & 63ull);
+        uint32_t pos = lead + local;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if ((emit >> j) & 1u) {
+                uint32_t b = (rs.w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                uint32_t code = (b >> 1) & 3u, bad = (b >> 3) & 1u;
+                if ((sep >> j) & 1u) { code = 0; bad = 1; }
+                stage[pos++] = (uint8_t)(code | (bad << 2));
+            }
+        }
+        __syncthreads();
+        const uint32_t span = lead + round_total;
+        const uint32_t n_groups = (span + 63) >> 6;
+        const uint64_t g_base = sym_base >> 6;
+        for (uint32_t g = wave; g < n_groups; g += PARSE_THREADS / 64) {
+            const uint32_t c = stage[g * 64 + lane];
+            const uint64_t b0 = __ballot(c & 1u), b1 = __ballot(c & 2u), bi = __ballot(c & 4u);
+            if (lane == 0) {
+                const uint64_t w0 = pack32_msb_first((uint32_t)b0, (uint32_t)b1);
+                const uint64_t w1 = pack32_msb_first((uint32_t)(b0 >> 32), (uint32_t)(b1 >> 32));
+                const uint64_t G = g_base + g;
+                const bool full = (g > 0 || lead == 0) && ((g + 1) * 64 <= span);
+                if (full) {
+                    sym2[2 * G] = w0; sym2[2 * G + 1] = w1; inv[G] = bi;
+                } else {   // group shared with a neighbouring round / tile: buffers are pre-zeroed
+                    if (w0) atomicOr((unsigned long long *)&sym2[2 * G], (unsigned long long)w0);
+                    if (w1) atomicOr((unsigned long long *)&sym2[2 * G + 1], (unsigned long long)w1);
+                    if (bi) atomicOr((unsigned long long *)&inv[G], (unsigned long long)bi);
+                }
+            }
+        }
+        __syncthreads();
+        sym_base += round_total;
+        if (block_last) carry = block_last;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Stage 1: canonical k-mers -> radix partition by hash bucket, per genome
+// ------------------------------------------------------------------------------------
+// genome of symbol position p: last g with genome_sym_off[g] <= p
+__device__ __forceinline__ uint32_t genome_of(const uint64_t *__restrict__ gso, uint32_t n_genomes, uint64_t p)
+{
+    uint32_t lo = 0, hi = n_genomes;   // invariant: gso[lo] <= p < gso[hi]
+    while (hi - lo > 1) {
+        uint32_t m = (lo + hi) >> 1;
+        if (gso[m] <= p) lo = m; else hi = m;
+    }
+    return lo;
+}
+
+// XCD-aware span order: workgroups are dealt round-robin to the 8 XCDs, so block b and
+// b+8 share an L2.  Give each XCD one contiguous eighth of the spans: the partition's open
+// write lines (one per bucket of the genome being scattered) then live in ONE L2.
+__device__ __forceinline__ uint64_t xcd_span(uint32_t block, uint32_t n_spans)
+{
+    const uint32_t per = (n_spans + 7) / 8;
+    return (uint64_t)(block & 7u) * per + (block >> 3);
+}
+
+struct KmerArgs {
+    const uint64_t *sym2;
+    const uint64_t *inv;
+    uint64_t total_syms;
+    uint64_t n_groups;
+    const uint64_t *genome_sym_off;
+    uint32_t n_genomes;
+    int k;
+    int bb;                     // log2(buckets per genome)
+    uint32_t groups_per_thread;
+};
+
+template <typename F>
+__device__ __forceinline__ void group_kmers(const KmerArgs &a, uint64_t grp, F &&f)
+{
+    const uint64_t p0 = grp << 6;
+    const int64_t nv = (int64_t)a.total_syms - a.k + 1 - (int64_t)p0;
+    if (nv <= 0) return;
+    const uint64_t A = a.sym2[2 * grp], B = a.sym2[2 * grp + 1], C = a.sym2[2 * grp + 2];
+    uint64_t valid = valid_starts(a.inv[grp], a.inv[grp + 1], a.k);
+    if (nv < 64) valid &= (1ull << nv) - 1;
+    for_each_kmer(A, B, C, valid, a.k, f);
+}
+
+// K1: per-(genome,bucket) occurrence histogram.
+// LDS path when the whole span lies in one genome; global atomics otherwise.
+__global__ __launch_bounds__(KMER_THREADS) void kmer_hist_kernel(KmerArgs a, uint32_t n_spans,
+                                                                 uint32_t *__restrict__ counts)
+{
+    extern __shared__ uint32_t lds_hist[];
+    const uint64_t span = xcd_span(blockIdx.x, n_spans);
+    if (span >= n_spans) return;
+    const uint32_t B = 1u << a.bb;
+    const uint64_t span_groups = (uint64_t)KMER_THREADS * a.groups_per_thread;
+    const uint64_t g_first = span * span_groups;
+    if (g_first >= a.n_groups) return;
+    const uint64_t g_last = min(g_first + span_groups, a.n_groups) - 1;
+    const uint64_t p_first = g_first << 6;
+    const uint64_t p_last = min((g_last << 6) + 63, a.total_syms - 1);
+    const uint32_t gen0 = genome_of(a.genome_sym_off, a.n_genomes, p_first);
+    const bool uniform = a.genome_sym_off[gen0 + 1] > p_last;
+
+    if (uniform) {
+        for (uint32_t i = threadIdx.x; i < B; i += KMER_THREADS) lds_hist[i] = 0;
+        __syncthreads();
+        for (uint32_t it = 0; it < a.groups_per_thread; it++) {
+            const uint64_t grp = g_first + (uint64_t)it * KMER_THREADS + threadIdx.x;
+            if (grp > g_last) break;
+            group_kmers(a, grp, [&](int, uint64_t canon) {
+                atomicAdd(&lds_hist[hash_bucket(mix64(canon), a.bb)], 1u);
+            });
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < B; i += KMER_THREADS) {
+            const uint32_t c = lds_hist[i];
+            if (c) atomicAdd(&counts[(uint64_t)gen0 * B + i], c);
+        }
+    } else {
+        for (uint32_t it = 0; it < a.groups_per_thread; it++) {
+            const uint64_t grp = g_first + (uint64_t)it * KMER_THREADS + threadIdx.x;
+            if (grp > g_last) break;
+            const uint64_t p0 = grp << 6;
+            uint32_t gen = genome_of(a.genome_sym_off, a.n_genomes, p0);
+            uint64_t gend = a.genome_sym_off[gen + 1];
+            group_kmers(a, grp, [&](int i, uint64_t canon) {
+                while (p0 + (uint64_t)i >= gend) { gen++; gend = a.genome_sym_off[gen + 1]; }
+                atomicAdd(&counts[(uint64_t)gen * B + hash_bucket(mix64(canon), a.bb)], 1u);
+            });
+        }
+    }
+}
+
+// K3: scatter the canonical k-mers into their (genome,bucket) segment of `keys`.
+// off[g*B+b] = first slot of the segment (exclusive scan of counts), cursor = fill level.
+// LDS path: span histogram -> one global atomicAdd per touched bucket reserves a run ->
+// second sweep recomputes the k-mers and drops each one at run_base + LDS rank.
+__global__ __launch_bounds__(KMER_THREADS) void kmer_scatter_kernel(
+    KmerArgs a, uint32_t n_spans, const uint64_t *__restrict__ off, uint32_t *__restrict__ cursor,
+    uint64_t *__restrict__ keys)
+{
+    extern __shared__ uint32_t lds[];
+    const uint64_t span = xcd_span(blockIdx.x, n_spans);
+    if (span >= n_spans) return;
+    const uint32_t B = 1u << a.bb;
+    uint32_t *hist = lds;          // [B] occurrence count, then running rank
+    uint32_t *rel = lds + B;       // [B] run start relative to the genome's first slot
+    const uint64_t span_groups = (uint64_t)KMER_THREADS * a.groups_per_thread;
+    const uint64_t g_first = span * span_groups;
+    if (g_first >= a.n_groups) return;
+    const uint64_t g_last = min(g_first + span_groups, a.n_groups) - 1;
+    const uint64_t p_first = g_first << 6;
+    const uint64_t p_last = min((g_last << 6) + 63, a.total_syms - 1);
+    const uint32_t gen0 = genome_of(a.genome_sym_off, a.n_genomes, p_first);
+    const bool uniform = a.genome_sym_off[gen0 + 1] > p_last;
+
+    if (uniform) {
+        for (uint32_t i = threadIdx.x; i < B; i += KMER_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t it = 0; it < a.groups_per_thread; it++) {
+            const uint64_t grp = g_first + (uint64_t)it * KMER_THREADS + threadIdx.x;
+            if (grp > g_last) break;
+            group_kmers(a, grp, [&](int, uint64_t canon) {
+                atomicAdd(&hist[hash_bucket(mix64(canon), a.bb)], 1u);
+            });
+        }
+        __syncthreads();
+        const uint64_t gbase = off[(uint64_t)gen0 * B];
+        for (uint32_t i = threadIdx.x; i < B; i += KMER_THREADS) {
+            const uint32_t c = hist[i];
+            uint32_t r = 0;
+            if (c) {
+                const uint64_t idx = (uint64_t)gen0 * B + i;
+                r = (uint32_t)(off[idx] - gbase) + atomicAdd(&cursor[idx], c);
+            }
+            rel[i] = r;
+            hist[i] = 0;
+        }
+        __syncthreads();
+        for (uint32_t it = 0; it < a.groups_per_thread; it++) {
+            const uint64_t grp = g_first + (uint64_t)it * KMER_THREADS + threadIdx.x;
+            if (grp > g_last) break;
+            group_kmers(a, grp, [&](int, uint64_t canon) {
+                const uint32_t b = hash_bucket(mix64(canon), a.bb);
+                const uint32_t rank = atomicAdd(&hist[b], 1u);
+                keys[gbase + rel[b] + rank] = canon;
+            });
+        }
+    } else {
+        for (uint32_t it = 0; it < a.groups_per_thread; it++) {
+            const uint64_t grp = g_first + (uint64_t)it * KMER_THREADS + threadIdx.x;
+            if (grp > g_last) break;
+            const uint64_t p0 = grp << 6;
+            uint32_t gen = genome_of(a.genome_sym_off, a.n_genomes, p0);
+            uint64_t gend = a.genome_sym_off[gen + 1];
+            group_kmers(a, grp, [&](int i, uint64_t canon) {
+                while (p0 + (uint64_t)i >= gend) { gen++; gend = a.genome_sym_off[gen + 1]; }
+                const uint64_t idx = (uint64_t)gen * B + hash_bucket(mix64(canon), a.bb);
+                keys[off[idx] + atomicAdd(&cursor[idx], 1u)] = canon;
+            });
+        }
+    }
+}
+
+// partition an explicit key list (grm_build_matrix from host-side sets): hist + scatter
+__global__ void keys_hist_kernel(const uint64_t *__restrict__ in, uint64_t n,
+                                 const uint64_t *__restrict__ genome_key_off, uint32_t n_genomes, int bb,
+                                 uint32_t *__restrict__ counts)
+{
+    const uint32_t B = 1u << bb;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t g = genome_of(genome_key_off, n_genomes, i);
+        atomicAdd(&counts[(uint64_t)g * B + hash_bucket(mix64(in[i]), bb)], 1u);
+    }
+}
+__global__ void keys_scatter_kernel(const uint64_t *__restrict__ in, uint64_t n,
+                                    const uint64_t *__restrict__ genome_key_off, uint32_t n_genomes, int bb,
+                                    const uint64_t *__restrict__ off, uint32_t *__restrict__ cursor,
+                                    uint64_t *__restrict__ keys)
+{
+    const uint32_t B = 1u << bb;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t g = genome_of(genome_key_off, n_genomes, i);
+        const uint64_t key = in[i];
+        const uint64_t idx = (uint64_t)g * B + hash_bucket(mix64(key), bb);
+        keys[off[idx] + atomicAdd(&cursor[idx], 1u)] = key;
+    }
+}
+
+// single-workgroup exclusive scan u32 -> u64 (n up to a few million entries); out[n] = total
+__global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t *__restrict__ in, uint64_t n,
+                                                        uint64_t *__restrict__ out)
+{
+    __shared__ uint64_t scratch[16];
+    const uint64_t per = (n + blockDim.x - 1) / blockDim.x;
+    const uint64_t i0 = min((uint64_t)threadIdx.x * per, n), i1 = min(i0 + per, n);
+    uint64_t s = 0;
+    for (uint64_t i = i0; i < i1; i++) s += in[i];
+    uint64_t total;
+    uint64_t o = block_scan_sum64(s, scratch, &total);
+    for (uint64_t i = i0; i < i1; i++) { out[i] = o; o += in[i]; }
+    if (threadIdx.x == 0) out[n] = total;
+}
+
+// ------------------------------------------------------------------------------------
+// LDS open-addressing table helpers (linear probing, 64-bit CAS = ds_cmpst_rtn_b64)
+// ------------------------------------------------------------------------------------
+// returns slot of key (inserting it if absent), or 0xffffffff when the table is full
+__device__ __forceinline__ uint32_t lds_find_or_insert(uint64_t *tkeys, uint32_t cap_mask, uint64_t key,
+                                                       uint64_t h, bool *inserted)
+{
+    uint32_t slot = hash_slot(h, cap_mask);
+    for (uint32_t probe = 0; probe <= cap_mask; probe++) {
+        const uint64_t prev = atomicCAS((unsigned long long *)&tkeys[slot], (unsigned long long)EMPTY_KEY,
+                                        (unsigned long long)key);
+        if (prev == EMPTY_KEY) { *inserted = true; return slot; }
+        if (prev == key) { *inserted = false; return slot; }
+        slot = (slot + 1) & cap_mask;
+    }
+    return 0xffffffffu;
+}
+__device__ __forceinline__ uint32_t lds_find(const uint64_t *tkeys, uint32_t cap_mask, uint64_t key, uint64_t h)
+{
+    uint32_t slot = hash_slot(h, cap_mask);
+    for (uint32_t probe = 0; probe <= cap_mask; probe++) {
+        const uint64_t cur = tkeys[slot];
+        if (cur == key) return slot;
+        if (cur == EMPTY_KEY) return 0xffffffffu;
+        slot = (slot + 1) & cap_mask;
+    }
+    return 0xffffffffu;
+}
+
+// block-wide ordered compaction of flagged table slots: returns exclusive position of this
+// thread's element within the current sweep; *sweep_total = #flagged in the sweep.
+__device__ __forceinline__ uint32_t sweep_compact(bool flag, uint32_t *scratch, uint32_t *sweep_total)
+{
+    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
+    const uint64_t m = __ballot(flag);
+    const uint32_t before = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) scratch[wave] = __popcll(m);
+    __syncthreads();
+    uint32_t prefix = 0, total = 0;
+    for (int w = 0; w < nw; w++) {
+        const uint32_t t = scratch[w];
+        if (w < wave) prefix += t;
+        total += t;
+    }
+    __syncthreads();
+    *sweep_total = total;
+    return prefix + before;
+}
+
+// K4: per-(genome,bucket) dedup + count + abundance filter, in place.
+// After the kernel the segment [off[i], off[i]+len_out[i]) holds the distinct k-mers whose
+// count >= abundance_min (order = table slot order); counts_out (optional) is parallel to keys.
+__global__ __launch_bounds__(TABLE_THREADS) void bucket_dedup_kernel(
+    uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, uint64_t n_segments, uint32_t cap_log2,
+    uint32_t abundance_min, uint32_t *__restrict__ len_out, uint32_t *__restrict__ counts_out,
+    int *__restrict__ overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
+    uint64_t *tkeys = reinterpret_cast<uint64_t *>(lds_raw);
+    uint32_t *tcnt = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 8);
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 12);   // [16] + flags
+    volatile int &full = *reinterpret_cast<volatile int *>(scratch + 16);
+    for (uint64_t seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
+        const uint64_t s0 = off[seg];
+        const uint64_t n = off[seg + 1] - s0;
+        for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tkeys[i] = EMPTY_KEY; tcnt[i] = 0; }
+        if (threadIdx.x == 0) full = 0;
+        __syncthreads();
+        for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint64_t key = keys[s0 + i];
+            bool ins;
+            const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, mix64(key), &ins);
+            if (slot == 0xffffffffu) full = 1;
+            else atomicAdd(&tcnt[slot], 1u);
+        }
+        __syncthreads();
+        if (full) {
+            if (threadIdx.x == 0) { atomicExch(overflow, 1); len_out[seg] = 0; }
+            __syncthreads();
+            continue;
+        }
+        uint32_t base = 0;
+        for (uint32_t s = 0; s < cap; s += blockDim.x) {
+            const uint32_t slot = s + threadIdx.x;
+            const uint64_t key = tkeys[slot];
+            const uint32_t c = tcnt[slot];
+            const bool keep = key != EMPTY_KEY && c >= abundance_min;
+            uint32_t sweep_total;
+            const uint32_t pos = sweep_compact(keep, scratch, &sweep_total);
+            if (keep) {
+                keys[s0 + base + pos] = key;
+                if (counts_out) counts_out[s0 + base + pos] = c;
+            }
+            base += sweep_total;
+        }
+        if (threadIdx.x == 0) len_out[seg] = base;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Stage 3a (K5): per-bucket dictionary.  One workgroup per (bucket, sub-bucket) unions the
+// bucket's segment of EVERY genome in an LDS table; a wave takes one genome at a time.
+// state[slot] = first genome seen + 1, bit31 set once a second genome shows up.
+// Output: staged, per workgroup at stride `cap`: distinct keys + flag (1 = one genome,
+// 2 = several) in table-slot order, and the count.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TABLE_THREADS) void dict_build_kernel(
+    const uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+    uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, uint64_t *__restrict__ stage_keys,
+    uint8_t *__restrict__ stage_flags, uint32_t *__restrict__ stage_cnt, int *__restrict__ overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
+    uint64_t *tkeys = reinterpret_cast<uint64_t *>(lds_raw);
+    uint32_t *tstate = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 8);
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 12);   // [16] + flags
+    volatile int &full = *reinterpret_cast<volatile int *>(scratch + 16);
+    uint32_t &n_distinct = scratch[17];
+    const uint32_t wg = blockIdx.x;
+    const uint32_t B = 1u << bb;
+    const uint32_t b = wg >> sb, sub = wg & ((1u << sb) - 1);
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tkeys[i] = EMPTY_KEY; tstate[i] = 0; }
+    if (threadIdx.x == 0) { full = 0; n_distinct = 0; }
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
+    const uint32_t max_fill = cap - (cap >> 3);     // 87.5 %
+    for (uint32_t g = wave; g < n_genomes; g += nw) {
+        const uint64_t idx = (uint64_t)g * B + b;
+        const uint64_t s0 = off[idx];
+        const uint64_t n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
+        for (uint64_t i = lane; i < n; i += 64) {
+            const uint64_t key = keys[s0 + i];
+            const uint64_t h = mix64(key);
+            if (sb && hash_sub(h, bb, sb) != sub) continue;
+            bool ins;
+            const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, h, &ins);
+            if (slot == 0xffffffffu) { full = 1; continue; }
+            if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
+            const uint32_t old = atomicCAS(&tstate[slot], 0u, g + 1);
+            if (old != 0 && (old & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
+        }
+        if (full) break;    // LDS flag: a stale read only delays the exit
+    }
+    __syncthreads();
+    if (full) {
+        if (threadIdx.x == 0) { atomicExch(overflow, 1); stage_cnt[wg] = 0; }
+        return;
+    }
+    uint32_t base = 0;
+    const uint64_t out0 = (uint64_t)wg * cap;
+    for (uint32_t s = 0; s < cap; s += blockDim.x) {
+        const uint32_t slot = s + threadIdx.x;
+        const uint64_t key = tkeys[slot];
+        const bool keep = key != EMPTY_KEY;
+        uint32_t sweep_total;
+        const uint32_t pos = sweep_compact(keep, scratch, &sweep_total);
+        if (keep) {
+            stage_keys[out0 + base + pos] = key;
+            stage_flags[out0 + base + pos] = (tstate[slot] & 0x80000000u) ? 2 : 1;
+        }
+        base += sweep_total;
+    }
+    if (threadIdx.x == 0) stage_cnt[wg] = base;
+}
+
+// gather the staged per-workgroup dictionaries into one dense list
+__global__ void dict_gather_kernel(const uint64_t *__restrict__ stage_keys, const uint8_t *__restrict__ stage_flags,
+                                   const uint64_t *__restrict__ stage_off /* scan of stage_cnt */, uint32_t cap,
+                                   uint64_t *__restrict__ out_keys, uint8_t *__restrict__ out_flags)
+{
+    const uint32_t wg = blockIdx.x;
+    const uint64_t o = stage_off[wg];
+    const uint32_t n = (uint32_t)(stage_off[wg + 1] - o);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        out_keys[o + i] = stage_keys[(uint64_t)wg * cap + i];
+        out_flags[o + i] = stage_flags[(uint64_t)wg * cap + i];
+    }
+}
+
+// After sorting the (possibly multi-rank) concatenated dictionaries by key: one thread per
+// element; the head of each run of equal keys decides keep/drop.
+// multi = run longer than 1 (k-mer seen on several ranks) or any member flagged 2.
+__global__ void dict_mark_kernel(const uint64_t *__restrict__ skeys, const uint8_t *__restrict__ sflags, uint64_t n,
+                                 int filter_singleton, uint32_t *__restrict__ keep)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = skeys[i];
+        uint32_t k = 0;
+        if (i == 0 || skeys[i - 1] != key) {
+            bool multi = sflags[i] >= 2;
+            for (uint64_t j = i + 1; j < n && skeys[j] == key; j++) multi = true;
+            k = (!filter_singleton || multi) ? 1u : 0u;
+        }
+        keep[i] = k;
+    }
+}
+__global__ void dict_select_kernel(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ keep,
+                                   const uint64_t *__restrict__ pos, uint64_t n, uint64_t *__restrict__ dict)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (keep[i]) dict[pos[i]] = skeys[i];
+}
+// bucket id ((bucket << sb) | sub) and identity column index of every dictionary entry
+__global__ void dict_bucket_ids_kernel(const uint64_t *__restrict__ dict, uint64_t n, int bb, int sb,
+                                       uint32_t *__restrict__ bucket_of, uint32_t *__restrict__ col_of)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = mix64(dict[i]);
+        bucket_of[i] = (hash_bucket(h, bb) << sb) | hash_sub(h, bb, sb);
+        col_of[i] = (uint32_t)i;
+    }
+}
+// copy variable-length segments to dense destinations: segment j = src[src_off[j] .. +len[j]) -> dst[dst_off[j]..)
+__global__ void segments_compact_kernel(const uint64_t *__restrict__ src, const uint32_t *__restrict__ src_cnt,
+                                        const uint64_t *__restrict__ src_off, const uint32_t *__restrict__ len,
+                                        const uint64_t *__restrict__ dst_off, uint32_t n_seg,
+                                        uint64_t *__restrict__ dst, uint32_t *__restrict__ dst_cnt)
+{
+    for (uint32_t j = blockIdx.x; j < n_seg; j += gridDim.x) {
+        const uint64_t s0 = src_off[j], d0 = dst_off[j];
+        const uint32_t n = len[j];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            dst[d0 + i] = src[s0 + i];
+            if (dst_cnt) dst_cnt[d0 + i] = src_cnt ? src_cnt[s0 + i] : 1u;
+        }
+    }
+}
+// segment starts of a sorted u32 id list: start[v] = first index with ids[i] >= v, v in [0, n_ids]
+__global__ void segment_starts_kernel(const uint32_t *__restrict__ ids, uint64_t n, uint32_t n_ids,
+                                      uint64_t *__restrict__ start)
+{
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v <= n_ids; v += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint64_t m = (lo + hi) >> 1;
+            if (ids[m] < v) lo = m + 1; else hi = m;
+        }
+        start[v] = lo;
+    }
+}
+__global__ void gather_u64_kernel(const uint64_t *__restrict__ src, const uint32_t *__restrict__ index, uint64_t n,
+                                  uint64_t *__restrict__ dst)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        dst[i] = src[index[i]];
+}
+
+// ------------------------------------------------------------------------------------
+// Stage 3b (K7): presence bits.  One workgroup per (bucket, sub-bucket): the bucket's slice
+// of the global dictionary sits in an LDS table; for each word-row (64 genomes) the waves
+// stream the genomes' segments, look every k-mer up and OR the genome's bit into
+// words[slot]; the finished 64-bit words go to matrix[row][column].
+// Bit layout: genome i -> row i/64, bit 63-(i%64)  (bin/kover/core/kover/utils.py:133-156).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TABLE_THREADS) void matrix_fill_kernel(
+    const uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+    uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint64_t *__restrict__ dkeys,
+    const uint32_t *__restrict__ dcol, const uint64_t *__restrict__ seg_start, uint64_t *__restrict__ matrix,
+    uint64_t n_cols, int *__restrict__ overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
+    uint64_t *tkeys = reinterpret_cast<uint64_t *>(lds_raw);
+    uint64_t *words = reinterpret_cast<uint64_t *>(lds_raw + (size_t)cap * 8);
+    const uint32_t wg = blockIdx.x;
+    const uint32_t B = 1u << bb;
+    const uint32_t b = wg >> sb, sub = wg & ((1u << sb) - 1);
+    const uint64_t d0 = seg_start[wg];
+    const uint32_t nd = (uint32_t)(seg_start[wg + 1] - d0);
+    if (nd == 0) return;
+    if (nd > cap - (cap >> 3)) {
+        if (threadIdx.x == 0) atomicExch(overflow, 1);
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) tkeys[i] = EMPTY_KEY;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) {
+        const uint64_t key = dkeys[d0 + i];
+        bool ins;
+        lds_find_or_insert(tkeys, cap_mask, key, mix64(key), &ins);
+    }
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
+    const uint32_t n_rows = (n_genomes + 63) >> 6;
+    for (uint32_t r = 0; r < n_rows; r++) {
+        for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) words[i] = 0;
+        __syncthreads();
+        const uint32_t g_end = min(r * 64 + 64, n_genomes);
+        for (uint32_t g = r * 64 + wave; g < g_end; g += nw) {
+            const unsigned long long bit = 1ull << (63 - (g & 63));
+            const uint64_t idx = (uint64_t)g * B + b;
+            const uint64_t s0 = off[idx];
+            const uint64_t n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
+            for (uint64_t i = lane; i < n; i += 64) {
+                const uint64_t key = keys[s0 + i];
+                const uint64_t h = mix64(key);
+                if (sb && hash_sub(h, bb, sb) != sub) continue;
+                const uint32_t slot = lds_find(tkeys, cap_mask, key, h);
+                if (slot != 0xffffffffu) atomicOr((unsigned long long *)&words[slot], bit);
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) {
+            const uint64_t key = dkeys[d0 + i];
+            const uint32_t slot = lds_find(tkeys, cap_mask, key, mix64(key));
+            matrix[(uint64_t)r * n_cols + dcol[d0 + i]] = words[slot];
+        }
+        __syncthreads();
+    }
+}
+
+// masked popcount over the packed matrix: out[c] = popcount(matrix[r][c] & mask[r]) summed
+// over rows -- the learner-side inner loop (learning/common/popcount.pyx:76-95 with
+// learning/common/rules.py:243-262), used here for self-checks (per-column carrier count).
+__global__ void column_popcount_kernel(const uint64_t *__restrict__ matrix, uint64_t n_rows, uint64_t n_cols,
+                                       const uint64_t *__restrict__ row_mask, uint32_t *__restrict__ out)
+{
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t s = 0;
+        for (uint64_t r = 0; r < n_rows; r++) s += __popcll(matrix[r * n_cols + c] & (row_mask ? row_mask[r] : ~0ull));
+        out[c] = s;
+    }
+}
+
+__global__ void iota_u32_kernel(uint32_t *p, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------------------------------
+// launchers (called from grm_api.cpp)
+// ------------------------------------------------------------------------------------
+static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap = 256u * 8u)
+{
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    return (uint32_t)(g > cap ? cap : g);
+}
+
+void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, TileSummary *sums)
+{
+    hipLaunchKernelGGL(parse_summarize_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, sums);
+}
+void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles, uint64_t *tile_off,
+                       uint8_t *tile_state, const uint32_t *genome_tile_off, uint32_t n_genomes,
+                       uint64_t *genome_sym_off)
+{
+    hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(1024), 0, s, sums, n_tiles, tile_off, tile_state,
+                       genome_tile_off, n_genomes, genome_sym_off);
+}
+void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint64_t *tile_off,
+                       const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv)
+{
+    hipLaunchKernelGGL(parse_pack_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_off,
+                       tile_state, sym2, inv);
+}
+
+static KmerArgs make_args(const KmerLaunch &L)
+{
+    KmerArgs a;
+    a.sym2 = L.sym2; a.inv = L.inv; a.total_syms = L.total_syms;
+    a.n_groups = (L.total_syms + 63) / 64;
+    a.genome_sym_off = L.genome_sym_off; a.n_genomes = L.n_genomes; a.k = L.k; a.bb = L.bb;
+    a.groups_per_thread = L.groups_per_thread;
+    return a;
+}
+static uint32_t n_spans_of(const KmerArgs &a)
+{
+    const uint64_t span_groups = (uint64_t)KMER_THREADS * a.groups_per_thread;
+    return (uint32_t)((a.n_groups + span_groups - 1) / span_groups);
+}
+void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts)
+{
+    KmerArgs a = make_args(L);
+    if (a.total_syms == 0) return;
+    const uint32_t n_spans = n_spans_of(a);
+    const uint32_t grid = ((n_spans + 7) / 8) * 8;     // xcd_span() needs the full 8 x per layout
+    hipLaunchKernelGGL(kmer_hist_kernel, dim3(grid), dim3(KMER_THREADS), (size_t)4 << L.bb, s, a, n_spans, counts);
+}
+void launch_kmer_scatter(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor, uint64_t *keys)
+{
+    KmerArgs a = make_args(L);
+    if (a.total_syms == 0) return;
+    const uint32_t n_spans = n_spans_of(a);
+    const uint32_t grid = ((n_spans + 7) / 8) * 8;
+    hipLaunchKernelGGL(kmer_scatter_kernel, dim3(grid), dim3(KMER_THREADS), (size_t)8 << L.bb, s, a, n_spans, off,
+                       cursor, keys);
+}
+void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
+                                uint32_t n_genomes, int bb, uint32_t *counts)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(keys_hist_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, in, n, genome_key_off, n_genomes, bb, counts);
+}
+void launch_keys_partition_scatter(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
+                                   uint32_t n_genomes, int bb, const uint64_t *off, uint32_t *cursor, uint64_t *keys)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(keys_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, in, n, genome_key_off, n_genomes, bb,
+                       off, cursor, keys);
+}
+void launch_scan_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *out)
+{
+    hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, s, in, n, out);
+}
+void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const uint64_t *off, uint64_t n_segments, uint32_t cap_log2,
+                         uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow)
+{
+    if (!n_segments) return;
+    const size_t lds = (((size_t)12) << cap_log2) + TABLE_SCRATCH_BYTES;
+    const uint32_t grid = (uint32_t)(n_segments < 256u * 16u ? n_segments : 256u * 16u);
+    hipLaunchKernelGGL(bucket_dedup_kernel, dim3(grid), dim3(TABLE_THREADS), lds, s, keys, off, n_segments, cap_log2,
+                       abundance_min, len_out, counts_out, overflow);
+}
+void launch_dict_build(hipStream_t s, const uint64_t *keys, const uint64_t *off, const uint32_t *len,
+                       uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, uint64_t *stage_keys,
+                       uint8_t *stage_flags, uint32_t *stage_cnt, int *overflow)
+{
+    const size_t lds = (((size_t)12) << cap_log2) + TABLE_SCRATCH_BYTES;
+    hipLaunchKernelGGL(dict_build_kernel, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, keys, off, len, n_genomes,
+                       bb, sb, cap_log2, stage_keys, stage_flags, stage_cnt, overflow);
+}
+void launch_dict_gather(hipStream_t s, const uint64_t *stage_keys, const uint8_t *stage_flags, const uint64_t *stage_off,
+                        uint32_t n_wg, uint32_t cap, uint64_t *out_keys, uint8_t *out_flags)
+{
+    hipLaunchKernelGGL(dict_gather_kernel, dim3(n_wg), dim3(256), 0, s, stage_keys, stage_flags, stage_off, cap, out_keys,
+                       out_flags);
+}
+void launch_dict_mark(hipStream_t s, const uint64_t *skeys, const uint8_t *sflags, uint64_t n, int filter_singleton,
+                      uint32_t *keep)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(dict_mark_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, skeys, sflags, n, filter_singleton, keep);
+}
+void launch_dict_select(hipStream_t s, const uint64_t *skeys, const uint32_t *keep, const uint64_t *pos, uint64_t n,
+                        uint64_t *dict)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(dict_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, skeys, keep, pos, n, dict);
+}
+void launch_dict_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int bb, int sb, uint32_t *bucket_of,
+                            uint32_t *col_of)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(dict_bucket_ids_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, dict, n, bb, sb, bucket_of, col_of);
+}
+void launch_segments_compact(hipStream_t s, const uint64_t *src, const uint32_t *src_cnt, const uint64_t *src_off,
+                             const uint32_t *len, const uint64_t *dst_off, uint32_t n_seg, uint64_t *dst,
+                             uint32_t *dst_cnt)
+{
+    if (!n_seg) return;
+    hipLaunchKernelGGL(segments_compact_kernel, dim3(n_seg < 4096u ? n_seg : 4096u), dim3(256), 0, s, src, src_cnt,
+                       src_off, len, dst_off, n_seg, dst, dst_cnt);
+}
+void launch_segment_starts(hipStream_t s, const uint32_t *ids, uint64_t n, uint32_t n_ids, uint64_t *start)
+{
+    hipLaunchKernelGGL(segment_starts_kernel, dim3(grid_for((uint64_t)n_ids + 1, 256)), dim3(256), 0, s, ids, n, n_ids, start);
+}
+void launch_gather_u64(hipStream_t s, const uint64_t *src, const uint32_t *index, uint64_t n, uint64_t *dst)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, index, n, dst);
+}
+void launch_matrix_fill(hipStream_t s, const uint64_t *keys, const uint64_t *off, const uint32_t *len,
+                        uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint64_t *dkeys,
+                        const uint32_t *dcol, const uint64_t *seg_start, uint64_t *matrix, uint64_t n_cols,
+                        int *overflow)
+{
+    const size_t lds = (((size_t)16) << cap_log2) + TABLE_SCRATCH_BYTES;
+    hipLaunchKernelGGL(matrix_fill_kernel, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, keys, off, len, n_genomes,
+                       bb, sb, cap_log2, dkeys, dcol, seg_start, matrix, n_cols, overflow);
+}
+void launch_column_popcount(hipStream_t s, const uint64_t *matrix, uint64_t n_rows, uint64_t n_cols,
+                            const uint64_t *row_mask, uint32_t *out)
+{
+    if (!n_cols) return;
+    hipLaunchKernelGGL(column_popcount_kernel, dim3(grid_for(n_cols, 256)), dim3(256), 0, s, matrix, n_rows, n_cols,
+                       row_mask, out);
+}
+void launch_iota_u32(hipStream_t s, uint32_t *p, uint64_t n)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(iota_u32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, n);
+}
+
+hipError_t set_max_dynamic_lds()
+{
+    // kernels that may ask for more than the default 64 KiB of dynamic LDS
+    hipError_t e;
+    const int max_lds = 160 * 1024;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmer_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmer_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_dedup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(matrix_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    return e;
+}
+
+}  // namespace grm

@@ -1,0 +1,294 @@
+"""Host-side mirror of the reference's k-mer tool boundary, on top of the C ABI.
+
+The reference has no in-process API for this path: Kover calls
+`multidsk` (dataset/tools/kmer_count.py:23-53) then `dsk2kover` (tools/kmer_pack.py:23-36).
+`count_genome` / `build_matrix` below are those two steps; `Batch` is the fused
+device-resident form.  numpy arrays out, plain pointers in: PyTorch is not needed here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+STATUS = {0: "GRM_OK", -1: "GRM_ERR_ARG", -2: "GRM_ERR_NO_DEVICE", -3: "GRM_ERR_HIP", -4: "GRM_ERR_IO",
+          -5: "GRM_ERR_OOM", -6: "GRM_ERR_UNSUPPORTED", -7: "GRM_ERR_STATE", -8: "GRM_ERR_OVERFLOW",
+          -9: "GRM_ERR_HDF5"}
+
+
+class GrmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (STATUS.get(code, "?"), code, msg))
+        self.code = code
+
+
+class Context:
+    """one HIP device + stream (grm_ctx).  Fails loudly when no device is present."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        self.h = self.L.grm_create(device, 1)
+        if not self.h:
+            raise GrmError(-2, "grm_create(%d) failed: no usable HIP device (there is no CPU fallback)" % device)
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.grm_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise GrmError(rc, (self.L.grm_last_error(self.h) or b"").decode(errors="replace"))
+
+    def set_option(self, name, value):
+        self._chk(self.L.grm_set_option(self.h, name.encode(), int(value)))
+
+    # ---- timings ----
+    def timing(self, on=True):
+        self._chk(self.L.grm_timing_enable(self.h, 1 if on else 0))
+
+    def timing_reset(self):
+        self._chk(self.L.grm_timing_reset(self.h))
+
+    def timings(self):
+        """-> list of (kernel name, ms, units)"""
+        out = []
+        buf = C.create_string_buffer(64)
+        for i in range(self.L.grm_timing_count(self.h)):
+            ms, units = C.c_double(), C.c_uint64()
+            self._chk(self.L.grm_timing_get(self.h, i, buf, 64, C.byref(ms), C.byref(units)))
+            out.append((buf.value.decode(), ms.value, int(units.value)))
+        return out
+
+    # ---- multidsk: one genome -> solid k-mer set ----
+    def count_genome(self, buffers, k, abundance_min=1):
+        """buffers: list[bytes] = the file images of ONE genome -> KmerSet"""
+        n = len(buffers)
+        arr = (C.c_char_p * max(1, n))(*buffers)
+        lens = (C.c_size_t * max(1, n))(*[len(b) for b in buffers])
+        h = C.c_void_p()
+        self._chk(self.L.grm_count_genome_buffers(self.h, arr, lens, n, k, abundance_min, C.byref(h)))
+        return KmerSet(self, h)
+
+    def count_genome_files(self, paths, k, abundance_min=1):
+        n = len(paths)
+        arr = (C.c_char_p * max(1, n))(*[p.encode() for p in paths])
+        h = C.c_void_p()
+        self._chk(self.L.grm_count_genome(self.h, arr, n, k, abundance_min, C.byref(h)))
+        return KmerSet(self, h)
+
+    def kmer_set_from_arrays(self, kmers, counts, k):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32).reshape(-1)
+        h = C.c_void_p()
+        self._chk(self.L.grm_kmer_set_from_host(self.h, kmers.ctypes.data, counts.ctypes.data, len(counts), k, C.byref(h)))
+        return KmerSet(self, h)
+
+    # ---- dsk2kover: N sets -> dictionary + presence matrix ----
+    def build_matrix(self, sets, filter_singleton=False):
+        n = len(sets)
+        arr = (C.c_void_p * max(1, n))(*[s.h for s in sets])
+        h = C.c_void_p()
+        self._chk(self.L.grm_build_matrix(self.h, arr, n, 1 if filter_singleton else 0, C.byref(h)))
+        return Matrix(self, h)
+
+    def batch(self, n_genomes):
+        return Batch(self, n_genomes)
+
+
+class KmerSet:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def __len__(self):
+        return self.ctx.L.grm_kmer_set_size(self.h)
+
+    @property
+    def k(self):
+        return self.ctx.L.grm_kmer_set_k(self.h)
+
+    @property
+    def occurrences(self):
+        return int(self.ctx.L.grm_kmer_set_occurrences(self.h))
+
+    def kmers(self):
+        n, w = len(self), self.ctx.L.grm_kmer_set_words(self.h)
+        if n == 0:
+            return np.zeros((0, w), np.uint64)
+        return np.ctypeslib.as_array(self.ctx.L.grm_kmer_set_kmers(self.h), shape=(n * w,)).copy().reshape(n, w)
+
+    def counts(self):
+        n = len(self)
+        if n == 0:
+            return np.zeros(0, np.uint32)
+        return np.ctypeslib.as_array(self.ctx.L.grm_kmer_set_counts(self.h), shape=(n,)).copy()
+
+    def free(self):
+        if self.h:
+            self.ctx.L.grm_kmer_set_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Matrix:
+    """dictionary (ascending, A<C<T<G) + uint64 presence matrix [ceil(N/64)][U], MSB-first"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    @property
+    def n_kmers(self):
+        return self.ctx.L.grm_matrix_n_kmers(self.h)
+
+    @property
+    def n_rows(self):
+        return self.ctx.L.grm_matrix_n_rows(self.h)
+
+    @property
+    def n_genomes(self):
+        return self.ctx.L.grm_matrix_n_genomes(self.h)
+
+    @property
+    def k(self):
+        return self.ctx.L.grm_matrix_k(self.h)
+
+    def kmers(self):
+        U, w = self.n_kmers, self.ctx.L.grm_matrix_words(self.h)
+        if U == 0:
+            return np.zeros((0, w), np.uint64)
+        p = self.ctx.L.grm_matrix_kmers(self.h)
+        if not p:
+            self.ctx._chk(-3)
+        return np.ctypeslib.as_array(p, shape=(U * w,)).copy().reshape(U, w)
+
+    def data(self):
+        U, r = self.n_kmers, self.n_rows
+        if U == 0 or r == 0:
+            return np.zeros((r, U), np.uint64)
+        p = self.ctx.L.grm_matrix_data(self.h)
+        if not p:
+            self.ctx._chk(-3)
+        return np.ctypeslib.as_array(p, shape=(r * U,)).copy().reshape(r, U)
+
+    def column_counts(self):
+        out = np.zeros(self.n_kmers, dtype=np.uint32)
+        self.ctx._chk(self.ctx.L.grm_matrix_column_counts(self.h, out.ctypes.data))
+        return out
+
+    def dev_ptrs(self):
+        return self.ctx.L.grm_matrix_dev_kmers(self.h), self.ctx.L.grm_matrix_dev_data(self.h)
+
+    def write_tsv(self, genome_ids, path):
+        arr = (C.c_char_p * max(1, len(genome_ids)))(*[g.encode() for g in genome_ids])
+        self.ctx._chk(self.ctx.L.grm_write_tsv(self.h, arr, path.encode()))
+
+    def write_kover_h5(self, path, gzip_level=4, chunk_cols=100000):
+        self.ctx._chk(self.ctx.L.grm_write_kover_h5(self.h, path.encode(), gzip_level, chunk_cols))
+
+    def free(self):
+        if self.h:
+            self.ctx.L.grm_matrix_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Batch:
+    """device-resident batch of genomes: parse -> partition -> dictionary -> presence bits"""
+
+    def __init__(self, ctx, n_genomes):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._chk(ctx.L.grm_batch_create(ctx.h, n_genomes, C.byref(h)))
+        self.h = h
+        self.n_genomes = n_genomes
+
+    def add(self, genome_index, data):
+        buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else None
+        self.ctx._chk(self.ctx.L.grm_batch_add(self.h, genome_index, C.cast(buf, C.c_void_p) if buf is not None else None, len(data)))
+
+    def add_array(self, genome_index, arr):
+        """arr: contiguous uint8 numpy array (no extra Python-side copy)"""
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.grm_batch_add(self.h, genome_index, arr.ctypes.data, arr.size))
+
+    def add_file(self, genome_index, path):
+        self.ctx._chk(self.ctx.L.grm_batch_add_file(self.h, genome_index, path.encode()))
+
+    def upload(self):
+        self.ctx._chk(self.ctx.L.grm_batch_upload(self.h))
+
+    def run(self, k, abundance_min=1, filter_singleton=False):
+        h = C.c_void_p()
+        self.ctx._chk(self.ctx.L.grm_batch_run(self.h, k, abundance_min, 1 if filter_singleton else 0, C.byref(h)))
+        return Matrix(self.ctx, h)
+
+    # staged form (multi-GPU: one collective between local_dict and set_global_dict)
+    def partition(self, k, abundance_min=1):
+        self.ctx._chk(self.ctx.L.grm_batch_partition(self.h, k, abundance_min))
+
+    def local_dict(self):
+        n = C.c_uint64()
+        self.ctx._chk(self.ctx.L.grm_batch_local_dict(self.h, C.byref(n)))
+        return int(n.value)
+
+    def export_dict(self, dev_keys_ptr, dev_flags_ptr):
+        self.ctx._chk(self.ctx.L.grm_batch_export_dict(self.h, dev_keys_ptr, dev_flags_ptr))
+
+    def set_global_dict(self, dev_keys_ptr, dev_flags_ptr, n, filter_singleton):
+        u = C.c_uint64()
+        self.ctx._chk(self.ctx.L.grm_batch_set_global_dict(self.h, dev_keys_ptr, dev_flags_ptr, n, 1 if filter_singleton else 0, C.byref(u)))
+        return int(u.value)
+
+    def fill(self):
+        h = C.c_void_p()
+        self.ctx._chk(self.ctx.L.grm_batch_fill(self.h, C.byref(h)))
+        return Matrix(self.ctx, h)
+
+    @property
+    def n_symbols(self):
+        return int(self.ctx.L.grm_batch_n_symbols(self.h))
+
+    @property
+    def n_occurrences(self):
+        return int(self.ctx.L.grm_batch_n_occurrences(self.h))
+
+    @property
+    def input_bytes(self):
+        return int(self.ctx.L.grm_batch_input_bytes(self.h))
+
+    def free(self):
+        if self.h:
+            self.ctx.L.grm_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def decode_kmers(values, k):
+    """uint64 k-mer values -> list of ACGT strings (GATB code A=0 C=1 T=2 G=3)"""
+    letters = np.frombuffer(b"ACTG", dtype="S1")
+    v = np.asarray(values, dtype=np.uint64).reshape(-1)
+    shifts = (2 * (k - 1 - np.arange(k))).astype(np.uint64)
+    codes = ((v[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.int64)
+    return [b"".join(row).decode() for row in letters[codes]]

@@ -1,0 +1,138 @@
+/*
+ * grm_kmer.h -- C ABI of libgrmkmer.so, the MI355X (gfx950) k-mer-matrix engine.
+ *
+ * Drop-in boundary.  The reference (editnori/Genomic-Resistance-Mapping-GRM-) has no
+ * in-process FFI for this path: it shells out to four native executables
+ *     bin/dsk/dsk                         (src/app.py:1372)
+ *     bin/ray/Ray  under mpiexec -n 4     (src/app.py:1310, conf: src/app.py:3820-3833)
+ *     kmer_tools/multidsk                 (bin/kover/core/kover/dataset/tools/kmer_count.py:28-37, :44-53)
+ *     kmer_tools/dsk2kover                (bin/kover/core/kover/dataset/tools/kmer_pack.py:28-36)
+ * The replacement executables (genomic-resistance-mapping-grm-_amd/cli/) keep that argv
+ * surface and call the functions below through ctypes; INTEGRATION.md shows the binding.
+ * The first block restates SURVEY.md 8(b)'s operator API verbatim; the "batch" block is
+ * the fused, device-resident form of the same path (parse -> partition -> dictionary ->
+ * presence bits) that the executables and bench.py actually drive.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative grm_status; grm_last_error(ctx)
+ *     returns a message owned by the ctx (valid until the next call on that ctx).
+ *   - k-mers are 2-bit packed, first base most significant, A=0 C=1 T=2 G=3 (GATB),
+ *     canonical = min(forward, reverse complement); `words` uint64 per k-mer (1 for k<=32).
+ *   - matrix: uint64 [n_rows][n_kmers] row-major, genome i -> row i/64, bit 63-(i%64)
+ *     (bin/kover/core/kover/utils.py:133-156); columns ascending by k-mer value.
+ *   - a grm_ctx is single-caller; HIP streams inside are the parallelism.
+ *   - plain pointers and sizes only: no Python / torch types cross this boundary.
+ *     Arguments named dev_* are HIP device pointers on the ctx's device.
+ */
+#ifndef GRM_KMER_H
+#define GRM_KMER_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GRM_OK = 0,
+    GRM_ERR_ARG = -1,          /* bad argument (k out of range, NULL, ...) */
+    GRM_ERR_NO_DEVICE = -2,    /* no usable gfx950 device: there is NO CPU fallback */
+    GRM_ERR_HIP = -3,          /* HIP runtime error, text in grm_last_error */
+    GRM_ERR_IO = -4,
+    GRM_ERR_OOM = -5,
+    GRM_ERR_UNSUPPORTED = -6,  /* e.g. k > 32 in this build */
+    GRM_ERR_STATE = -7,        /* calls out of order */
+    GRM_ERR_OVERFLOW = -8,     /* LDS table overflow that retries could not cure */
+    GRM_ERR_HDF5 = -9
+} grm_status;
+
+typedef struct grm_ctx grm_ctx;
+typedef struct grm_kmer_set grm_kmer_set;
+typedef struct grm_matrix grm_matrix;
+typedef struct grm_batch grm_batch;
+
+/* ---- context ------------------------------------------------------------------------ */
+/* device_ordinal >= 0: HIP device.  There is no CPU mode: -1 is rejected (GRM_ERR_NO_DEVICE). */
+grm_ctx    *grm_create(int device_ordinal, int n_streams);
+void        grm_destroy(grm_ctx *);
+const char *grm_last_error(grm_ctx *);
+const char *grm_version(void);
+/* tuning knobs (mainly for tests): name in {"groups_per_thread","bucket_bits","cap_log2",
+ * "sub_bits"}; value < 0 restores the automatic choice. */
+int         grm_set_option(grm_ctx *, const char *name, int value);
+/* per-kernel device timings (HIP events on the engine's stream) */
+int         grm_timing_enable(grm_ctx *, int on);
+int         grm_timing_reset(grm_ctx *);
+int         grm_timing_count(grm_ctx *);
+int         grm_timing_get(grm_ctx *, int i, char *name, size_t name_cap, double *ms, uint64_t *units);
+
+/* ---- SURVEY 8(b) operator API ----------------------------------------------------------- */
+/* replaces one DSK run = one multidsk list line (kmer_count.py:28-53): all files of ONE
+ * genome -> sorted distinct canonical k-mers with count >= abundance_min. */
+int  grm_count_genome(grm_ctx *, const char *const *paths, int n_paths, int k, uint32_t abundance_min,
+                      grm_kmer_set **out);
+int  grm_count_genome_buffers(grm_ctx *, const void *const *bufs, const size_t *lens, int n_bufs, int k,
+                              uint32_t abundance_min, grm_kmer_set **out);
+/* build a set from host arrays (used by dsk2kover when it re-loads multidsk's artefacts) */
+int  grm_kmer_set_from_host(grm_ctx *, const uint64_t *kmers, const uint32_t *counts, size_t n, int k,
+                            grm_kmer_set **out);
+size_t          grm_kmer_set_size(const grm_kmer_set *);
+int             grm_kmer_set_k(const grm_kmer_set *);
+int             grm_kmer_set_words(const grm_kmer_set *);
+uint64_t        grm_kmer_set_occurrences(const grm_kmer_set *);
+const uint64_t *grm_kmer_set_kmers(const grm_kmer_set *);    /* host, size*words */
+const uint32_t *grm_kmer_set_counts(const grm_kmer_set *);   /* host, size */
+void            grm_kmer_set_free(grm_kmer_set *);
+
+/* replaces dsk2kover's merge (kmer_pack.py:28-36): N per-genome sets -> dictionary + matrix */
+int  grm_build_matrix(grm_ctx *, grm_kmer_set *const *sets, int n_genomes, int filter_singleton,
+                      grm_matrix **out);
+size_t          grm_matrix_n_kmers(const grm_matrix *);
+size_t          grm_matrix_n_rows(const grm_matrix *);
+int             grm_matrix_n_genomes(const grm_matrix *);
+int             grm_matrix_k(const grm_matrix *);
+int             grm_matrix_words(const grm_matrix *);
+const uint64_t *grm_matrix_kmers(grm_matrix *);              /* host copy (lazy D2H) */
+const uint64_t *grm_matrix_data(grm_matrix *);               /* host copy (lazy D2H) */
+const void     *grm_matrix_dev_kmers(const grm_matrix *);    /* device pointers */
+const void     *grm_matrix_dev_data(const grm_matrix *);
+/* per-column carrier count = popcount down the column (the learner's sum_rows with an
+ * all-ones mask, learning/common/rules.py:243-262); host array of n_kmers uint32 */
+int             grm_matrix_column_counts(grm_matrix *, uint32_t *out);
+void            grm_matrix_free(grm_matrix *);
+
+/* Ray-Surveyor-compatible TSV (layout read by dataset/create.py:121-137,241) */
+int  grm_write_tsv(grm_matrix *, const char *const *genome_ids, const char *path);
+/* appends kmer_sequences / kmer_matrix / kmer_by_matrix_column to the EXISTING Kover HDF5
+ * exactly as dsk2kover does (schema dataset/create.py:214-238); libhdf5 is dlopen()ed. */
+int  grm_write_kover_h5(grm_matrix *, const char *existing_h5_path, int gzip_level, int chunk_cols);
+
+/* ---- fused device-resident batch path ------------------------------------------------- */
+int  grm_batch_create(grm_ctx *, int n_genomes, grm_batch **out);
+/* append one file image (FASTA) to genome `genome_index`; bytes are copied */
+int  grm_batch_add(grm_batch *, int genome_index, const void *buf, size_t len);
+int  grm_batch_add_file(grm_batch *, int genome_index, const char *path);
+/* assemble + host-to-device copy; afterwards the inputs are resident in HBM */
+int  grm_batch_upload(grm_batch *);
+/* whole hot path on the resident inputs: == partition + local_dict + set_global_dict(own) + fill */
+int  grm_batch_run(grm_batch *, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out);
+/* the same path in stages, so that the host can put ONE collective between them when the
+ * genomes are sharded over several GPUs: */
+int  grm_batch_partition(grm_batch *, int k, uint32_t abundance_min);
+int  grm_batch_local_dict(grm_batch *, uint64_t *n_local);
+int  grm_batch_export_dict(grm_batch *, void *dev_keys_out, void *dev_flags_out);
+int  grm_batch_set_global_dict(grm_batch *, const void *dev_keys, const void *dev_flags, uint64_t n,
+                               int filter_singleton, uint64_t *n_kmers);
+int  grm_batch_fill(grm_batch *, grm_matrix **out);
+/* statistics of the last partition */
+uint64_t grm_batch_n_symbols(const grm_batch *);
+uint64_t grm_batch_n_occurrences(const grm_batch *);     /* valid k-mer windows */
+uint64_t grm_batch_input_bytes(const grm_batch *);
+/* per-genome distinct k-mers after the last partition (+dedup): sorted set for genome g */
+int  grm_batch_genome_set(grm_batch *, int genome_index, grm_kmer_set **out);
+void grm_batch_free(grm_batch *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

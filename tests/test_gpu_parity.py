@@ -1,0 +1,249 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle, bit-exact.
+
+Run on the MI355X box: python -m pytest tests -m gpu
+"""
+import os
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_ctypes as orc
+from tests import cases
+
+grm = None
+synth = None
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    global grm, synth
+    import grm_amd
+    grm = grm_amd
+    synth = import_module("genomic-resistance-mapping-grm-_amd.synth")
+    c = grm_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _as_bytes(genomes):
+    return [[t.encode() if isinstance(t, str) else bytes(t) for t in g] for g in genomes]
+
+
+def _run_batch(ctx, genomes, k, amin, filt):
+    b = ctx.batch(len(genomes))
+    for g, files in enumerate(genomes):
+        for f in files:
+            b.add(g, f)
+    b.upload()
+    m = b.run(k, amin, filt)
+    out = (m.kmers(), m.data(), b.n_occurrences, m.column_counts())
+    m.free()
+    b.free()
+    return out
+
+
+def _check(ctx, genomes, k, amin, filt):
+    genomes = _as_bytes(genomes)
+    want = orc.build_matrix(genomes, k, amin, filt)
+    kmers, data, n_occ, colcnt = _run_batch(ctx, genomes, k, amin, filt)
+    assert n_occ == want["n_occurrences"]
+    assert kmers.shape == want["kmers"].shape
+    assert (kmers == want["kmers"]).all()
+    assert data.shape == want["matrix"].shape
+    assert (data == want["matrix"]).all()
+    assert (colcnt == want["n_genomes_with"]).all()
+
+
+MICRO = [c for c in cases.micro_cases() if c[1] <= 32]
+
+
+@pytest.mark.parametrize("name,k,genomes", MICRO, ids=lambda x: x if isinstance(x, str) else None)
+@pytest.mark.parametrize("amin,filt", [(1, False), (1, True), (2, False), (2, True)])
+def test_micro_matrix(ctx, name, k, genomes, amin, filt):
+    _check(ctx, genomes, k, amin, filt)
+
+
+@pytest.mark.parametrize("name,k,genomes", MICRO[:3], ids=lambda x: x if isinstance(x, str) else None)
+def test_count_genome_sets(ctx, name, k, genomes):
+    for texts in genomes:
+        files = [t.encode() for t in texts]
+        for amin in (1, 2):
+            km, ct, nocc = orc.count_genome(files, k, amin)
+            s = ctx.count_genome(files, k, amin)
+            assert s.occurrences == nocc
+            assert (s.kmers() == km).all() and s.kmers().shape == km.shape
+            assert (s.counts() == ct).all()
+            s.free()
+
+
+def test_build_matrix_from_sets(ctx):
+    name, k, genomes = MICRO[3]
+    bg = _as_bytes(genomes)
+    for filt in (False, True):
+        want = orc.build_matrix(bg, k, 1, filt)
+        sets = [ctx.count_genome(files, k, 1) for files in bg]
+        m = ctx.build_matrix(sets, filt)
+        assert (m.kmers() == want["kmers"]).all() and m.kmers().shape == want["kmers"].shape
+        assert (m.data() == want["matrix"]).all()
+        # sets rebuilt from host arrays (what dsk2kover does after re-loading multidsk output)
+        sets2 = [ctx.kmer_set_from_arrays(s.kmers(), s.counts(), k) for s in sets]
+        m2 = ctx.build_matrix(sets2, filt)
+        assert (m2.data() == want["matrix"]).all()
+        for o in sets + sets2 + [m, m2]:
+            o.free()
+
+
+def _medium_genomes(n=7, length=300_000, seed=5):
+    pg = synth.PanGenome(genome_len=length, n_snps=3000, n_accessory=12, accessory_len=2000, seed=seed, n_contigs=3)
+    return [[pg.genome(i).tobytes()] for i in range(n)]
+
+
+def test_medium_pangenome_all_paths(ctx):
+    """300 kbp genomes: the LDS (span-uniform) paths of hist / scatter and real bucket counts"""
+    genomes = _medium_genomes()
+    for (amin, filt) in [(1, True), (1, False), (2, True)]:
+        _check(ctx, genomes, 31, amin, filt)
+
+
+@pytest.mark.parametrize("opts", [
+    {"groups_per_thread": 1}, {"groups_per_thread": 3, "bucket_bits": 5},
+    {"bucket_bits": 0}, {"bucket_bits": 13}, {"sub_bits": 3},
+    {"cap_log2": 8, "bucket_bits": 4},          # forces overflow -> sub-bucket retries
+])
+def test_medium_with_forced_geometry(ctx, opts):
+    genomes = _medium_genomes(n=5, length=120_000, seed=9)
+    try:
+        for name, v in opts.items():
+            ctx.set_option(name, v)
+        _check(ctx, genomes, 31, 1, True)
+        _check(ctx, genomes, 21, 1, False)
+    finally:
+        for name in opts:
+            ctx.set_option(name, -1)
+
+
+def test_more_than_64_genomes_and_ragged(ctx):
+    rng = np.random.RandomState(17)
+    core = cases.rand_seq(rng, 3000)
+    genomes = []
+    for g in range(131):
+        s = list(core)
+        for p in rng.randint(0, len(core), size=5):
+            s[p] = "ACGT"[rng.randint(4)]
+        ln = int(rng.randint(0, len(core)))
+        genomes.append([cases.fasta([("g%d" % g, "".join(s[:ln]))], width=70)])
+    genomes[5] = [""]           # empty file
+    genomes[64] = [">only header\n"]
+    _check(ctx, genomes, 31, 1, True)
+    _check(ctx, genomes, 15, 1, False)
+
+
+def test_staged_equals_fused(ctx):
+    import torch
+    genomes = _medium_genomes(n=4, length=100_000, seed=3)
+    want = orc.build_matrix(genomes, 31, 1, True)
+    b = ctx.batch(len(genomes))
+    for g, files in enumerate(genomes):
+        b.add(g, files[0])
+    b.upload()
+    b.partition(31, 1)
+    n_local = b.local_dict()
+    keys = torch.empty(max(1, n_local), dtype=torch.int64, device="cuda:0")
+    flags = torch.empty(max(1, n_local), dtype=torch.uint8, device="cuda:0")
+    b.export_dict(keys.data_ptr(), flags.data_ptr())
+    torch.cuda.synchronize()
+    # local dictionary = every distinct k-mer of the union, flag 2 where >1 genome carries it
+    allm = orc.build_matrix(genomes, 31, 1, False)
+    k_host = keys.cpu().numpy().view(np.uint64)
+    order = np.argsort(k_host)
+    assert (k_host[order] == allm["kmers"][:, 0]).all()
+    assert ((flags.cpu().numpy()[order] == 2) == (allm["n_genomes_with"] > 1)).all()
+    u = b.set_global_dict(keys.data_ptr(), flags.data_ptr(), n_local, True)
+    assert u == want["kmers"].shape[0]
+    m = b.fill()
+    assert (m.kmers() == want["kmers"]).all() and (m.data() == want["matrix"]).all()
+    m.free()
+    b.free()
+
+
+def test_tsv_roundtrip(ctx, tmp_path):
+    name, k, genomes = MICRO[2]
+    bg = _as_bytes(genomes)
+    want = orc.build_matrix(bg, k, 1, False)
+    b = ctx.batch(len(bg))
+    for g, files in enumerate(bg):
+        for f in files:
+            b.add(g, f)
+    b.upload()
+    m = b.run(k, 1, False)
+    ids = ["genome_%d" % g for g in range(len(bg))]
+    path = str(tmp_path / "KmerMatrix.tsv")
+    m.write_tsv(ids, path)
+    lines = open(path).read().split("\n")
+    assert lines[0] == "kmers\t" + "\t".join(ids)
+    body = [l for l in lines[1:] if l]
+    assert len(body) == want["kmers"].shape[0]
+    assert len({len(l) for l in body}) == 1           # create.py:130-137 needs equal-length rows
+    strs = orc.decode_kmers(want["kmers"], k)
+    for c, line in enumerate(body):
+        cells = line.split("\t")
+        assert cells[0] == strs[c]
+        for g in range(len(bg)):
+            bit = (int(want["matrix"][g // 64, c]) >> (63 - g % 64)) & 1
+            assert cells[1 + g] == str(bit)
+    m.free()
+    b.free()
+
+
+def test_errors_are_loud(ctx):
+    b = ctx.batch(1)
+    b.add(0, b">x\nACGT\n")
+    with pytest.raises(grm.GrmError):
+        b.partition(31, 1)          # before upload
+    b.upload()
+    with pytest.raises(grm.GrmError):
+        b.run(0, 1, False)
+    with pytest.raises(grm.GrmError) as e:
+        b.run(63, 1, False)
+    assert e.value.code == -6
+    b.free()
+
+
+def test_scale_properties(ctx):
+    """size-independent properties on a larger batch (no oracle at this size):
+    sorted dictionary, carrier counts, singleton filter = columns with >= 2 carriers,
+    a shared core => all-genome columns, determinism."""
+    n, length = 96, 400_000
+    pg = synth.PanGenome(genome_len=length, n_snps=4000, n_accessory=20, accessory_len=3000, seed=77)
+    b = ctx.batch(n)
+    for g in range(n):
+        b.add_array(g, pg.genome(g))
+    b.upload()
+    m_all = b.run(31, 1, False)
+    k_all, d_all, cc_all = m_all.kmers()[:, 0], m_all.data(), m_all.column_counts()
+    assert (np.diff(k_all.astype(object)) > 0).all()
+    m_f = b.run(31, 1, True)
+    k_f, d_f, cc_f = m_f.kmers()[:, 0], m_f.data(), m_f.column_counts()
+    keep = cc_all >= 2
+    assert (k_f == k_all[keep]).all()
+    assert (d_f == d_all[:, keep]).all()
+    assert (cc_f == cc_all[keep]).all()
+    assert cc_all.max() == n and (cc_all >= 1).all()
+    # padding bits of the last word-row are zero
+    pad = (1 << (64 - (n - 64))) - 1 if n % 64 else 0
+    assert not (d_all[-1] & np.uint64(pad)).any()
+    # per-genome distinct count from the matrix == an independent per-genome count on the GPU
+    for g in (0, 37, 95):
+        s = ctx.count_genome([pg.genome(g).tobytes()], 31, 1)
+        col = (d_all[g // 64] >> np.uint64(63 - g % 64)) & np.uint64(1)
+        assert int(col.sum()) == len(s)
+        assert (k_all[col.astype(bool)] == s.kmers()[:, 0]).all()
+        s.free()
+    # two genomes against the CPU oracle
+    sub = orc.build_matrix([[pg.genome(g).tobytes()] for g in (3, 4)], 31, 1, False)
+    both = ((d_all[0] >> np.uint64(63 - 3)) & np.uint64(1)).astype(bool) | ((d_all[0] >> np.uint64(63 - 4)) & np.uint64(1)).astype(bool)
+    assert (k_all[both] == sub["kmers"][:, 0]).all()
+    m_all.free(); m_f.free(); b.free()

@@ -1,0 +1,139 @@
+"""Run the per-lane device primitives (csrc/grm_device_fns.h) on the CPU and compare them
+with the oracle.  No GPU needed: tests/host/host_emul.cpp includes the very header the
+gfx950 kernels include; block-level cooperation is replaced by its sequential meaning."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle_ctypes as orc
+from tests import cases
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TILE = 16384
+
+
+@pytest.fixture(scope="module")
+def emul():
+    src = os.path.join(HERE, "host", "host_emul.cpp")
+    so = os.path.join(HERE, "host", "libhost_emul.so")
+    hdr = os.path.join(HERE, "..", "genomic-resistance-mapping-grm-_amd", "csrc", "grm_device_fns.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+    L = C.CDLL(so)
+    L.emul_parse.restype = C.c_uint64
+    L.emul_parse.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.emul_kmers.restype = C.c_uint64
+    L.emul_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
+    L.emul_summarize.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64] + [C.POINTER(C.c_uint32)] * 3
+    L.emul_valid_starts.restype = C.c_uint64
+    L.emul_valid_starts.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
+    L.emul_revcomp.restype = C.c_uint64
+    L.emul_revcomp.argtypes = [C.c_uint64, C.c_int]
+    L.emul_mix64.restype = C.c_uint64
+    L.emul_mix64.argtypes = [C.c_uint64]
+    return L
+
+
+def layout(files):
+    """the raw image grm_batch_upload builds: '>\\n' + bytes + '\\n', '\\n'-padded to a tile"""
+    out = bytearray()
+    for f in files:
+        img = b">\n" + f + b"\n"
+        out += img
+        out += b"\n" * ((-len(out)) % TILE)
+    if not out:
+        out += b"\n" * TILE
+    return np.frombuffer(bytes(out), dtype=np.uint8).copy()
+
+
+def extract(emul, files, k):
+    raw = layout(files)
+    ng = len(raw) // 64 + 8
+    sym2 = np.zeros(2 * ng, dtype=np.uint64)
+    inv = np.zeros(ng, dtype=np.uint64)
+    nsym = emul.emul_parse(raw.ctypes.data, len(raw), sym2.ctypes.data, inv.ctypes.data, ng)
+    cap = max(1, int(nsym))
+    out = np.zeros(cap, dtype=np.uint64)
+    n = emul.emul_kmers(sym2.ctypes.data, inv.ctypes.data, nsym, k, out.ctypes.data, cap)
+    assert n <= cap
+    return raw, int(nsym), out[:n]
+
+
+@pytest.mark.parametrize("name,k,genomes", [c for c in cases.micro_cases() if c[1] <= 32], ids=lambda x: x if isinstance(x, str) else None)
+def test_extraction_matches_oracle(emul, name, k, genomes):
+    for texts in genomes:
+        files = [t.encode() for t in texts]
+        _, _, got = extract(emul, files, k)
+        km, ct, nocc = orc.count_genome(files, k)
+        assert len(got) == nocc
+        vals, counts = np.unique(got, return_counts=True)
+        assert (vals == km[:, 0]).all()
+        assert (counts == ct).all()
+
+
+def test_long_lines_and_tile_straddling(emul):
+    rng = np.random.RandomState(7)
+    # single-line 40 kb sequence (no newline inside several tiles), a header that straddles a
+    # tile boundary, and a very long header
+    seq = cases.rand_seq(rng, 40000)
+    f1 = (">one\n" + seq + "\n").encode()
+    pad = TILE - 2 - 5          # puts the next '>' header start near the end of tile 0
+    f2 = (">a\n" + cases.rand_seq(rng, pad - 3 - 1) + "\n>" + "h" * 40000 + "\n" + cases.rand_seq(rng, 500) + "\n").encode()
+    f3 = cases.fasta([("x", cases.rand_seq(rng, 70000))], width=61).encode()
+    for files in ([f1], [f2], [f3], [f1, f2, f3]):
+        for k in (31, 8):
+            raw, nsym, got = extract(emul, files, k)
+            km, ct, nocc = orc.count_genome(files, k)
+            assert len(got) == nocc
+            vals, counts = np.unique(got, return_counts=True)
+            assert (vals == km[:, 0]).all() and (counts == ct).all()
+            # tile-summary algebra (parse_summarize + parse_scan): resolving the incoming
+            # line type tile by tile must reproduce the symbol count
+            state, total = 0, 0
+            for t0 in range(0, len(raw), TILE):
+                kn, un, le = C.c_uint32(), C.c_uint32(), C.c_uint32()
+                emul.emul_summarize(raw.ctypes.data, t0, t0 + TILE, C.byref(kn), C.byref(un), C.byref(le))
+                total += kn.value + (un.value if state != 2 else 0)
+                if le.value:
+                    state = le.value
+            assert total == nsym
+
+
+def test_valid_starts_bruteforce(emul):
+    rng = np.random.RandomState(11)
+    for _ in range(300):
+        i0 = int(rng.randint(0, 2**31)) << 33 | int(rng.randint(0, 2**31)) if rng.rand() < 0.5 else (1 << int(rng.randint(0, 64)))
+        i1 = (1 << int(rng.randint(0, 64))) if rng.rand() < 0.7 else 0
+        k = int(rng.randint(1, 65))
+        got = emul.emul_valid_starts(i0 & (2**64 - 1), i1, k)
+        x = (i1 << 64) | (i0 & (2**64 - 1))
+        want = 0
+        for p in range(64):
+            if (x >> p) & ((1 << k) - 1) == 0:
+                want |= 1 << p
+        assert got == want, (hex(i0), hex(i1), k)
+
+
+def test_revcomp_and_mix_bijective(emul):
+    rng = np.random.RandomState(12)
+    for m in (1, 2, 15, 30, 31, 32):
+        for _ in range(50):
+            s = cases.rand_seq(rng, m)
+            v = 0
+            for ch in s:
+                v = (v << 2) | ((ord(ch) >> 1) & 3)
+            r = cases.revcomp(s)
+            w = 0
+            for ch in r:
+                w = (w << 2) | ((ord(ch) >> 1) & 3)
+            assert emul.emul_revcomp(v, m) == w
+    xs = rng.randint(0, 2**62, size=20000, dtype=np.int64).astype(np.uint64)
+    hs = np.array([emul.emul_mix64(int(x)) for x in xs], dtype=np.uint64)
+    assert len(np.unique(hs)) == len(np.unique(xs))
+    # top-bit buckets are balanced
+    b = (hs >> np.uint64(64 - 6)).astype(np.int64)
+    cnt = np.bincount(b, minlength=64)
+    assert cnt.min() > 0.6 * cnt.mean() and cnt.max() < 1.4 * cnt.mean()
