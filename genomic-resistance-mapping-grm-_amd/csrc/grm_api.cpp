@@ -428,6 +428,14 @@ static int pick_bucket_bits(grm_ctx *c, uint64_t max_genome_syms)
     return bb;
 }
 
+// LDS table size: 12 B (dict) / 16 B (fill) per slot; 2^12 slots = 64 KiB lets two
+// workgroups share a CU's 160 KiB.  Clamped to what one workgroup may allocate.
+static uint32_t pick_cap_log2(grm_ctx *c)
+{
+    int v = c->opt_cap_log2 > 0 ? c->opt_cap_log2 : 12;
+    return (uint32_t)std::min(13, std::max(6, v));
+}
+
 // parse + histogram + scan + scatter (+ dedup when abundance_min > 1)
 static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, bool want_counts)
 {
@@ -532,7 +540,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     HIPCHK(c, hipGetLastError());
 
     // ---- stage 2 (optional): per-bucket dedup / count / abundance filter ----
-    b->cap_log2 = c->opt_cap_log2 > 0 ? (uint32_t)c->opt_cap_log2 : 12u;
+    b->cap_log2 = pick_cap_log2(c);
     if (abundance_min > 1 || want_counts) {
         DevBuf d_flag;
         HIPCHK(c, d_flag.alloc(4));
@@ -917,7 +925,7 @@ extern "C" int grm_build_matrix(grm_ctx *c, grm_kmer_set *const *sets, int n_gen
         b->total_keys = n;
         b->total_syms = n;
         b->bb = pick_bucket_bits(c, max_g);
-        b->cap_log2 = c->opt_cap_log2 > 0 ? (uint32_t)c->opt_cap_log2 : 12u;
+        b->cap_log2 = pick_cap_log2(c);
         const uint64_t B = 1ull << b->bb, n_seg = (uint64_t)n_genomes * B;
         DevBuf d_in, d_gko;
         HIPCHK(c, d_in.alloc((n + 2) * 8));

@@ -565,8 +565,8 @@ __global__ __launch_bounds__(TABLE_THREADS) void bucket_dedup_kernel(
         uint32_t base = 0;
         for (uint32_t s = 0; s < cap; s += blockDim.x) {
             const uint32_t slot = s + threadIdx.x;
-            const uint64_t key = tkeys[slot];
-            const uint32_t c = tcnt[slot];
+            const uint64_t key = slot < cap ? tkeys[slot] : EMPTY_KEY;
+            const uint32_t c = slot < cap ? tcnt[slot] : 0u;
             const bool keep = key != EMPTY_KEY && c >= abundance_min;
             uint32_t sweep_total;
             const uint32_t pos = sweep_compact(keep, scratch, &sweep_total);
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void dict_build_kernel(
     const uint64_t out0 = (uint64_t)wg * cap;
     for (uint32_t s = 0; s < cap; s += blockDim.x) {
         const uint32_t slot = s + threadIdx.x;
-        const uint64_t key = tkeys[slot];
+        const uint64_t key = slot < cap ? tkeys[slot] : EMPTY_KEY;
         const bool keep = key != EMPTY_KEY;
         uint32_t sweep_total;
         const uint32_t pos = sweep_compact(keep, scratch, &sweep_total);
