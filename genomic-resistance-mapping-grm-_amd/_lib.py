@@ -81,6 +81,30 @@ def build_library(force=False, quiet=True):
     return LIB_PATH
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (soname libamdhip64.so.7) and ask for it by the un-versioned name, so if the system copy
+    were mapped first a later `import torch` would map a SECOND runtime and find no GPUs.
+    Mapping torch's copy first (when torch is installed) makes both users share it; without
+    torch the loader falls through to /opt/rocm's copy via libgrmkmer.so's RUNPATH."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen the library and attach prototypes.  Raises (never falls back) if absent."""
     global _lib
@@ -89,6 +113,7 @@ def load():
             raise ImportError(
                 "%s is missing: build it with __graft_entry__.build() / `make -C %s` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % (LIB_PATH, CSRC))
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, res, args in PROTOTYPES:
             fn = getattr(L, name)       # AttributeError if the symbol is not exported
