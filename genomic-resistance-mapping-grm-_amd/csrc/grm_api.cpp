@@ -84,6 +84,13 @@ struct DevBuf {
         else p = nullptr;
         return e;
     }
+    // grow-only: keeps the allocation when it is already large enough (hipMalloc / hipFree of
+    // multi-GB buffers costs far more than the kernels that use them)
+    hipError_t ensure(size_t n)
+    {
+        if (p && bytes >= n) return hipSuccess;
+        return alloc(n + n / 16);
+    }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -317,6 +324,9 @@ struct grm_batch {
     uint64_t n_dict = 0;
     DevBuf d_dkeys, d_dcol, d_seg_start;   // bucketised view for matrix_fill
     int filter_singleton = 0;
+    // scratch that survives between steps (grow-only)
+    DevBuf t_flag, t_stage_keys, t_stage_flags, t_stage_cnt, t_stage_off;
+    DevBuf t_sk, t_sf, t_keep, t_pos, t_tmp, t_bid, t_col, t_bid_sorted;
 };
 
 extern "C" int grm_batch_create(grm_ctx *c, int n_genomes, grm_batch **out)
@@ -457,9 +467,9 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         b->total_syms = b->total_keys = 0;
         b->bb = 0;
         b->h_genome_sym_off.assign(G + 1, 0);
-        HIPCHK(c, b->d_off.alloc((G + 2) * 8));
+        HIPCHK(c, b->d_off.ensure((G + 2) * 8));
         HIPCHK(c, hipMemsetAsync(b->d_off.p, 0, (G + 2) * 8, s));
-        HIPCHK(c, b->d_keys.alloc(16));
+        HIPCHK(c, b->d_keys.ensure(16));
         HIPCHK(c, hipStreamSynchronize(s));
         b->partitioned = true;
         return GRM_OK;
@@ -467,13 +477,13 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
 
     // ---- stage 0: parse ----
     const uint64_t max_groups = b->raw_bytes / 64 + 8;
-    if (!b->d_sums.p) {
-        HIPCHK(c, b->d_sums.alloc((size_t)b->n_tiles * sizeof(TileSummary)));
-        HIPCHK(c, b->d_tile_off.alloc(((size_t)b->n_tiles + 1) * 8));
-        HIPCHK(c, b->d_tile_state.alloc((size_t)b->n_tiles + 16));
-        HIPCHK(c, b->d_sym2.alloc(max_groups * 16));
-        HIPCHK(c, b->d_inv.alloc(max_groups * 8));
-        HIPCHK(c, b->d_genome_sym_off.alloc(((size_t)G + 1) * 8));
+    {
+        HIPCHK(c, b->d_sums.ensure((size_t)b->n_tiles * sizeof(TileSummary)));
+        HIPCHK(c, b->d_tile_off.ensure(((size_t)b->n_tiles + 1) * 8));
+        HIPCHK(c, b->d_tile_state.ensure((size_t)b->n_tiles + 16));
+        HIPCHK(c, b->d_sym2.ensure(max_groups * 16));
+        HIPCHK(c, b->d_inv.ensure(max_groups * 8));
+        HIPCHK(c, b->d_genome_sym_off.ensure(((size_t)G + 1) * 8));
     }
     HIPCHK(c, hipMemsetAsync(b->d_sym2.p, 0, max_groups * 16, s));
     HIPCHK(c, hipMemsetAsync(b->d_inv.p, 0, max_groups * 8, s));
@@ -516,23 +526,27 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     L.bb = b->bb;
     L.groups_per_thread = c->opt_groups_per_thread > 0 ? (uint32_t)c->opt_groups_per_thread : 16u;
 
-    HIPCHK(c, b->d_counts.alloc(n_seg * 4));
-    HIPCHK(c, b->d_cursor.alloc(n_seg * 4));
-    HIPCHK(c, b->d_off.alloc((n_seg + 1) * 8));
-    HIPCHK(c, hipMemsetAsync(b->d_counts.p, 0, n_seg * 4, s));
+    HIPCHK(c, b->d_counts.ensure((n_seg + 1) * 4));
+    HIPCHK(c, b->d_cursor.ensure(n_seg * 4));
+    HIPCHK(c, b->d_off.ensure((n_seg + 1) * 8));
+    HIPCHK(c, hipMemsetAsync(b->d_counts.p, 0, (n_seg + 1) * 4, s));
     HIPCHK(c, hipMemsetAsync(b->d_cursor.p, 0, n_seg * 4, s));
     {
         TimeScope t(c, "kmer_hist", b->total_syms);
         launch_kmer_hist(s, L, b->d_counts.as<uint32_t>());
     }
     {
+        // exclusive scan over n_seg+1 entries (the extra, zeroed entry yields the total)
         TimeScope t(c, "bucket_scan", n_seg);
-        launch_scan_u32(s, b->d_counts.as<uint32_t>(), n_seg, b->d_off.as<uint64_t>());
+        size_t tb = 0;
+        HIPCHK(c, exclusive_scan_u32_u64(s, b->d_counts.as<uint32_t>(), b->d_off.as<uint64_t>(), n_seg + 1, nullptr, tb));
+        HIPCHK(c, b->t_tmp.ensure(tb));
+        HIPCHK(c, exclusive_scan_u32_u64(s, b->d_counts.as<uint32_t>(), b->d_off.as<uint64_t>(), n_seg + 1, b->t_tmp.p, tb));
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(&b->total_keys, b->d_off.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, b->d_keys.alloc((b->total_keys + 2) * 8));
+    HIPCHK(c, b->d_keys.ensure((b->total_keys + 2) * 8));
     {
         TimeScope t(c, "kmer_scatter", b->total_keys);
         launch_kmer_scatter(s, L, b->d_off.as<uint64_t>(), b->d_cursor.as<uint32_t>(), b->d_keys.as<uint64_t>());
@@ -542,11 +556,11 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     // ---- stage 2 (optional): per-bucket dedup / count / abundance filter ----
     b->cap_log2 = pick_cap_log2(c);
     if (abundance_min > 1 || want_counts) {
-        DevBuf d_flag;
-        HIPCHK(c, d_flag.alloc(4));
+        DevBuf &d_flag = b->t_flag;
+        HIPCHK(c, d_flag.ensure(4));
         HIPCHK(c, hipMemsetAsync(d_flag.p, 0, 4, s));
-        HIPCHK(c, b->d_len.alloc(n_seg * 4));
-        if (want_counts) HIPCHK(c, b->d_kcnt.alloc((b->total_keys + 2) * 4));
+        HIPCHK(c, b->d_len.ensure(n_seg * 4));
+        if (want_counts) HIPCHK(c, b->d_kcnt.ensure((b->total_keys + 2) * 4));
         {
             TimeScope t(c, "bucket_dedup", b->total_keys);
             launch_bucket_dedup(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), n_seg, b->cap_log2, abundance_min,
@@ -586,23 +600,24 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
     const uint32_t G = (uint32_t)b->n_genomes;
     if (b->total_keys == 0) {
         b->n_local = 0;
-        HIPCHK(c, b->d_local_keys.alloc(16));
-        HIPCHK(c, b->d_local_flags.alloc(16));
+        HIPCHK(c, b->d_local_keys.ensure(16));
+        HIPCHK(c, b->d_local_flags.ensure(16));
         b->have_local = true;
         if (n_local) *n_local = 0;
         return GRM_OK;
     }
     const uint32_t cap = 1u << b->cap_log2;
     int sb = c->opt_sub_bits >= 0 ? c->opt_sub_bits : 0;
-    DevBuf d_flag, d_stage_keys, d_stage_flags, d_stage_cnt, d_stage_off;
-    HIPCHK(c, d_flag.alloc(4));
+    DevBuf &d_flag = b->t_flag, &d_stage_keys = b->t_stage_keys, &d_stage_flags = b->t_stage_flags,
+           &d_stage_cnt = b->t_stage_cnt, &d_stage_off = b->t_stage_off;
+    HIPCHK(c, d_flag.ensure(4));
     for (;; sb++) {
         if (b->bb + sb > 24) return fail(c, GRM_ERR_OVERFLOW, "dict_build: bucket union does not fit the LDS table even with 2^%d sub-buckets", sb);
         const uint32_t n_wg = 1u << (b->bb + sb);
-        HIPCHK(c, d_stage_keys.alloc((size_t)n_wg * cap * 8));
-        HIPCHK(c, d_stage_flags.alloc((size_t)n_wg * cap));
-        HIPCHK(c, d_stage_cnt.alloc((size_t)n_wg * 4));
-        HIPCHK(c, d_stage_off.alloc(((size_t)n_wg + 1) * 8));
+        HIPCHK(c, d_stage_keys.ensure((size_t)n_wg * cap * 8));
+        HIPCHK(c, d_stage_flags.ensure((size_t)n_wg * cap));
+        HIPCHK(c, d_stage_cnt.ensure((size_t)n_wg * 4));
+        HIPCHK(c, d_stage_off.ensure(((size_t)n_wg + 1) * 8));
         HIPCHK(c, hipMemsetAsync(d_flag.p, 0, 4, s));
         {
             TimeScope t(c, "dict_build", b->total_keys);
@@ -619,8 +634,8 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
             launch_scan_u32(s, d_stage_cnt.as<uint32_t>(), n_wg, d_stage_off.as<uint64_t>());
             HIPCHK(c, hipMemcpyAsync(&b->n_local, d_stage_off.as<uint64_t>() + n_wg, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
-            HIPCHK(c, b->d_local_keys.alloc((b->n_local + 2) * 8));
-            HIPCHK(c, b->d_local_flags.alloc(b->n_local + 16));
+            HIPCHK(c, b->d_local_keys.ensure((b->n_local + 2) * 8));
+            HIPCHK(c, b->d_local_flags.ensure(b->n_local + 16));
             {
                 TimeScope t(c, "dict_gather", b->n_local);
                 launch_dict_gather(s, d_stage_keys.as<uint64_t>(), d_stage_flags.as<uint8_t>(), d_stage_off.as<uint64_t>(),
@@ -660,24 +675,24 @@ static int bucketise_dict(grm_batch *b, int sb)
     hipStream_t s = c->stream;
     const uint64_t U = b->n_dict;
     const uint32_t n_wg = 1u << (b->bb + sb);
-    HIPCHK(c, b->d_seg_start.alloc(((size_t)n_wg + 2) * 8));
-    HIPCHK(c, b->d_dkeys.alloc((U + 2) * 8));
-    HIPCHK(c, b->d_dcol.alloc((U + 2) * 4));
+    HIPCHK(c, b->d_seg_start.ensure(((size_t)n_wg + 2) * 8));
+    HIPCHK(c, b->d_dkeys.ensure((U + 2) * 8));
+    HIPCHK(c, b->d_dcol.ensure((U + 2) * 4));
     if (U == 0) {
         HIPCHK(c, hipMemsetAsync(b->d_seg_start.p, 0, ((size_t)n_wg + 2) * 8, s));
         b->sb_fill = sb;
         return GRM_OK;
     }
-    DevBuf d_bid, d_col, d_bid_sorted, d_tmp;
-    HIPCHK(c, d_bid.alloc(U * 4));
-    HIPCHK(c, d_col.alloc(U * 4));
-    HIPCHK(c, d_bid_sorted.alloc(U * 4));
+    DevBuf &d_bid = b->t_bid, &d_col = b->t_col, &d_bid_sorted = b->t_bid_sorted, &d_tmp = b->t_tmp;
+    HIPCHK(c, d_bid.ensure(U * 4));
+    HIPCHK(c, d_col.ensure(U * 4));
+    HIPCHK(c, d_bid_sorted.ensure(U * 4));
     TimeScope t(c, "dict_bucketise", U);
     launch_dict_bucket_ids(s, b->d_dict.as<uint64_t>(), U, b->bb, sb, d_bid.as<uint32_t>(), d_col.as<uint32_t>());
     size_t tmp_bytes = 0;
     HIPCHK(c, sort_pairs_u32_u32(s, d_bid.as<uint32_t>(), d_bid_sorted.as<uint32_t>(), d_col.as<uint32_t>(),
                                  b->d_dcol.as<uint32_t>(), U, b->bb + sb, nullptr, tmp_bytes));
-    HIPCHK(c, d_tmp.alloc(tmp_bytes));
+    HIPCHK(c, d_tmp.ensure(tmp_bytes));
     HIPCHK(c, sort_pairs_u32_u32(s, d_bid.as<uint32_t>(), d_bid_sorted.as<uint32_t>(), d_col.as<uint32_t>(),
                                  b->d_dcol.as<uint32_t>(), U, b->bb + sb, d_tmp.p, tmp_bytes));
     launch_gather_u64(s, b->d_dict.as<uint64_t>(), b->d_dcol.as<uint32_t>(), U, b->d_dkeys.as<uint64_t>());
@@ -702,34 +717,34 @@ extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, con
     b->filter_singleton = filter_singleton;
     b->n_dict = 0;
     if (n) {
-        DevBuf d_sk, d_sf, d_keep, d_pos, d_tmp;
-        HIPCHK(c, d_sk.alloc(n * 8));
-        HIPCHK(c, d_sf.alloc(n));
-        HIPCHK(c, d_keep.alloc((n + 1) * 4));
-        HIPCHK(c, d_pos.alloc((n + 1) * 8));
+        DevBuf &d_sk = b->t_sk, &d_sf = b->t_sf, &d_keep = b->t_keep, &d_pos = b->t_pos, &d_tmp = b->t_tmp;
+        HIPCHK(c, d_sk.ensure(n * 8));
+        HIPCHK(c, d_sf.ensure(n));
+        HIPCHK(c, d_keep.ensure((n + 1) * 4));
+        HIPCHK(c, d_pos.ensure((n + 1) * 8));
         {
             TimeScope t(c, "dict_sort", n);
             size_t tmp_bytes = 0;
             HIPCHK(c, sort_pairs_u64_u8(s, (const uint64_t *)dev_keys, d_sk.as<uint64_t>(), (const uint8_t *)dev_flags,
                                         d_sf.as<uint8_t>(), n, nullptr, tmp_bytes));
-            HIPCHK(c, d_tmp.alloc(tmp_bytes));
+            HIPCHK(c, d_tmp.ensure(tmp_bytes));
             HIPCHK(c, sort_pairs_u64_u8(s, (const uint64_t *)dev_keys, d_sk.as<uint64_t>(), (const uint8_t *)dev_flags,
                                         d_sf.as<uint8_t>(), n, d_tmp.p, tmp_bytes));
             HIPCHK(c, hipMemsetAsync(d_keep.as<uint32_t>() + n, 0, 4, s));
             launch_dict_mark(s, d_sk.as<uint64_t>(), d_sf.as<uint8_t>(), n, filter_singleton, d_keep.as<uint32_t>());
             size_t tmp2 = 0;
             HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, nullptr, tmp2));
-            if (tmp2 > d_tmp.bytes) HIPCHK(c, d_tmp.alloc(tmp2));
+            HIPCHK(c, d_tmp.ensure(tmp2));
             HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, d_tmp.p, tmp2));
             HIPCHK(c, hipMemcpyAsync(&b->n_dict, d_pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
-            HIPCHK(c, b->d_dict.alloc((b->n_dict + 2) * 8));
+            HIPCHK(c, b->d_dict.ensure((b->n_dict + 2) * 8));
             launch_dict_select(s, d_sk.as<uint64_t>(), d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n, b->d_dict.as<uint64_t>());
         }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(s));
     } else {
-        HIPCHK(c, b->d_dict.alloc(16));
+        HIPCHK(c, b->d_dict.ensure(16));
     }
     // sub-bucket count for the fill: keep the mean dictionary slice under 1/4 of the table
     int sb = c->opt_sub_bits >= 0 ? c->opt_sub_bits : 0;
@@ -761,8 +776,8 @@ extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
     if (e == hipSuccess) e = m->d_kmers.alloc((m->n_kmers + 2) * 8);
     if (e != hipSuccess) { delete m; return fail(c, GRM_ERR_OOM, "matrix allocation failed (%zu cells)", cells); }
     int rc = GRM_OK;
-    DevBuf d_flag;
-    if (d_flag.alloc(4) != hipSuccess) { delete m; return fail(c, GRM_ERR_OOM, "alloc"); }
+    DevBuf &d_flag = b->t_flag;
+    if (d_flag.ensure(4) != hipSuccess) { delete m; return fail(c, GRM_ERR_OOM, "alloc"); }
     for (;;) {
         if (cells) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
         (void)hipMemsetAsync(d_flag.p, 0, 4, s);
@@ -934,10 +949,10 @@ extern "C" int grm_build_matrix(grm_ctx *c, grm_kmer_set *const *sets, int n_gen
             if (!sets[g]->kmers.empty())
                 HIPCHK(c, hipMemcpy(d_in.as<uint64_t>() + gko[g], sets[g]->kmers.data(), sets[g]->kmers.size() * 8, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(d_gko.p, gko.data(), (n_genomes + 1) * 8, hipMemcpyHostToDevice));
-        HIPCHK(c, b->d_counts.alloc((n_seg + 1) * 4));
-        HIPCHK(c, b->d_cursor.alloc((n_seg + 1) * 4));
-        HIPCHK(c, b->d_off.alloc((n_seg + 2) * 8));
-        HIPCHK(c, b->d_keys.alloc((n + 2) * 8));
+        HIPCHK(c, b->d_counts.ensure((n_seg + 1) * 4));
+        HIPCHK(c, b->d_cursor.ensure((n_seg + 1) * 4));
+        HIPCHK(c, b->d_off.ensure((n_seg + 2) * 8));
+        HIPCHK(c, b->d_keys.ensure((n + 2) * 8));
         HIPCHK(c, hipMemsetAsync(b->d_counts.p, 0, (n_seg + 1) * 4, s));
         HIPCHK(c, hipMemsetAsync(b->d_cursor.p, 0, (n_seg + 1) * 4, s));
         launch_keys_partition_hist(s, d_in.as<uint64_t>(), n, d_gko.as<uint64_t>(), (uint32_t)n_genomes, b->bb, b->d_counts.as<uint32_t>());
