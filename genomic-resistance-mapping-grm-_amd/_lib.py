@@ -47,6 +47,8 @@ PROTOTYPES = [
     ("grm_matrix_dev_kmers", _P, [_P]),
     ("grm_matrix_dev_data", _P, [_P]),
     ("grm_matrix_column_counts", C.c_int, [_P, _P]),
+    ("grm_matrix_from_host", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _PP]),
+    ("grm_matrix_last_error", C.c_char_p, [_P]),
     ("grm_matrix_free", None, [_P]),
     ("grm_write_tsv", C.c_int, [_P, C.POINTER(C.c_char_p), C.c_char_p]),
     ("grm_write_kover_h5", C.c_int, [_P, C.c_char_p, C.c_int, C.c_int]),
@@ -56,6 +58,7 @@ PROTOTYPES = [
     ("grm_batch_upload", C.c_int, [_P]),
     ("grm_batch_run", C.c_int, [_P, C.c_int, C.c_uint32, C.c_int, _PP]),
     ("grm_batch_partition", C.c_int, [_P, C.c_int, C.c_uint32]),
+    ("grm_batch_partition_counts", C.c_int, [_P, C.c_int, C.c_uint32]),
     ("grm_batch_local_dict", C.c_int, [_P, _U64P]),
     ("grm_batch_export_dict", C.c_int, [_P, _P, _P]),
     ("grm_batch_set_global_dict", C.c_int, [_P, _P, _P, C.c_uint64, C.c_int, _U64P]),

@@ -1,0 +1,76 @@
+"""shared helpers of the drop-in executables (dsk, multidsk, dsk2kover, Ray)"""
+import os
+import struct
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+MAGIC = b"GRMKSET1"
+
+
+def engine():
+    import grm_amd
+    return grm_amd
+
+
+def gatb_args(argv, known):
+    """GATB-style single-dash `-flag value` pairs (kmer_count.py:28-37, kmer_pack.py:28-36, src/app.py:1372).
+    known: {flag: default}.  Unknown flags with a value are accepted and ignored (DSK has many)."""
+    out = dict(known)
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        if not a.startswith("-"):
+            raise SystemExit("unexpected argument %r" % a)
+        key = a.lstrip("-")
+        if i + 1 < len(argv) and not (argv[i + 1].startswith("-") and not argv[i + 1].lstrip("-").isdigit()):
+            out[key] = argv[i + 1]
+            i += 2
+        else:
+            out[key] = "1"
+            i += 1
+    return out
+
+
+def die(msg, code=1):
+    """return codes are ignored by Kover (kmer_count.py:28, kmer_pack.py:28): be loud on stderr too"""
+    sys.stderr.write("ERROR: %s\n" % msg)
+    sys.stderr.flush()
+    sys.exit(code)
+
+
+def write_kset(path, k, abundance_min, kmers, counts, n_occ):
+    """per-genome solid k-mer set, the artefact multidsk leaves under the name Kover expects
+    (<out-dir>/<stem>.h5, dataset/create.py:375,488).  The pair multidsk/dsk2kover is opaque
+    to Kover, so the container is our own: magic, header, uint64 k-mers, uint32 counts."""
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(MAGIC)
+        f.write(struct.pack("<IIQQ", k, abundance_min, len(counts), n_occ))
+        f.write(np.ascontiguousarray(kmers, dtype="<u8").tobytes())
+        f.write(np.ascontiguousarray(counts, dtype="<u4").tobytes())
+    os.replace(tmp, path)
+
+
+def read_kset(path):
+    with open(path, "rb") as f:
+        if f.read(8) != MAGIC:
+            raise ValueError("%s is not a k-mer set written by this multidsk" % path)
+        k, amin, n, n_occ = struct.unpack("<IIQQ", f.read(24))
+        kmers = np.frombuffer(f.read(8 * n), dtype="<u8")
+        counts = np.frombuffer(f.read(4 * n), dtype="<u4")
+    if len(kmers) != n or len(counts) != n:
+        raise ValueError("%s is truncated" % path)
+    return k, amin, kmers, counts, n_occ
+
+
+def list_stem(line):
+    """output name of one multidsk list line: basename without extension of the LAST file of the
+    line (create.py:375 for contigs, :488 for reads; '.fastq.gz' keeps '.fastq')"""
+    last = line.strip().split(",")[-1]
+    return os.path.basename(os.path.splitext(last)[0])

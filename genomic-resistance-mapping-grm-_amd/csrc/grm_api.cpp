@@ -266,6 +266,7 @@ extern "C" int grm_matrix_column_counts(grm_matrix *m, uint32_t *out)
 {
     if (!m || !out) return GRM_ERR_ARG;
     grm_ctx *c = m->ctx;
+    if (!c) return GRM_ERR_NO_DEVICE;
     if (!m->n_kmers) return GRM_OK;
     HIPCHK(c, hipSetDevice(c->device));
     DevBuf d;
@@ -282,8 +283,40 @@ extern "C" int grm_matrix_column_counts(grm_matrix *m, uint32_t *out)
 extern "C" void grm_matrix_free(grm_matrix *m)
 {
     if (!m) return;
-    (void)hipSetDevice(m->ctx->device);
+    if (m->ctx) (void)hipSetDevice(m->ctx->device);
     delete m;
+}
+
+// host-only matrix (no device, no ctx): lets the writers run on rows gathered from several
+// ranks, and lets the CPU test-suite exercise the TSV / HDF5 writers without a GPU.
+extern "C" int grm_matrix_from_host(const uint64_t *kmers, const uint64_t *data, size_t n_kmers, int n_genomes, int k,
+                                    grm_matrix **out)
+{
+    if (!out || n_genomes < 0 || k < 1 || k > 32 || (n_kmers && (!kmers || (n_genomes && !data)))) return GRM_ERR_ARG;
+    grm_matrix *m = new grm_matrix();
+    m->k = k;
+    m->n_genomes = n_genomes;
+    m->n_rows = ((size_t)n_genomes + 63) / 64;
+    m->n_kmers = n_kmers;
+    m->h_kmers.assign(kmers, kmers + n_kmers);
+    m->h_kmers.push_back(0);
+    m->h_data.assign(data, data + n_kmers * m->n_rows);
+    m->h_data.push_back(0);
+    m->have_kmers = m->have_data = true;
+    *out = m;
+    return GRM_OK;
+}
+
+static std::string g_hostonly_err;
+extern "C" int grm_internal_fail(grm_matrix *m, int code, const char *msg)
+{
+    if (m && m->ctx) m->ctx->err = msg ? msg : "";
+    else g_hostonly_err = msg ? msg : "";
+    return code;
+}
+extern "C" const char *grm_matrix_last_error(const grm_matrix *m)
+{
+    return (m && m->ctx) ? m->ctx->err.c_str() : g_hostonly_err.c_str();
 }
 
 // --------------------------------------------------------------------------------------
@@ -582,6 +615,12 @@ extern "C" int grm_batch_partition(grm_batch *b, int k, uint32_t abundance_min)
 {
     if (!b) return GRM_ERR_ARG;
     return batch_partition_impl(b, k, abundance_min, false);
+}
+
+extern "C" int grm_batch_partition_counts(grm_batch *b, int k, uint32_t abundance_min)
+{
+    if (!b) return GRM_ERR_ARG;
+    return batch_partition_impl(b, k, abundance_min, true);
 }
 
 extern "C" uint64_t grm_batch_n_symbols(const grm_batch *b) { return b ? b->total_syms : 0; }

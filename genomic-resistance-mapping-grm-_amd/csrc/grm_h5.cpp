@@ -1,9 +1,246 @@
-// grm_h5.cpp -- Kover HDF5 writer (dsk2kover's output side).  Placeholder until the
-// libhdf5 dlopen() writer lands: fails loudly instead of writing nothing.
+// grm_h5.cpp -- Kover HDF5 writer: the output side of dsk2kover
+// (invoked at bin/kover/core/kover/dataset/tools/kmer_pack.py:28-36).
+//
+// dsk2kover opens the HDF5 file Kover has ALREADY created (attrs, phenotype,
+// genome_identifiers, phenotype_tags; closed at dataset/create.py:356) and appends three
+// datasets whose schema is fixed by dataset/create.py:214-238 and read back by
+// dataset/ds.py:72-94 and learning/common/rules.py:104-131:
+//     kmer_sequences         S<k>   [U]            gzip G
+//     kmer_matrix            uint64 [ceil(N/64)][U] chunks (1, chunk_cols), gzip G
+//     kmer_by_matrix_column  min-uint[U]           gzip G   (identity here: column c <-> k-mer c)
+//
+// libhdf5 is dlopen()ed at run time (h5py is not a dependency; the C library may live in a
+// conda prefix).  The matrix is the heavy part: its chunks are deflated on all host cores with
+// zlib and handed to H5Dwrite_chunk, because single-threaded deflate inside H5Dwrite is the
+// end-to-end bottleneck (hard part 4).
+#include <dlfcn.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
 #include "../../include/grm_kmer.h"
+
+typedef int64_t hid_t;
+typedef int herr_t;
+typedef unsigned long long hsize_t;
+
+namespace {
+
+struct H5 {
+    void *h = nullptr;
+    herr_t (*open)() = nullptr;
+    hid_t (*Fopen)(const char *, unsigned, hid_t) = nullptr;
+    herr_t (*Fclose)(hid_t) = nullptr;
+    hid_t (*Screate_simple)(int, const hsize_t *, const hsize_t *) = nullptr;
+    herr_t (*Sclose)(hid_t) = nullptr;
+    hid_t (*Pcreate)(hid_t) = nullptr;
+    herr_t (*Pset_chunk)(hid_t, int, const hsize_t *) = nullptr;
+    herr_t (*Pset_deflate)(hid_t, unsigned) = nullptr;
+    herr_t (*Pclose)(hid_t) = nullptr;
+    hid_t (*Tcopy)(hid_t) = nullptr;
+    herr_t (*Tset_size)(hid_t, size_t) = nullptr;
+    herr_t (*Tset_strpad)(hid_t, int) = nullptr;
+    herr_t (*Tclose)(hid_t) = nullptr;
+    hid_t (*Dcreate2)(hid_t, const char *, hid_t, hid_t, hid_t, hid_t, hid_t) = nullptr;
+    herr_t (*Dwrite)(hid_t, hid_t, hid_t, hid_t, hid_t, const void *) = nullptr;
+    herr_t (*Dwrite_chunk)(hid_t, hid_t, uint32_t, const hsize_t *, size_t, const void *) = nullptr;
+    herr_t (*Dclose)(hid_t) = nullptr;
+    int (*Lexists)(hid_t, const char *, hid_t) = nullptr;
+    herr_t (*Ldelete)(hid_t, const char *, hid_t) = nullptr;
+    herr_t (*Eset_auto2)(hid_t, void *, void *) = nullptr;
+    hid_t C_S1 = -1, U8 = -1, U16 = -1, U32 = -1, U64 = -1, DCPL = -1;
+    std::string err;
+
+    template <typename T> bool sym(T &fn, const char *name)
+    {
+        fn = reinterpret_cast<T>(dlsym(h, name));
+        if (!fn) { err = std::string("libhdf5: missing symbol ") + name; return false; }
+        return true;
+    }
+    bool global(hid_t &v, const char *name)
+    {
+        hid_t *p = reinterpret_cast<hid_t *>(dlsym(h, name));
+        if (!p) { err = std::string("libhdf5: missing global ") + name; return false; }
+        v = *p;
+        return true;
+    }
+    bool load()
+    {
+        if (h) return true;
+        std::vector<std::string> cands;
+        if (const char *e = getenv("GRM_HDF5_LIB")) cands.push_back(e);
+        for (const char *n : {"libhdf5.so", "libhdf5_serial.so", "libhdf5.so.103", "libhdf5.so.200", "libhdf5_serial.so.103",
+                              "/opt/conda/lib/libhdf5.so", "/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so"})
+            cands.push_back(n);
+        for (auto &c : cands) {
+            h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) { err = "libhdf5 not found (set GRM_HDF5_LIB=/path/to/libhdf5.so); the TSV writer does not need it"; return false; }
+        bool ok = sym(open, "H5open") && sym(Fopen, "H5Fopen") && sym(Fclose, "H5Fclose") &&
+                  sym(Screate_simple, "H5Screate_simple") && sym(Sclose, "H5Sclose") && sym(Pcreate, "H5Pcreate") &&
+                  sym(Pset_chunk, "H5Pset_chunk") && sym(Pset_deflate, "H5Pset_deflate") && sym(Pclose, "H5Pclose") &&
+                  sym(Tcopy, "H5Tcopy") && sym(Tset_size, "H5Tset_size") && sym(Tset_strpad, "H5Tset_strpad") && sym(Tclose, "H5Tclose") &&
+                  sym(Dcreate2, "H5Dcreate2") && sym(Dwrite, "H5Dwrite") && sym(Dclose, "H5Dclose") &&
+                  sym(Lexists, "H5Lexists") && sym(Ldelete, "H5Ldelete") && sym(Eset_auto2, "H5Eset_auto2");
+        if (!ok) { dlclose(h); h = nullptr; return false; }
+        Dwrite_chunk = reinterpret_cast<decltype(Dwrite_chunk)>(dlsym(h, "H5Dwrite_chunk"));   // >= 1.10.3, optional
+        if (open() < 0) { err = "H5open failed"; return false; }
+        ok = global(C_S1, "H5T_C_S1_g") && global(U8, "H5T_NATIVE_UINT8_g") && global(U16, "H5T_NATIVE_UINT16_g") &&
+             global(U32, "H5T_NATIVE_UINT32_g") && global(U64, "H5T_NATIVE_UINT64_g") &&
+             global(DCPL, "H5P_CLS_DATASET_CREATE_ID_g");
+        return ok;
+    }
+};
+
+H5 g_h5;
+
+inline void decode_kmer(uint64_t v, int k, char *out)
+{
+    static const char L[4] = {'A', 'C', 'T', 'G'};
+    for (int i = 0; i < k; i++) out[i] = L[(v >> (2 * (k - 1 - i))) & 3];
+}
+
+// chunked (optionally deflated) dataset creation property list
+hid_t make_dcpl(H5 &H, int rank, const hsize_t *chunk, int gzip)
+{
+    hid_t p = H.Pcreate(H.DCPL);
+    if (p < 0) return p;
+    if (H.Pset_chunk(p, rank, chunk) < 0) { H.Pclose(p); return -1; }
+    if (gzip > 0 && H.Pset_deflate(p, (unsigned)gzip) < 0) { H.Pclose(p); return -1; }
+    return p;
+}
+
+int write_1d(H5 &H, hid_t file, const char *name, hid_t type, const void *data, hsize_t n, int gzip, std::string &err)
+{
+    if (H.Lexists(file, name, 0) > 0) H.Ldelete(file, name, 0);
+    hsize_t dims[1] = {n};
+    hid_t space = H.Screate_simple(1, dims, nullptr);
+    hid_t dcpl = 0;
+    if (n > 0) {
+        hsize_t chunk[1] = {n < (1u << 20) ? n : (1u << 20)};
+        dcpl = make_dcpl(H, 1, chunk, gzip);
+        if (dcpl < 0) { H.Sclose(space); err = std::string("dcpl for ") + name; return -1; }
+    }
+    hid_t ds = H.Dcreate2(file, name, type, space, 0, dcpl, 0);
+    int rc = 0;
+    if (ds < 0) { err = std::string("H5Dcreate2 ") + name; rc = -1; }
+    else {
+        if (n > 0 && H.Dwrite(ds, type, 0, 0, 0, data) < 0) { err = std::string("H5Dwrite ") + name; rc = -1; }
+        H.Dclose(ds);
+    }
+    if (dcpl > 0) H.Pclose(dcpl);
+    H.Sclose(space);
+    return rc;
+}
+
+}  // namespace
+
+// ctx error plumbing lives in grm_api.cpp
+extern "C" int grm_internal_fail(grm_matrix *m, int code, const char *msg);
 
 extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, int gzip_level, int chunk_cols)
 {
-    (void)m; (void)existing_h5_path; (void)gzip_level; (void)chunk_cols;
-    return GRM_ERR_UNSUPPORTED;
+    if (!m || !existing_h5_path) return GRM_ERR_ARG;
+    if (gzip_level < 0 || gzip_level > 9) return grm_internal_fail(m, GRM_ERR_ARG, "gzip level must be 0..9");
+    if (chunk_cols <= 0) chunk_cols = 100000;                        // BLOCK_SIZE, dataset/create.py:41
+    H5 &H = g_h5;
+    if (!H.load()) return grm_internal_fail(m, GRM_ERR_HDF5, H.err.c_str());
+    const uint64_t *kmers = grm_matrix_kmers(m);
+    const uint64_t *data = grm_matrix_data(m);
+    if (!kmers || !data) return GRM_ERR_HIP;
+    const size_t U = grm_matrix_n_kmers(m), R = grm_matrix_n_rows(m);
+    const int k = grm_matrix_k(m);
+
+    H.Eset_auto2(0, nullptr, nullptr);
+    hid_t file = H.Fopen(existing_h5_path, 1u /* H5F_ACC_RDWR */, 0);
+    if (file < 0) return grm_internal_fail(m, GRM_ERR_HDF5, (std::string("cannot open existing Kover HDF5 ") + existing_h5_path).c_str());
+    std::string err;
+    int rc = 0;
+
+    // kmer_sequences: fixed-length S<k> (what numpy 'S31' becomes in h5py), null padded
+    {
+        std::vector<char> seq(U * (size_t)k + 1);
+        for (size_t c = 0; c < U; c++) decode_kmer(kmers[c], k, seq.data() + c * (size_t)k);
+        hid_t st = H.Tcopy(H.C_S1);
+        H.Tset_size(st, (size_t)k);
+        H.Tset_strpad(st, 1);   // H5T_STR_NULLPAD
+        rc = write_1d(H, file, "kmer_sequences", st, seq.data(), U, gzip_level, err);
+        H.Tclose(st);
+    }
+    // kmer_by_matrix_column: identity map in the minimum unsigned width (utils.py:117-130)
+    if (!rc) {
+        if (U <= 0xffu) { std::vector<uint8_t> v(U + 1); for (size_t i = 0; i < U; i++) v[i] = (uint8_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U8, v.data(), U, gzip_level, err); }
+        else if (U <= 0xffffu) { std::vector<uint16_t> v(U); for (size_t i = 0; i < U; i++) v[i] = (uint16_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U16, v.data(), U, gzip_level, err); }
+        else if (U <= 0xffffffffull) { std::vector<uint32_t> v(U); for (size_t i = 0; i < U; i++) v[i] = (uint32_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U32, v.data(), U, gzip_level, err); }
+        else { std::vector<uint64_t> v(U); for (size_t i = 0; i < U; i++) v[i] = i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U64, v.data(), U, gzip_level, err); }
+    }
+    // kmer_matrix: chunks (1, min(U, chunk_cols)) as from_tsv does (create.py:160,230)
+    if (!rc) {
+        if (H.Lexists(file, "kmer_matrix", 0) > 0) H.Ldelete(file, "kmer_matrix", 0);
+        hsize_t dims[2] = {R, U};
+        hid_t space = H.Screate_simple(2, dims, nullptr);
+        const hsize_t cw = U ? (U < (size_t)chunk_cols ? U : (hsize_t)chunk_cols) : 1;
+        hid_t dcpl = 0;
+        if (U && R) {
+            hsize_t chunk[2] = {1, cw};
+            dcpl = make_dcpl(H, 2, chunk, gzip_level);
+        }
+        hid_t ds = (dcpl < 0) ? -1 : H.Dcreate2(file, "kmer_matrix", H.U64, space, 0, dcpl, 0);
+        if (ds < 0) { err = "H5Dcreate2 kmer_matrix"; rc = -1; }
+        else if (U && R) {
+            const size_t chunks_per_row = (U + cw - 1) / cw;
+            const size_t n_chunks = chunks_per_row * R;
+            if (gzip_level > 0 && H.Dwrite_chunk) {
+                // deflate every chunk on the host cores, then hand the raw chunks to HDF5 in order
+                std::vector<std::vector<unsigned char>> z(n_chunks);
+                std::atomic<size_t> next(0);
+                std::atomic<int> bad(0);
+                unsigned nt = std::thread::hardware_concurrency();
+                if (nt == 0) nt = 4;
+                if (nt > 64) nt = 64;
+                if (nt > n_chunks) nt = (unsigned)n_chunks;
+                auto work = [&]() {
+                    std::vector<uint64_t> padded(cw);
+                    for (;;) {
+                        size_t i = next.fetch_add(1);
+                        if (i >= n_chunks) break;
+                        const size_t r = i / chunks_per_row, c0 = (i % chunks_per_row) * cw;
+                        const size_t n = (c0 + cw <= U) ? cw : U - c0;
+                        const uint64_t *src = data + r * U + c0;
+                        if (n < cw) {   // edge chunk: HDF5 stores full chunks, pad with the fill value 0
+                            memcpy(padded.data(), src, n * 8);
+                            memset(padded.data() + n, 0, (cw - n) * 8);
+                            src = padded.data();
+                        }
+                        uLongf zl = compressBound(cw * 8);
+                        z[i].resize(zl);
+                        if (compress2(z[i].data(), &zl, reinterpret_cast<const Bytef *>(src), cw * 8, gzip_level) != Z_OK) bad = 1;
+                        z[i].resize(zl);
+                    }
+                };
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < nt; t++) th.emplace_back(work);
+                for (auto &t : th) t.join();
+                if (bad) { err = "zlib compress2 failed"; rc = -1; }
+                for (size_t i = 0; i < n_chunks && !rc; i++) {
+                    hsize_t off[2] = {i / chunks_per_row, (i % chunks_per_row) * cw};
+                    if (H.Dwrite_chunk(ds, 0, 0, off, z[i].size(), z[i].data()) < 0) { err = "H5Dwrite_chunk kmer_matrix"; rc = -1; }
+                }
+            } else if (H.Dwrite(ds, H.U64, 0, 0, 0, data) < 0) { err = "H5Dwrite kmer_matrix"; rc = -1; }
+        }
+        if (ds >= 0) H.Dclose(ds);
+        if (dcpl > 0) H.Pclose(dcpl);
+        H.Sclose(space);
+    }
+    if (H.Fclose(file) < 0 && !rc) { err = "H5Fclose"; rc = -1; }
+    if (rc) return grm_internal_fail(m, GRM_ERR_HDF5, err.c_str());
+    return GRM_OK;
 }

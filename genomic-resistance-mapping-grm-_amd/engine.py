@@ -243,6 +243,14 @@ class Batch:
     def partition(self, k, abundance_min=1):
         self.ctx._chk(self.ctx.L.grm_batch_partition(self.h, k, abundance_min))
 
+    def partition_counts(self, k, abundance_min=1):
+        self.ctx._chk(self.ctx.L.grm_batch_partition_counts(self.h, k, abundance_min))
+
+    def genome_set(self, genome_index):
+        h = C.c_void_p()
+        self.ctx._chk(self.ctx.L.grm_batch_genome_set(self.h, genome_index, C.byref(h)))
+        return KmerSet(self.ctx, h)
+
     def local_dict(self):
         n = C.c_uint64()
         self.ctx._chk(self.ctx.L.grm_batch_local_dict(self.h, C.byref(n)))
@@ -283,6 +291,43 @@ class Batch:
             self.free()
         except Exception:
             pass
+
+
+class HostMatrix(Matrix):
+    """Matrix built from host arrays (rows gathered from several ranks, or tests): only the
+    accessors and the two writers work, no device behind it."""
+
+    class _NoCtx:
+        def __init__(self, L):
+            self.L = L
+
+        def _chk(self, rc):
+            if rc != 0:
+                raise GrmError(rc, "host-only matrix")
+
+    def __init__(self, kmers, data, n_genomes, k):
+        L = _lib.load()
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1)
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        h = C.c_void_p()
+        rc = L.grm_matrix_from_host(kmers.ctypes.data, data.ctypes.data, kmers.size, n_genomes, k, C.byref(h))
+        if rc:
+            raise GrmError(rc, "grm_matrix_from_host")
+        self.ctx, self.h = HostMatrix._NoCtx(L), h
+
+    def _err(self):
+        return (self.ctx.L.grm_matrix_last_error(self.h) or b"").decode(errors="replace")
+
+    def write_tsv(self, genome_ids, path):
+        arr = (C.c_char_p * max(1, len(genome_ids)))(*[g.encode() for g in genome_ids])
+        rc = self.ctx.L.grm_write_tsv(self.h, arr, path.encode())
+        if rc:
+            raise GrmError(rc, self._err())
+
+    def write_kover_h5(self, path, gzip_level=4, chunk_cols=100000):
+        rc = self.ctx.L.grm_write_kover_h5(self.h, path.encode(), gzip_level, chunk_cols)
+        if rc:
+            raise GrmError(rc, self._err())
 
 
 def decode_kmers(values, k):

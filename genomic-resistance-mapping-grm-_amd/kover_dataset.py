@@ -1,0 +1,250 @@
+"""Host-side restatement of Kover's dataset-creation glue around the k-mer tools
+(bin/kover/core/kover/dataset/create.py): `from_contigs` (:278-396), `from_tsv` layout
+(:119-275), `_parse_metadata` (:65-116), plus a reader that mirrors what
+dataset/ds.py:26-148 and learning/common/rules.py:201-267 (`sum_rows`) need from the file.
+
+The reference runs these as Python 2 + h5py and shells out to multidsk / dsk2kover; here the
+orchestration is Python 3 + libhdf5 (ctypes) and the two tools are the gfx950 engine.
+"""
+import os
+import time
+import uuid
+
+import numpy as np
+
+from . import h5lite
+
+KMER_MATRIX_PACKING_SIZE = 64          # create.py:38
+BLOCK_SIZE = 100000                    # create.py:41
+
+
+class KoverError(Exception):
+    pass
+
+
+def parse_metadata(metadata_path, matrix_genome_ids, warn=None):
+    """create.py:65-116.  -> (ids kept [metadata order], labels uint8, tags, classification_type)"""
+    warn = warn or (lambda m: None)
+    rows = [l.split() for l in open(metadata_path) if l.strip()]
+    md_ids = [r[0] for r in rows]
+    md_lab = [r[1] for r in rows]
+    uniq = sorted(set(md_lab))                       # np.unique sorts; the non-{0,1} branch re-sorts: same order
+    index = {l: i for i, l in enumerate(uniq)}
+    if len(uniq) < 2:
+        raise KoverError("The dataset must contain at least 2 different phenotypes")
+    if len(uniq) > 255:
+        raise KoverError("The dataset can contain at most 255 different phenotypes")
+    ctype = "binary" if len(uniq) == 2 else "multiclass"
+    if len(md_ids) > len(set(md_ids)):
+        raise KoverError("The metadata contains multiple values for the same genome.")
+    matrix = set(matrix_genome_ids)
+    only_matrix = matrix - set(md_ids)
+    if only_matrix:
+        warn("Missing metadata for %d genomes (%s). These genomes will be discarded." % (len(only_matrix), ", ".join(sorted(only_matrix))))
+    only_md = set(md_ids) - matrix
+    if only_md:
+        warn("The metadata contains values for %d genomes that are not in the genomic data (%s)." % (len(only_md), ", ".join(sorted(only_md))))
+    keep = [(i, index[l]) for i, l in zip(md_ids, md_lab) if i in matrix]
+    ids = [k[0] for k in keep]
+    labels = np.array([k[1] for k in keep], dtype=np.uint8)
+    return ids, labels, uniq, ctype
+
+
+def parse_genome_list(path):
+    """`GENOME_ID<ws>PATH` per line (create.py:302); duplicates are an error (:308-309)"""
+    out = {}
+    order = []
+    for l in open(path):
+        if not l.strip():
+            continue
+        gid, p = l.split()[:2]
+        if gid in out:
+            raise KoverError("The genomic data contains genomes with the same identifier.")
+        out[gid] = p
+        order.append(gid)
+    return out, order
+
+
+def write_header(output_path, source_type, genomic_data, phenotype_description, phenotype_metadata_path, gzip,
+                 genome_ids, labels, tags, classification_type, filter_singleton=None):
+    """attrs + phenotype / genome_identifiers / phenotype_tags (create.py:311-354); the file is
+    closed afterwards exactly as Kover closes it before calling the tools (:356)."""
+    with h5lite.File(output_path, "w") as f:
+        f.set_attr("created", float(time.time()))
+        f.set_attr("uuid", str(uuid.uuid1()))
+        f.set_attr("genome_source_type", source_type)
+        f.set_attr("genomic_data", genomic_data)
+        f.set_attr("phenotype_description", phenotype_description if phenotype_description is not None else "NA")
+        f.set_attr("phenotype_metadata_source", phenotype_metadata_path if phenotype_metadata_path is not None else "NA")
+        if filter_singleton is not None:
+            f.set_attr("filter", filter_singleton)
+        f.set_attr("compression", "gzip (level %d)" % gzip)
+        if labels is not None:
+            f.set_attr("classification_type", classification_type)
+            f.create_dataset("phenotype", np.asarray(labels, dtype=np.uint8), attrs={"description": phenotype_description})
+        f.create_dataset("genome_identifiers", np.array([g.encode() for g in genome_ids], dtype="S"), gzip=gzip)
+        if tags is not None:
+            f.create_dataset("phenotype_tags", np.array([t.encode() for t in tags], dtype="S"), gzip=gzip)
+
+
+def label_sorted(ids, labels):
+    """genomes argsorted by numeric label (create.py:334-336); stable for reproducibility"""
+    order = np.argsort(labels, kind="stable")
+    return [ids[i] for i in order], labels[order]
+
+
+def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton, phenotype_description,
+                 phenotype_metadata_path, gzip, progress=None, abundance_min=1, source_type="contigs"):
+    """create.py:278-396 with the two tool calls replaced by one fused engine pass."""
+    progress = progress or (lambda m: None)
+    if (phenotype_description is None) != (phenotype_metadata_path is None):
+        raise KoverError("If a phenotype is specified, it must have a description and a metadata file.")
+    paths, order = parse_genome_list(contig_list_path)
+    for gid, p in paths.items():
+        if not os.path.exists(p):
+            raise KoverError("The contig file for genome %s cannot be found: %s" % (gid, p))
+    labels = tags = ctype = None
+    ids = order
+    if phenotype_description is not None:
+        ids, labels, tags, ctype = parse_metadata(phenotype_metadata_path, list(paths.keys()), warn=progress)
+        ids, labels = label_sorted(ids, labels)
+    tmp = output_path + ".tmp"
+    write_header(tmp, source_type, contig_list_path, phenotype_description, phenotype_metadata_path, gzip,
+                 ids, labels, tags, ctype, "singleton" if filter_singleton else "nothing")
+    progress("multidsk+dsk2kover (gfx950): %d genomes, k=%d" % (len(ids), kmer_size))
+    batch = ctx.batch(len(ids))
+    for g, gid in enumerate(ids):
+        p = paths[gid]
+        files = sorted(os.path.join(p, f) for f in os.listdir(p)) if os.path.isdir(p) else [p]
+        for f in files:
+            batch.add_file(g, f)
+    batch.upload()
+    m = batch.run(kmer_size, abundance_min, bool(filter_singleton))
+    progress("dictionary: %d k-mers; writing HDF5 (gzip %d)" % (m.n_kmers, gzip))
+    m.write_kover_h5(tmp, gzip, BLOCK_SIZE)
+    n = m.n_kmers
+    m.free()
+    batch.free()
+    os.replace(tmp, output_path)        # never leave a plausible partial output
+    return n
+
+
+def from_tsv(tsv_path, output_path, phenotype_description, phenotype_metadata_path, gzip):
+    """create.py:119-275: TSV matrix -> Kover HDF5 (pure host code; packs with the MSB-first
+    layout of utils.py:133-156)."""
+    with open(tsv_path) as f:
+        header = f.readline().rstrip("\n").split("\t")
+        genome_ids = header[1:]
+        kmers, cols = [], []
+        for line in f:
+            if not line.strip():
+                continue
+            cells = line.rstrip("\n").split("\t")
+            kmers.append(cells[0].encode())
+            cols.append(np.array(cells[1:], dtype=np.uint8))
+    if len(set(genome_ids)) < len(genome_ids):
+        raise KoverError("The genomic data contains genomes with the same identifier.")
+    dense = np.array(cols, dtype=np.uint8).T if cols else np.zeros((len(genome_ids), 0), np.uint8)   # [genome][kmer]
+    labels = tags = ctype = None
+    ids = genome_ids
+    if phenotype_description is not None:
+        ids, labels, tags, ctype = parse_metadata(phenotype_metadata_path, genome_ids)
+        ids, labels = label_sorted(ids, labels)
+    row_of = {g: i for i, g in enumerate(genome_ids)}
+    dense = dense[[row_of[g] for g in ids]] if ids else dense
+    packed = pack_rows(dense)
+    tmp = output_path + ".tmp"
+    write_header(tmp, "tsv", tsv_path, phenotype_description, phenotype_metadata_path, gzip, ids, labels, tags, ctype)
+    U = len(kmers)
+    with h5lite.File(tmp, "r+") as f:
+        klen = len(kmers[0]) if kmers else 1
+        f.create_dataset("kmer_sequences", np.array(kmers, dtype="S%d" % klen), gzip=gzip)
+        f.create_dataset("kmer_matrix", packed, gzip=gzip, chunks=(1, max(1, min(U, BLOCK_SIZE))))
+        f.create_dataset("kmer_by_matrix_column", np.arange(U, dtype=minimum_uint(U)), gzip=gzip)
+    os.replace(tmp, output_path)
+    return U
+
+
+def minimum_uint(max_value):
+    """utils.py:117-130"""
+    for dt in (np.uint8, np.uint16, np.uint32, np.uint64):
+        if max_value <= np.iinfo(dt).max:
+            return dt
+    raise ValueError(max_value)
+
+
+def pack_rows(dense):
+    """utils.py:133-156 (_pack_binary_bytes_to_ints, pack_size 64): genome i -> word i//64, bit 63-(i%64)"""
+    n, U = dense.shape
+    rows = (n + 63) // 64
+    out = np.zeros((rows, U), dtype=np.uint64)
+    for i in range(n):
+        out[i // 64] |= dense[i].astype(np.uint64) << np.uint64(63 - (i % 64))
+    return out
+
+
+class KoverDatasetReader:
+    """what dataset/ds.py:26-148 exposes, for verification of files we wrote"""
+
+    def __init__(self, path):
+        self.path = path
+
+    def _open(self):
+        return h5lite.File(self.path, "r")
+
+    def attr(self, name):
+        with self._open() as f:
+            return f.get_attr(name)
+
+    @property
+    def genome_identifiers(self):
+        with self._open() as f:
+            return [x.decode() for x in f.read("genome_identifiers")]
+
+    @property
+    def phenotype(self):
+        with self._open() as f:
+            return f.read("phenotype"), [x.decode() for x in f.read("phenotype_tags")], f.dataset_attr("phenotype", "description")
+
+    @property
+    def kmer_sequences(self):
+        with self._open() as f:
+            return [x.decode() for x in f.read("kmer_sequences")]
+
+    @property
+    def kmer_matrix(self):
+        with self._open() as f:
+            return f.read("kmer_matrix")
+
+    @property
+    def kmer_by_matrix_column(self):
+        with self._open() as f:
+            return f.read("kmer_by_matrix_column")
+
+    def layout(self, name):
+        with self._open() as f:
+            return f.layout(name)
+
+    def sum_rows(self, rows):
+        """rules.py:201-267 (KmerRuleClassifications.sum_rows): for every k-mer, the number of
+        the given genomes that carry it = popcount(word & row_mask) summed over word-rows
+        (popcount.pyx:76-95)."""
+        m = self.kmer_matrix
+        n_rows = m.shape[0]
+        mask = np.zeros(n_rows, dtype=np.uint64)
+        for r in rows:
+            mask[r // 64] |= np.uint64(1) << np.uint64(63 - (r % 64))       # rules.py:210-222
+        out = np.zeros(m.shape[1], dtype=np.uint32)
+        for w in range(n_rows):
+            if mask[w]:
+                v = m[w] & mask[w]
+                out += np.array([bin(int(x)).count("1") for x in v], dtype=np.uint32) if v.size < 4096 else _popcount64(v)
+        return out
+
+
+def _popcount64(v):
+    v = v.copy()
+    v = v - ((v >> np.uint64(1)) & np.uint64(0x5555555555555555))
+    v = (v & np.uint64(0x3333333333333333)) + ((v >> np.uint64(2)) & np.uint64(0x3333333333333333))
+    v = (v + (v >> np.uint64(4))) & np.uint64(0x0F0F0F0F0F0F0F0F)
+    return ((v * np.uint64(0x0101010101010101)) >> np.uint64(56)).astype(np.uint32)

@@ -99,6 +99,11 @@ const void     *grm_matrix_dev_data(const grm_matrix *);
 /* per-column carrier count = popcount down the column (the learner's sum_rows with an
  * all-ones mask, learning/common/rules.py:243-262); host array of n_kmers uint32 */
 int             grm_matrix_column_counts(grm_matrix *, uint32_t *out);
+/* host-only matrix from caller arrays (copied): rows gathered from several ranks, or tests.
+ * Only the accessors and the two writers work on it (no device). */
+int             grm_matrix_from_host(const uint64_t *kmers, const uint64_t *data, size_t n_kmers, int n_genomes, int k,
+                                     grm_matrix **out);
+const char     *grm_matrix_last_error(const grm_matrix *);
 void            grm_matrix_free(grm_matrix *);
 
 /* Ray-Surveyor-compatible TSV (layout read by dataset/create.py:121-137,241) */
@@ -119,6 +124,9 @@ int  grm_batch_run(grm_batch *, int k, uint32_t abundance_min, int filter_single
 /* the same path in stages, so that the host can put ONE collective between them when the
  * genomes are sharded over several GPUs: */
 int  grm_batch_partition(grm_batch *, int k, uint32_t abundance_min);
+/* same, but keeps per-k-mer occurrence counts so that grm_batch_genome_set can return them
+ * (multidsk: one batch, one sorted counted set per genome) */
+int  grm_batch_partition_counts(grm_batch *, int k, uint32_t abundance_min);
 int  grm_batch_local_dict(grm_batch *, uint64_t *n_local);
 int  grm_batch_export_dict(grm_batch *, void *dev_keys_out, void *dev_flags_out);
 int  grm_batch_set_global_dict(grm_batch *, const void *dev_keys, const void *dev_flags, uint64_t n,

@@ -1,0 +1,139 @@
+"""N>1 path on CPU: world_size-2 gloo run of distributed.sharded_step / gather_rows.
+
+The per-rank compute engine is replaced by a TEST-ONLY stand-in backed by the oracle (the
+real engine needs a GPU); what is under test is the sharding plan, the single dictionary
+all-gather, the deterministic merge contract (flags 1/2 -> singleton filter) and the row
+assembly -- i.e. everything in genomic-resistance-mapping-grm-_amd/distributed.py."""
+import ctypes as C
+import os
+import socket
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+from oracle import oracle_ctypes as orc
+from tests import cases
+
+PKG = "genomic-resistance-mapping-grm-_amd"
+
+
+def test_shard_plan():
+    import grm_amd  # noqa: F401
+    D = import_module(PKG + ".distributed")
+    s = D.shard_genomes(1000, 8)
+    assert [b - a for a, b in s] == [128] * 7 + [104]
+    assert all(a % 64 == 0 for a, _ in s) and s[0][0] == 0 and s[-1][1] == 1000
+    assert D.shard_genomes(10, 4) == [(0, 10), (10, 10), (10, 10), (10, 10)]
+    assert D.shard_genomes(130, 2) == [(0, 128), (128, 130)]
+    assert D.shard_genomes(0, 2) == [(0, 0), (0, 0)]
+
+
+class FakeMatrix:
+    def __init__(self, kmers, data):
+        self._k, self._d = kmers, data
+
+    def kmers(self):
+        return self._k.reshape(-1, 1)
+
+    def data(self):
+        return self._d
+
+    def free(self):
+        pass
+
+
+class OracleBatch:
+    """same staged interface as engine.Batch, host memory instead of HBM"""
+
+    def __init__(self, genomes):
+        self.genomes = genomes
+
+    def partition(self, k, abundance_min):
+        self.sets = [orc.count_genome(g, k, abundance_min)[0][:, 0] for g in self.genomes]
+
+    def local_dict(self):
+        allk = np.concatenate(self.sets) if self.sets else np.zeros(0, np.uint64)
+        vals, counts = np.unique(allk, return_counts=True)
+        perm = np.random.RandomState(len(vals)).permutation(len(vals))      # order must not matter
+        self.lk = vals[perm].astype(np.uint64)
+        self.lf = np.where(counts[perm] > 1, 2, 1).astype(np.uint8)
+        return len(self.lk)
+
+    def export_dict(self, keys_ptr, flags_ptr):
+        C.memmove(keys_ptr, self.lk.ctypes.data, self.lk.nbytes)
+        C.memmove(flags_ptr, self.lf.ctypes.data, self.lf.nbytes)
+
+    def set_global_dict(self, keys_ptr, flags_ptr, n, filter_singleton):
+        keys = np.ctypeslib.as_array(C.cast(keys_ptr, C.POINTER(C.c_uint64)), shape=(max(n, 1),))[:n].copy()
+        flags = np.ctypeslib.as_array(C.cast(flags_ptr, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()
+        order = np.argsort(keys, kind="stable")
+        keys, flags = keys[order], flags[order]
+        vals, first, counts = np.unique(keys, return_index=True, return_counts=True)
+        multi = (counts > 1) | (np.maximum.reduceat(flags, first) >= 2 if len(keys) else np.zeros(0, bool))
+        self.dict = vals[multi] if filter_singleton else vals
+        return len(self.dict)
+
+    def fill(self):
+        rows = (len(self.genomes) + 63) // 64
+        out = np.zeros((rows, len(self.dict)), dtype=np.uint64)
+        for g, s in enumerate(self.sets):
+            idx = np.searchsorted(self.dict, s)
+            ok = (idx < len(self.dict))
+            ok[ok] &= self.dict[idx[ok]] == s[ok]
+            out[g // 64, idx[ok]] |= np.uint64(1) << np.uint64(63 - g % 64)
+        return FakeMatrix(self.dict, out)
+
+
+def _genomes(n):
+    rng = np.random.RandomState(2)
+    core = cases.rand_seq(rng, 400)
+    out = []
+    for g in range(n):
+        s = list(core)
+        for p in rng.randint(0, len(core), size=3):
+            s[p] = "ACGT"[rng.randint(4)]
+        private = cases.rand_seq(rng, 40)
+        out.append([cases.fasta([("g%d" % g, "".join(s)), ("p", private)]).encode()])
+    return out
+
+
+def _worker(rank, world, port, n_genomes, k, filt, q):
+    import torch
+    import torch.distributed as dist
+    import grm_amd  # noqa: F401
+    D = import_module(PKG + ".distributed")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        genomes = _genomes(n_genomes)
+        a, b = D.shard_genomes(n_genomes, world)[rank]
+        batch = OracleBatch(genomes[a:b])
+        m = D.sharded_step(batch, k, 1, filt, torch.device("cpu"))
+        rows = D.gather_rows(m.data(), torch.device("cpu"))
+        if rank == 0:
+            q.put((m.kmers()[:, 0].copy(), rows))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_genomes,filt", [(100, True), (70, False), (130, True)])
+def test_two_rank_gloo_matches_single_process_oracle(n_genomes, filt):
+    import torch.multiprocessing as mp
+    k = 15
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_genomes, k, filt, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    kmers, rows = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = orc.build_matrix(_genomes(n_genomes), k, 1, filt)
+    assert (kmers == want["kmers"][:, 0]).all()
+    assert rows.shape == want["matrix"].shape and (rows == want["matrix"]).all()

@@ -1,0 +1,126 @@
+"""GPU: the drop-in executables end to end (argv surface of the reference) vs the oracle."""
+import os
+import subprocess
+import sys
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_ctypes as orc
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "genomic-resistance-mapping-grm-_amd"
+CLI = os.path.join(ROOT, PKG, "cli")
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable] + args, capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    return r
+
+
+@pytest.fixture(scope="module")
+def genomes(tmp_path_factory):
+    d = tmp_path_factory.mktemp("fna")
+    rng = np.random.RandomState(8)
+    core = cases.rand_seq(rng, 5000)
+    out = []
+    for g in range(9):
+        s = list(core)
+        for p in rng.randint(0, len(core), size=20):
+            s[p] = "ACGT"[rng.randint(4)]
+        recs = [("c1", "".join(s[:3000])), ("c2", "".join(s[3000:]) + "NN" + cases.rand_seq(rng, 300))]
+        path = str(d / ("562.%d.fna" % (100 + g)))
+        open(path, "w").write(cases.fasta(recs, width=70))
+        out.append(path)
+    return out
+
+
+def test_multidsk_then_dsk2kover(genomes, tmp_path):
+    import grm_amd  # noqa: F401
+    kd = import_module(PKG + ".kover_dataset")
+    k = 31
+    tmp = str(tmp_path)
+    lst = os.path.join(tmp, "list_contigs_files")
+    open(lst, "w").writelines(p + "\n" for p in genomes)
+    # exactly kmer_count.py:28-37
+    _run([os.path.join(CLI, "multidsk"), "-file", lst, "-out-dir", tmp, "-kmer-size", str(k), "-abundance-min", "1",
+          "-out-compress", "4", "-nb-cores", "0", "-out-tmp", tmp, "-verbose", "0", "-progress", "True"])
+    h5s = [os.path.join(tmp, os.path.basename(os.path.splitext(p + "\n")[0]) + ".h5") for p in genomes]   # create.py:375
+    assert all(os.path.exists(p) for p in h5s)
+    list_h5 = os.path.join(tmp, "list_h5")
+    open(list_h5, "w").writelines(p + "\n" for p in h5s)
+    out = os.path.join(tmp, "DATASET.kover")
+    ids = [os.path.basename(p)[:-4] for p in genomes]
+    for filt in ("singleton", "nothing"):
+        kd.write_header(out, "contigs", lst, None, None, 4, ids, None, None, None, filt)
+        # exactly kmer_pack.py:28-36
+        _run([os.path.join(CLI, "dsk2kover"), "-file", list_h5, "-out", out, "-filter", filt, "-kmer-length", str(k),
+              "-compression", "4", "-chunk-size", "100000", "-nb-genomes", str(len(genomes)), "-verbose", "True"])
+        want = orc.build_matrix([[open(p, "rb").read()] for p in genomes], k, 1, filt == "singleton")
+        r = kd.KoverDatasetReader(out)
+        assert r.kmer_sequences == orc.decode_kmers(want["kmers"], k)
+        assert (r.kmer_matrix == want["matrix"]).all()
+        assert r.genome_identifiers == ids
+
+
+def test_ray_under_fake_mpiexec(genomes, tmp_path):
+    conf = str(tmp_path / "survey.conf")
+    outdir = str(tmp_path / "survey.res")
+    with open(conf, "w") as f:      # src/app.py:3820-3833
+        f.write("-k 21\n-run-surveyor\n-output %s\n-write-kmer-matrix\n" % outdir)
+        for p in genomes[:5]:
+            f.write("-read-sample-assembly %s %s\n" % (os.path.basename(p)[:-4], p))
+    for rank in (3, 1, 0, 2):       # mpiexec -n 4 starts four copies; only rank 0 works
+        _run([os.path.join(CLI, "Ray"), conf], env={"PMI_RANK": str(rank)})
+    tsv = os.path.join(outdir, "Surveyor", "KmerMatrix.tsv")
+    lines = open(tsv).read().split("\n")
+    want = orc.build_matrix([[open(p, "rb").read()] for p in genomes[:5]], 21, 1, False)
+    assert lines[0].split("\t") == ["kmers"] + [os.path.basename(p)[:-4] for p in genomes[:5]]
+    strs = orc.decode_kmers(want["kmers"], 21)
+    body = [l for l in lines[1:] if l]
+    assert [l.split("\t")[0] for l in body] == strs
+    for c in (0, len(body) // 2, len(body) - 1):
+        cells = body[c].split("\t")[1:]
+        assert cells == [str((int(want["matrix"][g // 64, c]) >> (63 - g % 64)) & 1) for g in range(5)]
+
+
+def test_dsk_pooled_count(genomes, tmp_path):
+    h5 = import_module(PKG + ".h5lite")
+    lst = str(tmp_path / "dsk_output")
+    open(lst, "w").writelines(p + "\n" for p in genomes)
+    _run([os.path.join(CLI, "dsk"), "-file", lst, "-out-dir", str(tmp_path), "-kmer-size", "31"])      # src/app.py:1372
+    km, ct, nocc = orc.count_genome([open(p, "rb").read() for p in genomes], 31, 2)                    # DSK default abundance-min 2
+    with h5.File(str(tmp_path / "dsk_output.h5")) as f:
+        assert (f.read("kmers") == km[:, 0]).all() and (f.read("abundances") == ct).all()
+        assert f.get_attr("nb_kmers_total") == float(nocc)
+
+
+def test_kover_create_from_contigs(genomes, tmp_path):
+    import grm_amd  # noqa: F401
+    kd = import_module(PKG + ".kover_dataset")
+    ids = [os.path.basename(p)[:-4] for p in genomes]
+    data = str(tmp_path / "paths.tsv")
+    open(data, "w").writelines("%s\t%s\n" % (i, p) for i, p in zip(ids, genomes))                       # src/kover.py:40-49
+    md = str(tmp_path / "md.tsv")
+    open(md, "w").writelines("%s\t%s\n" % (i, "R" if n % 3 else "S") for n, i in enumerate(ids))
+    out = str(tmp_path / "DATASET.kover")
+    # the command GRM builds (src/kover.py:52-108)
+    _run([os.path.join(CLI, "kover"), "dataset", "create", "from-contigs", "--genomic-data", data,
+          "--phenotype-description", "desc", "--phenotype-metadata", md, "--output", out, "--kmer-size", "31",
+          "--n-cpu", "4", "--compression", "4", "-x"])
+    r = kd.KoverDatasetReader(out)
+    order = r.genome_identifiers
+    labels = {i: (0 if n % 3 else 1) for n, i in enumerate(ids)}        # tags sorted: R=0, S=1
+    assert [labels[i] for i in order] == sorted(labels.values())        # rows label-sorted (create.py:334-336)
+    want = orc.build_matrix([[open(genomes[ids.index(i)], "rb").read()] for i in order], 31, 1, True)
+    assert r.kmer_sequences == orc.decode_kmers(want["kmers"], 31)
+    assert (r.kmer_matrix == want["matrix"]).all()
+    assert r.attr("filter") == "singleton" and r.attr("genome_source_type") == "contigs"
+    assert r.phenotype[1] == ["R", "S"]

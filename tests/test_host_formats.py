@@ -1,0 +1,174 @@
+"""Host-side logic that needs no GPU: Kover glue restatement, HDF5 / TSV writers on a
+host-only matrix (contents = oracle), the k-mer-set container, argv / conf parsing."""
+import importlib.util
+import os
+import subprocess
+import sys
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+from oracle import oracle_ctypes as orc
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "genomic-resistance-mapping-grm-_amd"
+
+
+def _load_cli(name):
+    path = os.path.join(ROOT, PKG, "cli", name)
+    sys.path.insert(0, os.path.dirname(path))
+    loader = importlib.machinery.SourceFileLoader("cli_" + name.replace("-", "_"), path)
+    spec = importlib.util.spec_from_loader(loader.name, loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module")
+def kd():
+    import grm_amd  # noqa: F401
+    return import_module(PKG + ".kover_dataset")
+
+
+@pytest.fixture(scope="module")
+def small_matrix():
+    name, k, genomes = [c for c in cases.micro_cases() if c[1] == 31][0]
+    bg = [[t.encode() for t in g] for g in genomes]
+    return k, bg, orc.build_matrix(bg, k, 1, False)
+
+
+def test_parse_metadata_and_label_sort(kd, tmp_path):
+    md = tmp_path / "md.tsv"
+    md.write_text("g1\tresistant\ng2\tsusceptible\ng3\tresistant\ng9\tsusceptible\n")
+    warns = []
+    ids, labels, tags, ctype = kd.parse_metadata(str(md), ["g3", "g1", "g2", "g7"], warn=warns.append)
+    assert ids == ["g1", "g2", "g3"] and labels.tolist() == [0, 1, 0]
+    assert tags == ["resistant", "susceptible"] and ctype == "binary"
+    assert len(warns) == 2                                   # g7 lacks metadata, g9 not in the data
+    ids2, lab2 = kd.label_sorted(ids, labels)
+    assert ids2 == ["g1", "g3", "g2"] and lab2.tolist() == [0, 0, 1]
+    # literal 0/1 labels keep their meaning (create.py:74-78)
+    md.write_text("a\t1\nb\t0\n")
+    ids, labels, tags, _ = kd.parse_metadata(str(md), ["a", "b"])
+    assert labels.tolist() == [1, 0] and tags == ["0", "1"]
+    md.write_text("a\tx\nb\tx\n")
+    with pytest.raises(kd.KoverError):
+        kd.parse_metadata(str(md), ["a", "b"])
+    md.write_text("a\tx\na\ty\n")
+    with pytest.raises(kd.KoverError):
+        kd.parse_metadata(str(md), ["a"])
+
+
+def test_pack_rows_matches_reference_vectors(kd, golden_dir):
+    import json
+    d = json.load(open(os.path.join(golden_dir, "pack_vectors.json")))
+    for case in d["pack_cases"]:
+        if case["pack_size"] != 64:
+            continue
+        want = np.array([[int(x) for x in row] for row in case["packed"]], dtype=np.uint64)
+        assert (kd.pack_rows(np.array(case["bits"], dtype=np.uint8)) == want).all()
+    for e in d["minimum_uint_size"]:
+        assert np.dtype(kd.minimum_uint(int(e["max_value"]))).name == e["dtype"]
+
+
+def test_h5_writer_on_host_matrix(kd, small_matrix, tmp_path):
+    import grm_amd
+    k, bg, want = small_matrix
+    n = len(bg)
+    ids = ["gen%d" % i for i in range(n)]
+    labels = np.array([i % 2 for i in range(n)], dtype=np.uint8)
+    path = str(tmp_path / "d.kover")
+    kd.write_header(path, "contigs", "list.tsv", "pheno", "md.tsv", 4, ids, labels, ["0", "1"], "binary", "nothing")
+    m = grm_amd.HostMatrix(want["kmers"][:, 0], want["matrix"], n, k)
+    m.write_kover_h5(path, 4, 50)                    # tiny chunk width: several chunks + a ragged edge chunk
+    r = kd.KoverDatasetReader(path)
+    assert r.genome_identifiers == ids
+    assert r.kmer_sequences == orc.decode_kmers(want["kmers"], k)
+    assert (r.kmer_matrix == want["matrix"]).all() and r.kmer_matrix.dtype == np.uint64
+    U = want["kmers"].shape[0]
+    assert (r.kmer_by_matrix_column == np.arange(U)).all()
+    assert r.kmer_by_matrix_column.dtype == kd.minimum_uint(U)
+    lay = r.layout("kmer_matrix")
+    assert lay["chunks"] == (1, 50) and lay["n_filters"] == 1        # rules.py:104-131 needs .chunks
+    assert r.attr("compression") == "gzip (level 4)" and r.attr("filter") == "nothing"
+    assert r.attr("genome_source_type") == "contigs" and isinstance(r.attr("created"), float)
+    ph, tags, desc = r.phenotype
+    assert ph.tolist() == labels.tolist() and tags == ["0", "1"] and desc == "pheno"
+    # sum_rows restatement == carrier counts from the oracle
+    assert (r.sum_rows(range(n)) == want["n_genomes_with"]).all()
+    some = [0, 3, 5]
+    dense = np.array([[(int(want["matrix"][g // 64, c]) >> (63 - g % 64)) & 1 for c in range(U)] for g in some])
+    assert (r.sum_rows(some) == dense.sum(axis=0)).all()
+    # gzip 0 path and an independent reader (h5dump) agree on the shape
+    path0 = str(tmp_path / "d0.kover")
+    kd.write_header(path0, "contigs", "l", None, None, 0, ids, None, None, None, "singleton")
+    m.write_kover_h5(path0, 0, 100000)
+    assert (kd.KoverDatasetReader(path0).kmer_matrix == want["matrix"]).all()
+    h5dump = "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        out = subprocess.run([h5dump, "-H", path], capture_output=True, text=True).stdout
+        assert "DATASET \"kmer_matrix\"" in out and "( %d, %d )" % (1, U) in out
+    with pytest.raises(grm_amd.GrmError):
+        m.write_kover_h5(str(tmp_path / "missing.kover"), 4, 100)    # must already exist (create.py:356)
+    m.free()
+
+
+def test_tsv_writer_and_from_tsv_roundtrip(kd, small_matrix, tmp_path):
+    import grm_amd
+    k, bg, want = small_matrix
+    n = len(bg)
+    ids = ["s%d" % i for i in range(n)]
+    m = grm_amd.HostMatrix(want["kmers"][:, 0], want["matrix"], n, k)
+    tsv = str(tmp_path / "KmerMatrix.tsv")
+    m.write_tsv(ids, tsv)
+    body = open(tsv).read().split("\n")
+    assert body[0].split("\t") == ["kmers"] + ids
+    md = tmp_path / "md.tsv"
+    md.write_text("".join("%s\t%d\n" % (g, i % 2) for i, g in enumerate(ids)))
+    out = str(tmp_path / "t.kover")
+    U = kd.from_tsv(tsv, out, "desc", str(md), 4)
+    assert U == want["kmers"].shape[0]
+    r = kd.KoverDatasetReader(out)
+    gids = r.genome_identifiers
+    assert sorted(gids) == sorted(ids)
+    mat = r.kmer_matrix
+    for new_row, g in enumerate(gids):                 # rows are label-sorted: compare per genome
+        old = ids.index(g)
+        got = (mat[new_row // 64] >> np.uint64(63 - new_row % 64)) & np.uint64(1)
+        ref = (want["matrix"][old // 64] >> np.uint64(63 - old % 64)) & np.uint64(1)
+        assert (got == ref).all()
+    assert r.phenotype[0].tolist() == sorted(i % 2 for i in range(n))
+    m.free()
+
+
+def test_kset_container_and_names(tmp_path):
+    C = _load_cli("_common.py")
+    p = str(tmp_path / "x.h5")
+    C.write_kset(p, 31, 1, np.array([3, 9, 11], dtype=np.uint64), np.array([1, 2, 7], dtype=np.uint32), 10)
+    k, amin, km, ct, nocc = C.read_kset(p)
+    assert (k, amin, nocc) == (31, 1, 10) and km.tolist() == [3, 9, 11] and ct.tolist() == [1, 2, 7]
+    open(p, "wb").write(b"garbage")
+    with pytest.raises(ValueError):
+        C.read_kset(p)
+    assert C.list_stem("/a/b/562.1234.fna\n") == "562.1234"
+    assert C.list_stem("/r/g/x_1.fastq.gz,/r/g/x_2.fastq.gz") == "x_2.fastq"     # create.py:488
+    a = C.gatb_args(["-file", "L", "-out-dir", "D", "-kmer-size", "31", "-abundance-min", "1", "-out-compress", "4",
+                     "-nb-cores", "0", "-out-tmp", "D", "-verbose", "0", "-progress", "True"], {"file": None})
+    assert a["file"] == "L" and a["kmer-size"] == "31" and a["progress"] == "True" and a["out-tmp"] == "D"
+
+
+def test_ray_conf_grammar(tmp_path):
+    ray = _load_cli("Ray")
+    conf = tmp_path / "survey.conf"
+    conf.write_text("-k 31\n-run-surveyor\n-output /mnt/c/out/survey.res\n-write-kmer-matrix\n"
+                    "-read-sample-assembly 562.100 /mnt/c/d/562.100.fna\n-read-sample-assembly 562.200 /mnt/c/d/562.200.fna\n")
+    c = ray.parse_conf(str(conf))
+    assert c["k"] == 31 and c["run_surveyor"] and c["write_matrix"] and c["output"] == "/mnt/c/out/survey.res"
+    assert c["samples"] == [("562.100", "/mnt/c/d/562.100.fna"), ("562.200", "/mnt/c/d/562.200.fna")]
+    os.environ["PMI_RANK"] = "2"
+    try:
+        assert ray.mpi_rank() == 2 and ray.main([str(conf)]) == 0     # non-zero ranks exit 0 without work
+    finally:
+        del os.environ["PMI_RANK"]
