@@ -37,6 +37,11 @@ def gatb_args(argv, known):
     return out
 
 
+def truthy(v):
+    """Kover passes Python values through str(): '-progress True', '-verbose 0' (kmer_count.py:36-37, kmer_pack.py:36)"""
+    return str(v).strip().lower() not in ("", "0", "false", "none", "no")
+
+
 def die(msg, code=1):
     """return codes are ignored by Kover (kmer_count.py:28, kmer_pack.py:28): be loud on stderr too"""
     sys.stderr.write("ERROR: %s\n" % msg)
