@@ -346,7 +346,7 @@ struct grm_batch {
     int k = 0, bb = 0;
     uint32_t abundance_min = 1;
     uint64_t total_keys = 0;       // k-mer occurrences
-    DevBuf d_counts, d_off, d_cursor, d_keys, d_len, d_kcnt;
+    DevBuf d_counts, d_off, d_cursor, d_cursor1, d_keys, d_keys1, d_len, d_kcnt;
     bool deduped = false;
     // dictionary
     int sb_dict = 0, sb_fill = 0;
@@ -581,8 +581,14 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, b->d_keys.ensure((b->total_keys + 2) * 8));
     {
+        const int b1 = scatter_b1_bits(b->bb);
+        const uint64_t n_coarse = (uint64_t)G << b1;
+        HIPCHK(c, b->d_cursor1.ensure(n_coarse * 4));
+        HIPCHK(c, hipMemsetAsync(b->d_cursor1.p, 0, n_coarse * 4, s));
+        if (b->bb > b1) HIPCHK(c, b->d_keys1.ensure((b->total_keys + 2) * 8));
         TimeScope t(c, "kmer_scatter", b->total_keys);
-        launch_kmer_scatter(s, L, b->d_off.as<uint64_t>(), b->d_cursor.as<uint32_t>(), b->d_keys.as<uint64_t>());
+        launch_kmer_scatter(s, L, b->d_off.as<uint64_t>(), b->d_cursor1.as<uint32_t>(), b->d_cursor.as<uint32_t>(),
+                            b->d_keys1.as<uint64_t>(), b->d_keys.as<uint64_t>());
     }
     HIPCHK(c, hipGetLastError());
 

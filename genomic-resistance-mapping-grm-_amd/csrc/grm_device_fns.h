@@ -188,4 +188,46 @@ GRM_HD void for_each_kmer(uint64_t a, uint64_t b, uint64_t c, uint64_t valid, in
     }
 }
 
+// ---- 32-position variant (one packed word of start positions + the next word) --------
+// valid-start mask of the 32 positions p0..p0+31 where p0 = 64G + 32*half; k in 1..32
+GRM_HD uint32_t valid_starts32(uint64_t i0, uint64_t i1, int half, int k)
+{
+    uint64_t acc = half ? ((i0 >> 32) | (i1 << 32)) : i0;   // inv bits of symbols p0 .. p0+63
+    int covered = 1;
+    while (covered * 2 <= k) {
+        acc |= acc >> covered;
+        covered *= 2;
+    }
+    const int r = k - covered;
+    if (r) acc |= acc >> r;
+    return ~(uint32_t)acc;          // positions 0..31 only look at bits 0..62
+}
+
+// a = packed word of symbols p0..p0+31, b = the next word; calls f(i, canonical) for the
+// valid start positions i in 0..31.  The loop is meant to be fully unrolled so that a caller
+// may keep the k-mers in registers (statically indexed array).
+template <typename F>
+GRM_HD void for_each_kmer32(uint64_t a, uint64_t b, uint32_t valid, int k, F &&f)
+{
+    if (!valid) return;
+    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const int rcshift = 2 * (k - 1);
+    const int m = k - 1;
+    uint64_t fwd = m ? (a >> (64 - 2 * m)) : 0;
+    uint64_t rc = m ? (revcomp_m(fwd, m) << 2) : 0;
+    // stream = the symbols after the first m (m <= 31), MSB-aligned: the next symbol is
+    // always the top 2 bits of hi
+    uint64_t hi = m ? ((a << (2 * m)) | (b >> (64 - 2 * m))) : a;
+    uint64_t lo = m ? (b << (2 * m)) : b;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const uint64_t s = hi >> 62;
+        hi = (hi << 2) | (lo >> 62);
+        lo <<= 2;
+        fwd = ((fwd << 2) | s) & mask;
+        rc = (rc >> 2) | ((s ^ 2) << rcshift);
+        if ((valid >> i) & 1u) f(i, fwd < rc ? fwd : rc);
+    }
+}
+
 }  // namespace grm

@@ -15,11 +15,16 @@ constexpr int RAW_FRONT_PAD = 64;                          // '\n' bytes in fron
 
 // ---- k-mer kernels ----
 constexpr int KMER_THREADS = 256;
-constexpr int MAX_BUCKET_BITS = 13;                        // LDS: 8 B per bucket in the scatter kernel
+constexpr int MAX_BUCKET_BITS = 13;                        // 8 coarse + 5 fine bits (two-level partition)
+constexpr int L1_THREADS = 256;
+constexpr int L1_TILE = L1_THREADS * 32;                   // 8192 k-mers staged in LDS per tile
+constexpr int L1_MAX_BITS = 8;                             // coarse fan-out 256: ~32 keys (256 B) per run
+constexpr int L1_LDS_BYTES = L1_TILE * 8 + 2048 + 1024 + 1024 + 64;
 
 // ---- LDS table kernels ----
 constexpr int TABLE_THREADS = 512;                         // 8 waves: one genome per wave at a time
 constexpr int TABLE_SCRATCH_BYTES = 128;
+constexpr int KEYS_IN_FLIGHT = 4;                          // independent key loads per lane in dict/fill
 
 struct TileSummary {
     uint32_t known;       // symbols whose emission does not depend on the incoming line type
@@ -45,7 +50,9 @@ void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles,
 void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint64_t *tile_off,
                        const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv);
 void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
-void launch_kmer_scatter(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor, uint64_t *keys);
+int scatter_b1_bits(int bb);
+void launch_kmer_scatter(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, uint32_t *cursor2,
+                         uint64_t *keys1, uint64_t *keys);
 void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
                                 uint32_t n_genomes, int bb, uint32_t *counts);
 void launch_keys_partition_scatter(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,

@@ -369,73 +369,145 @@ __global__ __launch_bounds__(KMER_THREADS) void kmer_hist_kernel(KmerArgs a, uin
     }
 }
 
-// K3: scatter the canonical k-mers into their (genome,bucket) segment of `keys`.
-// off[g*B+b] = first slot of the segment (exclusive scan of counts), cursor = fill level.
-// LDS path: span histogram -> one global atomicAdd per touched bucket reserves a run ->
-// second sweep recomputes the k-mers and drops each one at run_base + LDS rank.
-__global__ __launch_bounds__(KMER_THREADS) void kmer_scatter_kernel(
-    KmerArgs a, uint32_t n_spans, const uint64_t *__restrict__ off, uint32_t *__restrict__ cursor,
-    uint64_t *__restrict__ keys)
+// K3: two-level LDS-staged radix partition of the canonical k-mers.
+//
+// A single-pass scatter of 8-byte keys into 2^13 buckets leaves L2 as partial lines (measured
+// 4x HBM write amplification, profiles/r01/baseline_*).  Instead:
+//   level 1  tile of 8192 positions -> k-mers kept in registers -> counting sort by the top
+//            b1 (<= 8) hash bits in LDS -> every coarse bucket's run is copied out contiguously
+//            (32 keys = 256 B on average): full-line writes.
+//   level 2  each (genome, coarse bucket) region is re-read in tiles of 8192 keys and split by
+//            the remaining b2 (<= 5) bits the same way (runs of ~256 keys).
+// Fine bucket ids are contiguous inside a coarse bucket (bucket = top bits of the hash), so the
+// coarse region of level 1 IS the union of its fine segments and `off` (exclusive scan of the
+// fine histogram) serves both levels.
+__global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
+    KmerArgs a, int b1bits, uint32_t n_tiles, const uint64_t *__restrict__ off, uint32_t *__restrict__ cursor1,
+    uint64_t *__restrict__ keys1)
 {
-    extern __shared__ uint32_t lds[];
-    const uint64_t span = xcd_span(blockIdx.x, n_spans);
-    if (span >= n_spans) return;
-    const uint32_t B = 1u << a.bb;
-    uint32_t *hist = lds;          // [B] occurrence count, then running rank
-    uint32_t *rel = lds + B;       // [B] run start relative to the genome's first slot
-    const uint64_t span_groups = (uint64_t)KMER_THREADS * a.groups_per_thread;
-    const uint64_t g_first = span * span_groups;
-    if (g_first >= a.n_groups) return;
-    const uint64_t g_last = min(g_first + span_groups, a.n_groups) - 1;
-    const uint64_t p_first = g_first << 6;
-    const uint64_t p_last = min((g_last << 6) + 63, a.total_syms - 1);
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint64_t *skeys = reinterpret_cast<uint64_t *>(lds_raw);                             // [L1_TILE]
+    uint64_t *gbase = reinterpret_cast<uint64_t *>(lds_raw + (size_t)L1_TILE * 8);        // [256]
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + (size_t)L1_TILE * 8 + 2048);  // [256]
+    uint32_t *start = hist + 256;                                                        // [256]
+    uint32_t *scratch = start + 256;                                                     // [16]
+    const uint64_t tile = xcd_span(blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;
+    const int b2bits = a.bb - b1bits;
+    const uint32_t B1 = 1u << b1bits;
+    const uint64_t hg = tile * L1_THREADS + threadIdx.x;          // half-group: 32 start positions
+    const uint64_t p0 = hg << 5;
+    const uint64_t p_first = tile * L1_TILE;
+    if (p_first >= a.total_syms) return;
+    const uint64_t p_last = min(p_first + L1_TILE, a.total_syms) - 1;
     const uint32_t gen0 = genome_of(a.genome_sym_off, a.n_genomes, p_first);
     const bool uniform = a.genome_sym_off[gen0 + 1] > p_last;
 
+    uint32_t valid = 0;
+    uint64_t wa = 0, wb = 0;
+    const int64_t nv = (int64_t)a.total_syms - a.k + 1 - (int64_t)p0;
+    if (nv > 0) {
+        const uint64_t grp = hg >> 1;
+        wa = a.sym2[hg];
+        wb = a.sym2[hg + 1];
+        valid = valid_starts32(a.inv[grp], a.inv[grp + 1], (int)(hg & 1), a.k);
+        if (nv < 32) valid &= (1u << nv) - 1;
+    }
+
     if (uniform) {
-        for (uint32_t i = threadIdx.x; i < B; i += KMER_THREADS) hist[i] = 0;
+        hist[threadIdx.x] = 0;            // L1_THREADS == 256 >= B1
         __syncthreads();
-        for (uint32_t it = 0; it < a.groups_per_thread; it++) {
-            const uint64_t grp = g_first + (uint64_t)it * KMER_THREADS + threadIdx.x;
-            if (grp > g_last) break;
-            group_kmers(a, grp, [&](int, uint64_t canon) {
-                atomicAdd(&hist[hash_bucket(mix64(canon), a.bb)], 1u);
-            });
+        uint64_t kv[32];
+        uint32_t meta[32];                // (coarse bucket << 16) | rank inside the tile's bucket
+        for_each_kmer32(wa, wb, valid, a.k, [&](int i, uint64_t canon) {
+            kv[i] = canon;
+            const uint32_t b1 = hash_bucket(mix64(canon), b1bits);
+            meta[i] = (b1 << 16) | atomicAdd(&hist[b1], 1u);
+        });
+        __syncthreads();
+        const uint32_t c = threadIdx.x < B1 ? hist[threadIdx.x] : 0u;
+        uint32_t n_tile;
+        const uint32_t st = block_scan_sum(c, scratch, &n_tile);
+        start[threadIdx.x] = st;
+        if (c) {
+            const uint64_t fine0 = (uint64_t)gen0 * (1ull << a.bb) + ((uint64_t)threadIdx.x << b2bits);
+            gbase[threadIdx.x] = off[fine0] + atomicAdd(&cursor1[(uint64_t)gen0 * B1 + threadIdx.x], c);
         }
         __syncthreads();
-        const uint64_t gbase = off[(uint64_t)gen0 * B];
-        for (uint32_t i = threadIdx.x; i < B; i += KMER_THREADS) {
-            const uint32_t c = hist[i];
-            uint32_t r = 0;
-            if (c) {
-                const uint64_t idx = (uint64_t)gen0 * B + i;
-                r = (uint32_t)(off[idx] - gbase) + atomicAdd(&cursor[idx], c);
-            }
-            rel[i] = r;
-            hist[i] = 0;
-        }
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+            if ((valid >> i) & 1u) skeys[start[meta[i] >> 16] + (meta[i] & 0xffffu)] = kv[i];
         __syncthreads();
-        for (uint32_t it = 0; it < a.groups_per_thread; it++) {
-            const uint64_t grp = g_first + (uint64_t)it * KMER_THREADS + threadIdx.x;
-            if (grp > g_last) break;
-            group_kmers(a, grp, [&](int, uint64_t canon) {
-                const uint32_t b = hash_bucket(mix64(canon), a.bb);
-                const uint32_t rank = atomicAdd(&hist[b], 1u);
-                keys[gbase + rel[b] + rank] = canon;
-            });
+        for (uint32_t i = threadIdx.x; i < n_tile; i += L1_THREADS) {
+            const uint64_t key = skeys[i];
+            const uint32_t b1 = hash_bucket(mix64(key), b1bits);
+            keys1[gbase[b1] + (i - start[b1])] = key;
         }
     } else {
-        for (uint32_t it = 0; it < a.groups_per_thread; it++) {
-            const uint64_t grp = g_first + (uint64_t)it * KMER_THREADS + threadIdx.x;
-            if (grp > g_last) break;
-            const uint64_t p0 = grp << 6;
-            uint32_t gen = genome_of(a.genome_sym_off, a.n_genomes, p0);
-            uint64_t gend = a.genome_sym_off[gen + 1];
-            group_kmers(a, grp, [&](int i, uint64_t canon) {
-                while (p0 + (uint64_t)i >= gend) { gen++; gend = a.genome_sym_off[gen + 1]; }
-                const uint64_t idx = (uint64_t)gen * B + hash_bucket(mix64(canon), a.bb);
-                keys[off[idx] + atomicAdd(&cursor[idx], 1u)] = canon;
-            });
+        uint32_t gen = genome_of(a.genome_sym_off, a.n_genomes, min(p0, a.total_syms - 1));
+        uint64_t gend = a.genome_sym_off[gen + 1];
+        for_each_kmer32(wa, wb, valid, a.k, [&](int i, uint64_t canon) {
+            while (p0 + (uint64_t)i >= gend) { gen++; gend = a.genome_sym_off[gen + 1]; }
+            const uint32_t b1 = hash_bucket(mix64(canon), b1bits);
+            const uint64_t fine0 = (uint64_t)gen * (1ull << a.bb) + ((uint64_t)b1 << b2bits);
+            keys1[off[fine0] + atomicAdd(&cursor1[(uint64_t)gen * B1 + b1], 1u)] = canon;
+        });
+    }
+}
+
+__global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l2_kernel(
+    const uint64_t *__restrict__ keys1, uint64_t *__restrict__ keys, const uint64_t *__restrict__ off,
+    uint32_t *__restrict__ cursor2, uint64_t n_regions, int bb, int b1bits)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint64_t *skeys = reinterpret_cast<uint64_t *>(lds_raw);
+    uint64_t *gbase = reinterpret_cast<uint64_t *>(lds_raw + (size_t)L1_TILE * 8);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + (size_t)L1_TILE * 8 + 2048);
+    uint32_t *start = hist + 256;
+    uint32_t *scratch = start + 256;
+    const int b2bits = bb - b1bits;
+    const uint32_t B2 = 1u << b2bits;
+    for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
+        const uint64_t g = region >> b1bits, c1 = region & ((1u << b1bits) - 1);
+        const uint64_t fine0 = (g << bb) + (c1 << b2bits);
+        const uint64_t r0 = off[fine0], r1 = off[fine0 + B2];
+        for (uint64_t base = r0; base < r1; base += L1_TILE) {
+            const uint32_t n = (uint32_t)min((uint64_t)L1_TILE, r1 - base);
+            if (threadIdx.x < B2) hist[threadIdx.x] = 0;
+            __syncthreads();
+            uint64_t kv[32];
+            uint32_t meta[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const uint32_t i = (uint32_t)j * L1_THREADS + threadIdx.x;
+                kv[j] = i < n ? keys1[base + i] : EMPTY_KEY;
+            }
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                if (kv[j] != EMPTY_KEY) {
+                    const uint32_t b2 = hash_bucket(mix64(kv[j]), bb) & (B2 - 1);
+                    meta[j] = (b2 << 16) | atomicAdd(&hist[b2], 1u);
+                }
+            }
+            __syncthreads();
+            const uint32_t c = threadIdx.x < B2 ? hist[threadIdx.x] : 0u;
+            uint32_t n_tile;
+            const uint32_t st = block_scan_sum(c, scratch, &n_tile);
+            if (threadIdx.x < B2) {
+                start[threadIdx.x] = st;
+                if (c) gbase[threadIdx.x] = off[fine0 + threadIdx.x] + atomicAdd(&cursor2[fine0 + threadIdx.x], c);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 32; j++)
+                if (kv[j] != EMPTY_KEY) skeys[start[meta[j] >> 16] + (meta[j] & 0xffffu)] = kv[j];
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += L1_THREADS) {
+                const uint64_t key = skeys[i];
+                const uint32_t b2 = hash_bucket(mix64(key), bb) & (B2 - 1);
+                keys[gbase[b2] + (i - start[b2])] = key;
+            }
+            __syncthreads();
         }
     }
 }
@@ -612,16 +684,27 @@ __global__ __launch_bounds__(TABLE_THREADS) void dict_build_kernel(
         const uint64_t idx = (uint64_t)g * B + b;
         const uint64_t s0 = off[idx];
         const uint64_t n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
-        for (uint64_t i = lane; i < n; i += 64) {
-            const uint64_t key = keys[s0 + i];
-            const uint64_t h = mix64(key);
-            if (sb && hash_sub(h, bb, sb) != sub) continue;
-            bool ins;
-            const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, h, &ins);
-            if (slot == 0xffffffffu) { full = 1; continue; }
-            if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
-            const uint32_t old = atomicCAS(&tstate[slot], 0u, g + 1);
-            if (old != 0 && (old & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
+        // KEYS_IN_FLIGHT independent loads per lane before the (latency-bound) LDS probing
+        for (uint64_t i0 = lane; i0 < n; i0 += 64 * KEYS_IN_FLIGHT) {
+            uint64_t kv[KEYS_IN_FLIGHT];
+#pragma unroll
+            for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
+                const uint64_t i = i0 + 64u * j;
+                kv[j] = i < n ? keys[s0 + i] : EMPTY_KEY;
+            }
+#pragma unroll
+            for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
+                const uint64_t key = kv[j];
+                if (key == EMPTY_KEY) continue;
+                const uint64_t h = mix64(key);
+                if (sb && hash_sub(h, bb, sb) != sub) continue;
+                bool ins;
+                const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, h, &ins);
+                if (slot == 0xffffffffu) { full = 1; continue; }
+                if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
+                const uint32_t old = atomicCAS(&tstate[slot], 0u, g + 1);
+                if (old != 0 && (old & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
+            }
         }
         if (full) break;    // LDS flag: a stale read only delays the exit
     }
@@ -775,12 +858,22 @@ __global__ __launch_bounds__(TABLE_THREADS) void matrix_fill_kernel(
             const uint64_t idx = (uint64_t)g * B + b;
             const uint64_t s0 = off[idx];
             const uint64_t n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
-            for (uint64_t i = lane; i < n; i += 64) {
-                const uint64_t key = keys[s0 + i];
-                const uint64_t h = mix64(key);
-                if (sb && hash_sub(h, bb, sb) != sub) continue;
-                const uint32_t slot = lds_find(tkeys, cap_mask, key, h);
-                if (slot != 0xffffffffu) atomicOr((unsigned long long *)&words[slot], bit);
+            for (uint64_t i0 = lane; i0 < n; i0 += 64 * KEYS_IN_FLIGHT) {
+                uint64_t kv[KEYS_IN_FLIGHT];
+#pragma unroll
+                for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
+                    const uint64_t i = i0 + 64u * j;
+                    kv[j] = i < n ? keys[s0 + i] : EMPTY_KEY;
+                }
+#pragma unroll
+                for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
+                    const uint64_t key = kv[j];
+                    if (key == EMPTY_KEY) continue;
+                    const uint64_t h = mix64(key);
+                    if (sb && hash_sub(h, bb, sb) != sub) continue;
+                    const uint32_t slot = lds_find(tkeys, cap_mask, key, h);
+                    if (slot != 0xffffffffu) atomicOr((unsigned long long *)&words[slot], bit);
+                }
             }
         }
         __syncthreads();
@@ -861,14 +954,25 @@ void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts)
     const uint32_t grid = ((n_spans + 7) / 8) * 8;     // xcd_span() needs the full 8 x per layout
     hipLaunchKernelGGL(kmer_hist_kernel, dim3(grid), dim3(KMER_THREADS), (size_t)4 << L.bb, s, a, n_spans, counts);
 }
-void launch_kmer_scatter(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor, uint64_t *keys)
+int scatter_b1_bits(int bb) { return bb < L1_MAX_BITS ? bb : L1_MAX_BITS; }
+
+// keys1: level-1 output (== final keys when bb <= L1_MAX_BITS, then cursor2 / keys are unused)
+void launch_kmer_scatter(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, uint32_t *cursor2,
+                         uint64_t *keys1, uint64_t *keys)
 {
     KmerArgs a = make_args(L);
     if (a.total_syms == 0) return;
-    const uint32_t n_spans = n_spans_of(a);
-    const uint32_t grid = ((n_spans + 7) / 8) * 8;
-    hipLaunchKernelGGL(kmer_scatter_kernel, dim3(grid), dim3(KMER_THREADS), (size_t)8 << L.bb, s, a, n_spans, off,
-                       cursor, keys);
+    const int b1 = scatter_b1_bits(L.bb);
+    const uint32_t n_tiles = (uint32_t)((a.total_syms + L1_TILE - 1) / L1_TILE);
+    const uint32_t grid = ((n_tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(kmer_scatter_l1_kernel, dim3(grid), dim3(L1_THREADS), L1_LDS_BYTES, s, a, b1, n_tiles, off, cursor1,
+                       L.bb > b1 ? keys1 : keys);
+    if (L.bb > b1) {
+        const uint64_t n_regions = (uint64_t)L.n_genomes << b1;
+        const uint32_t grid2 = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
+        hipLaunchKernelGGL(kmer_scatter_l2_kernel, dim3(grid2), dim3(L1_THREADS), L1_LDS_BYTES, s, keys1, keys, off, cursor2,
+                           n_regions, L.bb, b1);
+    }
 }
 void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
                                 uint32_t n_genomes, int bb, uint32_t *counts)
@@ -974,7 +1078,9 @@ hipError_t set_max_dynamic_lds()
     const int max_lds = 160 * 1024;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmer_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmer_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmer_scatter_l1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmer_scatter_l2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_dedup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;

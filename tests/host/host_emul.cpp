@@ -102,6 +102,26 @@ uint64_t emul_kmers(const uint64_t *sym2, const uint64_t *inv, uint64_t total_sy
     return n;
 }
 
+// same, through the 32-position iterator used by the two-level partition kernels
+uint64_t emul_kmers32(const uint64_t *sym2, const uint64_t *inv, uint64_t total_syms, int k, uint64_t *out, uint64_t cap)
+{
+    uint64_t n = 0;
+    const uint64_t n_half = (total_syms + 31) / 32;
+    for (uint64_t hg = 0; hg < n_half; hg++) {
+        const uint64_t p0 = hg << 5, grp = hg >> 1;
+        const int half = (int)(hg & 1);
+        const int64_t nv = (int64_t)total_syms - k + 1 - (int64_t)p0;
+        if (nv <= 0) break;
+        uint32_t valid = valid_starts32(inv[grp], inv[grp + 1], half, k);
+        if (nv < 32) valid &= (1u << nv) - 1;
+        uint64_t kv[32];
+        for_each_kmer32(sym2[hg], sym2[hg + 1], valid, k, [&](int i, uint64_t canon) { kv[i] = canon; });
+        for (int i = 0; i < 32; i++)
+            if ((valid >> i) & 1u) { if (n < cap) out[n] = kv[i]; n++; }
+    }
+    return n;
+}
+
 uint64_t emul_mix64(uint64_t x) { return mix64(x); }
 uint32_t emul_bucket(uint64_t h, int bb) { return hash_bucket(h, bb); }
 uint32_t emul_sub(uint64_t h, int bb, int sb) { return hash_sub(h, bb, sb); }

@@ -27,6 +27,8 @@ def emul():
     L.emul_parse.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     L.emul_kmers.restype = C.c_uint64
     L.emul_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
+    L.emul_kmers32.restype = C.c_uint64
+    L.emul_kmers32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
     L.emul_summarize.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64] + [C.POINTER(C.c_uint32)] * 3
     L.emul_valid_starts.restype = C.c_uint64
     L.emul_valid_starts.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
@@ -59,6 +61,9 @@ def extract(emul, files, k):
     out = np.zeros(cap, dtype=np.uint64)
     n = emul.emul_kmers(sym2.ctypes.data, inv.ctypes.data, nsym, k, out.ctypes.data, cap)
     assert n <= cap
+    out32 = np.zeros(cap, dtype=np.uint64)
+    n32 = emul.emul_kmers32(sym2.ctypes.data, inv.ctypes.data, nsym, k, out32.ctypes.data, cap)
+    assert n32 == n and (out32[:n] == out[:n]).all()      # 32-position iterator == 64-position iterator
     return raw, int(nsym), out[:n]
 
 
