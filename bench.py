@@ -27,7 +27,8 @@ ALGO_BYTES = {
     "parse_summarize": 1.0,          # per input byte: read 1
     "parse_pack": 1.0 + 0.375,       # per input byte: read 1, write 2+1 bits per symbol (<= byte count)
     "kmer_hist": 0.375,              # per symbol: read packed stream
-    "kmer_scatter": 0.375 + 8.0,     # per k-mer occurrence: read packed stream, write one u64 key
+    "kmer_scatter_l1": 0.375 + 8.0,  # per k-mer occurrence: read packed stream, write one u64 key
+    "kmer_scatter_l2": 16.0,         # per key: read 8, write 8 (second radix level)
     "bucket_dedup": 16.0,            # per key: read 8, write <= 8
     "dict_build": 8.0,               # per key: read 8 (dictionary output is U-sized, negligible)
     "matrix_fill": 8.0,              # per key: read 8 (+ rows x U x 8 written, added per launch below)

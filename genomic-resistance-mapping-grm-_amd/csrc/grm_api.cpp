@@ -586,9 +586,16 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         HIPCHK(c, b->d_cursor1.ensure(n_coarse * 4));
         HIPCHK(c, hipMemsetAsync(b->d_cursor1.p, 0, n_coarse * 4, s));
         if (b->bb > b1) HIPCHK(c, b->d_keys1.ensure((b->total_keys + 2) * 8));
-        TimeScope t(c, "kmer_scatter", b->total_keys);
-        launch_kmer_scatter(s, L, b->d_off.as<uint64_t>(), b->d_cursor1.as<uint32_t>(), b->d_cursor.as<uint32_t>(),
-                            b->d_keys1.as<uint64_t>(), b->d_keys.as<uint64_t>());
+        {
+            TimeScope t(c, "kmer_scatter_l1", b->total_keys);
+            launch_kmer_scatter_l1(s, L, b->d_off.as<uint64_t>(), b->d_cursor1.as<uint32_t>(),
+                                   b->bb > b1 ? b->d_keys1.as<uint64_t>() : b->d_keys.as<uint64_t>());
+        }
+        if (b->bb > b1) {
+            TimeScope t(c, "kmer_scatter_l2", b->total_keys);
+            launch_kmer_scatter_l2(s, L, b->d_off.as<uint64_t>(), b->d_cursor.as<uint32_t>(), b->d_keys1.as<uint64_t>(),
+                                   b->d_keys.as<uint64_t>());
+        }
     }
     HIPCHK(c, hipGetLastError());
 

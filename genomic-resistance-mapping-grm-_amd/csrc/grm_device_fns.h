@@ -100,17 +100,20 @@ GRM_HD uint32_t hash_sub(uint64_t h, int bb, int sb)
 GRM_HD uint32_t hash_slot(uint64_t h, uint32_t cap_mask) { return (uint32_t)(h ^ (h >> 29)) & cap_mask; }
 
 // ---- FASTA byte classification -------------------------------------------------------
+// 4-bit mask of the bytes of x that equal c (SWAR exact zero-byte test, then bit gather)
+GRM_HD uint32_t byte_eq_mask4(uint32_t x, uint32_t c)
+{
+    const uint32_t y = x ^ (c * 0x01010101u);
+    const uint32_t z = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);   // 0x80 in every zero byte
+    return (((z >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xfu;
+}
 // masks over one 16-byte chunk: bit j <=> byte j
 GRM_HD void chunk_masks(const uint32_t w[4], uint32_t &nl, uint32_t &gt, uint32_t &cr)
 {
-    nl = gt = cr = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        uint32_t b = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
-        nl |= (uint32_t)(b == '\n') << i;
-        gt |= (uint32_t)(b == '>') << i;
-        cr |= (uint32_t)(b == '\r') << i;
-    }
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    nl = byte_eq_mask4(w0, '\n') | (byte_eq_mask4(w1, '\n') << 4) | (byte_eq_mask4(w2, '\n') << 8) | (byte_eq_mask4(w3, '\n') << 12);
+    gt = byte_eq_mask4(w0, '>') | (byte_eq_mask4(w1, '>') << 4) | (byte_eq_mask4(w2, '>') << 8) | (byte_eq_mask4(w3, '>') << 12);
+    cr = byte_eq_mask4(w0, '\r') | (byte_eq_mask4(w1, '\r') << 4) | (byte_eq_mask4(w2, '\r') << 8) | (byte_eq_mask4(w3, '\r') << 12);
 }
 
 // type of the LAST line that starts inside the chunk (T_NONE if no line starts here).
@@ -122,7 +125,7 @@ GRM_HD int chunk_last_event(uint32_t ls, uint32_t gt)
     return ((gt >> pos) & 1u) ? T_HDR : T_SEQ;
 }
 
-// Walk the 16 bytes with incoming line type `cur`.
+// Classify the 16 bytes given the incoming line type `cur` (bit-parallel, branch-free).
 //   emit  : bit j <=> byte j yields a symbol (a base of a sequence line, or the '>' that
 //           opens a header line, which yields one separator)
 //   sep   : subset of emit that are separators
@@ -130,16 +133,87 @@ GRM_HD int chunk_last_event(uint32_t ls, uint32_t gt)
 GRM_HD void chunk_classify(uint32_t nl, uint32_t gt, uint32_t cr, uint32_t ls, int cur,
                            uint32_t &emit, uint32_t &sep, uint32_t &unk)
 {
-    emit = sep = unk = 0;
+    const uint32_t hs = ls & gt;                    // header-line starts
+    const uint32_t ss = ls & ~gt;                   // sequence-line starts
+    // flood every sequence-line start upward until the next line start (Kogge-Stone fill)
+    uint32_t fill = ss, prop = ~ls;
+    fill |= (fill << 1) & prop; prop &= prop << 1;
+    fill |= (fill << 2) & prop; prop &= prop << 2;
+    fill |= (fill << 4) & prop; prop &= prop << 4;
+    fill |= (fill << 8) & prop;
+    const uint32_t first = ls ? (ls & (0u - ls)) : 0x10000u;
+    const uint32_t prefix = first - 1;              // bytes before the first line start of the chunk
+    const uint32_t plain = ~(nl | cr) & 0xffffu;
+    sep = hs;
+    emit = (hs | (plain & fill) | (cur == T_SEQ ? (plain & prefix) : 0u)) & 0xffffu;
+    unk = cur == T_NONE ? (plain & prefix) : 0u;
+}
+
+// ---- associative summary of a byte range (one scan per tile) ---------------------------
+// element = (ev, cs, ch): type of the last line starting in the range (0 = none), symbols the
+// range emits when the line running into it is a sequence line (cs) / a header line (ch).
+// Packed: ev bits 60-61, cs bits 30-59, ch bits 0-29.  combine(a, b) = summary of "a then b".
+GRM_HD uint64_t pelem_make(int ev, uint32_t cs, uint32_t ch)
+{
+    return ((uint64_t)ev << 60) | ((uint64_t)cs << 30) | (uint64_t)ch;
+}
+GRM_HD int pelem_ev(uint64_t e) { return (int)(e >> 60); }
+GRM_HD uint32_t pelem_cs(uint64_t e) { return (uint32_t)(e >> 30) & 0x3fffffffu; }
+GRM_HD uint32_t pelem_ch(uint64_t e) { return (uint32_t)e & 0x3fffffffu; }
+GRM_HD uint64_t pelem_combine(uint64_t a, uint64_t b)
+{
+    const int ea = pelem_ev(a), eb = pelem_ev(b);
+    const uint32_t b_after_seq = pelem_cs(b), b_after_hdr = pelem_ch(b);
+    // line type running into b: a's last line start if it has one, else what ran into a
+    const uint32_t cs = pelem_cs(a) + ((ea ? ea : T_SEQ) == T_SEQ ? b_after_seq : b_after_hdr);
+    const uint32_t ch = pelem_ch(a) + ((ea ? ea : T_HDR) == T_SEQ ? b_after_seq : b_after_hdr);
+    return pelem_make(eb ? eb : ea, cs, ch);
+}
+
+// the emitted symbols of one 16-byte chunk as bit strings: returns the count (0..16);
+// sym: 2 bits per symbol, first symbol most significant, in the low 2*count bits;
+// inv: bit i = symbol i is a separator / bad base.
+GRM_HD int chunk_pack(const uint32_t w[4], uint32_t emit, uint32_t sep, uint32_t &sym, uint32_t &inv)
+{
+    sym = 0; inv = 0;
+    int n = 0;
+    uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32), hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        uint32_t bit = 1u << j;
-        if (ls & bit) cur = (gt & bit) ? T_HDR : T_SEQ;
-        bool plain = !((nl | cr) & bit);
-        if ((ls & gt) & bit) { emit |= bit; sep |= bit; }
-        else if (plain && cur == T_SEQ) emit |= bit;
-        else if (plain && cur == T_NONE) unk |= bit;
+        const uint32_t b = (uint32_t)lo & 0xffu;          // byte j (no indexed access: stays in registers)
+        lo = (lo >> 8) | (hi << 56);
+        hi >>= 8;
+        if ((emit >> j) & 1u) {
+            uint32_t code = (b >> 1) & 3u, bad = (b >> 3) & 1u;
+            if ((sep >> j) & 1u) { code = 0; bad = 1; }
+            sym = (sym << 2) | code;
+            inv |= bad << n;
+            n++;
+        }
     }
+    return n;
+}
+
+// OR `cnt` symbols (bit strings as produced by chunk_pack) into a packed stream at symbol
+// position pos: sym words are MSB-first (32 symbols per uint64), inv words LSB-first (64 per
+// uint64).  or_sym(word_index, value) / or_inv(word_index, value) perform the OR (an LDS atomic
+// on the device, a plain |= in the host emulation).
+template <typename OS, typename OI>
+GRM_HD void stream_insert(uint32_t pos, int cnt, uint32_t sym, uint32_t inv, OS &&or_sym, OI &&or_inv)
+{
+    if (cnt == 0) return;
+    const uint32_t w = pos >> 5, o = pos & 31u;
+    const int first = (int)(32u - o) < cnt ? (int)(32u - o) : cnt;     // symbols that fit into word w
+    const int rest = cnt - first;
+    const uint64_t part1 = (uint64_t)(sym >> (2 * rest));              // top `first` symbols
+    or_sym(w, part1 << (64 - 2 * (int)o - 2 * first));
+    if (rest) {
+        const uint64_t part2 = (uint64_t)sym & ((1ull << (2 * rest)) - 1);
+        or_sym(w + 1, part2 << (64 - 2 * rest));
+    }
+    const uint32_t wi = pos >> 6, oi = pos & 63u;
+    or_inv(wi, (uint64_t)inv << oi);
+    if (oi + (uint32_t)cnt > 64u) or_inv(wi + 1, (uint64_t)inv >> (64 - oi));
 }
 
 // ---- k-mer windows of one 64-symbol group ------------------------------------------

@@ -51,8 +51,9 @@ void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, cons
                        const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv);
 void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
 int scatter_b1_bits(int bb);
-void launch_kmer_scatter(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, uint32_t *cursor2,
-                         uint64_t *keys1, uint64_t *keys);
+void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, uint64_t *out);
+void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor2, const uint64_t *keys1,
+                            uint64_t *keys);
 void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
                                 uint32_t n_genomes, int bb, uint32_t *counts);
 void launch_keys_partition_scatter(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,

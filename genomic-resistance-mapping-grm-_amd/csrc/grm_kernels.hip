@@ -106,55 +106,98 @@ __device__ __forceinline__ uint64_t block_scan_sum64(uint64_t v, uint64_t *scrat
 // Every other line emits each byte except '\n' / '\r' as a symbol:
 // code (c>>1)&3, inv bit (c>>3)&1  (SURVEY 8(c)(1),(3)).
 // ------------------------------------------------------------------------------------
-struct RoundState {
-    uint32_t nl, gt, cr, ls;
-    uint32_t w[4];
+// Per tile: every thread owns one 16-byte chunk in each of the 4 rounds (all four loads are
+// issued up front).  A chunk is summarised by an element (last line-start type, symbols if the
+// incoming line is a sequence line, symbols if it is a header line); pelem_combine is
+// associative, so ONE block scan in (round, thread) order gives every chunk its incoming line
+// type and its symbol offset for both possible tile in-states.
+struct TileChunks {
+    uint32_t w[ROUNDS_PER_TILE][4];
+    uint32_t ek[ROUNDS_PER_TILE], sep[ROUNDS_PER_TILE], unk[ROUNDS_PER_TILE];
+    uint64_t pre[ROUNDS_PER_TILE];     // exclusive prefix element of the chunk within the tile
+    uint64_t total;                    // element of the whole tile
 };
 
-__device__ __forceinline__ void load_round(const uint8_t *raw, uint64_t byte_base, RoundState &rs)
+template <int R>
+__device__ __forceinline__ void tile_round(const uint4 &v, uint32_t edge, int lane, TileChunks &tc, uint64_t &elem)
 {
-    const uint4 v = *reinterpret_cast<const uint4 *>(raw + byte_base);
-    rs.w[0] = v.x; rs.w[1] = v.y; rs.w[2] = v.z; rs.w[3] = v.w;
-    chunk_masks(rs.w, rs.nl, rs.gt, rs.cr);
-    const uint32_t prev_nl = raw[(int64_t)byte_base - 1] == '\n';
-    rs.ls = ((rs.nl << 1) | prev_nl) & 0xffffu;
+    tc.w[R][0] = v.x; tc.w[R][1] = v.y; tc.w[R][2] = v.z; tc.w[R][3] = v.w;
+    uint32_t nl, gt, cr;
+    chunk_masks(tc.w[R], nl, gt, cr);
+    const uint32_t up = __shfl_up((nl >> 15) & 1u, 1);
+    const uint32_t prev_nl = lane == 0 ? edge : up;
+    const uint32_t ls = ((nl << 1) | prev_nl) & 0xffffu;
+    uint32_t ek, sep, unk;
+    chunk_classify(nl, gt, cr, ls, T_NONE, ek, sep, unk);
+    tc.ek[R] = ek; tc.sep[R] = sep; tc.unk[R] = unk;
+    elem = pelem_make(chunk_last_event(ls, gt), __popc(ek) + __popc(unk), __popc(ek));
 }
 
-// P1: per tile -> {symbols that depend on the incoming line type, symbols that do not,
-//                  type of the last line that starts inside the tile}
+__device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint32_t tile, uint64_t *partial /* LDS [16] */,
+                                          TileChunks &tc)
+{
+    const int lane = lane_id(), wave = wave_id();
+    uint4 v[ROUNDS_PER_TILE];
+    uint32_t edge[ROUNDS_PER_TILE];
+#pragma unroll
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
+        v[r] = *reinterpret_cast<const uint4 *>(raw + base);
+        edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;   // lanes > 0 ask their neighbour
+    }
+    uint64_t inc[ROUNDS_PER_TILE];
+    tile_round<0>(v[0], edge[0], lane, tc, inc[0]);
+    tile_round<1>(v[1], edge[1], lane, tc, inc[1]);
+    tile_round<2>(v[2], edge[2], lane, tc, inc[2]);
+    tile_round<3>(v[3], edge[3], lane, tc, inc[3]);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+            const uint64_t o = __shfl_up(inc[r], d);
+            if (lane >= d) inc[r] = pelem_combine(o, inc[r]);
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS_PER_TILE; r++) partial[r * (PARSE_THREADS / 64) + wave] = inc[r];
+    }
+    __syncthreads();
+    // prefix of this (round, wave) over the 16 wave partials, kept in scalars (no indexed array)
+    static_assert(ROUNDS_PER_TILE == 4 && PARSE_THREADS == 256, "tile_scan assumes 4 rounds x 4 waves");
+    uint64_t acc = pelem_make(0, 0, 0);
+    uint64_t wp0 = acc, wp1 = acc, wp2 = acc, wp3 = acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i == wave) wp0 = acc;
+        if (i == 4 + wave) wp1 = acc;
+        if (i == 8 + wave) wp2 = acc;
+        if (i == 12 + wave) wp3 = acc;
+        acc = pelem_combine(acc, partial[i]);
+    }
+    tc.total = acc;
+    uint64_t e0 = __shfl_up(inc[0], 1), e1 = __shfl_up(inc[1], 1), e2 = __shfl_up(inc[2], 1), e3 = __shfl_up(inc[3], 1);
+    if (lane == 0) e0 = e1 = e2 = e3 = pelem_make(0, 0, 0);
+    tc.pre[0] = pelem_combine(wp0, e0);
+    tc.pre[1] = pelem_combine(wp1, e1);
+    tc.pre[2] = pelem_combine(wp2, e2);
+    tc.pre[3] = pelem_combine(wp3, e3);
+}
+
+// P1: per tile -> {symbols emitted for either incoming line type, type of the last line start}
 __global__ __launch_bounds__(PARSE_THREADS) void parse_summarize_kernel(
     const uint8_t *__restrict__ raw, uint32_t n_tiles, TileSummary *__restrict__ sums)
 {
-    __shared__ int scratch_i[16];
-    __shared__ uint32_t acc[2];
+    __shared__ uint64_t partial[ROUNDS_PER_TILE * (PARSE_THREADS / 64)];
     const uint32_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
-    if (threadIdx.x < 2) acc[threadIdx.x] = 0;
-    __syncthreads();
-    int carry = T_NONE;
-    uint32_t my_unk = 0, my_known = 0;
-    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-        RoundState rs;
-        load_round(raw, (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u, rs);
-        int ev = chunk_last_event(rs.ls, rs.gt);
-        int block_last;
-        int cin = block_scan_last_nonzero(ev, scratch_i, &block_last);
-        if (!cin) cin = carry;
-        uint32_t emit, sep, unk;
-        chunk_classify(rs.nl, rs.gt, rs.cr, rs.ls, cin, emit, sep, unk);
-        my_known += __popc(emit);
-        my_unk += __popc(unk);
-        if (block_last) carry = block_last;
-    }
-    // block reduce through LDS atomics (two counters, once per thread)
-    if (my_known) atomicAdd(&acc[0], my_known);
-    if (my_unk) atomicAdd(&acc[1], my_unk);
-    __syncthreads();
+    TileChunks tc;
+    tile_scan(raw, tile, partial, tc);
     if (threadIdx.x == 0) {
         TileSummary s;
-        s.known = acc[0];
-        s.unknown = acc[1];
-        s.last_event = (uint32_t)carry;
+        s.known = pelem_ch(tc.total);                          // emitted whatever runs into the tile
+        s.unknown = pelem_cs(tc.total) - pelem_ch(tc.total);   // only if a sequence line runs into it
+        s.last_event = (uint32_t)pelem_ev(tc.total);
         sums[tile] = s;
     }
 }
@@ -203,74 +246,57 @@ __global__ __launch_bounds__(1024) void parse_scan_kernel(
         genome_sym_off[g] = tile_off[genome_tile_off[g]];
 }
 
-// P2: re-classify with the known incoming type, compact the symbols of each 4-KiB round
-// in LDS, then pack 64 symbols per wave step with three ballots (wave64):
-// ballot(code bit0), ballot(code bit1), ballot(inv).
+// P2: same tile scan, now with the tile's incoming line type and first symbol index known.
+// Every chunk packs its symbols into two small bit strings and ORs them into the tile's
+// LDS image of the packed stream (ds_or_b64); the image is then stored with coalesced writes.
+// Groups shared with a neighbouring tile go out through global atomicOr (buffers pre-zeroed).
 __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
     const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint64_t *__restrict__ tile_off,
     const uint8_t *__restrict__ tile_state, uint64_t *__restrict__ sym2, uint64_t *__restrict__ inv)
 {
-    __shared__ int scratch_i[16];
-    __shared__ uint32_t scratch_u[16];
-    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE_BYTES];
+    constexpr int MAX_GROUPS = TILE_BYTES / 64 + 2;
+    __shared__ uint64_t partial[ROUNDS_PER_TILE * (PARSE_THREADS / 64)];
+    __shared__ uint64_t w2[2 * MAX_GROUPS];
+    __shared__ uint64_t wi[MAX_GROUPS];
     const uint32_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
-    int carry = (int)tile_state[tile];
-    uint64_t sym_base = tile_off[tile];
-    const int lane = lane_id(), wave = wave_id();
-
-    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-        RoundState rs;
-        load_round(raw, (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u, rs);
-        int ev = chunk_last_event(rs.ls, rs.gt);
-        int block_last;
-        int cin = block_scan_last_nonzero(ev, scratch_i, &block_last);
-        if (!cin) cin = carry;
-        if (cin == T_NONE) cin = T_SEQ;     // only possible before the first line start of the buffer
-        uint32_t emit, sep, unk;
-        chunk_classify(rs.nl, rs.gt, rs.cr, rs.ls, cin, emit, sep, unk);
-        uint32_t round_total;
-        uint32_t local = block_scan_sum((uint32_t)__popc(emit), scratch_u, &round_total);
-
-        // zero the staging area (bytes outside [lead, lead+round_total) must read as 0)
-        for (int i = threadIdx.x; i < STAGE_BYTES / 4; i += PARSE_THREADS)
-            reinterpret_cast<uint32_t *>(stage)[i] = 0;
-        __syncthreads();
-        const uint32_t lead = (uint32_t)(sym_base & 63ull);
-        uint32_t pos = lead + local;
+    for (int i = threadIdx.x; i < 2 * MAX_GROUPS; i += PARSE_THREADS) w2[i] = 0;
+    for (int i = threadIdx.x; i < MAX_GROUPS; i += PARSE_THREADS) wi[i] = 0;
+    TileChunks tc;
+    tile_scan(raw, tile, partial, tc);                 // its barrier also orders the zeroing above
+    int state = (int)tile_state[tile];
+    if (state == T_NONE) state = T_SEQ;                // only before the first line start of the buffer
+    const uint64_t sym_base = tile_off[tile];
+    const uint32_t lead = (uint32_t)(sym_base & 63ull);
+    const uint32_t n_tile = state == T_SEQ ? pelem_cs(tc.total) : pelem_ch(tc.total);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if ((emit >> j) & 1u) {
-                uint32_t b = (rs.w[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                uint32_t code = (b >> 1) & 3u, bad = (b >> 3) & 1u;
-                if ((sep >> j) & 1u) { code = 0; bad = 1; }
-                stage[pos++] = (uint8_t)(code | (bad << 2));
-            }
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        const int ev = pelem_ev(tc.pre[r]);
+        const int cin = ev ? ev : state;
+        const uint32_t emit = tc.ek[r] | (cin == T_SEQ ? tc.unk[r] : 0u);
+        uint32_t cs, ci;
+        const int cnt = chunk_pack(tc.w[r], emit, tc.sep[r], cs, ci);
+        const uint32_t pos = lead + (state == T_SEQ ? pelem_cs(tc.pre[r]) : pelem_ch(tc.pre[r]));
+        stream_insert(pos, cnt, cs, ci,
+                      [&](uint32_t i, uint64_t val) { atomicOr((unsigned long long *)&w2[i], (unsigned long long)val); },
+                      [&](uint32_t i, uint64_t val) { atomicOr((unsigned long long *)&wi[i], (unsigned long long)val); });
+    }
+    __syncthreads();
+    const uint32_t span = lead + n_tile;
+    const uint32_t n_groups = (span + 63) >> 6;
+    const uint64_t g_base = sym_base >> 6;
+    for (uint32_t g = threadIdx.x; g < n_groups; g += PARSE_THREADS) {
+        const uint64_t a0 = w2[2 * g], a1 = w2[2 * g + 1], bi = wi[g];
+        const uint64_t G = g_base + g;
+        const bool full = (g > 0 || lead == 0) && ((g + 1) * 64 <= span);
+        if (full) {
+            *reinterpret_cast<ulonglong2 *>(&sym2[2 * G]) = make_ulonglong2(a0, a1);
+            inv[G] = bi;
+        } else {
+            if (a0) atomicOr((unsigned long long *)&sym2[2 * G], (unsigned long long)a0);
+            if (a1) atomicOr((unsigned long long *)&sym2[2 * G + 1], (unsigned long long)a1);
+            if (bi) atomicOr((unsigned long long *)&inv[G], (unsigned long long)bi);
         }
-        __syncthreads();
-        const uint32_t span = lead + round_total;
-        const uint32_t n_groups = (span + 63) >> 6;
-        const uint64_t g_base = sym_base >> 6;
-        for (uint32_t g = wave; g < n_groups; g += PARSE_THREADS / 64) {
-            const uint32_t c = stage[g * 64 + lane];
-            const uint64_t b0 = __ballot(c & 1u), b1 = __ballot(c & 2u), bi = __ballot(c & 4u);
-            if (lane == 0) {
-                const uint64_t w0 = pack32_msb_first((uint32_t)b0, (uint32_t)b1);
-                const uint64_t w1 = pack32_msb_first((uint32_t)(b0 >> 32), (uint32_t)(b1 >> 32));
-                const uint64_t G = g_base + g;
-                const bool full = (g > 0 || lead == 0) && ((g + 1) * 64 <= span);
-                if (full) {
-                    sym2[2 * G] = w0; sym2[2 * G + 1] = w1; inv[G] = bi;
-                } else {   // group shared with a neighbouring round / tile: buffers are pre-zeroed
-                    if (w0) atomicOr((unsigned long long *)&sym2[2 * G], (unsigned long long)w0);
-                    if (w1) atomicOr((unsigned long long *)&sym2[2 * G + 1], (unsigned long long)w1);
-                    if (bi) atomicOr((unsigned long long *)&inv[G], (unsigned long long)bi);
-                }
-            }
-        }
-        __syncthreads();
-        sym_base += round_total;
-        if (block_last) carry = block_last;
     }
 }
 
@@ -956,23 +982,25 @@ void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts)
 }
 int scatter_b1_bits(int bb) { return bb < L1_MAX_BITS ? bb : L1_MAX_BITS; }
 
-// keys1: level-1 output (== final keys when bb <= L1_MAX_BITS, then cursor2 / keys are unused)
-void launch_kmer_scatter(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, uint32_t *cursor2,
-                         uint64_t *keys1, uint64_t *keys)
+// level 1 writes `out` = keys1 when a second level follows, else the final keys
+void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, uint64_t *out)
 {
     KmerArgs a = make_args(L);
     if (a.total_syms == 0) return;
-    const int b1 = scatter_b1_bits(L.bb);
     const uint32_t n_tiles = (uint32_t)((a.total_syms + L1_TILE - 1) / L1_TILE);
     const uint32_t grid = ((n_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(kmer_scatter_l1_kernel, dim3(grid), dim3(L1_THREADS), L1_LDS_BYTES, s, a, b1, n_tiles, off, cursor1,
-                       L.bb > b1 ? keys1 : keys);
-    if (L.bb > b1) {
-        const uint64_t n_regions = (uint64_t)L.n_genomes << b1;
-        const uint32_t grid2 = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
-        hipLaunchKernelGGL(kmer_scatter_l2_kernel, dim3(grid2), dim3(L1_THREADS), L1_LDS_BYTES, s, keys1, keys, off, cursor2,
-                           n_regions, L.bb, b1);
-    }
+    hipLaunchKernelGGL(kmer_scatter_l1_kernel, dim3(grid), dim3(L1_THREADS), L1_LDS_BYTES, s, a, scatter_b1_bits(L.bb), n_tiles,
+                       off, cursor1, out);
+}
+void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor2, const uint64_t *keys1,
+                            uint64_t *keys)
+{
+    const int b1 = scatter_b1_bits(L.bb);
+    if (L.total_syms == 0 || L.bb <= b1) return;
+    const uint64_t n_regions = (uint64_t)L.n_genomes << b1;
+    const uint32_t grid2 = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
+    hipLaunchKernelGGL(kmer_scatter_l2_kernel, dim3(grid2), dim3(L1_THREADS), L1_LDS_BYTES, s, keys1, keys, off, cursor2,
+                       n_regions, L.bb, b1);
 }
 void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
                                 uint32_t n_genomes, int bb, uint32_t *counts)

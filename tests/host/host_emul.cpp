@@ -60,6 +60,59 @@ uint64_t emul_parse(const uint8_t *raw, uint64_t n_bytes, uint64_t *sym2, uint64
     return nsym;
 }
 
+// The restructured parse path (parse_summarize2 / parse_pack2): per-chunk elements combined with
+// pelem_combine, bit strings inserted with stream_insert.  tile_bytes = scan granularity.
+uint64_t emul_parse2(const uint8_t *raw, uint64_t n_bytes, uint64_t tile_bytes, uint64_t *sym2, uint64_t *inv, uint64_t n_groups_cap)
+{
+    std::memset(sym2, 0, n_groups_cap * 16);
+    std::memset(inv, 0, n_groups_cap * 8);
+    // pass 1: tile summaries
+    const uint64_t n_tiles = n_bytes / tile_bytes;
+    std::vector<uint64_t> tsum(n_tiles);
+    auto chunk_elem = [&](uint64_t base, uint32_t w[4], uint32_t &nl, uint32_t &gt, uint32_t &cr, uint32_t &ls, uint32_t &ek, uint32_t &sep, uint32_t &unk) {
+        std::memcpy(w, raw + base, 16);
+        chunk_masks(w, nl, gt, cr);
+        uint32_t prev_nl = base == 0 ? 1u : (raw[base - 1] == '\n');
+        ls = ((nl << 1) | prev_nl) & 0xffffu;
+        chunk_classify(nl, gt, cr, ls, T_NONE, ek, sep, unk);
+        return pelem_make(chunk_last_event(ls, gt), __builtin_popcount(ek) + __builtin_popcount(unk), __builtin_popcount(ek));
+    };
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        uint64_t acc = pelem_make(0, 0, 0);
+        for (uint64_t base = t * tile_bytes; base < (t + 1) * tile_bytes; base += 16) {
+            uint32_t w[4], nl, gt, cr, ls, ek, sep, unk;
+            acc = pelem_combine(acc, chunk_elem(base, w, nl, gt, cr, ls, ek, sep, unk));
+        }
+        tsum[t] = acc;
+    }
+    // pass 2: tile scan -> (state, offset); pass 3: pack
+    int state = T_SEQ;
+    uint64_t off = 0;
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        uint64_t pre = pelem_make(0, 0, 0);
+        for (uint64_t base = t * tile_bytes; base < (t + 1) * tile_bytes; base += 16) {
+            uint32_t w[4], nl, gt, cr, ls, ek, sep, unk;
+            uint64_t e = chunk_elem(base, w, nl, gt, cr, ls, ek, sep, unk);
+            const int cin = pelem_ev(pre) ? pelem_ev(pre) : state;
+            const uint32_t emit = ek | (cin == T_SEQ ? unk : 0u);
+            uint32_t cs, ci;
+            const int cnt = chunk_pack(w, emit, sep, cs, ci);
+            const uint64_t pos = off + (state == T_SEQ ? pelem_cs(pre) : pelem_ch(pre));
+            // the device inserts relative to a 64-aligned tile base; absolute positions here
+            const uint64_t wbase = (pos >> 6) << 6;
+            stream_insert((uint32_t)(pos - wbase), cnt, cs, ci,
+                          [&](uint32_t wi, uint64_t v) { if ((wbase >> 5) + wi < n_groups_cap * 2) sym2[(wbase >> 5) + wi] |= v; },
+                          [&](uint32_t wi, uint64_t v) { if ((wbase >> 6) + wi < n_groups_cap) inv[(wbase >> 6) + wi] |= v; });
+            pre = pelem_combine(pre, e);
+        }
+        off += state == T_SEQ ? pelem_cs(tsum[t]) : pelem_ch(tsum[t]);
+        if (pelem_ev(tsum[t])) state = pelem_ev(tsum[t]);
+        // the scanned prefix of the whole tile must equal its summary
+        if (pre != tsum[t]) return ~0ull;
+    }
+    return off;
+}
+
 // the tile-summary path: counts symbols of [t0,t1) bytes the way parse_summarize does
 // (known / unknown / last_event), for checking the in-state algebra.
 void emul_summarize(const uint8_t *raw, uint64_t t0, uint64_t t1, uint32_t *known, uint32_t *unknown, uint32_t *last_event)

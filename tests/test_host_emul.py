@@ -27,6 +27,8 @@ def emul():
     L.emul_parse.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     L.emul_kmers.restype = C.c_uint64
     L.emul_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
+    L.emul_parse2.restype = C.c_uint64
+    L.emul_parse2.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     L.emul_kmers32.restype = C.c_uint64
     L.emul_kmers32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
     L.emul_summarize.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64] + [C.POINTER(C.c_uint32)] * 3
@@ -57,6 +59,12 @@ def extract(emul, files, k):
     sym2 = np.zeros(2 * ng, dtype=np.uint64)
     inv = np.zeros(ng, dtype=np.uint64)
     nsym = emul.emul_parse(raw.ctypes.data, len(raw), sym2.ctypes.data, inv.ctypes.data, ng)
+    # restructured parse path (associative tile scan + bit-string insertion): identical stream
+    for tile_bytes in (TILE, 256):
+        s2 = np.zeros(2 * ng, dtype=np.uint64)
+        i2 = np.zeros(ng, dtype=np.uint64)
+        n2 = emul.emul_parse2(raw.ctypes.data, len(raw), tile_bytes, s2.ctypes.data, i2.ctypes.data, ng)
+        assert n2 == nsym and (s2 == sym2).all() and (i2 == inv).all()
     cap = max(1, int(nsym))
     out = np.zeros(cap, dtype=np.uint64)
     n = emul.emul_kmers(sym2.ctypes.data, inv.ctypes.data, nsym, k, out.ctypes.data, cap)
