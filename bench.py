@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--abundance-min", type=int, default=1)
     ap.add_argument("--keep-singletons", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24, help="genomes in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--opt", action="append", default=[], help="engine tuning knob name=value (grm_set_option)")
     args = ap.parse_args()
 
     import numpy as np
@@ -70,6 +71,9 @@ def main():
     # ---- synthetic inputs: generate, hand to the engine, upload once (resident in HBM) ----
     t0 = time.time()
     ctx = grm_amd.Context(local_rank)
+    for kv in args.opt:
+        name, val = kv.split("=")
+        ctx.set_option(name, int(val))
     batch = ctx.batch(args.genomes)
     base = rank * args.genomes
     if args.mode == "P":

@@ -82,22 +82,35 @@ GRM_HD uint64_t pack32_msb_first(uint32_t b0, uint32_t b1)
     return spread32(brev32(b0)) | (spread32(brev32(b1)) << 1);
 }
 
-// 64-bit mixer used for bucket selection and LDS slots.  Bijective (odd multiplies,
-// xor-shift), so distinct k-mers never alias before the final masking.
+// Hash used for bucket selection and LDS slots.  It only has to spread k-mers evenly (tables
+// compare full keys), so it is built from FULL-RATE 24-bit multiplies (v_mul_u32_u24): a 64-bit
+// multiply costs ~4 quarter-rate 32-bit multiplies on CDNA and the hash is evaluated for every
+// k-mer occurrence in five kernels.  Product bit j depends on operand bits 0..j, so the TOP bits
+// of each 24x24 product depend on all 24 input bits: the bucket (top bits of h32) sees the whole key.
+GRM_HD uint32_t mul24(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (uint32_t)((uint64_t)(a & 0xffffffu) * (uint64_t)(b & 0xffffffu));
+#endif
+}
+// returns (h32 << 32) | slot_bits : bucket / sub-bucket come from the top of h32
 GRM_HD uint64_t mix64(uint64_t x)
 {
-    x *= 0x9E3779B97F4A7C15ull;
-    x ^= x >> 32;
-    x *= 0xD6E8FEB86659FD93ull;
-    return x;
+    const uint32_t a = (uint32_t)x & 0xffffffu, b = (uint32_t)(x >> 24) & 0xffffffu, c = (uint32_t)(x >> 48);
+    const uint32_t t = mul24(c, 0xC2B2AFu);
+    const uint32_t h32 = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + t + (t << 16);
+    const uint32_t low = mul24(h32 ^ (h32 >> 12), 0xD6E8FFu) ^ (h32 >> 7);
+    return ((uint64_t)h32 << 32) | low;
 }
-// radix bucket: top `bb` bits; sub-bucket: the next `sb` bits; slot bits: folded rest
+// radix bucket: top `bb` bits; sub-bucket: the next `sb` bits (bb + sb <= 24); slot: low word
 GRM_HD uint32_t hash_bucket(uint64_t h, int bb) { return bb ? (uint32_t)(h >> (64 - bb)) : 0u; }
 GRM_HD uint32_t hash_sub(uint64_t h, int bb, int sb)
 {
     return sb ? (uint32_t)((h << bb) >> (64 - sb)) : 0u;
 }
-GRM_HD uint32_t hash_slot(uint64_t h, uint32_t cap_mask) { return (uint32_t)(h ^ (h >> 29)) & cap_mask; }
+GRM_HD uint32_t hash_slot(uint64_t h, uint32_t cap_mask) { return (uint32_t)h & cap_mask; }
 
 // ---- FASTA byte classification -------------------------------------------------------
 // 4-bit mask of the bytes of x that equal c (SWAR exact zero-byte test, then bit gather)

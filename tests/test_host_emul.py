@@ -143,10 +143,32 @@ def test_revcomp_and_mix_bijective(emul):
             for ch in r:
                 w = (w << 2) | ((ord(ch) >> 1) & 3)
             assert emul.emul_revcomp(v, m) == w
-    xs = rng.randint(0, 2**62, size=20000, dtype=np.int64).astype(np.uint64)
-    hs = np.array([emul.emul_mix64(int(x)) for x in xs], dtype=np.uint64)
-    assert len(np.unique(hs)) == len(np.unique(xs))
-    # top-bit buckets are balanced
-    b = (hs >> np.uint64(64 - 6)).astype(np.int64)
-    cnt = np.bincount(b, minlength=64)
-    assert cnt.min() > 0.6 * cnt.mean() and cnt.max() < 1.4 * cnt.mean()
+
+
+def _hashes(emul, keys):
+    return np.array([emul.emul_mix64(int(x)) for x in keys], dtype=np.uint64)
+
+
+def test_hash_balance(emul):
+    """bucket (top 13 bits) and LDS slot (low 12 bits) spread for random keys AND for the
+    canonical k-mers of a genome-like sequence (consecutive, overlapping windows)"""
+    rng = np.random.RandomState(12)
+    rand = rng.randint(0, 2**62, size=60000, dtype=np.int64).astype(np.uint64)
+    seq = cases.rand_seq(rng, 60000)
+    _, _, walk = extract(emul, [(">g\n" + seq + "\n").encode()], 31)
+    lowc = ("ACGT" * 20 + "A" * 40 + cases.rand_seq(rng, 200)) * 150          # repeats / low complexity
+    _, _, rep = extract(emul, [(">g\n" + lowc + "\n").encode()], 31)
+    for name, keys in (("random", rand), ("genome walk", np.unique(walk)), ("repeats", np.unique(rep))):
+        hs = _hashes(emul, keys)
+        nb = 256 if len(keys) > 20000 else 16
+        b = (hs >> np.uint64(64 - int(np.log2(nb)))).astype(np.int64)
+        cnt = np.bincount(b, minlength=nb)
+        tol = 5 * np.sqrt(cnt.mean())                     # Poisson spread of an ideal hash
+        assert cnt.max() < cnt.mean() + tol and cnt.min() > cnt.mean() - tol, (name, cnt.min(), cnt.mean(), cnt.max())
+        # inside one bucket the slot bits must not cluster: expected distinct slots ~ m(1-exp(-n/m))
+        top = (hs >> np.uint64(64 - 4)).astype(np.int64)
+        sel = hs[top == 3]
+        slots = (sel & np.uint64(4095)).astype(np.int64)
+        n, m = len(sel), 4096
+        expect = m * (1 - np.exp(-n / m))
+        assert len(np.unique(slots)) > 0.9 * expect, (name, len(np.unique(slots)), expect)
