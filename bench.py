@@ -30,8 +30,8 @@ ALGO_BYTES = {
     "kmer_scatter_l1": 0.375 + 8.0,  # per k-mer occurrence: read packed stream, write one u64 key
     "kmer_scatter_l2": 16.0,         # per key: read 8, write 8 (second radix level)
     "bucket_dedup": 16.0,            # per key: read 8, write <= 8
-    "dict_build": 8.0,               # per key: read 8 (dictionary output is U-sized, negligible)
-    "matrix_fill": 8.0,              # per key: read 8 (+ rows x U x 8 written, added per launch below)
+    "dict_build": 8.0 + 2.0,         # per key: read 8, write the 2-byte slot id (dictionary output is U-sized)
+    "matrix_fill": 2.0,              # per key: read the 2-byte slot id (+ rows x U x 8 written, added per launch below)
 }
 
 

@@ -41,6 +41,7 @@ struct grm_ctx {
     int opt_bucket_bits = -1;
     int opt_cap_log2 = -1;
     int opt_sub_bits = -1;
+    int opt_no_slots = -1;      // > 0: force the probing form of the fill (tests)
 };
 
 static int fail(grm_ctx *c, int code, const char *fmt, ...)
@@ -150,6 +151,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "bucket_bits") c->opt_bucket_bits = value;
     else if (n == "cap_log2") c->opt_cap_log2 = value;
     else if (n == "sub_bits") c->opt_sub_bits = value;
+    else if (n == "no_slots") c->opt_no_slots = value;
     else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
     return GRM_OK;
 }
@@ -355,7 +357,11 @@ struct grm_batch {
     uint64_t n_local = 0;
     DevBuf d_dict;                 // sorted, filtered global dictionary (U)
     uint64_t n_dict = 0;
-    DevBuf d_dkeys, d_dcol, d_seg_start;   // bucketised view for matrix_fill
+    DevBuf d_dkeys, d_dcol, d_seg_start;   // bucketised view for matrix_fill (probing form)
+    // slot form: dict_build leaves a slot id per key + an image of every table; the fill then
+    // needs neither keys nor probes (used whenever sub id + slot id fit 16 bits)
+    DevBuf d_kslot, d_table_img, d_col_of_slot;
+    bool have_slots = false, fill_by_slots = false;
     int filter_singleton = 0;
     // scratch that survives between steps (grow-only)
     DevBuf t_flag, t_stage_keys, t_stage_flags, t_stage_cnt, t_stage_off;
@@ -557,7 +563,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     L.n_genomes = G;
     L.k = k;
     L.bb = b->bb;
-    L.groups_per_thread = c->opt_groups_per_thread > 0 ? (uint32_t)c->opt_groups_per_thread : 16u;
+    L.groups_per_thread = c->opt_groups_per_thread > 0 ? (uint32_t)c->opt_groups_per_thread : 4u;
 
     HIPCHK(c, b->d_counts.ensure((n_seg + 1) * 4));
     HIPCHK(c, b->d_cursor.ensure(n_seg * 4));
@@ -649,6 +655,7 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     b->have_local = b->have_global = false;
+    b->have_slots = false;
     const uint32_t G = (uint32_t)b->n_genomes;
     if (b->total_keys == 0) {
         b->n_local = 0;
@@ -671,13 +678,20 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
         HIPCHK(c, d_stage_cnt.ensure((size_t)n_wg * 4));
         HIPCHK(c, d_stage_off.ensure(((size_t)n_wg + 1) * 8));
         HIPCHK(c, hipMemsetAsync(d_flag.p, 0, 4, s));
+        const bool slots = (uint32_t)sb + b->cap_log2 <= 16 && c->opt_no_slots <= 0;
+        if (slots) {
+            HIPCHK(c, b->d_kslot.ensure((b->total_keys + 2) * 2));
+            HIPCHK(c, b->d_table_img.ensure((size_t)n_wg * cap * 8));
+        }
         {
             TimeScope t(c, "dict_build", b->total_keys);
             launch_dict_build(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(),
                               b->deduped ? b->d_len.as<uint32_t>() : nullptr, G, b->bb, sb, b->cap_log2,
                               d_stage_keys.as<uint64_t>(), d_stage_flags.as<uint8_t>(), d_stage_cnt.as<uint32_t>(),
+                              slots ? b->d_kslot.as<uint16_t>() : nullptr, slots ? b->d_table_img.as<uint64_t>() : nullptr,
                               d_flag.as<int>());
         }
+        b->have_slots = slots;
         HIPCHK(c, hipGetLastError());
         int ov = 0;
         HIPCHK(c, hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, s));
@@ -798,7 +812,25 @@ extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, con
     } else {
         HIPCHK(c, b->d_dict.ensure(16));
     }
-    // sub-bucket count for the fill: keep the mean dictionary slice under 1/4 of the table
+    b->fill_by_slots = false;
+    if (b->have_local && b->have_slots && b->total_keys) {
+        // slot form: give every table slot of the local dictionary its global column
+        const size_t n_slots = (size_t)1 << (b->bb + b->sb_dict + b->cap_log2);
+        HIPCHK(c, b->d_col_of_slot.ensure(n_slots * 4));
+        HIPCHK(c, hipMemsetAsync(b->d_col_of_slot.p, 0xff, n_slots * 4, s));
+        {
+            TimeScope t(c, "dict_slot_cols", b->n_dict);
+            launch_dict_slot_cols(s, b->d_dict.as<uint64_t>(), b->n_dict, b->bb, b->sb_dict, b->cap_log2,
+                                  b->d_table_img.as<uint64_t>(), b->d_col_of_slot.as<uint32_t>());
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(s));
+        b->fill_by_slots = true;
+        b->have_global = true;
+        if (n_kmers) *n_kmers = b->n_dict;
+        return GRM_OK;
+    }
+    // probing form.  sub-bucket count for the fill: keep the mean dictionary slice under 1/4 of the table
     int sb = c->opt_sub_bits >= 0 ? c->opt_sub_bits : 0;
     const uint64_t cap = 1ull << b->cap_log2;
     while (b->bb + sb < 24 && (b->n_dict >> (b->bb + sb)) > cap / 4) sb++;
@@ -833,7 +865,12 @@ extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
     for (;;) {
         if (cells) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
         (void)hipMemsetAsync(d_flag.p, 0, 4, s);
-        if (cells && b->total_keys) {
+        if (cells && b->total_keys && b->fill_by_slots) {
+            TimeScope t(c, "matrix_fill", b->total_keys);
+            launch_matrix_fill_slots(s, b->d_kslot.as<uint16_t>(), b->d_off.as<uint64_t>(),
+                                     b->deduped ? b->d_len.as<uint32_t>() : nullptr, (uint32_t)b->n_genomes, b->bb, b->sb_dict,
+                                     b->cap_log2, b->d_col_of_slot.as<uint32_t>(), m->d_data.as<uint64_t>(), m->n_kmers);
+        } else if (cells && b->total_keys) {
             TimeScope t(c, "matrix_fill", b->total_keys);
             launch_matrix_fill(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), b->deduped ? b->d_len.as<uint32_t>() : nullptr,
                                (uint32_t)b->n_genomes, b->bb, b->sb_fill, b->cap_log2, b->d_dkeys.as<uint64_t>(),

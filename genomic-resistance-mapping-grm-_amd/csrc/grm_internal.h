@@ -24,7 +24,8 @@ constexpr int L1_LDS_BYTES = L1_TILE * 8 + 2048 + 1024 + 1024 + 64;
 // ---- LDS table kernels ----
 constexpr int TABLE_THREADS = 512;                         // 8 waves: one genome per wave at a time
 constexpr int TABLE_SCRATCH_BYTES = 128;
-constexpr int KEYS_IN_FLIGHT = 4;                          // independent key loads per lane in dict/fill
+constexpr int KEYS_IN_FLIGHT = 4;
+constexpr int SLOTS_IN_FLIGHT = 8;                         // independent 2-byte slot loads per lane in the slot fill                          // independent key loads per lane in dict/fill
 
 struct TileSummary {
     uint32_t known;       // symbols whose emission does not depend on the incoming line type
@@ -63,7 +64,12 @@ void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const uint64_t *off, uin
                          uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow);
 void launch_dict_build(hipStream_t s, const uint64_t *keys, const uint64_t *off, const uint32_t *len,
                        uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, uint64_t *stage_keys,
-                       uint8_t *stage_flags, uint32_t *stage_cnt, int *overflow);
+                       uint8_t *stage_flags, uint32_t *stage_cnt, uint16_t *kslot, uint64_t *table_img, int *overflow);
+void launch_dict_slot_cols(hipStream_t s, const uint64_t *dict, uint64_t n, int bb, int sb, uint32_t cap_log2,
+                           const uint64_t *table_img, uint32_t *col_of_slot);
+void launch_matrix_fill_slots(hipStream_t s, const uint16_t *kslot, const uint64_t *off, const uint32_t *len,
+                              uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint32_t *col_of_slot,
+                              uint64_t *matrix, uint64_t n_cols);
 void launch_dict_gather(hipStream_t s, const uint64_t *stage_keys, const uint8_t *stage_flags, const uint64_t *stage_off,
                         uint32_t n_wg, uint32_t cap, uint64_t *out_keys, uint8_t *out_flags);
 void launch_dict_mark(hipStream_t s, const uint64_t *skeys, const uint8_t *sflags, uint64_t n, int filter_singleton,

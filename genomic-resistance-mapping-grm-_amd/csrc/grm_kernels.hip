@@ -587,10 +587,13 @@ __device__ __forceinline__ uint32_t lds_find_or_insert(uint64_t *tkeys, uint32_t
 {
     uint32_t slot = hash_slot(h, cap_mask);
     for (uint32_t probe = 0; probe <= cap_mask; probe++) {
-        const uint64_t prev = atomicCAS((unsigned long long *)&tkeys[slot], (unsigned long long)EMPTY_KEY,
-                                        (unsigned long long)key);
-        if (prev == EMPTY_KEY) { *inserted = true; return slot; }
-        if (prev == key) { *inserted = false; return slot; }
+        // plain read first: almost every probe of a pan-genome finds its key already present,
+        // and a ds_read_b64 is cheaper than a returning ds_cmpst_b64
+        uint64_t cur = *reinterpret_cast<volatile uint64_t *>(&tkeys[slot]);
+        if (cur == EMPTY_KEY)
+            cur = atomicCAS((unsigned long long *)&tkeys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        if (cur == EMPTY_KEY) { *inserted = true; return slot; }
+        if (cur == key) { *inserted = false; return slot; }
         slot = (slot + 1) & cap_mask;
     }
     return 0xffffffffu;
@@ -689,7 +692,8 @@ __global__ __launch_bounds__(TABLE_THREADS) void bucket_dedup_kernel(
 __global__ __launch_bounds__(TABLE_THREADS) void dict_build_kernel(
     const uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
     uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, uint64_t *__restrict__ stage_keys,
-    uint8_t *__restrict__ stage_flags, uint32_t *__restrict__ stage_cnt, int *__restrict__ overflow)
+    uint8_t *__restrict__ stage_flags, uint32_t *__restrict__ stage_cnt, uint16_t *__restrict__ kslot,
+    uint64_t *__restrict__ table_img, int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
@@ -728,8 +732,15 @@ __global__ __launch_bounds__(TABLE_THREADS) void dict_build_kernel(
                 const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, h, &ins);
                 if (slot == 0xffffffffu) { full = 1; continue; }
                 if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
-                const uint32_t old = atomicCAS(&tstate[slot], 0u, g + 1);
-                if (old != 0 && (old & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
+                // state: first genome + 1, bit 31 once a second genome shows up.  Plain read first:
+                // after a few genomes nearly every slot already carries the multi bit.
+                uint32_t st = *reinterpret_cast<volatile uint32_t *>(&tstate[slot]);
+                if (!(st & 0x80000000u) && st != g + 1) {
+                    st = atomicCAS(&tstate[slot], 0u, g + 1);
+                    if (st != 0 && (st & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
+                }
+                // remember where the key lives: the fill pass then needs neither the key nor a probe
+                if (kslot) kslot[s0 + i0 + 64u * j] = (uint16_t)((sub << cap_log2) | slot);
             }
         }
         if (full) break;    // LDS flag: a stale read only delays the exit
@@ -754,6 +765,84 @@ __global__ __launch_bounds__(TABLE_THREADS) void dict_build_kernel(
         base += sweep_total;
     }
     if (threadIdx.x == 0) stage_cnt[wg] = base;
+    if (table_img)
+        for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) table_img[out0 + i] = tkeys[i];
+}
+
+// column of every table slot: one thread per dictionary entry probes the saved table image of
+// its (bucket, sub-bucket) exactly as dict_build did and records its column there.
+__global__ void dict_slot_cols_kernel(const uint64_t *__restrict__ dict, uint64_t n, int bb, int sb, uint32_t cap_log2,
+                                      const uint64_t *__restrict__ table_img, uint32_t *__restrict__ col_of_slot)
+{
+    const uint32_t cap_mask = (1u << cap_log2) - 1;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = dict[c];
+        const uint64_t h = mix64(key);
+        const uint64_t wg = ((uint64_t)hash_bucket(h, bb) << sb) | hash_sub(h, bb, sb);
+        uint32_t slot = hash_slot(h, cap_mask);
+        for (uint32_t probe = 0; probe <= cap_mask; probe++) {
+            const uint64_t cur = table_img[(wg << cap_log2) + slot];
+            if (cur == key) { col_of_slot[(wg << cap_log2) + slot] = (uint32_t)c; break; }
+            if (cur == EMPTY_KEY) break;            // not carried by any local genome (multi-GPU)
+            slot = (slot + 1) & cap_mask;
+        }
+    }
+}
+
+// Stage 3b, slot form: presence bits from the slot ids dict_build left behind.
+// 2 bytes per k-mer occurrence instead of 8, no hashing, no probing.
+__global__ __launch_bounds__(TABLE_THREADS) void matrix_fill_slots_kernel(
+    const uint16_t *__restrict__ kslot, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+    uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint32_t *__restrict__ col_of_slot,
+    uint64_t *__restrict__ matrix, uint64_t n_cols)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
+    uint64_t *words = reinterpret_cast<uint64_t *>(lds_raw);
+    uint32_t *cols = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 8);
+    const uint32_t wg = blockIdx.x;
+    const uint32_t B = 1u << bb;
+    const uint32_t b = wg >> sb, sub = wg & ((1u << sb) - 1);
+    uint32_t any = 0;
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) {
+        const uint32_t c = col_of_slot[((uint64_t)wg << cap_log2) + i];
+        cols[i] = c;
+        any |= (c != 0xffffffffu);
+    }
+    if (!__syncthreads_or((int)any)) return;     // no column lives in this (bucket, sub-bucket)
+    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
+    const uint32_t n_rows = (n_genomes + 63) >> 6;
+    for (uint32_t r = 0; r < n_rows; r++) {
+        for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) words[i] = 0;
+        __syncthreads();
+        const uint32_t g_end = min(r * 64 + 64, n_genomes);
+        for (uint32_t g = r * 64 + wave; g < g_end; g += nw) {
+            const unsigned long long bit = 1ull << (63 - (g & 63));
+            const uint64_t idx = (uint64_t)g * B + b;
+            const uint64_t s0 = off[idx];
+            const uint64_t n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
+            for (uint64_t i0 = lane; i0 < n; i0 += 64 * SLOTS_IN_FLIGHT) {
+                uint32_t sv[SLOTS_IN_FLIGHT];
+#pragma unroll
+                for (int j = 0; j < SLOTS_IN_FLIGHT; j++) {
+                    const uint64_t i = i0 + 64u * j;
+                    sv[j] = i < n ? (uint32_t)kslot[s0 + i] : 0xffffffffu;
+                }
+#pragma unroll
+                for (int j = 0; j < SLOTS_IN_FLIGHT; j++) {
+                    if (sv[j] == 0xffffffffu) continue;
+                    if (sb && (sv[j] >> cap_log2) != sub) continue;
+                    atomicOr((unsigned long long *)&words[sv[j] & cap_mask], bit);
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) {
+            const uint32_t c = cols[i];
+            if (c != 0xffffffffu) matrix[(uint64_t)r * n_cols + c] = words[i];
+        }
+        __syncthreads();
+    }
 }
 
 // gather the staged per-workgroup dictionaries into one dense list
@@ -1030,11 +1119,26 @@ void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const uint64_t *off, uin
 }
 void launch_dict_build(hipStream_t s, const uint64_t *keys, const uint64_t *off, const uint32_t *len,
                        uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, uint64_t *stage_keys,
-                       uint8_t *stage_flags, uint32_t *stage_cnt, int *overflow)
+                       uint8_t *stage_flags, uint32_t *stage_cnt, uint16_t *kslot, uint64_t *table_img, int *overflow)
 {
     const size_t lds = (((size_t)12) << cap_log2) + TABLE_SCRATCH_BYTES;
     hipLaunchKernelGGL(dict_build_kernel, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, keys, off, len, n_genomes,
-                       bb, sb, cap_log2, stage_keys, stage_flags, stage_cnt, overflow);
+                       bb, sb, cap_log2, stage_keys, stage_flags, stage_cnt, kslot, table_img, overflow);
+}
+void launch_dict_slot_cols(hipStream_t s, const uint64_t *dict, uint64_t n, int bb, int sb, uint32_t cap_log2,
+                           const uint64_t *table_img, uint32_t *col_of_slot)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(dict_slot_cols_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, dict, n, bb, sb, cap_log2, table_img,
+                       col_of_slot);
+}
+void launch_matrix_fill_slots(hipStream_t s, const uint16_t *kslot, const uint64_t *off, const uint32_t *len,
+                              uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint32_t *col_of_slot,
+                              uint64_t *matrix, uint64_t n_cols)
+{
+    const size_t lds = ((size_t)12) << cap_log2;
+    hipLaunchKernelGGL(matrix_fill_slots_kernel, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, kslot, off, len,
+                       n_genomes, bb, sb, cap_log2, col_of_slot, matrix, n_cols);
 }
 void launch_dict_gather(hipStream_t s, const uint64_t *stage_keys, const uint8_t *stage_flags, const uint64_t *stage_off,
                         uint32_t n_wg, uint32_t cap, uint64_t *out_keys, uint8_t *out_flags)
@@ -1115,6 +1219,8 @@ hipError_t set_max_dynamic_lds()
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(matrix_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(matrix_fill_slots_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     return e;
 }
 

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-for o in "cap_log2=11" "cap_log2=10" "groups_per_thread=4" "groups_per_thread=64"; do
+for o in "groups_per_thread=16" "groups_per_thread=4" "groups_per_thread=2" "groups_per_thread=1"; do
   timeout -k 10 300 python bench.py --genomes 400 --steps 3 --warmup 1 --cpu-sample 0 --opt $o > gpurun_out/sweep_$o.log 2>&1
   tail -1 gpurun_out/sweep_$o.log | python -c "
 import json,sys

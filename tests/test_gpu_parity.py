@@ -112,6 +112,7 @@ def test_medium_pangenome_all_paths(ctx):
     {"groups_per_thread": 1}, {"groups_per_thread": 3, "bucket_bits": 5},
     {"bucket_bits": 0}, {"bucket_bits": 13}, {"sub_bits": 3},
     {"cap_log2": 8, "bucket_bits": 4},          # forces overflow -> sub-bucket retries
+    {"no_slots": 1}, {"no_slots": 1, "sub_bits": 2},   # probing form of the fill
 ])
 def test_medium_with_forced_geometry(ctx, opts):
     genomes = _medium_genomes(n=5, length=120_000, seed=9)
