@@ -275,11 +275,12 @@ GRM_HD void for_each_kmer(uint64_t a, uint64_t b, uint64_t c, uint64_t valid, in
     }
 }
 
-// ---- 32-position variant (one packed word of start positions + the next word) --------
-// valid-start mask of the 32 positions p0..p0+31 where p0 = 64G + 32*half; k in 1..32
-GRM_HD uint32_t valid_starts32(uint64_t i0, uint64_t i1, int half, int k)
+// ---- N-position variant (N = 16 or 32 start positions; N + k - 1 <= 64) ---------------
+// valid-start mask for the start positions at offset o (0..63) inside group G: bit i <=>
+// position 64G + o + i is valid.  Only bits i with i + k - 1 <= 63 are meaningful.  k in 1..32
+GRM_HD uint64_t valid_starts_at(uint64_t i0, uint64_t i1, int o, int k)
 {
-    uint64_t acc = half ? ((i0 >> 32) | (i1 << 32)) : i0;   // inv bits of symbols p0 .. p0+63
+    uint64_t acc = o ? ((i0 >> o) | (i1 << (64 - o))) : i0;     // inv bits of symbols o .. o+63
     int covered = 1;
     while (covered * 2 <= k) {
         acc |= acc >> covered;
@@ -287,16 +288,22 @@ GRM_HD uint32_t valid_starts32(uint64_t i0, uint64_t i1, int half, int k)
     }
     const int r = k - covered;
     if (r) acc |= acc >> r;
-    return ~(uint32_t)acc;          // positions 0..31 only look at bits 0..62
+    return ~acc;
+}
+GRM_HD uint32_t valid_starts32(uint64_t i0, uint64_t i1, int half, int k)
+{
+    return (uint32_t)valid_starts_at(i0, i1, half * 32, k);
 }
 
-// a = packed word of symbols p0..p0+31, b = the next word; calls f(i, canonical) for the
-// valid start positions i in 0..31.  The loop is meant to be fully unrolled so that a caller
-// may keep the k-mers in registers (statically indexed array).
-template <typename F>
-GRM_HD void for_each_kmer32(uint64_t a, uint64_t b, uint32_t valid, int k, F &&f)
+// w0 = packed word holding the first start position, at symbol offset `off` (0..31) inside
+// it; w1 = the next word.  Calls f(i, canonical) for the valid start positions i in 0..NPOS-1
+// (needs off + NPOS + k - 1 <= 64).  Fully unrolled: a caller may keep the k-mers in registers.
+template <int NPOS, typename F>
+GRM_HD void for_each_kmer_n(uint64_t w0, uint64_t w1, int off, uint32_t valid, int k, F &&f)
 {
     if (!valid) return;
+    const uint64_t a = off ? ((w0 << (2 * off)) | (w1 >> (64 - 2 * off))) : w0;
+    const uint64_t b = off ? (w1 << (2 * off)) : w1;
     const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     const int rcshift = 2 * (k - 1);
     const int m = k - 1;
@@ -307,7 +314,7 @@ GRM_HD void for_each_kmer32(uint64_t a, uint64_t b, uint32_t valid, int k, F &&f
     uint64_t hi = m ? ((a << (2 * m)) | (b >> (64 - 2 * m))) : a;
     uint64_t lo = m ? (b << (2 * m)) : b;
 #pragma unroll
-    for (int i = 0; i < 32; i++) {
+    for (int i = 0; i < NPOS; i++) {
         const uint64_t s = hi >> 62;
         hi = (hi << 2) | (lo >> 62);
         lo <<= 2;
@@ -315,6 +322,11 @@ GRM_HD void for_each_kmer32(uint64_t a, uint64_t b, uint32_t valid, int k, F &&f
         rc = (rc >> 2) | ((s ^ 2) << rcshift);
         if ((valid >> i) & 1u) f(i, fwd < rc ? fwd : rc);
     }
+}
+template <typename F>
+GRM_HD void for_each_kmer32(uint64_t a, uint64_t b, uint32_t valid, int k, F &&f)
+{
+    for_each_kmer_n<32>(a, b, 0, valid, k, f);
 }
 
 }  // namespace grm

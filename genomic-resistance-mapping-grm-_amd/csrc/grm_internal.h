@@ -16,8 +16,10 @@ constexpr int RAW_FRONT_PAD = 64;                          // '\n' bytes in fron
 // ---- k-mer kernels ----
 constexpr int KMER_THREADS = 256;
 constexpr int MAX_BUCKET_BITS = 13;                        // 8 coarse + 5 fine bits (two-level partition)
-constexpr int L1_THREADS = 256;
-constexpr int L1_TILE = L1_THREADS * 32;                   // 8192 k-mers staged in LDS per tile
+constexpr int L1_PPT = 16;                                 // start positions per thread in level 1
+constexpr int L1_THREADS = 512;                            // 8 waves per tile: 2 tiles (16 waves) per CU
+constexpr int L1_TILE = L1_THREADS * L1_PPT;               // 8192 k-mers staged in LDS per tile
+constexpr int L2_THREADS = 256;                            // level 2: 32 keys per thread, same tile size
 constexpr int L1_MAX_BITS = 8;                             // coarse fan-out 256: ~32 keys (256 B) per run
 constexpr int L1_LDS_BYTES = L1_TILE * 8 + 2048 + 1024 + 1024 + 64;
 

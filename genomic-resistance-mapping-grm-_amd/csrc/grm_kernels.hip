@@ -421,8 +421,7 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
     if (tile >= n_tiles) return;
     const int b2bits = a.bb - b1bits;
     const uint32_t B1 = 1u << b1bits;
-    const uint64_t hg = tile * L1_THREADS + threadIdx.x;          // half-group: 32 start positions
-    const uint64_t p0 = hg << 5;
+    const uint64_t p0 = tile * L1_TILE + (uint64_t)threadIdx.x * L1_PPT;      // L1_PPT start positions per thread
     const uint64_t p_first = tile * L1_TILE;
     if (p_first >= a.total_syms) return;
     const uint64_t p_last = min(p_first + L1_TILE, a.total_syms) - 1;
@@ -430,22 +429,23 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
     const bool uniform = a.genome_sym_off[gen0 + 1] > p_last;
 
     uint32_t valid = 0;
-    uint64_t wa = 0, wb = 0;
+    uint64_t w0 = 0, w1 = 0;
     const int64_t nv = (int64_t)a.total_syms - a.k + 1 - (int64_t)p0;
     if (nv > 0) {
-        const uint64_t grp = hg >> 1;
-        wa = a.sym2[hg];
-        wb = a.sym2[hg + 1];
-        valid = valid_starts32(a.inv[grp], a.inv[grp + 1], (int)(hg & 1), a.k);
-        if (nv < 32) valid &= (1u << nv) - 1;
+        const uint64_t grp = p0 >> 6;
+        w0 = a.sym2[p0 >> 5];
+        w1 = a.sym2[(p0 >> 5) + 1];
+        valid = (uint32_t)valid_starts_at(a.inv[grp], a.inv[grp + 1], (int)(p0 & 63), a.k) & ((1u << L1_PPT) - 1);
+        if (nv < L1_PPT) valid &= (1u << nv) - 1;
     }
+    const int off_in_word = (int)(p0 & 31);
 
     if (uniform) {
-        hist[threadIdx.x] = 0;            // L1_THREADS == 256 >= B1
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
-        uint64_t kv[32];
-        uint32_t meta[32];                // (coarse bucket << 16) | rank inside the tile's bucket
-        for_each_kmer32(wa, wb, valid, a.k, [&](int i, uint64_t canon) {
+        uint64_t kv[L1_PPT];
+        uint32_t meta[L1_PPT];            // (coarse bucket << 16) | rank inside the tile's bucket
+        for_each_kmer_n<L1_PPT>(w0, w1, off_in_word, valid, a.k, [&](int i, uint64_t canon) {
             kv[i] = canon;
             const uint32_t b1 = hash_bucket(mix64(canon), b1bits);
             meta[i] = (b1 << 16) | atomicAdd(&hist[b1], 1u);
@@ -454,14 +454,14 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
         const uint32_t c = threadIdx.x < B1 ? hist[threadIdx.x] : 0u;
         uint32_t n_tile;
         const uint32_t st = block_scan_sum(c, scratch, &n_tile);
-        start[threadIdx.x] = st;
+        if (threadIdx.x < 256) start[threadIdx.x] = st;
         if (c) {
             const uint64_t fine0 = (uint64_t)gen0 * (1ull << a.bb) + ((uint64_t)threadIdx.x << b2bits);
             gbase[threadIdx.x] = off[fine0] + atomicAdd(&cursor1[(uint64_t)gen0 * B1 + threadIdx.x], c);
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 32; i++)
+        for (int i = 0; i < L1_PPT; i++)
             if ((valid >> i) & 1u) skeys[start[meta[i] >> 16] + (meta[i] & 0xffffu)] = kv[i];
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n_tile; i += L1_THREADS) {
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
     } else {
         uint32_t gen = genome_of(a.genome_sym_off, a.n_genomes, min(p0, a.total_syms - 1));
         uint64_t gend = a.genome_sym_off[gen + 1];
-        for_each_kmer32(wa, wb, valid, a.k, [&](int i, uint64_t canon) {
+        for_each_kmer_n<L1_PPT>(w0, w1, off_in_word, valid, a.k, [&](int i, uint64_t canon) {
             while (p0 + (uint64_t)i >= gend) { gen++; gend = a.genome_sym_off[gen + 1]; }
             const uint32_t b1 = hash_bucket(mix64(canon), b1bits);
             const uint64_t fine0 = (uint64_t)gen * (1ull << a.bb) + ((uint64_t)b1 << b2bits);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
     }
 }
 
-__global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l2_kernel(
+__global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
     const uint64_t *__restrict__ keys1, uint64_t *__restrict__ keys, const uint64_t *__restrict__ off,
     uint32_t *__restrict__ cursor2, uint64_t n_regions, int bb, int b1bits)
 {
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l2_kernel(
             uint32_t meta[32];
 #pragma unroll
             for (int j = 0; j < 32; j++) {
-                const uint32_t i = (uint32_t)j * L1_THREADS + threadIdx.x;
+                const uint32_t i = (uint32_t)j * L2_THREADS + threadIdx.x;
                 kv[j] = i < n ? keys1[base + i] : EMPTY_KEY;
             }
 #pragma unroll
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l2_kernel(
             for (int j = 0; j < 32; j++)
                 if (kv[j] != EMPTY_KEY) skeys[start[meta[j] >> 16] + (meta[j] & 0xffffu)] = kv[j];
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n; i += L1_THREADS) {
+            for (uint32_t i = threadIdx.x; i < n; i += L2_THREADS) {
                 const uint64_t key = skeys[i];
                 const uint32_t b2 = hash_bucket(mix64(key), bb) & (B2 - 1);
                 keys[gbase[b2] + (i - start[b2])] = key;
@@ -1088,7 +1088,7 @@ void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *
     if (L.total_syms == 0 || L.bb <= b1) return;
     const uint64_t n_regions = (uint64_t)L.n_genomes << b1;
     const uint32_t grid2 = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
-    hipLaunchKernelGGL(kmer_scatter_l2_kernel, dim3(grid2), dim3(L1_THREADS), L1_LDS_BYTES, s, keys1, keys, off, cursor2,
+    hipLaunchKernelGGL(kmer_scatter_l2_kernel, dim3(grid2), dim3(L2_THREADS), L1_LDS_BYTES, s, keys1, keys, off, cursor2,
                        n_regions, L.bb, b1);
 }
 void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,

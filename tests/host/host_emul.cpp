@@ -175,6 +175,25 @@ uint64_t emul_kmers32(const uint64_t *sym2, const uint64_t *inv, uint64_t total_
     return n;
 }
 
+// 16 start positions per call, as the level-1 partition kernel does
+uint64_t emul_kmers16(const uint64_t *sym2, const uint64_t *inv, uint64_t total_syms, int k, uint64_t *out, uint64_t cap)
+{
+    uint64_t n = 0;
+    const uint64_t n_q = (total_syms + 15) / 16;
+    for (uint64_t q = 0; q < n_q; q++) {
+        const uint64_t p0 = q << 4, grp = p0 >> 6;
+        const int64_t nv = (int64_t)total_syms - k + 1 - (int64_t)p0;
+        if (nv <= 0) break;
+        uint32_t valid = (uint32_t)valid_starts_at(inv[grp], inv[grp + 1], (int)(p0 & 63), k) & 0xffffu;
+        if (nv < 16) valid &= (1u << nv) - 1;
+        uint64_t kv[16];
+        for_each_kmer_n<16>(sym2[p0 >> 5], sym2[(p0 >> 5) + 1], (int)(p0 & 31), valid, k, [&](int i, uint64_t canon) { kv[i] = canon; });
+        for (int i = 0; i < 16; i++)
+            if ((valid >> i) & 1u) { if (n < cap) out[n] = kv[i]; n++; }
+    }
+    return n;
+}
+
 uint64_t emul_mix64(uint64_t x) { return mix64(x); }
 uint32_t emul_bucket(uint64_t h, int bb) { return hash_bucket(h, bb); }
 uint32_t emul_sub(uint64_t h, int bb, int sb) { return hash_sub(h, bb, sb); }

@@ -29,6 +29,8 @@ def emul():
     L.emul_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
     L.emul_parse2.restype = C.c_uint64
     L.emul_parse2.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.emul_kmers16.restype = C.c_uint64
+    L.emul_kmers16.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
     L.emul_kmers32.restype = C.c_uint64
     L.emul_kmers32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
     L.emul_summarize.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64] + [C.POINTER(C.c_uint32)] * 3
@@ -72,6 +74,8 @@ def extract(emul, files, k):
     out32 = np.zeros(cap, dtype=np.uint64)
     n32 = emul.emul_kmers32(sym2.ctypes.data, inv.ctypes.data, nsym, k, out32.ctypes.data, cap)
     assert n32 == n and (out32[:n] == out[:n]).all()      # 32-position iterator == 64-position iterator
+    n16 = emul.emul_kmers16(sym2.ctypes.data, inv.ctypes.data, nsym, k, out32.ctypes.data, cap)
+    assert n16 == n and (out32[:n] == out[:n]).all()      # 16-position iterator too
     return raw, int(nsym), out[:n]
 
 
