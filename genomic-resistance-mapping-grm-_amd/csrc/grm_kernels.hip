@@ -344,7 +344,8 @@ __device__ __forceinline__ void group_kmers(const KmerArgs &a, uint64_t grp, F &
     const uint64_t A = a.sym2[2 * grp], B = a.sym2[2 * grp + 1], C = a.sym2[2 * grp + 2];
     uint64_t valid = valid_starts(a.inv[grp], a.inv[grp + 1], a.k);
     if (nv < 64) valid &= (1ull << nv) - 1;
-    for_each_kmer(A, B, C, valid, a.k, f);
+    for_each_kmer_n<32>(A, B, 0, (uint32_t)valid, a.k, f);
+    for_each_kmer_n<32>(B, C, 0, (uint32_t)(valid >> 32), a.k, [&](int i, uint64_t canon) { f(i + 32, canon); });
 }
 
 // K1: per-(genome,bucket) occurrence histogram.
@@ -714,9 +715,12 @@ __global__ __launch_bounds__(TABLE_THREADS) void dict_build_kernel(
         const uint64_t idx = (uint64_t)g * B + b;
         const uint64_t s0 = off[idx];
         const uint64_t n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
-        // KEYS_IN_FLIGHT independent loads per lane before the (latency-bound) LDS probing
+        // KEYS_IN_FLIGHT independent global loads per lane, then their first table probes (key and
+        // state word) are issued together; a k-mer that is already present and already known to
+        // several genomes -- the common case in a pan-genome -- needs nothing else.
         for (uint64_t i0 = lane; i0 < n; i0 += 64 * KEYS_IN_FLIGHT) {
-            uint64_t kv[KEYS_IN_FLIGHT];
+            uint64_t kv[KEYS_IN_FLIGHT], hv[KEYS_IN_FLIGHT], ck[KEYS_IN_FLIGHT];
+            uint32_t sl[KEYS_IN_FLIGHT], cs[KEYS_IN_FLIGHT];
 #pragma unroll
             for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
                 const uint64_t i = i0 + 64u * j;
@@ -724,20 +728,31 @@ __global__ __launch_bounds__(TABLE_THREADS) void dict_build_kernel(
             }
 #pragma unroll
             for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
+                hv[j] = mix64(kv[j]);
+                sl[j] = hash_slot(hv[j], cap_mask);
+            }
+#pragma unroll
+            for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
+                ck[j] = *reinterpret_cast<volatile uint64_t *>(&tkeys[sl[j]]);
+                cs[j] = *reinterpret_cast<volatile uint32_t *>(&tstate[sl[j]]);
+            }
+#pragma unroll
+            for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
                 const uint64_t key = kv[j];
                 if (key == EMPTY_KEY) continue;
-                const uint64_t h = mix64(key);
-                if (sb && hash_sub(h, bb, sb) != sub) continue;
-                bool ins;
-                const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, h, &ins);
-                if (slot == 0xffffffffu) { full = 1; continue; }
-                if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
-                // state: first genome + 1, bit 31 once a second genome shows up.  Plain read first:
-                // after a few genomes nearly every slot already carries the multi bit.
-                uint32_t st = *reinterpret_cast<volatile uint32_t *>(&tstate[slot]);
-                if (!(st & 0x80000000u) && st != g + 1) {
-                    st = atomicCAS(&tstate[slot], 0u, g + 1);
-                    if (st != 0 && (st & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
+                if (sb && hash_sub(hv[j], bb, sb) != sub) continue;
+                uint32_t slot = sl[j];
+                if (!(ck[j] == key && ((cs[j] & 0x80000000u) || cs[j] == g + 1))) {
+                    bool ins;
+                    slot = lds_find_or_insert(tkeys, cap_mask, key, hv[j], &ins);
+                    if (slot == 0xffffffffu) { full = 1; continue; }
+                    if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
+                    // state: first genome + 1, bit 31 once a second genome shows up
+                    uint32_t st = *reinterpret_cast<volatile uint32_t *>(&tstate[slot]);
+                    if (!(st & 0x80000000u) && st != g + 1) {
+                        st = atomicCAS(&tstate[slot], 0u, g + 1);
+                        if (st != 0 && (st & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
+                    }
                 }
                 // remember where the key lives: the fill pass then needs neither the key nor a probe
                 if (kslot) kslot[s0 + i0 + 64u * j] = (uint16_t)((sub << cap_log2) | slot);
