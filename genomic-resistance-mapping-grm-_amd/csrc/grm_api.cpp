@@ -42,6 +42,7 @@ struct grm_ctx {
     int opt_cap_log2 = -1;
     int opt_sub_bits = -1;
     int opt_no_slots = -1;      // > 0: force the probing form of the fill (tests)
+    int opt_keys_in_flight = -1, opt_table_threads = -1;
 };
 
 static int fail(grm_ctx *c, int code, const char *fmt, ...)
@@ -152,6 +153,8 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "cap_log2") c->opt_cap_log2 = value;
     else if (n == "sub_bits") c->opt_sub_bits = value;
     else if (n == "no_slots") c->opt_no_slots = value;
+    else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
+    else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
     return GRM_OK;
 }

@@ -93,6 +93,7 @@ void launch_column_popcount(hipStream_t s, const uint64_t *matrix, uint64_t n_ro
                             const uint64_t *row_mask, uint32_t *out);
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint64_t n);
 hipError_t set_max_dynamic_lds();
+void set_table_tuning(int keys_in_flight, int threads);
 
 // rocPRIM-backed plumbing for the (small) dictionary: radix sort of pairs, exclusive scan
 hipError_t sort_pairs_u64_u8(hipStream_t s, const uint64_t *kin, uint64_t *kout, const uint8_t *vin, uint8_t *vout,

@@ -690,7 +690,8 @@ __global__ __launch_bounds__(TABLE_THREADS) void bucket_dedup_kernel(
 // Output: staged, per workgroup at stride `cap`: distinct keys + flag (1 = one genome,
 // 2 = several) in table-slot order, and the count.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TABLE_THREADS) void dict_build_kernel(
+template <int KIF>
+__global__ __launch_bounds__(1024) void dict_build_kernel(
     const uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
     uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, uint64_t *__restrict__ stage_keys,
     uint8_t *__restrict__ stage_flags, uint32_t *__restrict__ stage_cnt, uint16_t *__restrict__ kslot,
@@ -711,53 +712,51 @@ __global__ __launch_bounds__(TABLE_THREADS) void dict_build_kernel(
     __syncthreads();
     const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
     const uint32_t max_fill = cap - (cap >> 3);     // 87.5 %
+    // segment of the NEXT genome is fetched while the current one is processed (the two dependent
+    // global round trips -- offsets, then keys -- would otherwise serialise per genome)
+    uint64_t s0 = 0, n = 0;
+    if ((uint32_t)wave < n_genomes) {
+        const uint64_t idx = (uint64_t)wave * B + b;
+        s0 = off[idx];
+        n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
+    }
     for (uint32_t g = wave; g < n_genomes; g += nw) {
-        const uint64_t idx = (uint64_t)g * B + b;
-        const uint64_t s0 = off[idx];
-        const uint64_t n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
-        // KEYS_IN_FLIGHT independent global loads per lane, then their first table probes (key and
-        // state word) are issued together; a k-mer that is already present and already known to
-        // several genomes -- the common case in a pan-genome -- needs nothing else.
-        for (uint64_t i0 = lane; i0 < n; i0 += 64 * KEYS_IN_FLIGHT) {
-            uint64_t kv[KEYS_IN_FLIGHT], hv[KEYS_IN_FLIGHT], ck[KEYS_IN_FLIGHT];
-            uint32_t sl[KEYS_IN_FLIGHT], cs[KEYS_IN_FLIGHT];
+        uint64_t s0_next = 0, n_next = 0;
+        if (g + nw < n_genomes) {
+            const uint64_t idx = (uint64_t)(g + nw) * B + b;
+            s0_next = off[idx];
+            n_next = len ? (uint64_t)len[idx] : off[idx + 1] - s0_next;
+        }
+        for (uint64_t i0 = lane; i0 < n; i0 += 64 * KIF) {
+            uint64_t kv[KIF];
 #pragma unroll
-            for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
+            for (int j = 0; j < KIF; j++) {
                 const uint64_t i = i0 + 64u * j;
                 kv[j] = i < n ? keys[s0 + i] : EMPTY_KEY;
             }
 #pragma unroll
-            for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
-                hv[j] = mix64(kv[j]);
-                sl[j] = hash_slot(hv[j], cap_mask);
-            }
-#pragma unroll
-            for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
-                ck[j] = *reinterpret_cast<volatile uint64_t *>(&tkeys[sl[j]]);
-                cs[j] = *reinterpret_cast<volatile uint32_t *>(&tstate[sl[j]]);
-            }
-#pragma unroll
-            for (int j = 0; j < KEYS_IN_FLIGHT; j++) {
+            for (int j = 0; j < KIF; j++) {
                 const uint64_t key = kv[j];
                 if (key == EMPTY_KEY) continue;
-                if (sb && hash_sub(hv[j], bb, sb) != sub) continue;
-                uint32_t slot = sl[j];
-                if (!(ck[j] == key && ((cs[j] & 0x80000000u) || cs[j] == g + 1))) {
-                    bool ins;
-                    slot = lds_find_or_insert(tkeys, cap_mask, key, hv[j], &ins);
-                    if (slot == 0xffffffffu) { full = 1; continue; }
-                    if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
-                    // state: first genome + 1, bit 31 once a second genome shows up
-                    uint32_t st = *reinterpret_cast<volatile uint32_t *>(&tstate[slot]);
-                    if (!(st & 0x80000000u) && st != g + 1) {
-                        st = atomicCAS(&tstate[slot], 0u, g + 1);
-                        if (st != 0 && (st & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
-                    }
+                const uint64_t h = mix64(key);
+                if (sb && hash_sub(h, bb, sb) != sub) continue;
+                bool ins;
+                const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, h, &ins);
+                if (slot == 0xffffffffu) { full = 1; continue; }
+                if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
+                // state: first genome + 1, bit 31 once a second genome shows up.  Plain read first:
+                // after a few genomes nearly every slot already carries the multi bit.
+                uint32_t st = *reinterpret_cast<volatile uint32_t *>(&tstate[slot]);
+                if (!(st & 0x80000000u) && st != g + 1) {
+                    st = atomicCAS(&tstate[slot], 0u, g + 1);
+                    if (st != 0 && (st & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
                 }
                 // remember where the key lives: the fill pass then needs neither the key nor a probe
                 if (kslot) kslot[s0 + i0 + 64u * j] = (uint16_t)((sub << cap_log2) | slot);
             }
         }
+        s0 = s0_next;
+        n = n_next;
         if (full) break;    // LDS flag: a stale read only delays the exit
     }
     __syncthreads();
@@ -806,7 +805,7 @@ __global__ void dict_slot_cols_kernel(const uint64_t *__restrict__ dict, uint64_
 
 // Stage 3b, slot form: presence bits from the slot ids dict_build left behind.
 // 2 bytes per k-mer occurrence instead of 8, no hashing, no probing.
-__global__ __launch_bounds__(TABLE_THREADS) void matrix_fill_slots_kernel(
+__global__ __launch_bounds__(1024) void matrix_fill_slots_kernel(
     const uint16_t *__restrict__ kslot, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
     uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint32_t *__restrict__ col_of_slot,
     uint64_t *__restrict__ matrix, uint64_t n_cols)
@@ -1132,13 +1131,28 @@ void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const uint64_t *off, uin
     hipLaunchKernelGGL(bucket_dedup_kernel, dim3(grid), dim3(TABLE_THREADS), lds, s, keys, off, n_segments, cap_log2,
                        abundance_min, len_out, counts_out, overflow);
 }
+static int g_dict_kif = 4, g_table_threads = TABLE_THREADS;
+void set_table_tuning(int kif, int threads)
+{
+    g_dict_kif = (kif == 1 || kif == 2 || kif == 8) ? kif : 4;
+    g_table_threads = (threads == 256 || threads == 1024) ? threads : TABLE_THREADS;
+}
 void launch_dict_build(hipStream_t s, const uint64_t *keys, const uint64_t *off, const uint32_t *len,
                        uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, uint64_t *stage_keys,
                        uint8_t *stage_flags, uint32_t *stage_cnt, uint16_t *kslot, uint64_t *table_img, int *overflow)
 {
     const size_t lds = (((size_t)12) << cap_log2) + TABLE_SCRATCH_BYTES;
-    hipLaunchKernelGGL(dict_build_kernel, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, keys, off, len, n_genomes,
-                       bb, sb, cap_log2, stage_keys, stage_flags, stage_cnt, kslot, table_img, overflow);
+    const dim3 grid(1u << (bb + sb)), block(g_table_threads);
+#define GRM_LAUNCH_DICT(K)                                                                                              \
+    hipLaunchKernelGGL(dict_build_kernel<K>, grid, block, lds, s, keys, off, len, n_genomes, bb, sb, cap_log2, stage_keys, \
+                       stage_flags, stage_cnt, kslot, table_img, overflow)
+    switch (g_dict_kif) {
+    case 1: GRM_LAUNCH_DICT(1); break;
+    case 2: GRM_LAUNCH_DICT(2); break;
+    case 8: GRM_LAUNCH_DICT(8); break;
+    default: GRM_LAUNCH_DICT(4); break;
+    }
+#undef GRM_LAUNCH_DICT
 }
 void launch_dict_slot_cols(hipStream_t s, const uint64_t *dict, uint64_t n, int bb, int sb, uint32_t cap_log2,
                            const uint64_t *table_img, uint32_t *col_of_slot)
@@ -1152,7 +1166,7 @@ void launch_matrix_fill_slots(hipStream_t s, const uint16_t *kslot, const uint64
                               uint64_t *matrix, uint64_t n_cols)
 {
     const size_t lds = ((size_t)12) << cap_log2;
-    hipLaunchKernelGGL(matrix_fill_slots_kernel, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, kslot, off, len,
+    hipLaunchKernelGGL(matrix_fill_slots_kernel, dim3(1u << (bb + sb)), dim3(g_table_threads), lds, s, kslot, off, len,
                        n_genomes, bb, sb, cap_log2, col_of_slot, matrix, n_cols);
 }
 void launch_dict_gather(hipStream_t s, const uint64_t *stage_keys, const uint8_t *stage_flags, const uint64_t *stage_off,
@@ -1231,7 +1245,13 @@ hipError_t set_max_dynamic_lds()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_dedup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(matrix_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
