@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--abundance-min", type=int, default=1)
     ap.add_argument("--keep-singletons", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=24, help="genomes in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=384, help="genomes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], help="engine tuning knob name=value (grm_set_option)")
     args = ap.parse_args()
 
@@ -146,10 +146,20 @@ def main():
         kernels[name] = e
     dom = max((n for n in kernels if "algo_GBps" in kernels[n]), key=lambda n: kernels[n]["avg_ms"] * kernels[n]["launches"], default=None)
     roofline = None
+    # HBM traffic of the dominant kernel: from the committed PMC passes (profiles/hbm_traffic.json),
+    # only when this run is the workload those passes were taken on
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        w = tj["workload"]
+        if (w["genomes"], w["genome_len"], w["mode"], w["k"]) == (args.genomes, args.genome_len, args.mode, args.k) and not args.opt:
+            traffic = tj["bytes_per_launch"].get(dom)
+    except (OSError, ValueError, KeyError):
+        pass
     if dom:
         a = kernels[dom]["algo_GBps"]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": kernels[dom]["avg_ms"]}
 
     # ---- CPU baseline: the oracle (a port), bounded sample of the same workload, rank 0, N=1 ----
