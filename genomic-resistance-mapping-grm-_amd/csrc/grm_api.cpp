@@ -7,6 +7,7 @@
 //   dsk2kover bin/kover/core/kover/dataset/tools/kmer_pack.py:28-36
 //   dsk       src/app.py:1372           Ray Surveyor  src/app.py:1310
 #include <hip/hip_runtime.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -329,8 +330,45 @@ extern "C" const char *grm_matrix_last_error(const grm_matrix *m)
 // --------------------------------------------------------------------------------------
 struct HostFile {
     int genome;
-    std::vector<uint8_t> bytes;
+    bool fastq = false;           // 4-line FASTQ (first non-blank byte '@'), else FASTA
+    std::vector<uint8_t> bytes;   // inflated image
 };
+
+// gzip / zlib streams (magic 1f 8b) are inflated on the host: Kover's from-reads accepts
+// .fastq.gz (dataset/create.py:402).  Concatenated members are handled.
+static bool inflate_gzip(const uint8_t *src, size_t len, std::vector<uint8_t> &out)
+{
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef *>(src);
+    zs.avail_in = (uInt)0;
+    size_t in_pos = 0;
+    std::vector<uint8_t> buf(1 << 20);
+    int rc = Z_OK;
+    for (;;) {
+        if (zs.avail_in == 0 && in_pos < len) {
+            const size_t chunk = std::min<size_t>(len - in_pos, 1u << 30);
+            zs.next_in = const_cast<Bytef *>(src + in_pos);
+            zs.avail_in = (uInt)chunk;
+            in_pos += chunk;
+        }
+        zs.next_out = buf.data();
+        zs.avail_out = (uInt)buf.size();
+        rc = inflate(&zs, Z_NO_FLUSH);
+        if (rc != Z_OK && rc != Z_STREAM_END) break;
+        out.insert(out.end(), buf.data(), buf.data() + (buf.size() - zs.avail_out));
+        if (rc == Z_STREAM_END) {
+            if (zs.avail_in == 0 && in_pos >= len) break;
+            if (inflateReset(&zs) != Z_OK) { rc = Z_DATA_ERROR; break; }      // next gzip member
+        } else if (zs.avail_in == 0 && in_pos >= len && zs.avail_out != 0) {
+            rc = Z_DATA_ERROR;      // truncated stream
+            break;
+        }
+    }
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END;
+}
 
 struct grm_batch {
     grm_ctx *ctx = nullptr;
@@ -343,6 +381,7 @@ struct grm_batch {
     uint32_t n_tiles = 0;
     DevBuf d_raw_alloc;       // front pad + image
     DevBuf d_genome_tile_off; // u32[n_genomes+1]
+    DevBuf d_tile_meta;       // u8[n_tiles]: TILE_META_FIRST | TILE_META_FASTQ
     // parse products
     DevBuf d_sums, d_tile_off, d_tile_state, d_sym2, d_inv, d_genome_sym_off;
     uint64_t total_syms = 0;
@@ -398,7 +437,15 @@ extern "C" int grm_batch_add(grm_batch *b, int genome_index, const void *buf, si
     if (b->uploaded) return fail(b->ctx, GRM_ERR_STATE, "grm_batch_add after upload");
     HostFile f;
     f.genome = genome_index;
-    f.bytes.assign((const uint8_t *)buf, (const uint8_t *)buf + len);
+    const uint8_t *p = (const uint8_t *)buf;
+    if (len >= 2 && p[0] == 0x1f && p[1] == 0x8b) {
+        if (!inflate_gzip(p, len, f.bytes)) return fail(b->ctx, GRM_ERR_IO, "grm_batch_add: corrupt gzip stream (genome %d)", genome_index);
+    } else {
+        f.bytes.assign(p, p + len);
+    }
+    size_t i = 0;
+    while (i < f.bytes.size() && (f.bytes[i] == '\n' || f.bytes[i] == '\r' || f.bytes[i] == ' ' || f.bytes[i] == '\t')) i++;
+    f.fastq = i < f.bytes.size() && f.bytes[i] == '@';
     b->files.push_back(std::move(f));
     return GRM_OK;
 }
@@ -426,10 +473,12 @@ extern "C" int grm_batch_upload(grm_batch *b)
     HIPCHK(c, hipSetDevice(c->device));
     // genome-major, stable in insertion order
     std::stable_sort(b->files.begin(), b->files.end(), [](const HostFile &x, const HostFile &y) { return x.genome < y.genome; });
-    // layout: every file = ">\n" + bytes + "\n", padded with '\n' to a tile boundary.  The
-    // synthetic header guarantees a separator in front of every file's first base and the
-    // trailing newline terminates an unterminated last line.
+    // layout: every FASTA file = ">\n" + bytes + "\n", every FASTQ file = bytes + "\n", padded with
+    // '\n' to a tile boundary.  The synthetic FASTA header guarantees a separator in front of a
+    // file's first base (a FASTQ file opens with its own header line); the trailing newline
+    // terminates an unterminated last line.
     std::vector<uint32_t> genome_tile_off(b->n_genomes + 1, 0);
+    std::vector<uint8_t> tile_meta;
     uint64_t pos = 0;
     std::vector<uint64_t> file_pos(b->files.size());
     size_t fi = 0;
@@ -439,12 +488,15 @@ extern "C" int grm_batch_upload(grm_batch *b)
         bool any = false;
         while (fi < b->files.size() && b->files[fi].genome == g) {
             file_pos[fi] = pos;
-            pos = round_up(pos + 2 + b->files[fi].bytes.size() + 1, TILE_BYTES);
+            const uint64_t end = round_up(pos + (b->files[fi].fastq ? 0 : 2) + b->files[fi].bytes.size() + 1, TILE_BYTES);
+            const uint8_t fmt = b->files[fi].fastq ? TILE_META_FASTQ : 0;
+            for (uint64_t t = pos; t < end; t += TILE_BYTES) tile_meta.push_back(fmt | (t == pos ? TILE_META_FIRST : 0));
+            pos = end;
             b->input_bytes += b->files[fi].bytes.size();
             fi++;
             any = true;
         }
-        if (!any) pos += TILE_BYTES;   // an empty genome still owns one (all-newline) tile
+        if (!any) { pos += TILE_BYTES; tile_meta.push_back(TILE_META_FIRST); }   // an empty genome owns one all-newline tile
     }
     genome_tile_off[b->n_genomes] = (uint32_t)(pos / TILE_BYTES);
     if (pos / TILE_BYTES >= 0xffffffffull) return fail(c, GRM_ERR_ARG, "batch too large (%llu bytes)", (unsigned long long)pos);
@@ -457,14 +509,16 @@ extern "C" int grm_batch_upload(grm_batch *b)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<uint8_t> img;
     for (size_t i = 0; i < b->files.size(); i++) {
-        img.resize(b->files[i].bytes.size() + 3);
-        img[0] = '>';
-        img[1] = '\n';
-        if (!b->files[i].bytes.empty()) memcpy(img.data() + 2, b->files[i].bytes.data(), b->files[i].bytes.size());
+        const size_t head = b->files[i].fastq ? 0 : 2;
+        img.resize(b->files[i].bytes.size() + head + 1);
+        if (head) { img[0] = '>'; img[1] = '\n'; }
+        if (!b->files[i].bytes.empty()) memcpy(img.data() + head, b->files[i].bytes.data(), b->files[i].bytes.size());
         img[img.size() - 1] = '\n';
         HIPCHK(c, hipMemcpy(d_raw + RAW_FRONT_PAD + file_pos[i], img.data(), img.size(), hipMemcpyHostToDevice));
         std::vector<uint8_t>().swap(b->files[i].bytes);
     }
+    HIPCHK(c, b->d_tile_meta.alloc(tile_meta.size() + 16));
+    if (!tile_meta.empty()) HIPCHK(c, hipMemcpy(b->d_tile_meta.p, tile_meta.data(), tile_meta.size(), hipMemcpyHostToDevice));
     HIPCHK(c, b->d_genome_tile_off.alloc((b->n_genomes + 1) * 4));
     HIPCHK(c, hipMemcpy(b->d_genome_tile_off.p, genome_tile_off.data(), (b->n_genomes + 1) * 4, hipMemcpyHostToDevice));
     b->uploaded = true;
@@ -531,17 +585,17 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     HIPCHK(c, hipMemsetAsync(b->d_inv.p, 0, max_groups * 8, s));
     {
         TimeScope t(c, "parse_summarize", b->raw_bytes);
-        launch_parse_summarize(s, raw, b->n_tiles, b->d_sums.as<TileSummary>());
+        launch_parse_summarize(s, raw, b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_sums.as<TileSummary>());
     }
     {
         TimeScope t(c, "parse_scan", b->n_tiles);
-        launch_parse_scan(s, b->d_sums.as<TileSummary>(), b->n_tiles, b->d_tile_off.as<uint64_t>(),
+        launch_parse_scan(s, b->d_sums.as<TileSummary>(), b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_tile_off.as<uint64_t>(),
                           b->d_tile_state.as<uint8_t>(), b->d_genome_tile_off.as<uint32_t>(), G,
                           b->d_genome_sym_off.as<uint64_t>());
     }
     {
         TimeScope t(c, "parse_pack", b->raw_bytes);
-        launch_parse_pack(s, raw, b->n_tiles, b->d_tile_off.as<uint64_t>(), b->d_tile_state.as<uint8_t>(),
+        launch_parse_pack(s, raw, b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_tile_off.as<uint64_t>(), b->d_tile_state.as<uint8_t>(),
                           b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>());
     }
     HIPCHK(c, hipGetLastError());

@@ -183,6 +183,49 @@ GRM_HD uint64_t pelem_combine(uint64_t a, uint64_t b)
     return pelem_make(eb ? eb : ea, cs, ch);
 }
 
+// ---- FASTQ (4-line records: header, sequence, '+', quality) -------------------------------
+// A byte's role depends on its line index mod 4 ("phase").  Header lines (phase 0) emit one
+// separator at their first byte, sequence lines (phase 1) emit every byte except \n / \r.
+// exclusive prefix parity of a 16-bit mask
+GRM_HD uint32_t excl_prefix_xor16(uint32_t x)
+{
+    x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8;
+    return (x << 1) & 0xffffu;
+}
+// masks of the chunk's bytes by (number of newlines before the byte inside the chunk) mod 4
+GRM_HD void fq_phase_masks(uint32_t nl, uint32_t m[4])
+{
+    const uint32_t e0 = excl_prefix_xor16(nl);           // bit 0 of the running newline count
+    const uint32_t e1 = excl_prefix_xor16(nl & e0);      // bit 1: parity of the carries
+    m[0] = ~e0 & ~e1 & 0xffffu;
+    m[1] = e0 & ~e1 & 0xffffu;
+    m[2] = ~e0 & e1 & 0xffffu;
+    m[3] = e0 & e1 & 0xffffu;
+}
+// emit / separator masks of a chunk that starts in line phase s (0..3)
+GRM_HD void fq_classify(uint32_t nl, uint32_t cr, uint32_t ls, const uint32_t m[4], int s, uint32_t &emit, uint32_t &sep)
+{
+    const uint32_t plain = ~(nl | cr) & 0xffffu;
+    sep = ls & m[(0 - s) & 3];                          // first byte of a header line
+    emit = sep | (plain & m[(1 - s) & 3]);              // + the bytes of a sequence line
+}
+// FASTQ scan element: newline count mod 4 (bits 60-61) and, for each starting phase s, the
+// symbols the range emits (15 bits each, bits 15s..15s+14; a tile holds <= 16384 bytes).
+GRM_HD uint64_t fq_elem_make(uint32_t nl_mod4, const uint32_t cnt[4])
+{
+    return ((uint64_t)nl_mod4 << 60) | (uint64_t)cnt[0] | ((uint64_t)cnt[1] << 15) | ((uint64_t)cnt[2] << 30) | ((uint64_t)cnt[3] << 45);
+}
+GRM_HD uint32_t fq_elem_nl(uint64_t e) { return (uint32_t)(e >> 60) & 3u; }
+GRM_HD uint32_t fq_elem_cnt(uint64_t e, int s) { return (uint32_t)(e >> (15 * s)) & 0x7fffu; }
+GRM_HD uint64_t fq_elem_combine(uint64_t a, uint64_t b)
+{
+    const uint32_t na = fq_elem_nl(a);
+    uint32_t c[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) c[s] = fq_elem_cnt(a, s) + fq_elem_cnt(b, (s + (int)na) & 3);
+    return fq_elem_make((na + fq_elem_nl(b)) & 3u, c);
+}
+
 // the emitted symbols of one 16-byte chunk as bit strings: returns the count (0..16);
 // sym: 2 bits per symbol, first symbol most significant, in the low 2*count bits;
 // inv: bit i = symbol i is a separator / bad base.

@@ -29,10 +29,14 @@ constexpr int TABLE_SCRATCH_BYTES = 128;
 constexpr int KEYS_IN_FLIGHT = 4;
 constexpr int SLOTS_IN_FLIGHT = 8;                         // independent 2-byte slot loads per lane in the slot fill                          // independent key loads per lane in dict/fill
 
+// per-tile flags (host-built): every file starts on a tile boundary
+constexpr uint8_t TILE_META_FIRST = 1;   // first tile of a file: the parser state restarts
+constexpr uint8_t TILE_META_FASTQ = 2;   // 4-line FASTQ records instead of FASTA
+
 struct TileSummary {
-    uint32_t known;       // symbols whose emission does not depend on the incoming line type
-    uint32_t unknown;     // symbols emitted only if the line running into the tile is a sequence line
-    uint32_t last_event;  // T_SEQ / T_HDR of the last line starting inside the tile, 0 if none
+    uint32_t v[4];   // FASTA: v0 = symbols emitted whatever runs into the tile, v1 = extra if a sequence line does
+                     // FASTQ: v[s] = symbols when the tile starts in line phase s
+    uint32_t tag;    // FASTA: type of the last line start (0 none, 1 seq, 2 header); FASTQ: 4 | newlines mod 4
 };
 
 struct KmerLaunch {
@@ -46,11 +50,11 @@ struct KmerLaunch {
     uint32_t groups_per_thread;
 };
 
-void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, TileSummary *sums);
-void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles, uint64_t *tile_off,
+void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, TileSummary *sums);
+void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles, const uint8_t *tile_meta, uint64_t *tile_off,
                        uint8_t *tile_state, const uint32_t *genome_tile_off, uint32_t n_genomes,
                        uint64_t *genome_sym_off);
-void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint64_t *tile_off,
+void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, const uint64_t *tile_off,
                        const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv);
 void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
 int scatter_b1_bits(int bb);

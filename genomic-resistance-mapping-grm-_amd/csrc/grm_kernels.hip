@@ -184,61 +184,190 @@ __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint3
     tc.pre[3] = pelem_combine(wp3, e3);
 }
 
-// P1: per tile -> {symbols emitted for either incoming line type, type of the last line start}
+// FASTQ variant of the tile scan: the element carries the newline count mod 4 and the symbol
+// count for each of the 4 possible starting line phases (fq_elem_* in grm_device_fns.h).
+struct TileChunksFq {
+    uint32_t w[ROUNDS_PER_TILE][4];
+    uint32_t nl[ROUNDS_PER_TILE], cr[ROUNDS_PER_TILE], ls[ROUNDS_PER_TILE];
+    uint64_t pre[ROUNDS_PER_TILE];
+    uint64_t total;
+};
+
+template <int R>
+__device__ __forceinline__ void tile_round_fq(const uint4 &v, uint32_t edge, int lane, TileChunksFq &tc, uint64_t &elem)
+{
+    tc.w[R][0] = v.x; tc.w[R][1] = v.y; tc.w[R][2] = v.z; tc.w[R][3] = v.w;
+    uint32_t nl, gt, cr;
+    chunk_masks(tc.w[R], nl, gt, cr);
+    const uint32_t up = __shfl_up((nl >> 15) & 1u, 1);
+    const uint32_t prev_nl = lane == 0 ? edge : up;
+    const uint32_t ls = ((nl << 1) | prev_nl) & 0xffffu;
+    tc.nl[R] = nl; tc.cr[R] = cr; tc.ls[R] = ls;
+    uint32_t m[4];
+    fq_phase_masks(nl, m);
+    uint32_t c0, c1, c2, c3, em, sp;
+    fq_classify(nl, cr, ls, m, 0, em, sp); c0 = __popc(em);
+    fq_classify(nl, cr, ls, m, 1, em, sp); c1 = __popc(em);
+    fq_classify(nl, cr, ls, m, 2, em, sp); c2 = __popc(em);
+    fq_classify(nl, cr, ls, m, 3, em, sp); c3 = __popc(em);
+    const uint32_t c[4] = {c0, c1, c2, c3};
+    elem = fq_elem_make(__popc(nl) & 3u, c);
+}
+
+__device__ __forceinline__ void tile_scan_fq(const uint8_t *__restrict__ raw, uint32_t tile, uint64_t *partial /* LDS [16] */,
+                                             TileChunksFq &tc)
+{
+    const int lane = lane_id(), wave = wave_id();
+    uint4 v[ROUNDS_PER_TILE];
+    uint32_t edge[ROUNDS_PER_TILE];
+#pragma unroll
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
+        v[r] = *reinterpret_cast<const uint4 *>(raw + base);
+        edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;
+    }
+    uint64_t inc[ROUNDS_PER_TILE];
+    tile_round_fq<0>(v[0], edge[0], lane, tc, inc[0]);
+    tile_round_fq<1>(v[1], edge[1], lane, tc, inc[1]);
+    tile_round_fq<2>(v[2], edge[2], lane, tc, inc[2]);
+    tile_round_fq<3>(v[3], edge[3], lane, tc, inc[3]);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+            const uint64_t o = __shfl_up(inc[r], d);
+            if (lane >= d) inc[r] = fq_elem_combine(o, inc[r]);
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS_PER_TILE; r++) partial[r * (PARSE_THREADS / 64) + wave] = inc[r];
+    }
+    __syncthreads();
+    uint64_t acc = 0;        // identity: nl 0, counts 0
+    uint64_t wp0 = acc, wp1 = acc, wp2 = acc, wp3 = acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i == wave) wp0 = acc;
+        if (i == 4 + wave) wp1 = acc;
+        if (i == 8 + wave) wp2 = acc;
+        if (i == 12 + wave) wp3 = acc;
+        acc = fq_elem_combine(acc, partial[i]);
+    }
+    tc.total = acc;
+    uint64_t e0 = __shfl_up(inc[0], 1), e1 = __shfl_up(inc[1], 1), e2 = __shfl_up(inc[2], 1), e3 = __shfl_up(inc[3], 1);
+    if (lane == 0) e0 = e1 = e2 = e3 = 0;
+    tc.pre[0] = fq_elem_combine(wp0, e0);
+    tc.pre[1] = fq_elem_combine(wp1, e1);
+    tc.pre[2] = fq_elem_combine(wp2, e2);
+    tc.pre[3] = fq_elem_combine(wp3, e3);
+}
+
+// P1: per tile -> summary.  FASTA: {v0 = symbols emitted whatever runs into the tile, v1 = extra
+// symbols if a sequence line runs into it, tag = type of the last line start}.
+// FASTQ: {v[s] = symbols when the tile starts in line phase s, tag = 4 | newlines mod 4}.
 __global__ __launch_bounds__(PARSE_THREADS) void parse_summarize_kernel(
-    const uint8_t *__restrict__ raw, uint32_t n_tiles, TileSummary *__restrict__ sums)
+    const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint8_t *__restrict__ tile_meta,
+    TileSummary *__restrict__ sums)
 {
     __shared__ uint64_t partial[ROUNDS_PER_TILE * (PARSE_THREADS / 64)];
     const uint32_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
-    TileChunks tc;
-    tile_scan(raw, tile, partial, tc);
-    if (threadIdx.x == 0) {
-        TileSummary s;
-        s.known = pelem_ch(tc.total);                          // emitted whatever runs into the tile
-        s.unknown = pelem_cs(tc.total) - pelem_ch(tc.total);   // only if a sequence line runs into it
-        s.last_event = (uint32_t)pelem_ev(tc.total);
-        sums[tile] = s;
+    TileSummary s;
+    if (tile_meta[tile] & TILE_META_FASTQ) {
+        TileChunksFq tc;
+        tile_scan_fq(raw, tile, partial, tc);
+        s.v[0] = fq_elem_cnt(tc.total, 0); s.v[1] = fq_elem_cnt(tc.total, 1);
+        s.v[2] = fq_elem_cnt(tc.total, 2); s.v[3] = fq_elem_cnt(tc.total, 3);
+        s.tag = 4u | fq_elem_nl(tc.total);
+    } else {
+        TileChunks tc;
+        tile_scan(raw, tile, partial, tc);
+        s.v[0] = pelem_ch(tc.total);
+        s.v[1] = pelem_cs(tc.total) - pelem_ch(tc.total);
+        s.v[2] = s.v[3] = 0;
+        s.tag = (uint32_t)pelem_ev(tc.total);
     }
+    if (threadIdx.x == 0) sums[tile] = s;
 }
 
-// P-scan: ONE workgroup walks all tile summaries: resolves each tile's incoming line type
-// (rightmost-non-zero scan of last_event) and its first symbol index (exclusive sum).
-// Also emits the first symbol index of every genome (genome_tile_off: first tile of
-// genome g; entry [n_genomes] = n_tiles) and the total.
+// P-scan: ONE workgroup walks all tile summaries.  The parser state carried from tile to tile
+// is a value in 0..3 (FASTA: 0 none / 1 sequence line / 2 header line; FASTQ: line index mod 4);
+// each tile is a function on it, encoded as a 4-entry table (2 bits per entry).  Function
+// composition is associative, so a block scan of the tables gives every thread the state running
+// into its first tile; the first tile of every file restarts from state 0.
+__device__ __forceinline__ uint32_t tbl_apply(uint32_t t, uint32_t s) { return (t >> (2 * s)) & 3u; }
+__device__ __forceinline__ uint32_t tbl_compose(uint32_t f, uint32_t g)     // "f then g"
+{
+    return tbl_apply(g, tbl_apply(f, 0)) | (tbl_apply(g, tbl_apply(f, 1)) << 2) | (tbl_apply(g, tbl_apply(f, 2)) << 4) |
+           (tbl_apply(g, tbl_apply(f, 3)) << 6);
+}
+__device__ __forceinline__ uint32_t tile_table(const TileSummary &s, uint8_t meta)
+{
+    uint32_t t;
+    if (s.tag & 4u) {
+        const uint32_t n = s.tag & 3u;
+        t = (n & 3u) | (((1 + n) & 3u) << 2) | (((2 + n) & 3u) << 4) | (((3 + n) & 3u) << 6);
+    } else {
+        t = s.tag ? (s.tag * 0x55u) : 0xE4u;          // constant last_event, or identity {0,1,2,3}
+    }
+    if (meta & TILE_META_FIRST) t = tbl_apply(t, 0) * 0x55u;   // restart from state 0: constant function
+    return t;
+}
+__device__ __forceinline__ uint64_t tile_count(const TileSummary &s, uint32_t state)
+{
+    if (s.tag & 4u) return s.v[state];
+    return (uint64_t)s.v[0] + (state != (uint32_t)T_HDR ? s.v[1] : 0u);
+}
+
 __global__ __launch_bounds__(1024) void parse_scan_kernel(
-    const TileSummary *__restrict__ sums, uint32_t n_tiles, uint64_t *tile_off,
+    const TileSummary *__restrict__ sums, uint32_t n_tiles, const uint8_t *__restrict__ tile_meta, uint64_t *tile_off,
     uint8_t *__restrict__ tile_state, const uint32_t *__restrict__ genome_tile_off,
     uint32_t n_genomes, uint64_t *__restrict__ genome_sym_off /* n_genomes+1 */)
 {
-    __shared__ int scratch_i[16];
+    __shared__ uint32_t scratch_t[16];
     __shared__ uint64_t scratch_l[16];
     const uint32_t per = (n_tiles + blockDim.x - 1) / blockDim.x;
     const uint32_t t0 = min((uint64_t)threadIdx.x * per, (uint64_t)n_tiles);
     const uint32_t t1 = min((uint64_t)t0 + per, (uint64_t)n_tiles);
-    int last = 0;
-    for (uint32_t t = t0; t < t1; t++) {
-        int e = (int)sums[t].last_event;
-        if (e) last = e;
+    uint32_t tbl = 0xE4u;        // identity
+    for (uint32_t t = t0; t < t1; t++) tbl = tbl_compose(tbl, tile_table(sums[t], tile_meta[t]));
+    // exclusive block scan of the tables (composition, thread order)
+    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
+    uint32_t inc = tbl;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc = tbl_compose(o, inc);
     }
-    int dummy;
-    int cur = block_scan_last_nonzero(last, scratch_i, &dummy);
+    uint32_t exc = __shfl_up(inc, 1);
+    if (lane == 0) exc = 0xE4u;
+    if (lane == 63) scratch_t[wave] = inc;
+    __syncthreads();
+    uint32_t prefix = 0xE4u;
+    for (int w = 0; w < nw; w++)
+        if (w < wave) prefix = tbl_compose(prefix, scratch_t[w]);
+    const uint32_t state0 = tbl_apply(tbl_compose(prefix, exc), 0);   // the buffer starts in state 0
     uint64_t sum = 0;
-    int c = cur;
+    uint32_t st = state0;
     for (uint32_t t = t0; t < t1; t++) {
-        TileSummary s = sums[t];
-        sum += s.known + (c != T_HDR ? s.unknown : 0u);
-        if (s.last_event) c = (int)s.last_event;
+        const TileSummary s = sums[t];
+        const uint8_t meta = tile_meta[t];
+        if (meta & TILE_META_FIRST) st = 0;
+        sum += tile_count(s, st);
+        st = tbl_apply(tile_table(s, 0), st);
     }
     uint64_t total;
     uint64_t off = block_scan_sum64(sum, scratch_l, &total);
-    c = cur;
+    st = state0;
     for (uint32_t t = t0; t < t1; t++) {
-        TileSummary s = sums[t];
+        const TileSummary s = sums[t];
+        const uint8_t meta = tile_meta[t];
+        if (meta & TILE_META_FIRST) st = 0;
         tile_off[t] = off;
-        tile_state[t] = (uint8_t)c;
-        off += s.known + (c != T_HDR ? s.unknown : 0u);
-        if (s.last_event) c = (int)s.last_event;
+        tile_state[t] = (uint8_t)st;
+        off += tile_count(s, st);
+        st = tbl_apply(tile_table(s, 0), st);
     }
     if (threadIdx.x == 0) tile_off[n_tiles] = total;
     __syncthreads();   // tile_off written by this block is visible to it after the barrier
@@ -251,8 +380,9 @@ __global__ __launch_bounds__(1024) void parse_scan_kernel(
 // LDS image of the packed stream (ds_or_b64); the image is then stored with coalesced writes.
 // Groups shared with a neighbouring tile go out through global atomicOr (buffers pre-zeroed).
 __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
-    const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint64_t *__restrict__ tile_off,
-    const uint8_t *__restrict__ tile_state, uint64_t *__restrict__ sym2, uint64_t *__restrict__ inv)
+    const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint8_t *__restrict__ tile_meta,
+    const uint64_t *__restrict__ tile_off, const uint8_t *__restrict__ tile_state, uint64_t *__restrict__ sym2,
+    uint64_t *__restrict__ inv)
 {
     constexpr int MAX_GROUPS = TILE_BYTES / 64 + 2;
     __shared__ uint64_t partial[ROUNDS_PER_TILE * (PARSE_THREADS / 64)];
@@ -262,24 +392,38 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
     if (tile >= n_tiles) return;
     for (int i = threadIdx.x; i < 2 * MAX_GROUPS; i += PARSE_THREADS) w2[i] = 0;
     for (int i = threadIdx.x; i < MAX_GROUPS; i += PARSE_THREADS) wi[i] = 0;
-    TileChunks tc;
-    tile_scan(raw, tile, partial, tc);                 // its barrier also orders the zeroing above
-    int state = (int)tile_state[tile];
-    if (state == T_NONE) state = T_SEQ;                // only before the first line start of the buffer
     const uint64_t sym_base = tile_off[tile];
     const uint32_t lead = (uint32_t)(sym_base & 63ull);
-    const uint32_t n_tile = state == T_SEQ ? pelem_cs(tc.total) : pelem_ch(tc.total);
+    const int state = (int)tile_state[tile];
+    uint32_t n_tile;
+    auto or_sym = [&](uint32_t i, uint64_t val) { atomicOr((unsigned long long *)&w2[i], (unsigned long long)val); };
+    auto or_inv = [&](uint32_t i, uint64_t val) { atomicOr((unsigned long long *)&wi[i], (unsigned long long)val); };
+    if (tile_meta[tile] & TILE_META_FASTQ) {
+        TileChunksFq tc;
+        tile_scan_fq(raw, tile, partial, tc);           // its barrier also orders the zeroing above
+        n_tile = fq_elem_cnt(tc.total, state);
 #pragma unroll
-    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-        const int ev = pelem_ev(tc.pre[r]);
-        const int cin = ev ? ev : state;
-        const uint32_t emit = tc.ek[r] | (cin == T_SEQ ? tc.unk[r] : 0u);
-        uint32_t cs, ci;
-        const int cnt = chunk_pack(tc.w[r], emit, tc.sep[r], cs, ci);
-        const uint32_t pos = lead + (state == T_SEQ ? pelem_cs(tc.pre[r]) : pelem_ch(tc.pre[r]));
-        stream_insert(pos, cnt, cs, ci,
-                      [&](uint32_t i, uint64_t val) { atomicOr((unsigned long long *)&w2[i], (unsigned long long)val); },
-                      [&](uint32_t i, uint64_t val) { atomicOr((unsigned long long *)&wi[i], (unsigned long long)val); });
+        for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+            uint32_t m[4], emit, sep, cs, ci;
+            fq_phase_masks(tc.nl[r], m);
+            fq_classify(tc.nl[r], tc.cr[r], tc.ls[r], m, (state + (int)fq_elem_nl(tc.pre[r])) & 3, emit, sep);
+            const int cnt = chunk_pack(tc.w[r], emit, sep, cs, ci);
+            stream_insert(lead + fq_elem_cnt(tc.pre[r], state), cnt, cs, ci, or_sym, or_inv);
+        }
+    } else {
+        TileChunks tc;
+        tile_scan(raw, tile, partial, tc);
+        const int st = state == T_NONE ? T_SEQ : state;   // only before the first line start of a file
+        n_tile = st == T_SEQ ? pelem_cs(tc.total) : pelem_ch(tc.total);
+#pragma unroll
+        for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+            const int ev = pelem_ev(tc.pre[r]);
+            const int cin = ev ? ev : st;
+            const uint32_t emit = tc.ek[r] | (cin == T_SEQ ? tc.unk[r] : 0u);
+            uint32_t cs, ci;
+            const int cnt = chunk_pack(tc.w[r], emit, tc.sep[r], cs, ci);
+            stream_insert(lead + (st == T_SEQ ? pelem_cs(tc.pre[r]) : pelem_ch(tc.pre[r])), cnt, cs, ci, or_sym, or_inv);
+        }
     }
     __syncthreads();
     const uint32_t span = lead + n_tile;
@@ -1043,21 +1187,21 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap = 256u 
     return (uint32_t)(g > cap ? cap : g);
 }
 
-void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, TileSummary *sums)
+void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, TileSummary *sums)
 {
-    hipLaunchKernelGGL(parse_summarize_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, sums);
+    hipLaunchKernelGGL(parse_summarize_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, sums);
 }
-void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles, uint64_t *tile_off,
+void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles, const uint8_t *tile_meta, uint64_t *tile_off,
                        uint8_t *tile_state, const uint32_t *genome_tile_off, uint32_t n_genomes,
                        uint64_t *genome_sym_off)
 {
-    hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(1024), 0, s, sums, n_tiles, tile_off, tile_state,
+    hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(1024), 0, s, sums, n_tiles, tile_meta, tile_off, tile_state,
                        genome_tile_off, n_genomes, genome_sym_off);
 }
-void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint64_t *tile_off,
+void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, const uint64_t *tile_off,
                        const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv)
 {
-    hipLaunchKernelGGL(parse_pack_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_off,
+    hipLaunchKernelGGL(parse_pack_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, tile_off,
                        tile_state, sym2, inv);
 }
 

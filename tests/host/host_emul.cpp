@@ -113,6 +113,49 @@ uint64_t emul_parse2(const uint8_t *raw, uint64_t n_bytes, uint64_t tile_bytes, 
     return off;
 }
 
+// FASTQ through the device primitives: per-chunk phase masks + associative elements.  Layout as
+// the batch builds it for FASTQ files: bytes + '\n', padded with '\n' (no synthetic header).
+uint64_t emul_parse_fastq(const uint8_t *raw, uint64_t n_bytes, uint64_t tile_bytes, uint64_t *sym2, uint64_t *inv, uint64_t n_groups_cap)
+{
+    std::memset(sym2, 0, n_groups_cap * 16);
+    std::memset(inv, 0, n_groups_cap * 8);
+    const uint64_t n_tiles = n_bytes / tile_bytes;
+    uint32_t zero[4] = {0, 0, 0, 0};
+    auto chunk = [&](uint64_t base, uint32_t w[4], uint32_t &nl, uint32_t &cr, uint32_t &ls, uint32_t m[4]) {
+        std::memcpy(w, raw + base, 16);
+        uint32_t gt;
+        chunk_masks(w, nl, gt, cr);
+        uint32_t prev_nl = base == 0 ? 1u : (raw[base - 1] == '\n');
+        ls = ((nl << 1) | prev_nl) & 0xffffu;
+        fq_phase_masks(nl, m);
+        uint32_t c[4];
+        for (int s = 0; s < 4; s++) { uint32_t em, sp; fq_classify(nl, cr, ls, m, s, em, sp); c[s] = __builtin_popcount(em); }
+        return fq_elem_make(__builtin_popcount(nl) & 3, c);
+    };
+    int phase = 0;
+    uint64_t off = 0;
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        uint64_t pre = fq_elem_make(0, zero);
+        for (uint64_t base = t * tile_bytes; base < (t + 1) * tile_bytes; base += 16) {
+            uint32_t w[4], nl, cr, ls, m[4];
+            uint64_t e = chunk(base, w, nl, cr, ls, m);
+            const int ph = (phase + (int)fq_elem_nl(pre)) & 3;
+            uint32_t emit, sep, cs, ci;
+            fq_classify(nl, cr, ls, m, ph, emit, sep);
+            const int cnt = chunk_pack(w, emit, sep, cs, ci);
+            const uint64_t pos = off + fq_elem_cnt(pre, phase);
+            const uint64_t wbase = (pos >> 6) << 6;
+            stream_insert((uint32_t)(pos - wbase), cnt, cs, ci,
+                          [&](uint32_t wi, uint64_t v) { if ((wbase >> 5) + wi < n_groups_cap * 2) sym2[(wbase >> 5) + wi] |= v; },
+                          [&](uint32_t wi, uint64_t v) { if ((wbase >> 6) + wi < n_groups_cap) inv[(wbase >> 6) + wi] |= v; });
+            pre = fq_elem_combine(pre, e);
+        }
+        off += fq_elem_cnt(pre, phase);
+        phase = (phase + (int)fq_elem_nl(pre)) & 3;
+    }
+    return off;
+}
+
 // the tile-summary path: counts symbols of [t0,t1) bytes the way parse_summarize does
 // (known / unknown / last_event), for checking the in-state algebra.
 void emul_summarize(const uint8_t *raw, uint64_t t0, uint64_t t1, uint32_t *known, uint32_t *unknown, uint32_t *last_event)

@@ -142,6 +142,37 @@ def test_more_than_64_genomes_and_ragged(ctx):
     _check(ctx, genomes, 15, 1, False)
 
 
+@pytest.mark.parametrize("name,k,genomes", cases.fastq_cases(), ids=lambda x: x if isinstance(x, str) else None)
+@pytest.mark.parametrize("amin,filt", [(1, False), (2, False), (2, True)])
+def test_fastq_reads(ctx, name, k, genomes, amin, filt):
+    _check(ctx, genomes, k, amin, filt)
+
+
+def test_fastq_gzip_and_mixed_formats(ctx):
+    import gzip
+    rng = np.random.RandomState(31)
+    ref = cases.rand_seq(rng, 30000)
+    reads = [ref[s:s + 150] for s in rng.randint(0, len(ref) - 150, size=3000)]
+    for i in range(0, len(reads), 7):
+        reads[i] = cases.revcomp(reads[i])
+    fq1 = cases.fastq(reads[:1500]).encode()
+    fq2 = cases.fastq(reads[1500:]).encode()
+    fa = cases.fasta([("ref", ref)], width=80).encode()
+    plain = [[fq1, fq2], [fa], [fq2]]
+    gz = [[gzip.compress(fq1), fq2], [gzip.compress(fa)], [gzip.compress(fq2[:len(fq2) // 2]) + gzip.compress(fq2[len(fq2) // 2:])]]
+    for amin in (1, 2, 3):
+        want = orc.build_matrix(plain, 21, amin, False)
+        kmers, data, n_occ, _ = _run_batch(ctx, gz, 21, amin, False)
+        assert n_occ == want["n_occurrences"]
+        assert (kmers == want["kmers"]).all() and kmers.shape == want["kmers"].shape
+        assert (data == want["matrix"]).all()
+    # per-genome counted set of a read set (multidsk on reads: abundance-min 2)
+    km, ct, nocc = orc.count_genome([fq1, fq2], 21, 2)
+    s = ctx.count_genome([gzip.compress(fq1), fq2], 21, 2)
+    assert s.occurrences == nocc and (s.kmers() == km).all() and (s.counts() == ct).all()
+    s.free()
+
+
 def test_staged_equals_fused(ctx):
     import torch
     genomes = _medium_genomes(n=4, length=100_000, seed=3)

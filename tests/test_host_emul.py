@@ -29,6 +29,8 @@ def emul():
     L.emul_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
     L.emul_parse2.restype = C.c_uint64
     L.emul_parse2.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.emul_parse_fastq.restype = C.c_uint64
+    L.emul_parse_fastq.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     L.emul_kmers16.restype = C.c_uint64
     L.emul_kmers16.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
     L.emul_kmers32.restype = C.c_uint64
@@ -176,3 +178,25 @@ def test_hash_balance(emul):
         n, m = len(sel), 4096
         expect = m * (1 - np.exp(-n / m))
         assert len(np.unique(slots)) > 0.9 * expect, (name, len(np.unique(slots)), expect)
+
+
+def test_fastq_primitives_match_oracle(emul):
+    """FASTQ classification (phase masks, associative elements) on the CPU vs the oracle"""
+    for name, k, genomes in cases.fastq_cases():
+        for texts in genomes:
+            for t in texts:
+                f = t.encode()
+                img = f + b"\n"
+                img += b"\n" * ((-len(img)) % TILE)
+                raw = np.frombuffer(img, dtype=np.uint8).copy()
+                for tile_bytes in (TILE, 64):
+                    ng = len(raw) // 64 + 8
+                    sym2 = np.zeros(2 * ng, dtype=np.uint64)
+                    inv = np.zeros(ng, dtype=np.uint64)
+                    nsym = emul.emul_parse_fastq(raw.ctypes.data, len(raw), tile_bytes, sym2.ctypes.data, inv.ctypes.data, ng)
+                    out = np.zeros(max(1, int(nsym)), dtype=np.uint64)
+                    n = emul.emul_kmers(sym2.ctypes.data, inv.ctypes.data, nsym, k, out.ctypes.data, len(out))
+                    km, ct, nocc = orc.count_genome([f], k)
+                    assert n == nocc
+                    vals, counts = np.unique(out[:n], return_counts=True)
+                    assert (vals == km[:, 0]).all() and (counts == ct).all()
