@@ -383,7 +383,7 @@ struct grm_batch {
     DevBuf d_genome_tile_off; // u32[n_genomes+1]
     DevBuf d_tile_meta;       // u8[n_tiles]: TILE_META_FIRST | TILE_META_FASTQ
     // parse products
-    DevBuf d_sums, d_tile_off, d_tile_state, d_sym2, d_inv, d_genome_sym_off;
+    DevBuf d_sums, d_tile_off, d_tile_state, d_sym2, d_inv, d_genome_sym_off, d_scan_scratch;
     uint64_t total_syms = 0;
     std::vector<uint64_t> h_genome_sym_off;
     // partition products
@@ -580,6 +580,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         HIPCHK(c, b->d_sym2.ensure(max_groups * 16));
         HIPCHK(c, b->d_inv.ensure(max_groups * 8));
         HIPCHK(c, b->d_genome_sym_off.ensure(((size_t)G + 1) * 8));
+        HIPCHK(c, b->d_scan_scratch.ensure(parse_scan_scratch_bytes(b->n_tiles)));
     }
     HIPCHK(c, hipMemsetAsync(b->d_sym2.p, 0, max_groups * 16, s));
     HIPCHK(c, hipMemsetAsync(b->d_inv.p, 0, max_groups * 8, s));
@@ -591,7 +592,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         TimeScope t(c, "parse_scan", b->n_tiles);
         launch_parse_scan(s, b->d_sums.as<TileSummary>(), b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_tile_off.as<uint64_t>(),
                           b->d_tile_state.as<uint8_t>(), b->d_genome_tile_off.as<uint32_t>(), G,
-                          b->d_genome_sym_off.as<uint64_t>());
+                          b->d_genome_sym_off.as<uint64_t>(), b->d_scan_scratch.p);
     }
     {
         TimeScope t(c, "parse_pack", b->raw_bytes);

@@ -53,7 +53,8 @@ struct KmerLaunch {
 void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, TileSummary *sums);
 void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles, const uint8_t *tile_meta, uint64_t *tile_off,
                        uint8_t *tile_state, const uint32_t *genome_tile_off, uint32_t n_genomes,
-                       uint64_t *genome_sym_off);
+                       uint64_t *genome_sym_off, void *scratch);
+size_t parse_scan_scratch_bytes(uint32_t n_tiles);
 void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, const uint64_t *tile_off,
                        const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv);
 void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);

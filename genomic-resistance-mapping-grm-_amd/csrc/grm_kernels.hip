@@ -320,58 +320,143 @@ __device__ __forceinline__ uint64_t tile_count(const TileSummary &s, uint32_t st
     return (uint64_t)s.v[0] + (state != (uint32_t)T_HDR ? s.v[1] : 0u);
 }
 
-__global__ __launch_bounds__(1024) void parse_scan_kernel(
-    const TileSummary *__restrict__ sums, uint32_t n_tiles, const uint8_t *__restrict__ tile_meta, uint64_t *tile_off,
-    uint8_t *__restrict__ tile_state, const uint32_t *__restrict__ genome_tile_off,
-    uint32_t n_genomes, uint64_t *__restrict__ genome_sym_off /* n_genomes+1 */)
+// The scan element of a run of tiles: its state table plus, for each incoming state, the
+// symbols it emits.  combine(a, b) = "a then b"; associative.
+template <typename C>
+struct ScanElem {
+    uint32_t tbl;
+    C c[4];
+};
+template <typename C>
+__device__ __forceinline__ ScanElem<C> selem_identity()
 {
-    __shared__ uint32_t scratch_t[16];
-    __shared__ uint64_t scratch_l[16];
-    const uint32_t per = (n_tiles + blockDim.x - 1) / blockDim.x;
-    const uint32_t t0 = min((uint64_t)threadIdx.x * per, (uint64_t)n_tiles);
-    const uint32_t t1 = min((uint64_t)t0 + per, (uint64_t)n_tiles);
-    uint32_t tbl = 0xE4u;        // identity
-    for (uint32_t t = t0; t < t1; t++) tbl = tbl_compose(tbl, tile_table(sums[t], tile_meta[t]));
-    // exclusive block scan of the tables (composition, thread order)
+    ScanElem<C> e;
+    e.tbl = 0xE4u;
+    e.c[0] = e.c[1] = e.c[2] = e.c[3] = 0;
+    return e;
+}
+template <typename C>
+__device__ __forceinline__ ScanElem<C> selem_combine(const ScanElem<C> &a, const ScanElem<C> &b)
+{
+    ScanElem<C> r;
+    r.tbl = tbl_compose(a.tbl, b.tbl);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const uint32_t mid = tbl_apply(a.tbl, s);
+        r.c[s] = a.c[s] + (mid == 0 ? b.c[0] : mid == 1 ? b.c[1] : mid == 2 ? b.c[2] : b.c[3]);
+    }
+    return r;
+}
+template <typename C>
+__device__ __forceinline__ ScanElem<C> selem_shfl_up(const ScanElem<C> &e, int d)
+{
+    ScanElem<C> r;
+    r.tbl = __shfl_up(e.tbl, d);
+#pragma unroll
+    for (int s = 0; s < 4; s++) r.c[s] = __shfl_up(e.c[s], d);
+    return r;
+}
+// block-wide scan of elements in thread order.  Returns the exclusive prefix of this thread;
+// *total = combination of all.  lds: >= 16 elements.  Two barriers.
+template <typename C>
+__device__ __forceinline__ ScanElem<C> selem_block_scan(ScanElem<C> v, ScanElem<C> *lds, ScanElem<C> *total)
+{
     const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
-    uint32_t inc = tbl;
+    ScanElem<C> inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d);
-        if (lane >= d) inc = tbl_compose(o, inc);
+        const ScanElem<C> o = selem_shfl_up(inc, d);
+        if (lane >= d) inc = selem_combine(o, inc);
     }
-    uint32_t exc = __shfl_up(inc, 1);
-    if (lane == 0) exc = 0xE4u;
-    if (lane == 63) scratch_t[wave] = inc;
+    ScanElem<C> exc = selem_shfl_up(inc, 1);
+    if (lane == 0) exc = selem_identity<C>();
+    if (lane == 63) lds[wave] = inc;
     __syncthreads();
-    uint32_t prefix = 0xE4u;
-    for (int w = 0; w < nw; w++)
-        if (w < wave) prefix = tbl_compose(prefix, scratch_t[w]);
-    const uint32_t state0 = tbl_apply(tbl_compose(prefix, exc), 0);   // the buffer starts in state 0
-    uint64_t sum = 0;
-    uint32_t st = state0;
-    for (uint32_t t = t0; t < t1; t++) {
-        const TileSummary s = sums[t];
-        const uint8_t meta = tile_meta[t];
-        if (meta & TILE_META_FIRST) st = 0;
-        sum += tile_count(s, st);
-        st = tbl_apply(tile_table(s, 0), st);
+    ScanElem<C> prefix = selem_identity<C>(), all = selem_identity<C>();
+    for (int w = 0; w < nw; w++) {
+        const ScanElem<C> t = lds[w];
+        if (w < wave) prefix = selem_combine(prefix, t);
+        all = selem_combine(all, t);
     }
-    uint64_t total;
-    uint64_t off = block_scan_sum64(sum, scratch_l, &total);
-    st = state0;
-    for (uint32_t t = t0; t < t1; t++) {
-        const TileSummary s = sums[t];
-        const uint8_t meta = tile_meta[t];
-        if (meta & TILE_META_FIRST) st = 0;
-        tile_off[t] = off;
-        tile_state[t] = (uint8_t)st;
-        off += tile_count(s, st);
-        st = tbl_apply(tile_table(s, 0), st);
+    __syncthreads();
+    *total = all;
+    return selem_combine(prefix, exc);
+}
+__device__ __forceinline__ ScanElem<uint32_t> tile_elem(const TileSummary &s, uint8_t meta)
+{
+    ScanElem<uint32_t> e;
+    e.tbl = tile_table(s, meta);
+#pragma unroll
+    for (int st = 0; st < 4; st++) e.c[st] = (uint32_t)tile_count(s, (meta & TILE_META_FIRST) ? 0u : (uint32_t)st);
+    return e;
+}
+
+// scan phase A: one tile per thread; exclusive prefix inside the 256-tile block + block totals
+__global__ __launch_bounds__(256) void parse_scan_a_kernel(const TileSummary *__restrict__ sums, uint32_t n_tiles,
+                                                           const uint8_t *__restrict__ tile_meta,
+                                                           ScanElem<uint32_t> *__restrict__ tile_pre,
+                                                           ScanElem<uint32_t> *__restrict__ block_tot)
+{
+    __shared__ ScanElem<uint32_t> lds[16];
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    ScanElem<uint32_t> e = selem_identity<uint32_t>();
+    if (t < n_tiles) e = tile_elem(sums[t], tile_meta[t]);
+    ScanElem<uint32_t> total;
+    const ScanElem<uint32_t> pre = selem_block_scan(e, lds, &total);
+    if (t < n_tiles) tile_pre[t] = pre;
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = total;
+}
+// scan phase B: ONE workgroup over the block totals; the buffer starts in state 0, so only the
+// state and symbol offset running into each block are kept.
+__global__ __launch_bounds__(1024) void parse_scan_b_kernel(const ScanElem<uint32_t> *__restrict__ block_tot, uint32_t n_blocks,
+                                                            uint8_t *__restrict__ block_state, uint64_t *__restrict__ block_off,
+                                                            uint64_t *__restrict__ total_out)
+{
+    __shared__ ScanElem<uint64_t> lds[16];
+    const uint32_t per = (n_blocks + blockDim.x - 1) / blockDim.x;
+    const uint32_t b0 = min((uint64_t)threadIdx.x * per, (uint64_t)n_blocks), b1 = min((uint64_t)b0 + per, (uint64_t)n_blocks);
+    ScanElem<uint64_t> acc = selem_identity<uint64_t>();
+    for (uint32_t b = b0; b < b1; b++) {
+        const ScanElem<uint32_t> t = block_tot[b];
+        ScanElem<uint64_t> w;
+        w.tbl = t.tbl;
+        w.c[0] = t.c[0]; w.c[1] = t.c[1]; w.c[2] = t.c[2]; w.c[3] = t.c[3];
+        acc = selem_combine(acc, w);
     }
-    if (threadIdx.x == 0) tile_off[n_tiles] = total;
-    __syncthreads();   // tile_off written by this block is visible to it after the barrier
-    for (uint32_t g = threadIdx.x; g <= n_genomes; g += blockDim.x)
+    ScanElem<uint64_t> total;
+    const ScanElem<uint64_t> pre = selem_block_scan(acc, lds, &total);
+    uint32_t st = tbl_apply(pre.tbl, 0);
+    uint64_t off = pre.c[0];
+    for (uint32_t b = b0; b < b1; b++) {
+        const ScanElem<uint32_t> t = block_tot[b];
+        block_state[b] = (uint8_t)st;
+        block_off[b] = off;
+        off += st == 0 ? t.c[0] : st == 1 ? t.c[1] : st == 2 ? t.c[2] : t.c[3];
+        st = tbl_apply(t.tbl, st);
+    }
+    if (threadIdx.x == 0) *total_out = total.c[0];
+}
+// scan phase C: every tile gets its incoming state and first symbol index
+__global__ __launch_bounds__(256) void parse_scan_c_kernel(const ScanElem<uint32_t> *__restrict__ tile_pre, uint32_t n_tiles,
+                                                           const uint8_t *__restrict__ tile_meta,
+                                                           const uint8_t *__restrict__ block_state,
+                                                           const uint64_t *__restrict__ block_off, const uint64_t *__restrict__ total,
+                                                           uint64_t *__restrict__ tile_off, uint8_t *__restrict__ tile_state)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n_tiles) {
+        const ScanElem<uint32_t> pre = tile_pre[t];
+        const uint32_t bs = block_state[blockIdx.x];
+        const uint32_t st = tbl_apply(pre.tbl, bs);
+        tile_off[t] = block_off[blockIdx.x] + (bs == 0 ? pre.c[0] : bs == 1 ? pre.c[1] : bs == 2 ? pre.c[2] : pre.c[3]);
+        tile_state[t] = (uint8_t)((tile_meta[t] & TILE_META_FIRST) ? 0u : st);
+    }
+    if (t == 0) tile_off[n_tiles] = *total;
+}
+__global__ void genome_offsets_kernel(const uint64_t *__restrict__ tile_off, const uint32_t *__restrict__ genome_tile_off,
+                                      uint32_t n_genomes, uint64_t *__restrict__ genome_sym_off)
+{
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g <= n_genomes; g += gridDim.x * blockDim.x)
         genome_sym_off[g] = tile_off[genome_tile_off[g]];
 }
 
@@ -1191,12 +1276,29 @@ void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles,
 {
     hipLaunchKernelGGL(parse_summarize_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, sums);
 }
+// scratch: n_tiles * 20 B (tile prefixes) + n_blocks * (20 + 1 + 8) B + 8 B
+size_t parse_scan_scratch_bytes(uint32_t n_tiles)
+{
+    const size_t n_blocks = ((size_t)n_tiles + 255) / 256;
+    return (size_t)n_tiles * sizeof(ScanElem<uint32_t>) + n_blocks * (sizeof(ScanElem<uint32_t>) + 16) + 64;
+}
 void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles, const uint8_t *tile_meta, uint64_t *tile_off,
                        uint8_t *tile_state, const uint32_t *genome_tile_off, uint32_t n_genomes,
-                       uint64_t *genome_sym_off)
+                       uint64_t *genome_sym_off, void *scratch)
 {
-    hipLaunchKernelGGL(parse_scan_kernel, dim3(1), dim3(1024), 0, s, sums, n_tiles, tile_meta, tile_off, tile_state,
-                       genome_tile_off, n_genomes, genome_sym_off);
+    const uint32_t n_blocks = (n_tiles + 255) / 256;
+    uint8_t *p = reinterpret_cast<uint8_t *>(scratch);
+    uint64_t *total = reinterpret_cast<uint64_t *>(p); p += 16;
+    uint64_t *block_off = reinterpret_cast<uint64_t *>(p); p += (size_t)n_blocks * 8;
+    ScanElem<uint32_t> *tile_pre = reinterpret_cast<ScanElem<uint32_t> *>(p); p += (size_t)n_tiles * sizeof(ScanElem<uint32_t>);
+    ScanElem<uint32_t> *block_tot = reinterpret_cast<ScanElem<uint32_t> *>(p); p += (size_t)n_blocks * sizeof(ScanElem<uint32_t>);
+    uint8_t *block_state = p;
+    hipLaunchKernelGGL(parse_scan_a_kernel, dim3(n_blocks), dim3(256), 0, s, sums, n_tiles, tile_meta, tile_pre, block_tot);
+    hipLaunchKernelGGL(parse_scan_b_kernel, dim3(1), dim3(1024), 0, s, block_tot, n_blocks, block_state, block_off, total);
+    hipLaunchKernelGGL(parse_scan_c_kernel, dim3(n_blocks), dim3(256), 0, s, tile_pre, n_tiles, tile_meta, block_state, block_off,
+                       total, tile_off, tile_state);
+    hipLaunchKernelGGL(genome_offsets_kernel, dim3((n_genomes + 256) / 256), dim3(256), 0, s, tile_off, genome_tile_off, n_genomes,
+                       genome_sym_off);
 }
 void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, const uint64_t *tile_off,
                        const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv)
