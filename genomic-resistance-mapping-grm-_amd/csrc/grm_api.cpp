@@ -548,7 +548,6 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     grm_ctx *c = b->ctx;
     if (!b->uploaded) return fail(c, GRM_ERR_STATE, "grm_batch_partition before grm_batch_upload");
     if (k < 1 || k > 64) return fail(c, GRM_ERR_ARG, "k=%d out of range", k);
-    if (k > 32) return fail(c, GRM_ERR_UNSUPPORTED, "k=%d: two-word k-mers (33..64) are not built yet", k);
     if (abundance_min < 1) abundance_min = 1;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -608,6 +607,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     for (uint32_t g = 0; g < G; g++) max_g = std::max(max_g, b->h_genome_sym_off[g + 1] - b->h_genome_sym_off[g]);
     if (max_g >= 0xffffffffull) return fail(c, GRM_ERR_ARG, "a genome has %llu symbols (limit 2^32-1)", (unsigned long long)max_g);
     if (b->total_syms > max_groups * 64 - 256) return fail(c, GRM_ERR_HIP, "internal: symbol count exceeds the packed buffers");
+    if (k > 32) return GRM_OK;       // two-word k-mers: the caller continues on the sort-based path (grm_wide.hip)
     b->bb = pick_bucket_bits(c, max_g);
     const uint64_t B = 1ull << b->bb;
     const uint64_t n_seg = (uint64_t)G * B;
@@ -691,12 +691,14 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
 extern "C" int grm_batch_partition(grm_batch *b, int k, uint32_t abundance_min)
 {
     if (!b) return GRM_ERR_ARG;
+    if (k > 32 && k <= 64) return fail(b->ctx, GRM_ERR_UNSUPPORTED, "k=%d: the staged (multi-GPU) API handles k <= 32; use grm_batch_run", k);
     return batch_partition_impl(b, k, abundance_min, false);
 }
 
 extern "C" int grm_batch_partition_counts(grm_batch *b, int k, uint32_t abundance_min)
 {
     if (!b) return GRM_ERR_ARG;
+    if (k > 32 && k <= 64) return fail(b->ctx, GRM_ERR_UNSUPPORTED, "k=%d: counted batches handle k <= 32; use grm_count_genome per genome", k);
     return batch_partition_impl(b, k, abundance_min, true);
 }
 
@@ -955,11 +957,189 @@ extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
     return GRM_OK;
 }
 
+// ---- two-word k-mers (33..64): sort-based path ------------------------------------------------
+struct WideSorted {
+    DevBuf khi, klo, pos;      // sorted (hi, lo) + original symbol position, first n entries are real k-mers
+    DevBuf key_head, kg_head, sub_id, sub_start, sub_key_head, sub_ok, tmp;
+    uint32_t n = 0, n_sub = 0;
+};
+
+static int wide_scan(grm_ctx *c, DevBuf &tmp, bool inclusive, const uint32_t *in, uint32_t *out, uint64_t n)
+{
+    size_t tb = 0;
+    hipError_t e = inclusive ? inclusive_scan_u32(c->stream, in, out, n, nullptr, tb) : exclusive_scan_u32(c->stream, in, out, n, nullptr, tb);
+    if (e == hipSuccess) e = tmp.ensure(tb);
+    if (e == hipSuccess)
+        e = inclusive ? inclusive_scan_u32(c->stream, in, out, n, tmp.p, tb) : exclusive_scan_u32(c->stream, in, out, n, tmp.p, tb);
+    if (e != hipSuccess) return fail(c, GRM_ERR_HIP, "scan: %s", hipGetErrorString(e));
+    return GRM_OK;
+}
+
+// parse must have run (batch_partition_impl with k > 32).  Extract, sort, mark runs.
+static int wide_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, WideSorted &W)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    const uint64_t N = b->total_syms;
+    if (N >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "k > 32 path is limited to 2^32-1 symbols per batch (got %llu)", (unsigned long long)N);
+    W.n = W.n_sub = 0;
+    b->total_keys = 0;
+    if (N == 0) return GRM_OK;
+    DevBuf hi0, lo0, idx0, lo_s, idx1, hi_g, n_valid;
+    HIPCHK(c, hi0.alloc(N * 8)); HIPCHK(c, lo0.alloc(N * 8)); HIPCHK(c, n_valid.alloc(8));
+    HIPCHK(c, hipMemsetAsync(n_valid.p, 0, 8, s));
+    {
+        TimeScope t(c, "wide_extract", N);
+        launch_wide_extract(s, b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>(), N, k, hi0.as<uint64_t>(), lo0.as<uint64_t>(),
+                            n_valid.as<unsigned long long>());
+    }
+    HIPCHK(c, hipGetLastError());
+    unsigned long long nv = 0;
+    HIPCHK(c, hipMemcpyAsync(&nv, n_valid.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    b->total_keys = nv;
+    W.n = (uint32_t)nv;
+    {
+        TimeScope t(c, "wide_sort", N);
+        HIPCHK(c, idx0.alloc(N * 4));
+        launch_iota_u32(s, idx0.as<uint32_t>(), N);
+        HIPCHK(c, lo_s.alloc(N * 8)); HIPCHK(c, idx1.alloc(N * 4));
+        size_t tb = 0;
+        HIPCHK(c, sort_pairs_u64_u32(s, lo0.as<uint64_t>(), lo_s.as<uint64_t>(), idx0.as<uint32_t>(), idx1.as<uint32_t>(), N, nullptr, tb));
+        HIPCHK(c, W.tmp.ensure(tb));
+        HIPCHK(c, sort_pairs_u64_u32(s, lo0.as<uint64_t>(), lo_s.as<uint64_t>(), idx0.as<uint32_t>(), idx1.as<uint32_t>(), N, W.tmp.p, tb));
+        HIPCHK(c, hipStreamSynchronize(s));
+        lo_s.release(); idx0.release();
+        HIPCHK(c, hi_g.alloc(N * 8));
+        launch_gather_u64(s, hi0.as<uint64_t>(), idx1.as<uint32_t>(), N, hi_g.as<uint64_t>());
+        HIPCHK(c, W.khi.alloc(N * 8)); HIPCHK(c, W.pos.alloc(N * 4));
+        tb = 0;
+        HIPCHK(c, sort_pairs_u64_u32(s, hi_g.as<uint64_t>(), W.khi.as<uint64_t>(), idx1.as<uint32_t>(), W.pos.as<uint32_t>(), N, nullptr, tb));
+        HIPCHK(c, W.tmp.ensure(tb));
+        HIPCHK(c, sort_pairs_u64_u32(s, hi_g.as<uint64_t>(), W.khi.as<uint64_t>(), idx1.as<uint32_t>(), W.pos.as<uint32_t>(), N, W.tmp.p, tb));
+        HIPCHK(c, hipStreamSynchronize(s));
+        hi_g.release(); idx1.release(); hi0.release();
+        HIPCHK(c, W.klo.alloc(N * 8));
+        launch_gather_u64(s, lo0.as<uint64_t>(), W.pos.as<uint32_t>(), N, W.klo.as<uint64_t>());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(s));
+        lo0.release();
+    }
+    const uint32_t n = W.n;
+    if (n == 0) return GRM_OK;
+    TimeScope t(c, "wide_mark", n);
+    HIPCHK(c, W.key_head.alloc((size_t)n * 4)); HIPCHK(c, W.kg_head.alloc((size_t)n * 4)); HIPCHK(c, W.sub_id.alloc(((size_t)n + 1) * 4));
+    launch_wide_mark(s, W.khi.as<uint64_t>(), W.klo.as<uint64_t>(), W.pos.as<uint32_t>(), b->d_genome_sym_off.as<uint64_t>(),
+                     (uint32_t)b->n_genomes, n, W.key_head.as<uint32_t>(), W.kg_head.as<uint32_t>());
+    int rc = wide_scan(c, W.tmp, false, W.kg_head.as<uint32_t>(), W.sub_id.as<uint32_t>(), n);
+    if (rc) return rc;
+    uint32_t last_id = 0, last_flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&last_id, W.sub_id.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&last_flag, W.kg_head.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    W.n_sub = last_id + last_flag;
+    HIPCHK(c, W.sub_start.alloc(((size_t)W.n_sub + 1) * 4));
+    HIPCHK(c, W.sub_key_head.alloc((size_t)W.n_sub * 4 + 4)); HIPCHK(c, W.sub_ok.alloc((size_t)W.n_sub * 4 + 4));
+    launch_wide_sub_start(s, W.kg_head.as<uint32_t>(), W.sub_id.as<uint32_t>(), n, W.n_sub, W.sub_start.as<uint32_t>());
+    launch_wide_sub(s, W.sub_start.as<uint32_t>(), W.key_head.as<uint32_t>(), W.n_sub, abundance_min, W.sub_key_head.as<uint32_t>(),
+                    W.sub_ok.as<uint32_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    W.key_head.release(); W.kg_head.release(); W.sub_id.release();
+    return GRM_OK;
+}
+
+static int wide_matrix(grm_batch *b, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    WideSorted W;
+    int rc = wide_sort_and_mark(b, k, abundance_min, W);
+    if (rc) return rc;
+    grm_matrix *m = new grm_matrix();
+    m->ctx = c; m->k = k; m->words = 2; m->n_genomes = b->n_genomes;
+    m->n_rows = ((size_t)b->n_genomes + 63) / 64;
+    auto bail = [&](int code) { delete m; return code; };
+    uint32_t U = 0;
+    DevBuf key_incl, carriers, keep, col;
+    if (W.n_sub) {
+        TimeScope t(c, "wide_reduce", W.n_sub);
+        if (key_incl.alloc((size_t)W.n_sub * 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
+        rc = wide_scan(c, W.tmp, true, W.sub_key_head.as<uint32_t>(), key_incl.as<uint32_t>(), W.n_sub);
+        if (rc) return bail(rc);
+        uint32_t n_keys = 0;
+        if (hipMemcpyAsync(&n_keys, key_incl.as<uint32_t>() + (W.n_sub - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "D2H"));
+        if (carriers.alloc((size_t)n_keys * 4 + 4) != hipSuccess || keep.alloc((size_t)n_keys * 4 + 4) != hipSuccess ||
+            col.alloc((size_t)n_keys * 4 + 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
+        (void)hipMemsetAsync(carriers.p, 0, (size_t)n_keys * 4 + 4, s);
+        launch_wide_key_count(s, key_incl.as<uint32_t>(), W.sub_ok.as<uint32_t>(), W.n_sub, carriers.as<uint32_t>());
+        launch_wide_keep(s, carriers.as<uint32_t>(), n_keys, filter_singleton ? 2u : 1u, keep.as<uint32_t>());
+        rc = wide_scan(c, W.tmp, false, keep.as<uint32_t>(), col.as<uint32_t>(), n_keys);
+        if (rc) return bail(rc);
+        uint32_t last_col = 0, last_keep = 0;
+        if (hipMemcpyAsync(&last_col, col.as<uint32_t>() + (n_keys - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(&last_keep, keep.as<uint32_t>() + (n_keys - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "D2H"));
+        U = last_col + last_keep;
+    }
+    m->n_kmers = U;
+    const size_t cells = m->n_rows * (size_t)U;
+    if (m->d_data.alloc(cells * 8) != hipSuccess || m->d_kmers.alloc(((size_t)U + 1) * 16) != hipSuccess)
+        return bail(fail(c, GRM_ERR_OOM, "matrix allocation failed"));
+    if (cells) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
+    if (U) {
+        TimeScope t(c, "wide_emit", W.n_sub);
+        launch_wide_emit(s, W.khi.as<uint64_t>(), W.klo.as<uint64_t>(), W.pos.as<uint32_t>(), b->d_genome_sym_off.as<uint64_t>(),
+                         (uint32_t)b->n_genomes, W.sub_start.as<uint32_t>(), W.sub_key_head.as<uint32_t>(), W.sub_ok.as<uint32_t>(),
+                         key_incl.as<uint32_t>(), keep.as<uint32_t>(), col.as<uint32_t>(), W.n_sub, m->d_kmers.as<uint64_t>(),
+                         m->d_data.as<uint64_t>(), U);
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "wide_emit failed"));
+    *out = m;
+    return GRM_OK;
+}
+
+// single-genome batch -> sorted counted set (two words per k-mer)
+static int wide_set(grm_batch *b, int k, uint32_t abundance_min, grm_kmer_set **out)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    WideSorted W;
+    int rc = wide_sort_and_mark(b, k, abundance_min, W);
+    if (rc) return rc;
+    grm_kmer_set *set = new grm_kmer_set();
+    set->k = k; set->words = 2; set->occurrences = b->total_keys;
+    *out = set;
+    if (!W.n_sub) return GRM_OK;
+    DevBuf opos, dk, dc;
+    HIPCHK(c, opos.alloc((size_t)W.n_sub * 4));
+    rc = wide_scan(c, W.tmp, false, W.sub_ok.as<uint32_t>(), opos.as<uint32_t>(), W.n_sub);
+    if (rc) return rc;
+    uint32_t last_pos = 0, last_ok = 0;
+    HIPCHK(c, hipMemcpyAsync(&last_pos, opos.as<uint32_t>() + (W.n_sub - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&last_ok, W.sub_ok.as<uint32_t>() + (W.n_sub - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const size_t n_out = (size_t)last_pos + last_ok;
+    if (!n_out) return GRM_OK;
+    HIPCHK(c, dk.alloc(n_out * 16)); HIPCHK(c, dc.alloc(n_out * 4));
+    launch_wide_set(s, W.khi.as<uint64_t>(), W.klo.as<uint64_t>(), W.sub_start.as<uint32_t>(), W.sub_ok.as<uint32_t>(),
+                    opos.as<uint32_t>(), W.n_sub, dk.as<uint64_t>(), dc.as<uint32_t>());
+    HIPCHK(c, hipGetLastError());
+    set->kmers.resize(n_out * 2);
+    set->counts.resize(n_out);
+    HIPCHK(c, hipMemcpyAsync(set->kmers.data(), dk.p, n_out * 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(set->counts.data(), dc.p, n_out * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return GRM_OK;
+}
+
 extern "C" int grm_batch_run(grm_batch *b, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out)
 {
     if (!b || !out) return GRM_ERR_ARG;
     int rc = batch_partition_impl(b, k, abundance_min, false);
     if (rc) return rc;
+    if (k > 32) return wide_matrix(b, k, abundance_min < 1 ? 1 : abundance_min, filter_singleton, out);
     uint64_t n_local = 0, n_kmers = 0;
     rc = grm_batch_local_dict(b, &n_local);
     if (rc) return rc;
@@ -1035,7 +1215,7 @@ extern "C" int grm_count_genome_buffers(grm_ctx *c, const void *const *bufs, con
     for (int i = 0; i < n_bufs && !rc; i++) rc = grm_batch_add(b, 0, bufs[i], lens[i]);
     if (!rc) rc = grm_batch_upload(b);
     if (!rc) rc = batch_partition_impl(b, k, abundance_min, true);
-    if (!rc) rc = genome_set_impl(b, 0, true, out);
+    if (!rc) rc = k > 32 ? wide_set(b, k, abundance_min < 1 ? 1 : abundance_min, out) : genome_set_impl(b, 0, true, out);
     if (rc && *out) { grm_kmer_set_free(*out); *out = nullptr; }
     grm_batch_free(b);
     return rc;
@@ -1053,7 +1233,7 @@ extern "C" int grm_count_genome(grm_ctx *c, const char *const *paths, int n_path
     for (int i = 0; i < n_paths && !rc; i++) rc = grm_batch_add_file(b, 0, paths[i]);
     if (!rc) rc = grm_batch_upload(b);
     if (!rc) rc = batch_partition_impl(b, k, abundance_min, true);
-    if (!rc) rc = genome_set_impl(b, 0, true, out);
+    if (!rc) rc = k > 32 ? wide_set(b, k, abundance_min < 1 ? 1 : abundance_min, out) : genome_set_impl(b, 0, true, out);
     if (rc && *out) { grm_kmer_set_free(*out); *out = nullptr; }
     grm_batch_free(b);
     return rc;
@@ -1124,10 +1304,15 @@ extern "C" int grm_build_matrix(grm_ctx *c, grm_kmer_set *const *sets, int n_gen
 // --------------------------------------------------------------------------------------
 // writers
 // --------------------------------------------------------------------------------------
-static inline void decode_kmer(uint64_t v, int k, char *out)
+// w: `words` uint64, most significant first (1 word for k <= 32, 2 for k <= 64)
+static inline void decode_kmer(const uint64_t *w, int words, int k, char *out)
 {
     static const char L[4] = {'A', 'C', 'T', 'G'};
-    for (int i = 0; i < k; i++) out[i] = L[(v >> (2 * (k - 1 - i))) & 3];
+    for (int i = 0; i < k; i++) {
+        const int bit = 2 * (k - 1 - i);                  // position from the least significant end
+        const uint64_t word = words == 1 ? w[0] : (bit >= 64 ? w[0] : w[1]);
+        out[i] = L[(word >> (bit & 63)) & 3];
+    }
 }
 
 extern "C" int grm_write_tsv(grm_matrix *m, const char *const *genome_ids, const char *path)
@@ -1148,7 +1333,7 @@ extern "C" int grm_write_tsv(grm_matrix *m, const char *const *genome_ids, const
     const size_t line_len = (size_t)m->k + 2 * (size_t)m->n_genomes + 1;
     std::vector<char> line(line_len);
     for (size_t col = 0; col < m->n_kmers; col++) {
-        decode_kmer(kmers[col], m->k, line.data());
+        decode_kmer(kmers + col * (size_t)m->words, m->words, m->k, line.data());
         size_t p = (size_t)m->k;
         for (int g = 0; g < m->n_genomes; g++) {
             line[p++] = '\t';

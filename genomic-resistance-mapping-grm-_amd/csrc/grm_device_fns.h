@@ -372,4 +372,40 @@ GRM_HD void for_each_kmer32(uint64_t a, uint64_t b, uint32_t valid, int k, F &&f
     for_each_kmer_n<32>(a, b, 0, valid, k, f);
 }
 
+// ---- two-word k-mers (33 <= k <= 64): value = hi:lo, first base most significant -------
+struct K128 {
+    uint64_t hi, lo;
+};
+GRM_HD bool k128_less(const K128 &a, const K128 &b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+
+// NPOS start positions beginning at symbol offset `off` (0..31) of w0; needs
+// off + NPOS + k - 1 <= 96 (three packed words).  Calls f(i, canonical) for the valid ones.
+template <int NPOS, typename F>
+GRM_HD void for_each_kmer_wide(uint64_t w0, uint64_t w1, uint64_t w2, int off, uint32_t valid, int k, F &&f)
+{
+    if (!valid) return;
+    // 192-bit stream, MSB-aligned at the first symbol
+    uint64_t s0 = w0, s1 = w1, s2 = w2;
+    if (off) {
+        s0 = (w0 << (2 * off)) | (w1 >> (64 - 2 * off));
+        s1 = (w1 << (2 * off)) | (w2 >> (64 - 2 * off));
+        s2 = w2 << (2 * off);
+    }
+    const int top = 2 * (k - 1) - 64;                  // bit of the hi word that receives the complement
+    const uint64_t mask_hi = k == 64 ? ~0ull : ((1ull << (2 * k - 64)) - 1);
+    K128 fwd = {0, 0}, rc = {0, 0};
+    for (int j = 0; j < k - 1 + NPOS; j++) {
+        const uint64_t sym = s0 >> 62;
+        s0 = (s0 << 2) | (s1 >> 62);
+        s1 = (s1 << 2) | (s2 >> 62);
+        s2 <<= 2;
+        fwd.hi = ((fwd.hi << 2) | (fwd.lo >> 62)) & mask_hi;
+        fwd.lo = (fwd.lo << 2) | sym;
+        rc.lo = (rc.lo >> 2) | (rc.hi << 62);
+        rc.hi = (rc.hi >> 2) | ((sym ^ 2) << top);
+        const int i = j - (k - 1);
+        if (i >= 0 && ((valid >> i) & 1u)) f(i, k128_less(fwd, rc) ? fwd : rc);
+    }
+}
+
 }  // namespace grm

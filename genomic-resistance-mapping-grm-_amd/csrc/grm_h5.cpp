@@ -102,10 +102,14 @@ struct H5 {
 
 H5 g_h5;
 
-inline void decode_kmer(uint64_t v, int k, char *out)
+inline void decode_kmer(const uint64_t *w, int words, int k, char *out)
 {
     static const char L[4] = {'A', 'C', 'T', 'G'};
-    for (int i = 0; i < k; i++) out[i] = L[(v >> (2 * (k - 1 - i))) & 3];
+    for (int i = 0; i < k; i++) {
+        const int bit = 2 * (k - 1 - i);
+        const uint64_t word = words == 1 ? w[0] : (bit >= 64 ? w[0] : w[1]);
+        out[i] = L[(word >> (bit & 63)) & 3];
+    }
 }
 
 // chunked (optionally deflated) dataset creation property list
@@ -168,7 +172,8 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
     // kmer_sequences: fixed-length S<k> (what numpy 'S31' becomes in h5py), null padded
     {
         std::vector<char> seq(U * (size_t)k + 1);
-        for (size_t c = 0; c < U; c++) decode_kmer(kmers[c], k, seq.data() + c * (size_t)k);
+        const int words = grm_matrix_words(m);
+        for (size_t c = 0; c < U; c++) decode_kmer(kmers + c * (size_t)words, words, k, seq.data() + c * (size_t)k);
         hid_t st = H.Tcopy(H.C_S1);
         H.Tset_size(st, (size_t)k);
         H.Tset_strpad(st, 1);   // H5T_STR_NULLPAD

@@ -110,4 +110,25 @@ hipError_t sort_pairs_u64_u32(hipStream_t s, const uint64_t *kin, uint64_t *kout
 hipError_t exclusive_scan_u32_u64(hipStream_t s, const uint32_t *in, uint64_t *out, uint64_t n, void *tmp,
                                   size_t &tmp_bytes);
 
+hipError_t exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n, void *tmp, size_t &tmp_bytes);
+hipError_t inclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n, void *tmp, size_t &tmp_bytes);
+
+// ---- two-word k-mers (grm_wide.hip) ----
+void launch_wide_extract(hipStream_t s, const uint64_t *sym2, const uint64_t *inv, uint64_t total_syms, int k, uint64_t *khi,
+                         uint64_t *klo, unsigned long long *n_valid);
+void launch_wide_mark(hipStream_t s, const uint64_t *khi, const uint64_t *klo, const uint32_t *pos, const uint64_t *gso,
+                      uint32_t n_genomes, uint32_t n, uint32_t *key_head, uint32_t *kg_head);
+void launch_wide_sub_start(hipStream_t s, const uint32_t *kg_head, const uint32_t *sub_id, uint32_t n, uint32_t n_sub,
+                           uint32_t *sub_start);
+void launch_wide_sub(hipStream_t s, const uint32_t *sub_start, const uint32_t *key_head, uint32_t n_sub, uint32_t abundance_min,
+                     uint32_t *sub_key_head, uint32_t *sub_ok);
+void launch_wide_key_count(hipStream_t s, const uint32_t *key_incl, const uint32_t *sub_ok, uint32_t n_sub, uint32_t *carriers);
+void launch_wide_keep(hipStream_t s, const uint32_t *carriers, uint32_t n_keys, uint32_t min_carriers, uint32_t *keep);
+void launch_wide_emit(hipStream_t s, const uint64_t *khi, const uint64_t *klo, const uint32_t *pos, const uint64_t *gso,
+                      uint32_t n_genomes, const uint32_t *sub_start, const uint32_t *sub_key_head, const uint32_t *sub_ok,
+                      const uint32_t *key_incl, const uint32_t *keep, const uint32_t *col, uint32_t n_sub, uint64_t *dict,
+                      uint64_t *matrix, uint64_t n_cols);
+void launch_wide_set(hipStream_t s, const uint64_t *khi, const uint64_t *klo, const uint32_t *sub_start, const uint32_t *sub_ok,
+                     const uint32_t *out_pos, uint32_t n_sub, uint64_t *kmers, uint32_t *counts);
+
 }  // namespace grm

@@ -33,4 +33,13 @@ hipError_t exclusive_scan_u32_u64(hipStream_t s, const uint32_t *in, uint64_t *o
     return rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s);
 }
 
+hipError_t exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n, void *tmp, size_t &tmp_bytes)
+{
+    return rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), s);
+}
+hipError_t inclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n, void *tmp, size_t &tmp_bytes)
+{
+    return rocprim::inclusive_scan(tmp, tmp_bytes, in, out, (size_t)n, rocprim::plus<uint32_t>(), s);
+}
+
 }  // namespace grm

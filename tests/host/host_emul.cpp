@@ -237,6 +237,26 @@ uint64_t emul_kmers16(const uint64_t *sym2, const uint64_t *inv, uint64_t total_
     return n;
 }
 
+// two-word k-mers (33..64), 16 start positions per call; out: hi,lo interleaved
+uint64_t emul_kmers_wide(const uint64_t *sym2, const uint64_t *inv, uint64_t total_syms, int k, uint64_t *out, uint64_t cap)
+{
+    uint64_t n = 0;
+    const uint64_t n_q = (total_syms + 15) / 16;
+    for (uint64_t q = 0; q < n_q; q++) {
+        const uint64_t p0 = q << 4, grp = p0 >> 6;
+        const int64_t nv = (int64_t)total_syms - k + 1 - (int64_t)p0;
+        if (nv <= 0) break;
+        uint32_t valid = (uint32_t)(valid_starts(inv[grp], inv[grp + 1], k) >> (p0 & 63)) & 0xffffu;
+        if (nv < 16) valid &= (1u << nv) - 1;
+        const uint64_t wi = p0 >> 5;
+        for_each_kmer_wide<16>(sym2[wi], sym2[wi + 1], sym2[wi + 2], (int)(p0 & 31), valid, k, [&](int, K128 c) {
+            if (n < cap) { out[2 * n] = c.hi; out[2 * n + 1] = c.lo; }
+            n++;
+        });
+    }
+    return n;
+}
+
 uint64_t emul_mix64(uint64_t x) { return mix64(x); }
 uint32_t emul_bucket(uint64_t h, int bb) { return hash_bucket(h, bb); }
 uint32_t emul_sub(uint64_t h, int bb, int sb) { return hash_sub(h, bb, sb); }

@@ -31,6 +31,8 @@ def emul():
     L.emul_parse2.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     L.emul_parse_fastq.restype = C.c_uint64
     L.emul_parse_fastq.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.emul_kmers_wide.restype = C.c_uint64
+    L.emul_kmers_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
     L.emul_kmers16.restype = C.c_uint64
     L.emul_kmers16.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
     L.emul_kmers32.restype = C.c_uint64
@@ -200,3 +202,25 @@ def test_fastq_primitives_match_oracle(emul):
                     assert n == nocc
                     vals, counts = np.unique(out[:n], return_counts=True)
                     assert (vals == km[:, 0]).all() and (counts == ct).all()
+
+
+@pytest.mark.parametrize("k", [33, 47, 63, 64])
+def test_wide_kmers_match_oracle(emul, k):
+    rng = np.random.RandomState(k)
+    a = cases.rand_seq(rng, 700)
+    texts = [cases.fasta([("a", a), ("b", cases.revcomp(a)[:300]), ("c", a[:90] + "N" + a[91:200]), ("short", a[:k - 1])], width=70)]
+    files = [t.encode() for t in texts]
+    raw = layout(files)
+    ng = len(raw) // 64 + 8
+    sym2 = np.zeros(2 * ng, dtype=np.uint64)
+    inv = np.zeros(ng, dtype=np.uint64)
+    nsym = emul.emul_parse(raw.ctypes.data, len(raw), sym2.ctypes.data, inv.ctypes.data, ng)
+    out = np.zeros(2 * max(1, int(nsym)), dtype=np.uint64)
+    n = emul.emul_kmers_wide(sym2.ctypes.data, inv.ctypes.data, nsym, k, out.ctypes.data, len(out) // 2)
+    km, ct, nocc = orc.count_genome(files, k)
+    assert n == nocc
+    got = out[:2 * n].reshape(n, 2)
+    order = np.lexsort((got[:, 1], got[:, 0]))
+    got = got[order]
+    uniq, counts = np.unique(got, axis=0, return_counts=True)
+    assert uniq.shape == km.shape and (uniq == km).all() and (counts == ct).all()
