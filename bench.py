@@ -61,10 +61,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GRM_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend (collectives staged through
+    # host memory) -- lets the N>1 code path run on a one-GPU box; never used for reported numbers
+    rehearsal = os.environ.get("GRM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     filt = not args.keep_singletons
 
@@ -101,6 +109,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+
     for _ in range(args.warmup):
         m = step()
         m.free()
@@ -115,12 +124,12 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     occ = batch.n_occurrences
     if world > 1:
-        t = torch.tensor([occ], dtype=torch.int64, device=device)
+        t = torch.tensor([occ], dtype=torch.int64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         occ_total = int(t.item())
     else:

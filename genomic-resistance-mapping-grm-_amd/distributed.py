@@ -35,6 +35,18 @@ def shard_genomes(n_genomes, world_size, block=64):
     return out
 
 
+def _all_gather(out, inp, group):
+    """all_gather_into_tensor; with the gloo backend and device tensors (single-GPU rehearsal of
+    the multi-rank path) the exchange is staged through host memory."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo" and inp.is_cuda:
+        o = out.cpu()
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def allgather_dict(batch, n_local, device, group=None):
     """the single data-path collective.  batch: object with export_dict(keys_ptr, flags_ptr).
     -> (keys int64 tensor [n_total], flags uint8 tensor [n_total]) on `device`."""
@@ -48,7 +60,7 @@ def allgather_dict(batch, n_local, device, group=None):
         return keys[:n_local], flags[:n_local]
     counts = torch.zeros(world, dtype=torch.int64, device=device)
     mine = torch.tensor([n_local], dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(counts, mine, group=group)
+    _all_gather(counts, mine, group)
     counts_h = counts.cpu().tolist()
     n_max = max(1, max(counts_h))
     kpad = torch.zeros(n_max, dtype=torch.int64, device=device)
@@ -57,8 +69,8 @@ def allgather_dict(batch, n_local, device, group=None):
     fpad[:n_local] = flags[:n_local]
     kall = torch.empty(world * n_max, dtype=torch.int64, device=device)
     fall = torch.empty(world * n_max, dtype=torch.uint8, device=device)
-    dist.all_gather_into_tensor(kall, kpad, group=group)
-    dist.all_gather_into_tensor(fall, fpad, group=group)
+    _all_gather(kall, kpad, group)
+    _all_gather(fall, fpad, group)
     ks = [kall[r * n_max: r * n_max + counts_h[r]] for r in range(world)]
     fs = [fall[r * n_max: r * n_max + counts_h[r]] for r in range(world)]
     return torch.cat(ks).contiguous(), torch.cat(fs).contiguous()
@@ -85,13 +97,13 @@ def gather_rows(local_rows, device, group=None):
     U = local_rows.shape[1]
     nrows = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=device)
     allr = torch.zeros(world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(allr, nrows, group=group)
+    _all_gather(allr, nrows, group)
     allr_h = allr.cpu().tolist()
     rmax = max(1, max(allr_h))
     pad = torch.zeros((rmax, U), dtype=torch.int64, device=device)
     if local_rows.size:
         pad[: local_rows.shape[0]] = torch.from_numpy(local_rows.view(np.int64)).to(device)
     out = torch.empty((world * rmax, U), dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    _all_gather(out, pad, group)
     parts = [out[r * rmax: r * rmax + allr_h[r]] for r in range(world)]
     return torch.cat(parts).cpu().numpy().view(np.uint64)

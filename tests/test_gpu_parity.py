@@ -201,6 +201,56 @@ def test_staged_equals_fused(ctx):
     b.free()
 
 
+def _rank_worker(rank, world, port, n_genomes, q):
+    """one rank of the sharded path with the REAL engine; both ranks share cuda:0 (gloo, host-staged)"""
+    import torch
+    import torch.distributed as dist
+    import grm_amd
+    D = import_module("genomic-resistance-mapping-grm-_amd.distributed")
+    S = import_module("genomic-resistance-mapping-grm-_amd.synth")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        pg = S.PanGenome(genome_len=60_000, n_snps=600, n_accessory=6, accessory_len=1500, seed=21, n_contigs=2)
+        a, b_ = D.shard_genomes(n_genomes, world)[rank]
+        with grm_amd.Context(0) as c:
+            batch = c.batch(b_ - a)
+            for g in range(a, b_):
+                batch.add_array(g - a, pg.genome(g))
+            batch.upload()
+            dev = torch.device("cuda", 0)
+            m = D.sharded_step(batch, 31, 1, True, dev)
+            rows = D.gather_rows(m.data(), dev)
+            if rank == 0:
+                q.put((m.kmers()[:, 0].copy(), rows))
+            m.free()
+            batch.free()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_real_engine_one_gpu(ctx):
+    """N>1 path end to end with the HIP engine: 2 processes, genomes sharded 64 + 36, dictionary
+    all-gather, identical global dictionary, rows stacked == single-process oracle matrix"""
+    import socket
+    import torch.multiprocessing as mp
+    n_genomes = 100
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rank_worker, args=(r, 2, port, n_genomes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    kmers, rows = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    pg = synth.PanGenome(genome_len=60_000, n_snps=600, n_accessory=6, accessory_len=1500, seed=21, n_contigs=2)
+    want = orc.build_matrix([[pg.genome(g).tobytes()] for g in range(n_genomes)], 31, 1, True)
+    assert (kmers == want["kmers"][:, 0]).all() and kmers.shape[0] == want["kmers"].shape[0]
+    assert rows.shape == want["matrix"].shape and (rows == want["matrix"]).all()
+
+
 def test_tsv_roundtrip(ctx, tmp_path):
     name, k, genomes = MICRO[2]
     bg = _as_bytes(genomes)
