@@ -370,8 +370,13 @@ static bool inflate_gzip(const uint8_t *src, size_t len, std::vector<uint8_t> &o
     return rc == Z_STREAM_END;
 }
 
+struct WideSorted;
+static void wide_free(WideSorted *w);
+
 struct grm_batch {
     grm_ctx *ctx = nullptr;
+    WideSorted *wide = nullptr;      // two-word (k > 32) path buffers, created on first use
+    ~grm_batch() { wide_free(wide); }
     int n_genomes = 0;
     std::vector<HostFile> files;
     bool uploaded = false, partitioned = false, have_local = false, have_global = false;
@@ -958,10 +963,17 @@ extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
 }
 
 // ---- two-word k-mers (33..64): sort-based path ------------------------------------------------
+// Buffers live in the batch and are reused across runs (grow-only).  Four N-sized uint64 and two
+// N-sized uint32 arrays are ping-ponged through extract / sort / gather; the head flags alias the
+// dead extract buffers:  A0=hi0 A1=lo0 | sort1 (A1,I0)->(A2,I1) | A2=hi0[I1] | sort2 (A2,I1)->(A3,I0)
+// | A2=lo0[I0]  =>  khi=A3, klo=A2, pos=I0 ; key_head/kg_head in A0, sub_id in A1.
 struct WideSorted {
-    DevBuf khi, klo, pos;      // sorted (hi, lo) + original symbol position, first n entries are real k-mers
-    DevBuf key_head, kg_head, sub_id, sub_start, sub_key_head, sub_ok, tmp;
+    DevBuf A[4], I[2];
+    DevBuf sub_start, sub_key_head, sub_ok, key_incl, carriers, keep, col, opos, tmp, n_valid;
     uint32_t n = 0, n_sub = 0;
+    uint64_t *khi() const { return A[3].as<uint64_t>(); }
+    uint64_t *klo() const { return A[2].as<uint64_t>(); }
+    uint32_t *pos() const { return I[0].as<uint32_t>(); }
 };
 
 static int wide_scan(grm_ctx *c, DevBuf &tmp, bool inclusive, const uint32_t *in, uint32_t *out, uint64_t n)
@@ -985,75 +997,68 @@ static int wide_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, WideS
     W.n = W.n_sub = 0;
     b->total_keys = 0;
     if (N == 0) return GRM_OK;
-    DevBuf hi0, lo0, idx0, lo_s, idx1, hi_g, n_valid;
-    HIPCHK(c, hi0.alloc(N * 8)); HIPCHK(c, lo0.alloc(N * 8)); HIPCHK(c, n_valid.alloc(8));
-    HIPCHK(c, hipMemsetAsync(n_valid.p, 0, 8, s));
+    for (int i = 0; i < 4; i++) HIPCHK(c, W.A[i].ensure((N + 2) * 8));
+    for (int i = 0; i < 2; i++) HIPCHK(c, W.I[i].ensure((N + 2) * 4));
+    HIPCHK(c, W.n_valid.ensure(8));
+    uint64_t *hi0 = W.A[0].as<uint64_t>(), *lo0 = W.A[1].as<uint64_t>(), *t2 = W.A[2].as<uint64_t>(), *t3 = W.A[3].as<uint64_t>();
+    uint32_t *i0 = W.I[0].as<uint32_t>(), *i1 = W.I[1].as<uint32_t>();
+    HIPCHK(c, hipMemsetAsync(W.n_valid.p, 0, 8, s));
     {
         TimeScope t(c, "wide_extract", N);
-        launch_wide_extract(s, b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>(), N, k, hi0.as<uint64_t>(), lo0.as<uint64_t>(),
-                            n_valid.as<unsigned long long>());
+        launch_wide_extract(s, b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>(), N, k, hi0, lo0, W.n_valid.as<unsigned long long>());
     }
     HIPCHK(c, hipGetLastError());
     unsigned long long nv = 0;
-    HIPCHK(c, hipMemcpyAsync(&nv, n_valid.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&nv, W.n_valid.p, 8, hipMemcpyDeviceToHost, s));
+    {
+        TimeScope t(c, "wide_sort", N);
+        launch_iota_u32(s, i0, N);
+        size_t tb = 0;
+        HIPCHK(c, sort_pairs_u64_u32(s, lo0, t2, i0, i1, N, nullptr, tb));
+        HIPCHK(c, W.tmp.ensure(tb));
+        HIPCHK(c, sort_pairs_u64_u32(s, lo0, t2, i0, i1, N, W.tmp.p, tb));           // by lo
+        launch_gather_u64(s, hi0, i1, N, t2);                                          // hi in lo-order
+        tb = 0;
+        HIPCHK(c, sort_pairs_u64_u32(s, t2, t3, i1, i0, N, nullptr, tb));
+        HIPCHK(c, W.tmp.ensure(tb));
+        HIPCHK(c, sort_pairs_u64_u32(s, t2, t3, i1, i0, N, W.tmp.p, tb));              // stable by hi: khi = A3, pos = I0
+        launch_gather_u64(s, lo0, i0, N, t2);                                          // klo = A2
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipStreamSynchronize(s));
     b->total_keys = nv;
     W.n = (uint32_t)nv;
-    {
-        TimeScope t(c, "wide_sort", N);
-        HIPCHK(c, idx0.alloc(N * 4));
-        launch_iota_u32(s, idx0.as<uint32_t>(), N);
-        HIPCHK(c, lo_s.alloc(N * 8)); HIPCHK(c, idx1.alloc(N * 4));
-        size_t tb = 0;
-        HIPCHK(c, sort_pairs_u64_u32(s, lo0.as<uint64_t>(), lo_s.as<uint64_t>(), idx0.as<uint32_t>(), idx1.as<uint32_t>(), N, nullptr, tb));
-        HIPCHK(c, W.tmp.ensure(tb));
-        HIPCHK(c, sort_pairs_u64_u32(s, lo0.as<uint64_t>(), lo_s.as<uint64_t>(), idx0.as<uint32_t>(), idx1.as<uint32_t>(), N, W.tmp.p, tb));
-        HIPCHK(c, hipStreamSynchronize(s));
-        lo_s.release(); idx0.release();
-        HIPCHK(c, hi_g.alloc(N * 8));
-        launch_gather_u64(s, hi0.as<uint64_t>(), idx1.as<uint32_t>(), N, hi_g.as<uint64_t>());
-        HIPCHK(c, W.khi.alloc(N * 8)); HIPCHK(c, W.pos.alloc(N * 4));
-        tb = 0;
-        HIPCHK(c, sort_pairs_u64_u32(s, hi_g.as<uint64_t>(), W.khi.as<uint64_t>(), idx1.as<uint32_t>(), W.pos.as<uint32_t>(), N, nullptr, tb));
-        HIPCHK(c, W.tmp.ensure(tb));
-        HIPCHK(c, sort_pairs_u64_u32(s, hi_g.as<uint64_t>(), W.khi.as<uint64_t>(), idx1.as<uint32_t>(), W.pos.as<uint32_t>(), N, W.tmp.p, tb));
-        HIPCHK(c, hipStreamSynchronize(s));
-        hi_g.release(); idx1.release(); hi0.release();
-        HIPCHK(c, W.klo.alloc(N * 8));
-        launch_gather_u64(s, lo0.as<uint64_t>(), W.pos.as<uint32_t>(), N, W.klo.as<uint64_t>());
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(s));
-        lo0.release();
-    }
     const uint32_t n = W.n;
     if (n == 0) return GRM_OK;
     TimeScope t(c, "wide_mark", n);
-    HIPCHK(c, W.key_head.alloc((size_t)n * 4)); HIPCHK(c, W.kg_head.alloc((size_t)n * 4)); HIPCHK(c, W.sub_id.alloc(((size_t)n + 1) * 4));
-    launch_wide_mark(s, W.khi.as<uint64_t>(), W.klo.as<uint64_t>(), W.pos.as<uint32_t>(), b->d_genome_sym_off.as<uint64_t>(),
-                     (uint32_t)b->n_genomes, n, W.key_head.as<uint32_t>(), W.kg_head.as<uint32_t>());
-    int rc = wide_scan(c, W.tmp, false, W.kg_head.as<uint32_t>(), W.sub_id.as<uint32_t>(), n);
+    uint32_t *key_head = W.A[0].as<uint32_t>(), *kg_head = W.A[0].as<uint32_t>() + N, *sub_id = W.A[1].as<uint32_t>();
+    launch_wide_mark(s, W.khi(), W.klo(), W.pos(), b->d_genome_sym_off.as<uint64_t>(), (uint32_t)b->n_genomes, n, key_head, kg_head);
+    int rc = wide_scan(c, W.tmp, false, kg_head, sub_id, n);
     if (rc) return rc;
     uint32_t last_id = 0, last_flag = 0;
-    HIPCHK(c, hipMemcpyAsync(&last_id, W.sub_id.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&last_flag, W.kg_head.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&last_id, sub_id + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&last_flag, kg_head + (n - 1), 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     W.n_sub = last_id + last_flag;
-    HIPCHK(c, W.sub_start.alloc(((size_t)W.n_sub + 1) * 4));
-    HIPCHK(c, W.sub_key_head.alloc((size_t)W.n_sub * 4 + 4)); HIPCHK(c, W.sub_ok.alloc((size_t)W.n_sub * 4 + 4));
-    launch_wide_sub_start(s, W.kg_head.as<uint32_t>(), W.sub_id.as<uint32_t>(), n, W.n_sub, W.sub_start.as<uint32_t>());
-    launch_wide_sub(s, W.sub_start.as<uint32_t>(), W.key_head.as<uint32_t>(), W.n_sub, abundance_min, W.sub_key_head.as<uint32_t>(),
+    HIPCHK(c, W.sub_start.ensure(((size_t)W.n_sub + 1) * 4));
+    HIPCHK(c, W.sub_key_head.ensure((size_t)W.n_sub * 4 + 4));
+    HIPCHK(c, W.sub_ok.ensure((size_t)W.n_sub * 4 + 4));
+    launch_wide_sub_start(s, kg_head, sub_id, n, W.n_sub, W.sub_start.as<uint32_t>());
+    launch_wide_sub(s, W.sub_start.as<uint32_t>(), key_head, W.n_sub, abundance_min, W.sub_key_head.as<uint32_t>(),
                     W.sub_ok.as<uint32_t>());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
-    W.key_head.release(); W.kg_head.release(); W.sub_id.release();
     return GRM_OK;
 }
+
+static void wide_free(WideSorted *w) { delete w; }
 
 static int wide_matrix(grm_batch *b, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out)
 {
     grm_ctx *c = b->ctx;
     hipStream_t s = c->stream;
-    WideSorted W;
+    if (!b->wide) b->wide = new WideSorted();
+    WideSorted &W = *b->wide;
     int rc = wide_sort_and_mark(b, k, abundance_min, W);
     if (rc) return rc;
     grm_matrix *m = new grm_matrix();
@@ -1061,17 +1066,17 @@ static int wide_matrix(grm_batch *b, int k, uint32_t abundance_min, int filter_s
     m->n_rows = ((size_t)b->n_genomes + 63) / 64;
     auto bail = [&](int code) { delete m; return code; };
     uint32_t U = 0;
-    DevBuf key_incl, carriers, keep, col;
+    DevBuf &key_incl = W.key_incl, &carriers = W.carriers, &keep = W.keep, &col = W.col;
     if (W.n_sub) {
         TimeScope t(c, "wide_reduce", W.n_sub);
-        if (key_incl.alloc((size_t)W.n_sub * 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
+        if (key_incl.ensure((size_t)W.n_sub * 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
         rc = wide_scan(c, W.tmp, true, W.sub_key_head.as<uint32_t>(), key_incl.as<uint32_t>(), W.n_sub);
         if (rc) return bail(rc);
         uint32_t n_keys = 0;
         if (hipMemcpyAsync(&n_keys, key_incl.as<uint32_t>() + (W.n_sub - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "D2H"));
-        if (carriers.alloc((size_t)n_keys * 4 + 4) != hipSuccess || keep.alloc((size_t)n_keys * 4 + 4) != hipSuccess ||
-            col.alloc((size_t)n_keys * 4 + 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
+        if (carriers.ensure((size_t)n_keys * 4 + 4) != hipSuccess || keep.ensure((size_t)n_keys * 4 + 4) != hipSuccess ||
+            col.ensure((size_t)n_keys * 4 + 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
         (void)hipMemsetAsync(carriers.p, 0, (size_t)n_keys * 4 + 4, s);
         launch_wide_key_count(s, key_incl.as<uint32_t>(), W.sub_ok.as<uint32_t>(), W.n_sub, carriers.as<uint32_t>());
         launch_wide_keep(s, carriers.as<uint32_t>(), n_keys, filter_singleton ? 2u : 1u, keep.as<uint32_t>());
@@ -1090,7 +1095,7 @@ static int wide_matrix(grm_batch *b, int k, uint32_t abundance_min, int filter_s
     if (cells) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
     if (U) {
         TimeScope t(c, "wide_emit", W.n_sub);
-        launch_wide_emit(s, W.khi.as<uint64_t>(), W.klo.as<uint64_t>(), W.pos.as<uint32_t>(), b->d_genome_sym_off.as<uint64_t>(),
+        launch_wide_emit(s, W.khi(), W.klo(), W.pos(), b->d_genome_sym_off.as<uint64_t>(),
                          (uint32_t)b->n_genomes, W.sub_start.as<uint32_t>(), W.sub_key_head.as<uint32_t>(), W.sub_ok.as<uint32_t>(),
                          key_incl.as<uint32_t>(), keep.as<uint32_t>(), col.as<uint32_t>(), W.n_sub, m->d_kmers.as<uint64_t>(),
                          m->d_data.as<uint64_t>(), U);
@@ -1105,15 +1110,17 @@ static int wide_set(grm_batch *b, int k, uint32_t abundance_min, grm_kmer_set **
 {
     grm_ctx *c = b->ctx;
     hipStream_t s = c->stream;
-    WideSorted W;
+    if (!b->wide) b->wide = new WideSorted();
+    WideSorted &W = *b->wide;
     int rc = wide_sort_and_mark(b, k, abundance_min, W);
     if (rc) return rc;
     grm_kmer_set *set = new grm_kmer_set();
     set->k = k; set->words = 2; set->occurrences = b->total_keys;
     *out = set;
     if (!W.n_sub) return GRM_OK;
-    DevBuf opos, dk, dc;
-    HIPCHK(c, opos.alloc((size_t)W.n_sub * 4));
+    DevBuf &opos = W.opos;
+    DevBuf dk, dc;
+    HIPCHK(c, opos.ensure((size_t)W.n_sub * 4));
     rc = wide_scan(c, W.tmp, false, W.sub_ok.as<uint32_t>(), opos.as<uint32_t>(), W.n_sub);
     if (rc) return rc;
     uint32_t last_pos = 0, last_ok = 0;
@@ -1123,7 +1130,7 @@ static int wide_set(grm_batch *b, int k, uint32_t abundance_min, grm_kmer_set **
     const size_t n_out = (size_t)last_pos + last_ok;
     if (!n_out) return GRM_OK;
     HIPCHK(c, dk.alloc(n_out * 16)); HIPCHK(c, dc.alloc(n_out * 4));
-    launch_wide_set(s, W.khi.as<uint64_t>(), W.klo.as<uint64_t>(), W.sub_start.as<uint32_t>(), W.sub_ok.as<uint32_t>(),
+    launch_wide_set(s, W.khi(), W.klo(), W.sub_start.as<uint32_t>(), W.sub_ok.as<uint32_t>(),
                     opos.as<uint32_t>(), W.n_sub, dk.as<uint64_t>(), dc.as<uint32_t>());
     HIPCHK(c, hipGetLastError());
     set->kmers.resize(n_out * 2);
