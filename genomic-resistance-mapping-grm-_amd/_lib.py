@@ -47,6 +47,7 @@ PROTOTYPES = [
     ("grm_matrix_dev_kmers", _P, [_P]),
     ("grm_matrix_dev_data", _P, [_P]),
     ("grm_matrix_column_counts", C.c_int, [_P, _P]),
+    ("grm_matrix_sum_rows", C.c_int, [_P, _P, _P]),
     ("grm_matrix_from_host", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _PP]),
     ("grm_matrix_last_error", C.c_char_p, [_P]),
     ("grm_matrix_free", None, [_P]),

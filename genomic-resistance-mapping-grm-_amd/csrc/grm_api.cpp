@@ -286,6 +286,29 @@ extern "C" int grm_matrix_column_counts(grm_matrix *m, uint32_t *out)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GRM_OK;
 }
+// KmerRuleClassifications.sum_rows (learning/common/rules.py:201-267 + popcount.pyx:76-95):
+// out[c] = sum over word-rows of popcount(matrix[r][c] & row_mask[r]).
+extern "C" int grm_matrix_sum_rows(grm_matrix *m, const uint64_t *row_mask, uint32_t *out)
+{
+    if (!m || !out || !row_mask) return GRM_ERR_ARG;
+    grm_ctx *c = m->ctx;
+    if (!c) return GRM_ERR_NO_DEVICE;
+    if (!m->n_kmers) return GRM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf d, dm;
+    HIPCHK(c, d.alloc(m->n_kmers * 4));
+    HIPCHK(c, dm.alloc((m->n_rows + 1) * 8));
+    HIPCHK(c, hipMemcpyAsync(dm.p, row_mask, m->n_rows * 8, hipMemcpyHostToDevice, c->stream));
+    {
+        TimeScope t(c, "sum_rows", m->n_kmers * m->n_rows);
+        launch_column_popcount(c->stream, m->d_data.as<uint64_t>(), m->n_rows, m->n_kmers, dm.as<uint64_t>(), d.as<uint32_t>());
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, d.p, m->n_kmers * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GRM_OK;
+}
+
 extern "C" void grm_matrix_free(grm_matrix *m)
 {
     if (!m) return;

@@ -187,6 +187,15 @@ class Matrix:
         self.ctx._chk(self.ctx.L.grm_matrix_column_counts(self.h, out.ctypes.data))
         return out
 
+    def sum_rows(self, genomes):
+        """rules.py:201-267: per k-mer, how many of the given genome indices carry it (on the GPU)"""
+        mask = np.zeros(max(1, self.n_rows), dtype=np.uint64)
+        for g in genomes:
+            mask[g // 64] |= np.uint64(1) << np.uint64(63 - (g % 64))
+        out = np.zeros(self.n_kmers, dtype=np.uint32)
+        self.ctx._chk(self.ctx.L.grm_matrix_sum_rows(self.h, mask.ctypes.data, out.ctypes.data))
+        return out
+
     def dev_ptrs(self):
         return self.ctx.L.grm_matrix_dev_kmers(self.h), self.ctx.L.grm_matrix_dev_data(self.h)
 

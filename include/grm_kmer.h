@@ -17,7 +17,8 @@
  *   - every function returns 0 on success or a negative grm_status; grm_last_error(ctx)
  *     returns a message owned by the ctx (valid until the next call on that ctx).
  *   - k-mers are 2-bit packed, first base most significant, A=0 C=1 T=2 G=3 (GATB),
- *     canonical = min(forward, reverse complement); `words` uint64 per k-mer (1 for k<=32).
+ *     canonical = min(forward, reverse complement); `words` uint64 per k-mer, most significant
+ *     first (1 for k<=32, 2 for 33<=k<=64).  Inputs: FASTA or 4-line FASTQ, optionally gzip.
  *   - matrix: uint64 [n_rows][n_kmers] row-major, genome i -> row i/64, bit 63-(i%64)
  *     (bin/kover/core/kover/utils.py:133-156); columns ascending by k-mer value.
  *   - a grm_ctx is single-caller; HIP streams inside are the parallelism.
@@ -40,7 +41,7 @@ typedef enum {
     GRM_ERR_HIP = -3,          /* HIP runtime error, text in grm_last_error */
     GRM_ERR_IO = -4,
     GRM_ERR_OOM = -5,
-    GRM_ERR_UNSUPPORTED = -6,  /* e.g. k > 32 in this build */
+    GRM_ERR_UNSUPPORTED = -6,  /* e.g. k > 32 through the staged multi-GPU calls */
     GRM_ERR_STATE = -7,        /* calls out of order */
     GRM_ERR_OVERFLOW = -8,     /* LDS table overflow that retries could not cure */
     GRM_ERR_HDF5 = -9
@@ -99,6 +100,9 @@ const void     *grm_matrix_dev_data(const grm_matrix *);
 /* per-column carrier count = popcount down the column (the learner's sum_rows with an
  * all-ones mask, learning/common/rules.py:243-262); host array of n_kmers uint32 */
 int             grm_matrix_column_counts(grm_matrix *, uint32_t *out);
+/* masked form = KmerRuleClassifications.sum_rows (rules.py:201-267, popcount.pyx:76-95):
+ * row_mask: n_rows host words (bit 63-(i%64) of word i/64 selects genome i); out: n_kmers uint32 */
+int             grm_matrix_sum_rows(grm_matrix *, const uint64_t *row_mask, uint32_t *out);
 /* host-only matrix from caller arrays (copied): rows gathered from several ranks, or tests.
  * Only the accessors and the two writers work on it (no device). */
 int             grm_matrix_from_host(const uint64_t *kmers, const uint64_t *data, size_t n_kmers, int n_genomes, int k,

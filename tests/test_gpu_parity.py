@@ -366,6 +366,11 @@ def test_scale_properties(ctx):
     assert (d_f == d_all[:, keep]).all()
     assert (cc_f == cc_all[keep]).all()
     assert cc_all.max() == n and (cc_all >= 1).all()
+    # sum_rows (the learner's masked popcount) on the GPU == numpy on the host copy
+    some = [0, 5, 63, 64, 70, 95]
+    dense = np.array([((d_all[g // 64] >> np.uint64(63 - g % 64)) & np.uint64(1)) for g in some]).sum(axis=0)
+    assert (m_all.sum_rows(some) == dense).all()
+    assert (m_all.sum_rows(range(n)) == cc_all).all()
     # padding bits of the last word-row are zero
     pad = (1 << (64 - (n - 64))) - 1 if n % 64 else 0
     assert not (d_all[-1] & np.uint64(pad)).any()
