@@ -418,7 +418,7 @@ struct grm_batch {
     int k = 0, bb = 0;
     uint32_t abundance_min = 1;
     uint64_t total_keys = 0;       // k-mer occurrences
-    DevBuf d_counts, d_off, d_cursor, d_cursor1, d_keys, d_keys1, d_len, d_kcnt;
+    DevBuf d_counts, d_off, d_cursor, d_cursor1, d_counts1, d_off1, d_keys, d_keys1, d_len, d_kcnt;
     bool deduped = false;
     // dictionary
     int sb_dict = 0, sb_fill = 0;
@@ -556,9 +556,11 @@ extern "C" int grm_batch_upload(grm_batch *b)
 static int pick_bucket_bits(grm_ctx *c, uint64_t max_genome_syms)
 {
     if (c->opt_bucket_bits >= 0) return std::min(c->opt_bucket_bits, MAX_BUCKET_BITS);
-    // aim at ~512 k-mer occurrences per (genome, bucket)
+    // aim at ~512 k-mer occurrences per (genome, bucket); past 2^13 buckets (deep mode: one more
+    // pass over the keys for the fine histogram) only when segments would exceed 2048 occurrences
     int bb = 0;
-    while (bb < MAX_BUCKET_BITS && (max_genome_syms >> bb) > 512) bb++;
+    while (bb < MAX_HIST_BITS && (max_genome_syms >> bb) > 512) bb++;
+    while (bb < MAX_BUCKET_BITS && (max_genome_syms >> bb) > 2048) bb++;
     return bb;
 }
 
@@ -651,43 +653,70 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     L.bb = b->bb;
     L.groups_per_thread = c->opt_groups_per_thread > 0 ? (uint32_t)c->opt_groups_per_thread : 4u;
 
+    const int b1 = scatter_b1_bits(b->bb);
+    const bool deep = b->bb > MAX_HIST_BITS;
+    const uint64_t n_coarse = (uint64_t)G << b1;
     HIPCHK(c, b->d_counts.ensure((n_seg + 1) * 4));
     HIPCHK(c, b->d_cursor.ensure(n_seg * 4));
     HIPCHK(c, b->d_off.ensure((n_seg + 1) * 8));
+    HIPCHK(c, b->d_cursor1.ensure(n_coarse * 4));
     HIPCHK(c, hipMemsetAsync(b->d_counts.p, 0, (n_seg + 1) * 4, s));
     HIPCHK(c, hipMemsetAsync(b->d_cursor.p, 0, n_seg * 4, s));
-    {
-        TimeScope t(c, "kmer_hist", b->total_syms);
-        launch_kmer_hist(s, L, b->d_counts.as<uint32_t>());
-    }
-    {
-        // exclusive scan over n_seg+1 entries (the extra, zeroed entry yields the total)
-        TimeScope t(c, "bucket_scan", n_seg);
+    HIPCHK(c, hipMemsetAsync(b->d_cursor1.p, 0, n_coarse * 4, s));
+    auto scan_counts = [&](DevBuf &counts, DevBuf &off, uint64_t n) -> int {
+        // exclusive scan over n+1 entries (the extra, zeroed entry yields the total)
         size_t tb = 0;
-        HIPCHK(c, exclusive_scan_u32_u64(s, b->d_counts.as<uint32_t>(), b->d_off.as<uint64_t>(), n_seg + 1, nullptr, tb));
+        HIPCHK(c, exclusive_scan_u32_u64(s, counts.as<uint32_t>(), off.as<uint64_t>(), n + 1, nullptr, tb));
         HIPCHK(c, b->t_tmp.ensure(tb));
-        HIPCHK(c, exclusive_scan_u32_u64(s, b->d_counts.as<uint32_t>(), b->d_off.as<uint64_t>(), n_seg + 1, b->t_tmp.p, tb));
+        HIPCHK(c, exclusive_scan_u32_u64(s, counts.as<uint32_t>(), off.as<uint64_t>(), n + 1, b->t_tmp.p, tb));
+        return GRM_OK;
+    };
+    if (!deep) {
+        {
+            TimeScope t(c, "kmer_hist", b->total_syms);
+            launch_kmer_hist(s, L, b->d_counts.as<uint32_t>());
+        }
+        TimeScope t(c, "bucket_scan", n_seg);
+        int r = scan_counts(b->d_counts, b->d_off, n_seg);
+        if (r) return r;
+    } else {
+        // coarse histogram in the k-mer pass; the fine one is taken from the level-1 output
+        HIPCHK(c, b->d_counts1.ensure((n_coarse + 1) * 4));
+        HIPCHK(c, b->d_off1.ensure((n_coarse + 1) * 8));
+        HIPCHK(c, hipMemsetAsync(b->d_counts1.p, 0, (n_coarse + 1) * 4, s));
+        KmerLaunch Lc = L;
+        Lc.bb = b1;
+        {
+            TimeScope t(c, "kmer_hist", b->total_syms);
+            launch_kmer_hist(s, Lc, b->d_counts1.as<uint32_t>());
+        }
+        TimeScope t(c, "bucket_scan", n_coarse);
+        int r = scan_counts(b->d_counts1, b->d_off1, n_coarse);
+        if (r) return r;
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(&b->total_keys, b->d_off.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&b->total_keys, (deep ? b->d_off1.as<uint64_t>() + n_coarse : b->d_off.as<uint64_t>() + n_seg), 8,
+                             hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, b->d_keys.ensure((b->total_keys + 2) * 8));
+    if (b->bb > b1) HIPCHK(c, b->d_keys1.ensure((b->total_keys + 2) * 8));
     {
-        const int b1 = scatter_b1_bits(b->bb);
-        const uint64_t n_coarse = (uint64_t)G << b1;
-        HIPCHK(c, b->d_cursor1.ensure(n_coarse * 4));
-        HIPCHK(c, hipMemsetAsync(b->d_cursor1.p, 0, n_coarse * 4, s));
-        if (b->bb > b1) HIPCHK(c, b->d_keys1.ensure((b->total_keys + 2) * 8));
+        TimeScope t(c, "kmer_scatter_l1", b->total_keys);
+        launch_kmer_scatter_l1(s, L, b->d_off.as<uint64_t>(), deep ? b->d_off1.as<uint64_t>() : nullptr, b->d_cursor1.as<uint32_t>(),
+                               b->bb > b1 ? b->d_keys1.as<uint64_t>() : b->d_keys.as<uint64_t>());
+    }
+    if (deep) {
         {
-            TimeScope t(c, "kmer_scatter_l1", b->total_keys);
-            launch_kmer_scatter_l1(s, L, b->d_off.as<uint64_t>(), b->d_cursor1.as<uint32_t>(),
-                                   b->bb > b1 ? b->d_keys1.as<uint64_t>() : b->d_keys.as<uint64_t>());
+            TimeScope t(c, "region_hist", b->total_keys);
+            launch_region_hist(s, b->d_keys1.as<uint64_t>(), b->d_off1.as<uint64_t>(), n_coarse, b->bb, b->d_counts.as<uint32_t>());
         }
-        if (b->bb > b1) {
-            TimeScope t(c, "kmer_scatter_l2", b->total_keys);
-            launch_kmer_scatter_l2(s, L, b->d_off.as<uint64_t>(), b->d_cursor.as<uint32_t>(), b->d_keys1.as<uint64_t>(),
-                                   b->d_keys.as<uint64_t>());
-        }
+        int r = scan_counts(b->d_counts, b->d_off, n_seg);
+        if (r) return r;
+    }
+    if (b->bb > b1) {
+        TimeScope t(c, "kmer_scatter_l2", b->total_keys);
+        launch_kmer_scatter_l2(s, L, b->d_off.as<uint64_t>(), b->d_cursor.as<uint32_t>(), b->d_keys1.as<uint64_t>(),
+                               b->d_keys.as<uint64_t>());
     }
     HIPCHK(c, hipGetLastError());
 

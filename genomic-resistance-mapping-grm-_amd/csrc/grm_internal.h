@@ -15,7 +15,8 @@ constexpr int RAW_FRONT_PAD = 64;                          // '\n' bytes in fron
 
 // ---- k-mer kernels ----
 constexpr int KMER_THREADS = 256;
-constexpr int MAX_BUCKET_BITS = 13;                        // 8 coarse + 5 fine bits (two-level partition)
+constexpr int MAX_BUCKET_BITS = 16;                        // 8 coarse + up to 8 fine bits (two-level partition)
+constexpr int MAX_HIST_BITS = 13;                          // largest LDS histogram of the k-mer pass; deeper: region_hist
 constexpr int L1_PPT = 16;                                 // start positions per thread in level 1
 constexpr int L1_THREADS = 512;                            // 8 waves per tile: 2 tiles (16 waves) per CU
 constexpr int L1_TILE = L1_THREADS * L1_PPT;               // 8192 k-mers staged in LDS per tile
@@ -59,7 +60,10 @@ void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, cons
                        const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv);
 void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
 int scatter_b1_bits(int bb);
-void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, uint64_t *out);
+void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *coarse_off,
+                            uint32_t *cursor1, uint64_t *out);
+void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *coarse_off, uint64_t n_regions, int bb,
+                        uint32_t *counts);
 void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor2, const uint64_t *keys1,
                             uint64_t *keys);
 void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,

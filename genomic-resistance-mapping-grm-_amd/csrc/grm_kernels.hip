@@ -638,8 +638,8 @@ __global__ __launch_bounds__(KMER_THREADS) void kmer_hist_kernel(KmerArgs a, uin
 // coarse region of level 1 IS the union of its fine segments and `off` (exclusive scan of the
 // fine histogram) serves both levels.
 __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
-    KmerArgs a, int b1bits, uint32_t n_tiles, const uint64_t *__restrict__ off, uint32_t *__restrict__ cursor1,
-    uint64_t *__restrict__ keys1)
+    KmerArgs a, int b1bits, uint32_t n_tiles, const uint64_t *__restrict__ off, const uint64_t *__restrict__ coarse_off,
+    uint32_t *__restrict__ cursor1, uint64_t *__restrict__ keys1)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint64_t *skeys = reinterpret_cast<uint64_t *>(lds_raw);                             // [L1_TILE]
@@ -686,8 +686,11 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
         const uint32_t st = block_scan_sum(c, scratch, &n_tile);
         if (threadIdx.x < 256) start[threadIdx.x] = st;
         if (c) {
-            const uint64_t fine0 = (uint64_t)gen0 * (1ull << a.bb) + ((uint64_t)threadIdx.x << b2bits);
-            gbase[threadIdx.x] = off[fine0] + atomicAdd(&cursor1[(uint64_t)gen0 * B1 + threadIdx.x], c);
+            // start of the coarse region: from the coarse scan (deep mode: fine offsets do not exist
+            // yet) or from the fine scan (fine ids are nested inside the coarse bucket)
+            const uint64_t cidx = (uint64_t)gen0 * B1 + threadIdx.x;
+            const uint64_t region0 = coarse_off ? coarse_off[cidx] : off[(uint64_t)gen0 * (1ull << a.bb) + ((uint64_t)threadIdx.x << b2bits)];
+            gbase[threadIdx.x] = region0 + atomicAdd(&cursor1[cidx], c);
         }
         __syncthreads();
 #pragma unroll
@@ -705,9 +708,30 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
         for_each_kmer_n<L1_PPT>(w0, w1, off_in_word, valid, a.k, [&](int i, uint64_t canon) {
             while (p0 + (uint64_t)i >= gend) { gen++; gend = a.genome_sym_off[gen + 1]; }
             const uint32_t b1 = hash_bucket(mix64(canon), b1bits);
-            const uint64_t fine0 = (uint64_t)gen * (1ull << a.bb) + ((uint64_t)b1 << b2bits);
-            keys1[off[fine0] + atomicAdd(&cursor1[(uint64_t)gen * B1 + b1], 1u)] = canon;
+            const uint64_t cidx = (uint64_t)gen * B1 + b1;
+            const uint64_t region0 = coarse_off ? coarse_off[cidx] : off[(uint64_t)gen * (1ull << a.bb) + ((uint64_t)b1 << b2bits)];
+            keys1[region0 + atomicAdd(&cursor1[cidx], 1u)] = canon;
         });
+    }
+}
+
+// deep mode (more than 2^13 buckets per genome, e.g. read sets at high coverage): the fine
+// histogram does not fit an LDS histogram in the k-mer pass, so it is taken from the level-1
+// output: one workgroup per (genome, coarse bucket) region counts its <= 256 fine buckets.
+__global__ __launch_bounds__(256) void region_hist_kernel(const uint64_t *__restrict__ keys1,
+                                                          const uint64_t *__restrict__ coarse_off, uint64_t n_regions, int bb,
+                                                          int b1bits, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t hist[256];
+    const uint32_t B2 = 1u << (bb - b1bits);
+    for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t r0 = coarse_off[region], r1 = coarse_off[region + 1];
+        for (uint64_t i = r0 + threadIdx.x; i < r1; i += 256) atomicAdd(&hist[hash_bucket(mix64(keys1[i]), bb) & (B2 - 1)], 1u);
+        __syncthreads();
+        if (threadIdx.x < B2) counts[region * B2 + threadIdx.x] = hist[threadIdx.x];
+        __syncthreads();
     }
 }
 
@@ -1332,14 +1356,22 @@ void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts)
 int scatter_b1_bits(int bb) { return bb < L1_MAX_BITS ? bb : L1_MAX_BITS; }
 
 // level 1 writes `out` = keys1 when a second level follows, else the final keys
-void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, uint64_t *out)
+void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *coarse_off,
+                            uint32_t *cursor1, uint64_t *out)
 {
     KmerArgs a = make_args(L);
     if (a.total_syms == 0) return;
     const uint32_t n_tiles = (uint32_t)((a.total_syms + L1_TILE - 1) / L1_TILE);
     const uint32_t grid = ((n_tiles + 7) / 8) * 8;
     hipLaunchKernelGGL(kmer_scatter_l1_kernel, dim3(grid), dim3(L1_THREADS), L1_LDS_BYTES, s, a, scatter_b1_bits(L.bb), n_tiles,
-                       off, cursor1, out);
+                       off, coarse_off, cursor1, out);
+}
+void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *coarse_off, uint64_t n_regions, int bb,
+                        uint32_t *counts)
+{
+    if (!n_regions) return;
+    const uint32_t grid = (uint32_t)(n_regions < 256u * 32u ? n_regions : 256u * 32u);
+    hipLaunchKernelGGL(region_hist_kernel, dim3(grid), dim3(256), 0, s, keys1, coarse_off, n_regions, bb, scatter_b1_bits(bb), counts);
 }
 void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor2, const uint64_t *keys1,
                             uint64_t *keys)

@@ -111,6 +111,7 @@ def test_medium_pangenome_all_paths(ctx):
 @pytest.mark.parametrize("opts", [
     {"groups_per_thread": 1}, {"groups_per_thread": 3, "bucket_bits": 5},
     {"bucket_bits": 0}, {"bucket_bits": 13}, {"sub_bits": 3},
+    {"bucket_bits": 14}, {"bucket_bits": 16},          # deep mode: fine histogram from the level-1 output
     {"cap_log2": 8, "bucket_bits": 4},          # forces overflow -> sub-bucket retries
     {"no_slots": 1}, {"no_slots": 1, "sub_bits": 2},   # probing form of the fill
 ])
@@ -171,6 +172,35 @@ def test_fastq_gzip_and_mixed_formats(ctx):
     s = ctx.count_genome([gzip.compress(fq1), fq2], 21, 2)
     assert s.occurrences == nocc and (s.kmers() == km).all() and (s.counts() == ct).all()
     s.free()
+
+
+def test_deep_read_set_counts(ctx):
+    """one genome sequenced at ~40x with errors, k=21, abundance-min 2 (multidsk on reads): enough
+    occurrences per bucket that the engine switches to more than 2^13 buckets on its own"""
+    rng = np.random.RandomState(41)
+    ref = cases.rand_seq(rng, 150_000)
+    starts = rng.randint(0, len(ref) - 150, size=40_000)
+    reads = []
+    for s0 in starts:
+        r = list(ref[s0:s0 + 150])
+        for p in np.nonzero(rng.rand(150) < 0.005)[0]:
+            r[p] = "ACGT"[rng.randint(4)]
+        r = "".join(r)
+        reads.append(cases.revcomp(r) if rng.rand() < 0.5 else r)
+    fq = cases.fastq(reads).encode()
+    for opts in ({}, {"bucket_bits": 15}):
+        try:
+            for name, v in opts.items():
+                ctx.set_option(name, v)
+            for amin in (1, 2):
+                km, ct, nocc = orc.count_genome([fq], 21, amin)
+                s = ctx.count_genome([fq], 21, amin)
+                assert s.occurrences == nocc
+                assert s.kmers().shape == km.shape and (s.kmers() == km).all() and (s.counts() == ct).all()
+                s.free()
+        finally:
+            for name in opts:
+                ctx.set_option(name, -1)
 
 
 def test_staged_equals_fused(ctx):
