@@ -93,6 +93,53 @@ def label_sorted(ids, labels):
     return [ids[i] for i in order], labels[order]
 
 
+def _input_bytes(path):
+    n = os.path.getsize(path)
+    return n * 4 if path.endswith(".gz") else n        # rough inflate factor for FASTA/FASTQ text
+
+
+def plan_chunks(files_per_genome, budget_bytes):
+    """greedy consecutive chunks of genomes whose (estimated, inflated) input stays under the
+    budget; a genome larger than the budget gets a chunk of its own"""
+    chunks, cur, cur_bytes = [], [], 0
+    for g, files in enumerate(files_per_genome):
+        b = sum(_input_bytes(f) for f in files)
+        if cur and cur_bytes + b > budget_bytes:
+            chunks.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(g)
+        cur_bytes += b
+    if cur:
+        chunks.append(cur)
+    return chunks
+
+
+def counted_sets(ctx, files_per_genome, kmer_size, abundance_min, budget_bytes, progress=None):
+    """multidsk's job: one solid k-mer set per genome, genomes processed in device batches that fit
+    the byte budget (deep read sets do not fit one batch: 100x coverage = 100x the k-mers)"""
+    progress = progress or (lambda m: None)
+    sets = [None] * len(files_per_genome)
+    for chunk in plan_chunks(files_per_genome, budget_bytes):
+        if kmer_size > 32:                                  # two-word k-mers: per-genome counting path
+            for g in chunk:
+                sets[g] = ctx.count_genome_files(files_per_genome[g], kmer_size, abundance_min)
+            continue
+        b = ctx.batch(len(chunk))
+        for j, g in enumerate(chunk):
+            for f in files_per_genome[g]:
+                b.add_file(j, f)
+        b.upload()
+        b.partition_counts(kmer_size, abundance_min)
+        for j, g in enumerate(chunk):
+            sets[g] = b.genome_set(j)
+        progress("counted genomes %d..%d (%d k-mer occurrences)" % (chunk[0], chunk[-1], b.n_occurrences))
+        b.free()
+    return sets
+
+
+DEFAULT_BATCH_BYTES = int(os.environ.get("GRM_BATCH_BYTES", str(6 * 10**9)))
+
+
 def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton, phenotype_description,
                  phenotype_metadata_path, gzip, progress=None, abundance_min=1, source_type="contigs"):
     """create.py:278-396 with the two tool calls replaced by one fused engine pass."""
@@ -112,19 +159,42 @@ def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton
     write_header(tmp, source_type, contig_list_path, phenotype_description, phenotype_metadata_path, gzip,
                  ids, labels, tags, ctype, "singleton" if filter_singleton else "nothing")
     progress("multidsk+dsk2kover (gfx950): %d genomes, k=%d" % (len(ids), kmer_size))
-    batch = ctx.batch(len(ids))
-    for g, gid in enumerate(ids):
+    files_per_genome = []
+    for gid in ids:
         p = paths[gid]
-        files = sorted(os.path.join(p, f) for f in os.listdir(p)) if os.path.isdir(p) else [p]
-        for f in files:
-            batch.add_file(g, f)
-    batch.upload()
-    m = batch.run(kmer_size, abundance_min, bool(filter_singleton))
+        if os.path.isdir(p):        # from-reads: every .fastq / .fastq.gz of the directory (create.py:402,484-487)
+            fl = sorted(os.path.join(p, f) for f in os.listdir(p) if f.endswith((".fastq", ".fastq.gz", ".fq", ".fq.gz", ".fna", ".fa", ".fasta")))
+        else:
+            fl = [p]
+        files_per_genome.append(fl)
+    total = sum(_input_bytes(f) for fl in files_per_genome for f in fl)
+    if total <= DEFAULT_BATCH_BYTES and abundance_min <= 1 and kmer_size <= 32:
+        batch = ctx.batch(len(ids))                 # everything resident at once: fused pass
+        for g, fl in enumerate(files_per_genome):
+            for f in fl:
+                batch.add_file(g, f)
+        batch.upload()
+        m = batch.run(kmer_size, abundance_min, bool(filter_singleton))
+        batch.free()
+    elif kmer_size > 32 and total <= DEFAULT_BATCH_BYTES:
+        batch = ctx.batch(len(ids))
+        for g, fl in enumerate(files_per_genome):
+            for f in fl:
+                batch.add_file(g, f)
+        batch.upload()
+        m = batch.run(kmer_size, abundance_min, bool(filter_singleton))
+        batch.free()
+    else:                                           # the reference's own two steps: multidsk, then dsk2kover
+        if kmer_size > 32:
+            raise KoverError("k > 32 with inputs beyond one device batch is not supported yet")
+        sets = counted_sets(ctx, files_per_genome, kmer_size, abundance_min, DEFAULT_BATCH_BYTES, progress)
+        m = ctx.build_matrix(sets, bool(filter_singleton))
+        for s_ in sets:
+            s_.free()
     progress("dictionary: %d k-mers; writing HDF5 (gzip %d)" % (m.n_kmers, gzip))
     m.write_kover_h5(tmp, gzip, BLOCK_SIZE)
     n = m.n_kmers
     m.free()
-    batch.free()
     os.replace(tmp, output_path)        # never leave a plausible partial output
     return n
 

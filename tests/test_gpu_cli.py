@@ -124,3 +124,43 @@ def test_kover_create_from_contigs(genomes, tmp_path):
     assert (r.kmer_matrix == want["matrix"]).all()
     assert r.attr("filter") == "singleton" and r.attr("genome_source_type") == "contigs"
     assert r.phenotype[1] == ["R", "S"]
+
+
+def test_kover_create_from_reads_chunked(tmp_path):
+    """from-reads (create.py:399-523): a directory of FASTQ files per genome, k=21, abundance-min 2;
+    a tiny byte budget forces the multidsk-style chunked counting + dsk2kover-style merge"""
+    import gzip
+    import grm_amd  # noqa: F401
+    kd = import_module(PKG + ".kover_dataset")
+    rng = np.random.RandomState(3)
+    ref = cases.rand_seq(rng, 20000)
+    ids, dirs, imgs = [], [], []
+    for g in range(5):
+        var = list(ref)
+        for p in rng.randint(0, len(ref), size=15):
+            var[p] = "ACGT"[rng.randint(4)]
+        var = "".join(var)
+        reads = [var[s:s + 120] for s in rng.randint(0, len(var) - 120, size=1500)]
+        reads = [cases.revcomp(r) if i % 3 == 0 else r for i, r in enumerate(reads)]
+        d = tmp_path / ("reads_%d" % g)
+        d.mkdir()
+        f1, f2 = cases.fastq(reads[:750]).encode(), cases.fastq(reads[750:]).encode()
+        (d / "a_1.fastq").write_bytes(f1)
+        (d / "a_2.fastq.gz").write_bytes(gzip.compress(f2))
+        ids.append("G%d" % g)
+        dirs.append(str(d))
+        imgs.append([f1, f2])
+    data = str(tmp_path / "reads.tsv")
+    open(data, "w").writelines("%s\t%s\n" % (i, d) for i, d in zip(ids, dirs))
+    md = str(tmp_path / "md.tsv")
+    open(md, "w").writelines("%s\t%d\n" % (i, n % 2) for n, i in enumerate(ids))
+    out = str(tmp_path / "READS.kover")
+    _run([os.path.join(CLI, "kover"), "dataset", "create", "from-reads", "--genomic-data", data,
+          "--phenotype-description", "d", "--phenotype-metadata", md, "--output", out, "--kmer-size", "21",
+          "--kmer-min-abundance", "2", "--singleton-kmers", "--compression", "4", "-x"], env={"GRM_BATCH_BYTES": "300000"})
+    r = kd.KoverDatasetReader(out)
+    order = r.genome_identifiers
+    want = orc.build_matrix([imgs[ids.index(i)] for i in order], 21, 2, False)
+    assert r.kmer_sequences == orc.decode_kmers(want["kmers"], 21)
+    assert (r.kmer_matrix == want["matrix"]).all()
+    assert r.attr("genome_source_type") == "reads" and r.attr("filter") == "nothing"

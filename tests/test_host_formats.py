@@ -172,3 +172,18 @@ def test_ray_conf_grammar(tmp_path):
         assert ray.mpi_rank() == 2 and ray.main([str(conf)]) == 0     # non-zero ranks exit 0 without work
     finally:
         del os.environ["PMI_RANK"]
+
+
+def test_chunk_plan(kd, tmp_path):
+    sizes = [100, 300, 50, 700, 20, 20]
+    files = []
+    for i, n in enumerate(sizes):
+        p = tmp_path / ("g%d.fna" % i)
+        p.write_bytes(b"A" * n)
+        files.append([str(p)])
+    gz = tmp_path / "r.fastq.gz"
+    gz.write_bytes(b"x" * 100)                      # counted 4x (inflate estimate)
+    files.append([str(gz)])
+    assert kd.plan_chunks(files, 400) == [[0, 1], [2], [3], [4, 5], [6]]
+    assert kd.plan_chunks(files, 10**9) == [list(range(7))]
+    assert kd.plan_chunks([], 10) == []
