@@ -27,8 +27,6 @@ constexpr int L1_LDS_BYTES = L1_TILE * 8 + 2048 + 1024 + 1024 + 64;
 // ---- LDS table kernels ----
 constexpr int TABLE_THREADS = 512;                         // 8 waves: one genome per wave at a time
 constexpr int TABLE_SCRATCH_BYTES = 128;
-constexpr int DICT_PREFETCH_PAIRS = 6;                     // key pairs per lane prefetched for the next genome (768 keys)
-constexpr int FILL_PREFETCH = 2;                           // 16-byte slot-id loads per lane prefetched for the next genome (1024 ids)
 constexpr int KEYS_IN_FLIGHT = 4;
 constexpr int SLOTS_IN_FLIGHT = 8;                         // independent 2-byte slot loads per lane in the slot fill                          // independent key loads per lane in dict/fill
 

@@ -965,78 +965,75 @@ __global__ __launch_bounds__(1024) void dict_build_kernel(
     __syncthreads();
     const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
     const uint32_t max_fill = cap - (cap >> 3);     // 87.5 %
-    // Software pipeline over the wave's genomes: segment offsets are fetched two genomes ahead
-    // and the first DICT_PREFETCH_PAIRS*128 keys of the NEXT genome are loaded into registers while
-    // the current genome is processed, so only one global round trip per genome is ever exposed
-    // (segments are short: a few hundred keys, so the load latency, not bandwidth, sets the pace).
-    auto seg_of = [&](uint32_t g, uint64_t &s_, uint64_t &n_) {
-        s_ = 0; n_ = 0;
-        if (g < n_genomes) {
-            const uint64_t idx = (uint64_t)g * B + b;
-            s_ = off[idx];
-            n_ = len ? (uint64_t)len[idx] : off[idx + 1] - s_;
-        }
-    };
-    // each lane owns PAIRS of consecutive keys: one aligned 16-byte load per pair, and the two
-    // slot ids go out as one 4-byte store.  The aligned head / tail element of a pair may belong
-    // to the neighbouring segment: it is neither processed nor written.
-    auto load_pair = [&](uint64_t s_, uint64_t e_, uint64_t c, uint64_t &kx, uint64_t &ky) {
-        kx = ky = EMPTY_KEY;
-        if (c < e_) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + c);
-            if (c >= s_) kx = v.x;
-            if (c + 1 < e_) ky = v.y;
-        }
-    };
-    auto insert_key = [&](uint64_t key, uint32_t g) -> uint32_t {
-        if (key == EMPTY_KEY) return 0xffffffffu;
-        const uint64_t h = mix64(key);
-        if (sb && hash_sub(h, bb, sb) != sub) return 0xffffffffu;
-        bool ins;
-        const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, h, &ins);
-        if (slot == 0xffffffffu) { full = 1; return 0xffffffffu; }
-        if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
-        // state: first genome + 1, bit 31 once a second genome shows up.  Plain read first:
-        // after a few genomes nearly every slot already carries the multi bit.
-        uint32_t st = *reinterpret_cast<volatile uint32_t *>(&tstate[slot]);
-        if (!(st & 0x80000000u) && st != g + 1) {
-            st = atomicCAS(&tstate[slot], 0u, g + 1);
-            if (st != 0 && (st & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
-        }
-        return (sub << cap_log2) | slot;
-    };
-    auto do_pair = [&](uint64_t c, uint64_t kx, uint64_t ky, uint32_t g) {
-        const uint32_t x = insert_key(kx, g), y = insert_key(ky, g);
-        // remember where the keys live: the fill pass then needs neither the key nor a probe
-        if (kslot) {
-            if (x != 0xffffffffu && y != 0xffffffffu) *reinterpret_cast<uint32_t *>(kslot + c) = x | (y << 16);
-            else if (x != 0xffffffffu) kslot[c] = (uint16_t)x;
-            else if (y != 0xffffffffu) kslot[c + 1] = (uint16_t)y;
-        }
-    };
-    uint64_t s0, n, s1, n1, s2, n2;
-    seg_of((uint32_t)wave, s0, n);
-    seg_of((uint32_t)wave + nw, s1, n1);
-    uint64_t cx[DICT_PREFETCH_PAIRS], cy[DICT_PREFETCH_PAIRS];
-#pragma unroll
-    for (int q = 0; q < DICT_PREFETCH_PAIRS; q++) load_pair(s0, s0 + n, (s0 & ~1ull) + 2ull * lane + 128ull * q, cx[q], cy[q]);
+    // segment of the NEXT genome is fetched while the current one is processed (the two dependent
+    // global round trips -- offsets, then keys -- would otherwise serialise per genome)
+    uint64_t s0 = 0, n = 0;
+    if ((uint32_t)wave < n_genomes) {
+        const uint64_t idx = (uint64_t)wave * B + b;
+        s0 = off[idx];
+        n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
+    }
     for (uint32_t g = wave; g < n_genomes; g += nw) {
-        seg_of(g + 2 * nw, s2, n2);
-        uint64_t nx[DICT_PREFETCH_PAIRS], ny[DICT_PREFETCH_PAIRS];
-#pragma unroll
-        for (int q = 0; q < DICT_PREFETCH_PAIRS; q++) load_pair(s1, s1 + n1, (s1 & ~1ull) + 2ull * lane + 128ull * q, nx[q], ny[q]);
-        const uint64_t a0 = s0 & ~1ull, e0 = s0 + n;
-#pragma unroll
-        for (int q = 0; q < DICT_PREFETCH_PAIRS; q++) do_pair(a0 + 2ull * lane + 128ull * q, cx[q], cy[q], g);
-        for (uint64_t c = a0 + 2ull * lane + 128ull * DICT_PREFETCH_PAIRS; c < e0; c += 128) {   // long segments: the rest
-            uint64_t kx, ky;
-            load_pair(s0, e0, c, kx, ky);
-            do_pair(c, kx, ky, g);
+        uint64_t s0_next = 0, n_next = 0;
+        if (g + nw < n_genomes) {
+            const uint64_t idx = (uint64_t)(g + nw) * B + b;
+            s0_next = off[idx];
+            n_next = len ? (uint64_t)len[idx] : off[idx + 1] - s0_next;
         }
+        // each lane owns PAIRS of consecutive keys: one aligned 16-byte load per pair, and the two
+        // slot ids go out as one 4-byte store.  KIF/2 pairs per lane are in flight.  The aligned
+        // head / tail element of a pair may belong to the neighbouring segment: it is neither
+        // processed nor written.
+        const uint64_t a0 = s0 & ~1ull, e0 = s0 + n;
+        constexpr int PAIRS = KIF >= 2 ? KIF / 2 : 1;
+        for (uint64_t c0 = a0 + 2ull * lane; c0 < e0; c0 += 2ull * 64 * PAIRS) {
+            uint64_t kv[2 * PAIRS];
 #pragma unroll
-        for (int q = 0; q < DICT_PREFETCH_PAIRS; q++) { cx[q] = nx[q]; cy[q] = ny[q]; }
-        s0 = s1; n = n1;
-        s1 = s2; n1 = n2;
+            for (int q = 0; q < PAIRS; q++) {
+                const uint64_t c = c0 + 128ull * q;
+                if (c < e0) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + c);
+                    kv[2 * q] = c >= s0 ? v.x : EMPTY_KEY;
+                    kv[2 * q + 1] = c + 1 < e0 ? v.y : EMPTY_KEY;
+                } else {
+                    kv[2 * q] = kv[2 * q + 1] = EMPTY_KEY;
+                }
+            }
+            uint32_t sl[2 * PAIRS];
+#pragma unroll
+            for (int j = 0; j < 2 * PAIRS; j++) {
+                const uint64_t key = kv[j];
+                sl[j] = 0xffffffffu;
+                if (key == EMPTY_KEY) continue;
+                const uint64_t h = mix64(key);
+                if (sb && hash_sub(h, bb, sb) != sub) continue;
+                bool ins;
+                const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, h, &ins);
+                if (slot == 0xffffffffu) { full = 1; continue; }
+                if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
+                // state: first genome + 1, bit 31 once a second genome shows up.  Plain read first:
+                // after a few genomes nearly every slot already carries the multi bit.
+                uint32_t st = *reinterpret_cast<volatile uint32_t *>(&tstate[slot]);
+                if (!(st & 0x80000000u) && st != g + 1) {
+                    st = atomicCAS(&tstate[slot], 0u, g + 1);
+                    if (st != 0 && (st & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
+                }
+                sl[j] = (sub << cap_log2) | slot;
+            }
+            // remember where the keys live: the fill pass then needs neither the key nor a probe
+            if (kslot) {
+#pragma unroll
+                for (int q = 0; q < PAIRS; q++) {
+                    const uint64_t c = c0 + 128ull * q;
+                    const uint32_t x = sl[2 * q], y = sl[2 * q + 1];
+                    if (x != 0xffffffffu && y != 0xffffffffu) *reinterpret_cast<uint32_t *>(kslot + c) = x | (y << 16);
+                    else if (x != 0xffffffffu) kslot[c] = (uint16_t)x;
+                    else if (y != 0xffffffffu) kslot[c + 1] = (uint16_t)y;
+                }
+            }
+        }
+        s0 = s0_next;
+        n = n_next;
         if (full) break;    // LDS flag: a stale read only delays the exit
     }
     __syncthreads();
@@ -1110,53 +1107,26 @@ __global__ __launch_bounds__(1024) void matrix_fill_slots_kernel(
         for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) words[i] = 0;
         __syncthreads();
         const uint32_t g_end = min(r * 64 + 64, n_genomes);
-        // software pipeline as in dict_build: offsets two genomes ahead, the first
-        // FILL_PREFETCH*512 slot ids of the next genome in registers while the current one is applied.
-        // One aligned 16-byte load = 8 slot ids per lane; ids outside [s0, s0+n) (the aligned head /
-        // tail belongs to neighbouring segments) are ignored.
-        auto seg_of = [&](uint32_t g, uint64_t &s_, uint64_t &n_) {
-            s_ = 0; n_ = 0;
-            if (g < g_end) {
-                const uint64_t idx = (uint64_t)g * B + b;
-                s_ = off[idx];
-                n_ = len ? (uint64_t)len[idx] : off[idx + 1] - s_;
-            }
-        };
-        auto load8 = [&](uint64_t e_, uint64_t c) -> uint4 {
-            return c < e_ ? *reinterpret_cast<const uint4 *>(kslot + c) : make_uint4(0, 0, 0, 0);
-        };
-        auto apply8 = [&](uint64_t s_, uint64_t e_, uint64_t c, const uint4 &v, unsigned long long bit) {
-            if (c >= e_) return;
-            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint64_t i = c + j;
-                if (i < s_ || i >= e_) continue;
-                const uint32_t sv = (wv[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                if (sb && (sv >> cap_log2) != sub) continue;
-                atomicOr((unsigned long long *)&words[sv & cap_mask], bit);
-            }
-        };
-        uint64_t s0, n, s1, n1, s2, n2;
-        seg_of(r * 64 + wave, s0, n);
-        seg_of(r * 64 + wave + nw, s1, n1);
-        uint4 cur[FILL_PREFETCH];
-#pragma unroll
-        for (int q = 0; q < FILL_PREFETCH; q++) cur[q] = load8(s0 + n, (s0 & ~7ull) + 8ull * lane + 512ull * q);
         for (uint32_t g = r * 64 + wave; g < g_end; g += nw) {
             const unsigned long long bit = 1ull << (63 - (g & 63));
-            seg_of(g + 2 * nw, s2, n2);
-            uint4 nxt[FILL_PREFETCH];
-#pragma unroll
-            for (int q = 0; q < FILL_PREFETCH; q++) nxt[q] = load8(s1 + n1, (s1 & ~7ull) + 8ull * lane + 512ull * q);
+            const uint64_t idx = (uint64_t)g * B + b;
+            const uint64_t s0 = off[idx];
+            const uint64_t n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
+            // one aligned 16-byte load = 8 slot ids per lane; ids outside [s0, s0+n) (the aligned
+            // head / tail belongs to neighbouring segments) are ignored
             const uint64_t a0 = s0 & ~7ull, e0 = s0 + n;
+            for (uint64_t c0 = a0 + 8ull * lane; c0 < e0; c0 += 8ull * 64) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(kslot + c0);
+                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int q = 0; q < FILL_PREFETCH; q++) apply8(s0, e0, a0 + 8ull * lane + 512ull * q, cur[q], bit);
-            for (uint64_t c = a0 + 8ull * lane + 512ull * FILL_PREFETCH; c < e0; c += 512) apply8(s0, e0, c, load8(e0, c), bit);
-#pragma unroll
-            for (int q = 0; q < FILL_PREFETCH; q++) cur[q] = nxt[q];
-            s0 = s1; n = n1;
-            s1 = s2; n1 = n2;
+                for (int j = 0; j < 8; j++) {
+                    const uint64_t i = c0 + j;
+                    if (i < s0 || i >= e0) continue;
+                    const uint32_t sv = (wv[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                    if (sb && (sv >> cap_log2) != sub) continue;
+                    atomicOr((unsigned long long *)&words[sv & cap_mask], bit);
+                }
+            }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) {
