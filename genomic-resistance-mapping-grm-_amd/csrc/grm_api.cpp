@@ -698,7 +698,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     HIPCHK(c, hipMemcpyAsync(&b->total_keys, (deep ? b->d_off1.as<uint64_t>() + n_coarse : b->d_off.as<uint64_t>() + n_seg), 8,
                              hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, b->d_keys.ensure((b->total_keys + 8) * 8));      // slack: dict_build reads aligned key pairs
+    HIPCHK(c, b->d_keys.ensure((b->total_keys + 2) * 8));
     if (b->bb > b1) HIPCHK(c, b->d_keys1.ensure((b->total_keys + 2) * 8));
     {
         TimeScope t(c, "kmer_scatter_l1", b->total_keys);
@@ -797,7 +797,7 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
         HIPCHK(c, hipMemsetAsync(d_flag.p, 0, 4, s));
         const bool slots = (uint32_t)sb + b->cap_log2 <= 16 && c->opt_no_slots <= 0;
         if (slots) {
-            HIPCHK(c, b->d_kslot.ensure((b->total_keys + 64) * 2));      // slack: the fill reads aligned 16-byte groups
+            HIPCHK(c, b->d_kslot.ensure((b->total_keys + 2) * 2));
             HIPCHK(c, b->d_table_img.ensure((size_t)n_wg * cap * 8));
         }
         {

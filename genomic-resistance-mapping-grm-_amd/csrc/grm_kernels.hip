@@ -980,30 +980,16 @@ __global__ __launch_bounds__(1024) void dict_build_kernel(
             s0_next = off[idx];
             n_next = len ? (uint64_t)len[idx] : off[idx + 1] - s0_next;
         }
-        // each lane owns PAIRS of consecutive keys: one aligned 16-byte load per pair, and the two
-        // slot ids go out as one 4-byte store.  KIF/2 pairs per lane are in flight.  The aligned
-        // head / tail element of a pair may belong to the neighbouring segment: it is neither
-        // processed nor written.
-        const uint64_t a0 = s0 & ~1ull, e0 = s0 + n;
-        constexpr int PAIRS = KIF >= 2 ? KIF / 2 : 1;
-        for (uint64_t c0 = a0 + 2ull * lane; c0 < e0; c0 += 2ull * 64 * PAIRS) {
-            uint64_t kv[2 * PAIRS];
+        for (uint64_t i0 = lane; i0 < n; i0 += 64 * KIF) {
+            uint64_t kv[KIF];
 #pragma unroll
-            for (int q = 0; q < PAIRS; q++) {
-                const uint64_t c = c0 + 128ull * q;
-                if (c < e0) {
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + c);
-                    kv[2 * q] = c >= s0 ? v.x : EMPTY_KEY;
-                    kv[2 * q + 1] = c + 1 < e0 ? v.y : EMPTY_KEY;
-                } else {
-                    kv[2 * q] = kv[2 * q + 1] = EMPTY_KEY;
-                }
+            for (int j = 0; j < KIF; j++) {
+                const uint64_t i = i0 + 64u * j;
+                kv[j] = i < n ? keys[s0 + i] : EMPTY_KEY;
             }
-            uint32_t sl[2 * PAIRS];
 #pragma unroll
-            for (int j = 0; j < 2 * PAIRS; j++) {
+            for (int j = 0; j < KIF; j++) {
                 const uint64_t key = kv[j];
-                sl[j] = 0xffffffffu;
                 if (key == EMPTY_KEY) continue;
                 const uint64_t h = mix64(key);
                 if (sb && hash_sub(h, bb, sb) != sub) continue;
@@ -1018,18 +1004,8 @@ __global__ __launch_bounds__(1024) void dict_build_kernel(
                     st = atomicCAS(&tstate[slot], 0u, g + 1);
                     if (st != 0 && (st & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
                 }
-                sl[j] = (sub << cap_log2) | slot;
-            }
-            // remember where the keys live: the fill pass then needs neither the key nor a probe
-            if (kslot) {
-#pragma unroll
-                for (int q = 0; q < PAIRS; q++) {
-                    const uint64_t c = c0 + 128ull * q;
-                    const uint32_t x = sl[2 * q], y = sl[2 * q + 1];
-                    if (x != 0xffffffffu && y != 0xffffffffu) *reinterpret_cast<uint32_t *>(kslot + c) = x | (y << 16);
-                    else if (x != 0xffffffffu) kslot[c] = (uint16_t)x;
-                    else if (y != 0xffffffffu) kslot[c + 1] = (uint16_t)y;
-                }
+                // remember where the key lives: the fill pass then needs neither the key nor a probe
+                if (kslot) kslot[s0 + i0 + 64u * j] = (uint16_t)((sub << cap_log2) | slot);
             }
         }
         s0 = s0_next;
@@ -1112,19 +1088,18 @@ __global__ __launch_bounds__(1024) void matrix_fill_slots_kernel(
             const uint64_t idx = (uint64_t)g * B + b;
             const uint64_t s0 = off[idx];
             const uint64_t n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
-            // one aligned 16-byte load = 8 slot ids per lane; ids outside [s0, s0+n) (the aligned
-            // head / tail belongs to neighbouring segments) are ignored
-            const uint64_t a0 = s0 & ~7ull, e0 = s0 + n;
-            for (uint64_t c0 = a0 + 8ull * lane; c0 < e0; c0 += 8ull * 64) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(kslot + c0);
-                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+            for (uint64_t i0 = lane; i0 < n; i0 += 64 * SLOTS_IN_FLIGHT) {
+                uint32_t sv[SLOTS_IN_FLIGHT];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint64_t i = c0 + j;
-                    if (i < s0 || i >= e0) continue;
-                    const uint32_t sv = (wv[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                    if (sb && (sv >> cap_log2) != sub) continue;
-                    atomicOr((unsigned long long *)&words[sv & cap_mask], bit);
+                for (int j = 0; j < SLOTS_IN_FLIGHT; j++) {
+                    const uint64_t i = i0 + 64u * j;
+                    sv[j] = i < n ? (uint32_t)kslot[s0 + i] : 0xffffffffu;
+                }
+#pragma unroll
+                for (int j = 0; j < SLOTS_IN_FLIGHT; j++) {
+                    if (sv[j] == 0xffffffffu) continue;
+                    if (sb && (sv[j] >> cap_log2) != sub) continue;
+                    atomicOr((unsigned long long *)&words[sv[j] & cap_mask], bit);
                 }
             }
         }
