@@ -980,8 +980,15 @@ __global__ __launch_bounds__(1024) void dict_build_kernel(
             s0_next = off[idx];
             n_next = len ? (uint64_t)len[idx] : off[idx + 1] - s0_next;
         }
+        // The kernel is instruction-issue bound (SQ counters: more scalar than vector instructions in
+        // the divergent probing loops), so the common case is straight-line: KIF keys per lane, their
+        // hashes, then all first-probe reads (key word + state word) back to back.  A key that is
+        // already present in its first-probe slot and already known to this or several genomes -- almost
+        // every key of a pan-genome after the first few genomes -- is done after two LDS reads.  The
+        // others go through ONE shared copy of the general insertion code, one key at a time.
         for (uint64_t i0 = lane; i0 < n; i0 += 64 * KIF) {
-            uint64_t kv[KIF];
+            uint64_t kv[KIF], hv[KIF], ck[KIF];
+            uint32_t sl[KIF], cs[KIF];
 #pragma unroll
             for (int j = 0; j < KIF; j++) {
                 const uint64_t i = i0 + 64u * j;
@@ -989,23 +996,43 @@ __global__ __launch_bounds__(1024) void dict_build_kernel(
             }
 #pragma unroll
             for (int j = 0; j < KIF; j++) {
-                const uint64_t key = kv[j];
-                if (key == EMPTY_KEY) continue;
-                const uint64_t h = mix64(key);
-                if (sb && hash_sub(h, bb, sb) != sub) continue;
+                hv[j] = mix64(kv[j]);
+                sl[j] = hash_slot(hv[j], cap_mask);
+            }
+#pragma unroll
+            for (int j = 0; j < KIF; j++) {
+                ck[j] = tkeys[sl[j]];
+                cs[j] = tstate[sl[j]];
+            }
+            uint32_t todo = 0, act = 0;
+#pragma unroll
+            for (int j = 0; j < KIF; j++) {
+                const bool active = kv[j] != EMPTY_KEY && (!sb || hash_sub(hv[j], bb, sb) == sub);
+                const bool done = ck[j] == kv[j] && ((cs[j] >> 31) || cs[j] == g + 1);
+                act |= (uint32_t)active << j;
+                todo |= (uint32_t)(active && !done) << j;
+            }
+            while (todo) {
+                const int j = __ffs(todo) - 1;
+                todo &= todo - 1;
+                uint64_t key = kv[0], h = hv[0];
+#pragma unroll
+                for (int q = 1; q < KIF; q++) { if (j == q) { key = kv[q]; h = hv[q]; } }
                 bool ins;
                 const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, h, &ins);
-                if (slot == 0xffffffffu) { full = 1; continue; }
+                if (slot == 0xffffffffu) { full = 1; act &= ~(1u << j); continue; }
                 if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
-                // state: first genome + 1, bit 31 once a second genome shows up.  Plain read first:
-                // after a few genomes nearly every slot already carries the multi bit.
-                uint32_t st = *reinterpret_cast<volatile uint32_t *>(&tstate[slot]);
-                if (!(st & 0x80000000u) && st != g + 1) {
-                    st = atomicCAS(&tstate[slot], 0u, g + 1);
-                    if (st != 0 && (st & 0x7fffffffu) != g + 1) atomicOr(&tstate[slot], 0x80000000u);
-                }
-                // remember where the key lives: the fill pass then needs neither the key nor a probe
-                if (kslot) kslot[s0 + i0 + 64u * j] = (uint16_t)((sub << cap_log2) | slot);
+                // state: first genome + 1, bit 31 once a second genome shows up
+                const uint32_t st = atomicCAS(&tstate[slot], 0u, g + 1);
+                if (st != 0 && !(st >> 31) && st != g + 1) atomicOr(&tstate[slot], 0x80000000u);
+#pragma unroll
+                for (int q = 0; q < KIF; q++) { if (j == q) sl[q] = slot; }
+            }
+            // remember where the key lives: the fill pass then needs neither the key nor a probe
+            if (kslot) {
+#pragma unroll
+                for (int j = 0; j < KIF; j++)
+                    if ((act >> j) & 1u) kslot[s0 + i0 + 64u * j] = (uint16_t)((sub << cap_log2) | sl[j]);
             }
         }
         s0 = s0_next;
