@@ -22,7 +22,7 @@ constexpr int L1_THREADS = 512;                            // 8 waves per tile: 
 constexpr int L1_TILE = L1_THREADS * L1_PPT;               // 8192 k-mers staged in LDS per tile
 constexpr int L2_THREADS = 256;                            // level 2: 32 keys per thread, same tile size
 constexpr int L1_MAX_BITS = 8;                             // coarse fan-out 256: ~32 keys (256 B) per run
-constexpr int L1_LDS_BYTES = L1_TILE * 8 + 2048 + 1040 + 1040 + 64;   // keys, gbase[256], hist[260], start[260], scratch[16]
+constexpr int L1_LDS_BYTES = L1_TILE * 8 + 2048 + 1024 + 1024 + 64;
 
 // ---- LDS table kernels ----
 constexpr int TABLE_THREADS = 512;                         // 8 waves: one genome per wave at a time

@@ -644,9 +644,9 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint64_t *skeys = reinterpret_cast<uint64_t *>(lds_raw);                             // [L1_TILE]
     uint64_t *gbase = reinterpret_cast<uint64_t *>(lds_raw + (size_t)L1_TILE * 8);        // [256]
-    uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + (size_t)L1_TILE * 8 + 2048);  // [257]
-    uint32_t *start = hist + 260;                                                        // [257]
-    uint32_t *scratch = start + 260;                                                     // [16]
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + (size_t)L1_TILE * 8 + 2048);  // [256]
+    uint32_t *start = hist + 256;                                                        // [256]
+    uint32_t *scratch = start + 256;                                                     // [16]
     const uint64_t tile = xcd_span(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
     const int b2bits = a.bb - b1bits;
@@ -671,16 +671,13 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
     const int off_in_word = (int)(p0 & 31);
 
     if (uniform) {
-        // bin 256 collects the invalid start positions (separators, bad bases, stream end): no
-        // per-position branch in the hot loops; they are placed behind the valid keys and never
-        // copied out.  The tile holds exactly L1_TILE positions, so skeys cannot overflow.
-        if (threadIdx.x <= 256) hist[threadIdx.x] = 0;
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
         uint64_t kv[L1_PPT];
         uint32_t meta[L1_PPT];            // (coarse bucket << 16) | rank inside the tile's bucket
-        for_each_kmer_n<L1_PPT>(w0, w1, off_in_word, 0xffffu, a.k, [&](int i, uint64_t canon) {
+        for_each_kmer_n<L1_PPT>(w0, w1, off_in_word, valid, a.k, [&](int i, uint64_t canon) {
             kv[i] = canon;
-            const uint32_t b1 = ((valid >> i) & 1u) ? hash_bucket(mix64(canon), b1bits) : 256u;
+            const uint32_t b1 = hash_bucket(mix64(canon), b1bits);
             meta[i] = (b1 << 16) | atomicAdd(&hist[b1], 1u);
         });
         __syncthreads();
@@ -688,7 +685,6 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
         uint32_t n_tile;
         const uint32_t st = block_scan_sum(c, scratch, &n_tile);
         if (threadIdx.x < 256) start[threadIdx.x] = st;
-        if (threadIdx.x == 256) start[256] = n_tile;
         if (c) {
             // start of the coarse region: from the coarse scan (deep mode: fine offsets do not exist
             // yet) or from the fine scan (fine ids are nested inside the coarse bucket)
@@ -698,7 +694,8 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < L1_PPT; i++) skeys[start[meta[i] >> 16] + (meta[i] & 0xffffu)] = kv[i];
+        for (int i = 0; i < L1_PPT; i++)
+            if ((valid >> i) & 1u) skeys[start[meta[i] >> 16] + (meta[i] & 0xffffu)] = kv[i];
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n_tile; i += L1_THREADS) {
             const uint64_t key = skeys[i];
@@ -746,8 +743,8 @@ __global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
     uint64_t *skeys = reinterpret_cast<uint64_t *>(lds_raw);
     uint64_t *gbase = reinterpret_cast<uint64_t *>(lds_raw + (size_t)L1_TILE * 8);
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + (size_t)L1_TILE * 8 + 2048);
-    uint32_t *start = hist + 260;
-    uint32_t *scratch = start + 260;
+    uint32_t *start = hist + 256;
+    uint32_t *scratch = start + 256;
     const int b2bits = bb - b1bits;
     const uint32_t B2 = 1u << b2bits;
     for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
@@ -1127,9 +1124,9 @@ __global__ __launch_bounds__(1024) void matrix_fill_slots_kernel(
                 }
 #pragma unroll
                 for (int j = 0; j < SLOTS_IN_FLIGHT; j++) {
-                    // no branch: an id that is out of range or belongs to another sub-bucket ORs 0
-                    const bool on = sv[j] != 0xffffffffu && (!sb || (sv[j] >> cap_log2) == sub);
-                    atomicOr((unsigned long long *)&words[on ? (sv[j] & cap_mask) : 0u], on ? bit : 0ull);
+                    if (sv[j] == 0xffffffffu) continue;
+                    if (sb && (sv[j] >> cap_log2) != sub) continue;
+                    atomicOr((unsigned long long *)&words[sv[j] & cap_mask], bit);
                 }
             }
         }
