@@ -674,11 +674,14 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
         uint64_t kv[L1_PPT];
-        uint32_t meta[L1_PPT];            // (coarse bucket << 16) | rank inside the tile's bucket
+        uint32_t bk[L1_PPT], rk[L1_PPT];  // coarse bucket, rank inside the tile's bucket.  The rank is
+                                          // the RETURN value of an LDS atomic: it is not touched until the
+                                          // placement loop, so the 16 atomics stay in flight instead of
+                                          // costing one LDS round trip each.
         for_each_kmer_n<L1_PPT>(w0, w1, off_in_word, valid, a.k, [&](int i, uint64_t canon) {
             kv[i] = canon;
-            const uint32_t b1 = hash_bucket(mix64(canon), b1bits);
-            meta[i] = (b1 << 16) | atomicAdd(&hist[b1], 1u);
+            bk[i] = hash_bucket(mix64(canon), b1bits);
+            rk[i] = atomicAdd(&hist[bk[i]], 1u);
         });
         __syncthreads();
         const uint32_t c = threadIdx.x < B1 ? hist[threadIdx.x] : 0u;
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < L1_PPT; i++)
-            if ((valid >> i) & 1u) skeys[start[meta[i] >> 16] + (meta[i] & 0xffffu)] = kv[i];
+            if ((valid >> i) & 1u) skeys[start[bk[i]] + rk[i]] = kv[i];
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n_tile; i += L1_THREADS) {
             const uint64_t key = skeys[i];
@@ -756,7 +759,7 @@ __global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
             if (threadIdx.x < B2) hist[threadIdx.x] = 0;
             __syncthreads();
             uint64_t kv[32];
-            uint32_t meta[32];
+            uint32_t bk[32], rk[32];      // fine sub-bucket, returned rank (left in flight, see level 1)
 #pragma unroll
             for (int j = 0; j < 32; j++) {
                 const uint32_t i = (uint32_t)j * L2_THREADS + threadIdx.x;
@@ -765,8 +768,8 @@ __global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
 #pragma unroll
             for (int j = 0; j < 32; j++) {
                 if (kv[j] != EMPTY_KEY) {
-                    const uint32_t b2 = hash_bucket(mix64(kv[j]), bb) & (B2 - 1);
-                    meta[j] = (b2 << 16) | atomicAdd(&hist[b2], 1u);
+                    bk[j] = hash_bucket(mix64(kv[j]), bb) & (B2 - 1);
+                    rk[j] = atomicAdd(&hist[bk[j]], 1u);
                 }
             }
             __syncthreads();
@@ -780,7 +783,7 @@ __global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < 32; j++)
-                if (kv[j] != EMPTY_KEY) skeys[start[meta[j] >> 16] + (meta[j] & 0xffffu)] = kv[j];
+                if (kv[j] != EMPTY_KEY) skeys[start[bk[j]] + rk[j]] = kv[j];
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n; i += L2_THREADS) {
                 const uint64_t key = skeys[i];
