@@ -73,7 +73,13 @@ def allgather_dict(batch, n_local, device, group=None):
     _all_gather(fall, fpad, group)
     ks = [kall[r * n_max: r * n_max + counts_h[r]] for r in range(world)]
     fs = [fall[r * n_max: r * n_max + counts_h[r]] for r in range(world)]
-    return torch.cat(ks).contiguous(), torch.cat(fs).contiguous()
+    keys_all, flags_all = torch.cat(ks).contiguous(), torch.cat(fs).contiguous()
+    if keys_all.is_cuda:
+        # the engine launches on ITS OWN stream: the collective and the concatenation above were
+        # only enqueued on torch's stream, so they must have finished before the raw pointers are
+        # handed over (RCCL collectives return to the host before the GPU work is done)
+        torch.cuda.current_stream(keys_all.device).synchronize()
+    return keys_all, flags_all
 
 
 def sharded_step(batch, k, abundance_min, filter_singleton, device, group=None):
