@@ -127,6 +127,24 @@ def test_medium_with_forced_geometry(ctx, opts):
             ctx.set_option(name, -1)
 
 
+def test_parser_stress_layouts(ctx):
+    """single-line sequences spanning many 16 KiB tiles, headers longer than a tile, headers that
+    straddle tile boundaries, CRLF, blank lines, no trailing newline, lowercase / N runs"""
+    rng = np.random.RandomState(77)
+    a = cases.rand_seq(rng, 120_000)
+    b = cases.rand_seq(rng, 50_000)
+    g0 = (">single line\n" + a + "\n").encode()                                  # no newline for 7 tiles
+    g1 = (">" + "h" * 40_000 + "\n" + b[:20_000] + "\n>" + "x" * 16_380 + "\n" + b[20_000:]).encode()   # huge headers, no final newline
+    g2 = cases.fasta([("crlf", a[:60_000].lower()), ("n", a[60_000:61_000] + "N" * 5000 + a[61_000:70_000])], width=61, crlf=True).encode()
+    g3 = (">e\n\n\n" + b[:100] + "\n\n>f\n" + b[100:300] + "\n\n").encode()
+    pad = 16384 - 2 - len(">p\n") - 1          # put the next header's '>' on the last byte of a tile
+    g4 = (">p\n" + a[:pad - 1] + "\n>q straddle\n" + a[pad:pad + 5000] + "\n").encode()
+    genomes = [[g0], [g1], [g2], [g3], [g4], [g0, g4], [g1, g3, g2]]
+    for k in (31, 12):
+        _check(ctx, genomes, k, 1, False)
+    _check(ctx, genomes, 31, 2, True)
+
+
 def test_more_than_64_genomes_and_ragged(ctx):
     rng = np.random.RandomState(17)
     core = cases.rand_seq(rng, 3000)
