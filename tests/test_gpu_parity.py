@@ -434,3 +434,32 @@ def test_scale_properties(ctx):
     both = ((d_all[0] >> np.uint64(63 - 3)) & np.uint64(1)).astype(bool) | ((d_all[0] >> np.uint64(63 - 4)) & np.uint64(1)).astype(bool)
     assert (k_all[both] == sub["kmers"][:, 0]).all()
     m_all.free(); m_f.free(); b.free()
+
+
+def test_full_size_properties(ctx):
+    """BASELINE.json configs[1] at full size (1000 x 5 Mbp, k=31, singleton filter): no oracle can
+    run this, so the result is checked through size-independent properties and a 2-genome oracle slice"""
+    n = 1000
+    pg = synth.PanGenome(genome_len=5_000_000, seed=1234)
+    b = ctx.batch(n)
+    for g in range(n):
+        b.add_array(g, pg.genome(g))
+    b.upload()
+    m = b.run(31, 1, True)
+    kmers = m.kmers()[:, 0]
+    cc = m.column_counts()
+    assert b.n_occurrences > 4.9e9
+    assert (np.diff(kmers.astype(np.int64)) > 0).all()          # 62-bit values: strictly ascending dictionary
+    assert cc.min() >= 2 and cc.max() == n                        # singleton filter; the conserved core is in every genome
+    # a second pass over the same resident inputs gives the identical result (the partition order inside
+    # buckets is not deterministic, the output must be)
+    m2 = b.run(31, 1, True)
+    assert (m2.kmers()[:, 0] == kmers).all() and (m2.column_counts() == cc).all()
+    # masked popcount of two genomes == their oracle sets restricted to the kept columns
+    for g in (17, 700):
+        km, ct, nocc = orc.count_genome([pg.genome(g).tobytes()], 31, 1)
+        sel = m.sum_rows([g]).astype(bool)
+        assert np.isin(kmers[sel], km[:, 0]).all()                # every set bit is a real k-mer of the genome
+        kept = np.isin(km[:, 0], kmers)                           # its k-mers that survived the filter ...
+        assert int(sel.sum()) == int(kept.sum())                  # ... are exactly the set bits
+    m.free(); m2.free(); b.free()
