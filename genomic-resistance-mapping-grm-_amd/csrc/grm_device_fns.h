@@ -99,8 +99,8 @@ GRM_HD uint32_t mul24(uint32_t a, uint32_t b)
 GRM_HD uint64_t mix64(uint64_t x)
 {
     const uint32_t a = (uint32_t)x & 0xffffffu, b = (uint32_t)(x >> 24) & 0xffffffu, c = (uint32_t)(x >> 48);
-    const uint32_t t = mul24(c, 0xC2B2AFu);
-    const uint32_t h32 = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + t + (t << 16);
+    // (no "t + (t << 16)" style term: the compiler folds it into a quarter-rate v_mul_lo_u32)
+    const uint32_t h32 = mul24(a, 0x9E3779u) + mul24(b, 0x85EBCBu) + mul24(c, 0xC2B2AFu);
     const uint32_t low = mul24(h32 ^ (h32 >> 12), 0xD6E8FFu) ^ (h32 >> 7);
     return ((uint64_t)h32 << 32) | low;
 }

@@ -22,7 +22,7 @@ constexpr int L1_THREADS = 512;                            // 8 waves per tile: 
 constexpr int L1_TILE = L1_THREADS * L1_PPT;               // 8192 k-mers staged in LDS per tile
 constexpr int L2_THREADS = 256;                            // level 2: 32 keys per thread, same tile size
 constexpr int L1_MAX_BITS = 8;                             // coarse fan-out 256: ~32 keys (256 B) per run
-constexpr int L1_LDS_BYTES = L1_TILE * 8 + 2048 + 1024 + 1024 + 64;
+constexpr int L1_LDS_BYTES = L1_TILE * 8 + 2048 + 1024 + 1024 + 64 + L1_TILE;   // keys, gbase[256], hist[256], start[256], scratch[16], bucket bytes
 
 // ---- LDS table kernels ----
 constexpr int TABLE_THREADS = 512;                         // 8 waves: one genome per wave at a time

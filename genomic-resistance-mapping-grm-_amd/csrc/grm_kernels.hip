@@ -647,6 +647,7 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + (size_t)L1_TILE * 8 + 2048);  // [256]
     uint32_t *start = hist + 256;                                                        // [256]
     uint32_t *scratch = start + 256;                                                     // [16]
+    uint8_t *sbkt = reinterpret_cast<uint8_t *>(scratch + 16);                           // [L1_TILE] coarse bucket of skeys[i]
     const uint64_t tile = xcd_span(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
     const int b2bits = a.bb - b1bits;
@@ -698,12 +699,15 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < L1_PPT; i++)
-            if ((valid >> i) & 1u) skeys[start[bk[i]] + rk[i]] = kv[i];
+            if ((valid >> i) & 1u) {
+                const uint32_t at = start[bk[i]] + rk[i];
+                skeys[at] = kv[i];
+                sbkt[at] = (uint8_t)bk[i];        // the copy-out then needs no hash
+            }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n_tile; i += L1_THREADS) {
-            const uint64_t key = skeys[i];
-            const uint32_t b1 = hash_bucket(mix64(key), b1bits);
-            keys1[gbase[b1] + (i - start[b1])] = key;
+            const uint32_t b1 = sbkt[i];
+            keys1[gbase[b1] + (i - start[b1])] = skeys[i];
         }
     } else {
         uint32_t gen = genome_of(a.genome_sym_off, a.n_genomes, min(p0, a.total_syms - 1));
