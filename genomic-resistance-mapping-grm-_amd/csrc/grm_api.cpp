@@ -44,7 +44,9 @@ struct grm_ctx {
     int opt_sub_bits = -1;
     int opt_no_slots = -1;      // > 0: force the probing form of the fill (tests)
     int opt_keys_in_flight = -1, opt_table_threads = -1;
+    int opt_wide_sort = -1;     // > 0: k > 32 always through the sort-based path (tests)
 };
+static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
 
 static int fail(grm_ctx *c, int code, const char *fmt, ...)
 {
@@ -154,6 +156,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "cap_log2") c->opt_cap_log2 = value;
     else if (n == "sub_bits") c->opt_sub_bits = value;
     else if (n == "no_slots") c->opt_no_slots = value;
+    else if (n == "wide_sort") c->opt_wide_sort = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
@@ -395,11 +398,14 @@ static bool inflate_gzip(const uint8_t *src, size_t len, std::vector<uint8_t> &o
 
 struct WideSorted;
 static void wide_free(WideSorted *w);
+struct WideHash;
+static void wide_hash_free(WideHash *w);
 
 struct grm_batch {
     grm_ctx *ctx = nullptr;
-    WideSorted *wide = nullptr;      // two-word (k > 32) path buffers, created on first use
-    ~grm_batch() { wide_free(wide); }
+    WideSorted *wide = nullptr;      // two-word (k > 32) sort path buffers, created on first use
+    WideHash *whash = nullptr;       // two-word hash-partition path buffers
+    ~grm_batch() { wide_free(wide); wide_hash_free(whash); }
     int n_genomes = 0;
     std::vector<HostFile> files;
     bool uploaded = false, partitioned = false, have_local = false, have_global = false;
@@ -1126,6 +1132,158 @@ static int wide_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, WideS
 
 static void wide_free(WideSorted *w) { delete w; }
 
+// ---- two-word k-mers: hash-partition pipeline (grm_wide_hash.hip) ------------------------------
+struct WideHash {
+    DevBuf counts, off, cursor1, cursor2, keys, keys1, kslot;
+    DevBuf stage_lo, stage_hi, stage_flags, stage_cnt, stage_off, img_lo, img_hi, col_of_slot, flag;
+    DevBuf loc_lo, loc_hi, loc_flags, idx0, idx1, idx2, t_a, t_b, keep, pos, tmp;
+};
+static void wide_hash_free(WideHash *w) { delete w; }
+
+// returns GRM_OK with *fallback = true when the input does not suit this path (the caller then
+// uses the sort-based path); parse must have run.
+static int wide_hash_matrix(grm_batch *b, int k, int filter_singleton, grm_matrix **out, bool *fallback)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    *fallback = false;
+    const uint32_t G = (uint32_t)b->n_genomes;
+    if (b->total_syms == 0 || G == 0) { *fallback = true; return GRM_OK; }
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) { HIPCHK(c, wh_set_max_dynamic_lds()); lds_attr_set = true; }
+    if (!b->whash) b->whash = new WideHash();
+    WideHash &W = *b->whash;
+    uint64_t max_g = 0;
+    for (uint32_t g = 0; g < G; g++) max_g = std::max(max_g, b->h_genome_sym_off[g + 1] - b->h_genome_sym_off[g]);
+    int bb = 0;
+    while (bb < MAX_HIST_BITS && (max_g >> bb) > 512) bb++;
+    if (c->opt_bucket_bits >= 0) bb = std::min(c->opt_bucket_bits, MAX_HIST_BITS);
+    if ((max_g >> bb) > 4096) { *fallback = true; return GRM_OK; }        // deep inputs: not on this path yet
+    const uint32_t cap_log2 = c->opt_cap_log2 > 0 ? (uint32_t)std::min(12, std::max(6, c->opt_cap_log2)) : 11u;
+    const uint32_t cap = 1u << cap_log2;
+    const uint64_t B = 1ull << bb, n_seg = (uint64_t)G * B;
+    const int b1 = scatter_b1_bits(bb);
+    const uint64_t n_coarse = (uint64_t)G << b1;
+    b->bb = bb;
+
+    KmerLaunch L;
+    L.sym2 = b->d_sym2.as<uint64_t>(); L.inv = b->d_inv.as<uint64_t>(); L.total_syms = b->total_syms;
+    L.genome_sym_off = b->d_genome_sym_off.as<uint64_t>(); L.n_genomes = G; L.k = k; L.bb = bb; L.groups_per_thread = 1;
+
+    HIPCHK(c, W.counts.ensure((n_seg + 1) * 4)); HIPCHK(c, W.off.ensure((n_seg + 1) * 8));
+    HIPCHK(c, W.cursor2.ensure(n_seg * 4)); HIPCHK(c, W.cursor1.ensure(n_coarse * 4)); HIPCHK(c, W.flag.ensure(4));
+    HIPCHK(c, hipMemsetAsync(W.counts.p, 0, (n_seg + 1) * 4, s));
+    HIPCHK(c, hipMemsetAsync(W.cursor2.p, 0, n_seg * 4, s));
+    HIPCHK(c, hipMemsetAsync(W.cursor1.p, 0, n_coarse * 4, s));
+    {
+        TimeScope t(c, "wh_hist", b->total_syms);
+        launch_wh_hist(s, L, W.counts.as<uint32_t>());
+    }
+    {
+        size_t tb = 0;
+        HIPCHK(c, exclusive_scan_u32_u64(s, W.counts.as<uint32_t>(), W.off.as<uint64_t>(), n_seg + 1, nullptr, tb));
+        HIPCHK(c, W.tmp.ensure(tb));
+        HIPCHK(c, exclusive_scan_u32_u64(s, W.counts.as<uint32_t>(), W.off.as<uint64_t>(), n_seg + 1, W.tmp.p, tb));
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&b->total_keys, W.off.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const uint64_t NK = b->total_keys;
+    HIPCHK(c, W.keys.ensure((NK + 4) * 16));
+    if (bb > b1) HIPCHK(c, W.keys1.ensure((NK + 4) * 16));
+    {
+        TimeScope t(c, "wh_scatter_l1", NK);
+        launch_wh_l1(s, L, W.off.as<uint64_t>(), W.cursor1.as<uint32_t>(), bb > b1 ? W.keys1.p : W.keys.p);
+    }
+    if (bb > b1) {
+        TimeScope t(c, "wh_scatter_l2", NK);
+        launch_wh_l2(s, L, W.off.as<uint64_t>(), W.cursor2.as<uint32_t>(), W.keys1.p, W.keys.p);
+    }
+    HIPCHK(c, hipGetLastError());
+
+    // ---- per-bucket dictionary, retried with more sub-buckets on LDS overflow ----
+    HIPCHK(c, W.kslot.ensure((NK + 64) * 2));
+    int sb = c->opt_sub_bits >= 0 ? c->opt_sub_bits : 0;
+    uint32_t n_wg = 0;
+    for (;; sb++) {
+        if ((uint32_t)sb + cap_log2 > 16 || bb + sb > 22) { *fallback = true; return GRM_OK; }
+        n_wg = 1u << (bb + sb);
+        const size_t slots = (size_t)n_wg * cap;
+        HIPCHK(c, W.stage_lo.ensure(slots * 8)); HIPCHK(c, W.stage_hi.ensure(slots * 8)); HIPCHK(c, W.stage_flags.ensure(slots));
+        HIPCHK(c, W.img_lo.ensure(slots * 8)); HIPCHK(c, W.img_hi.ensure(slots * 8));
+        HIPCHK(c, W.stage_cnt.ensure((size_t)n_wg * 4 + 4)); HIPCHK(c, W.stage_off.ensure(((size_t)n_wg + 1) * 8));
+        HIPCHK(c, hipMemsetAsync(W.flag.p, 0, 4, s));
+        {
+            TimeScope t(c, "wh_dict_build", NK);
+            launch_wh_dict_build(s, W.keys.p, W.off.as<uint64_t>(), G, bb, sb, cap_log2, W.stage_lo.as<uint64_t>(), W.stage_hi.as<uint64_t>(),
+                                 W.stage_flags.as<uint8_t>(), W.stage_cnt.as<uint32_t>(), W.kslot.as<uint16_t>(), W.img_lo.as<uint64_t>(),
+                                 W.img_hi.as<uint64_t>(), W.flag.as<int>());
+        }
+        HIPCHK(c, hipGetLastError());
+        int ov = 0;
+        HIPCHK(c, hipMemcpyAsync(&ov, W.flag.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (!ov) break;
+    }
+    uint64_t n_local = 0;
+    launch_scan_u32(s, W.stage_cnt.as<uint32_t>(), n_wg, W.stage_off.as<uint64_t>());
+    HIPCHK(c, hipMemcpyAsync(&n_local, W.stage_off.as<uint64_t>() + n_wg, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (n_local >= 0xffffffffull) { *fallback = true; return GRM_OK; }
+    const uint64_t n = n_local;
+    uint32_t U = 0;
+    grm_matrix *m = new grm_matrix();
+    m->ctx = c; m->k = k; m->words = 2; m->n_genomes = b->n_genomes; m->n_rows = ((size_t)b->n_genomes + 63) / 64;
+    auto bail = [&](int code) { delete m; return code; };
+    if (n) {
+        TimeScope t(c, "wh_dict_sort", n);
+        hipError_t e = hipSuccess;
+        auto need = [&](DevBuf &d, size_t bytes) { if (e == hipSuccess) e = d.ensure(bytes); };
+        need(W.loc_lo, n * 8); need(W.loc_hi, n * 8); need(W.loc_flags, n + 16); need(W.idx0, n * 4); need(W.idx1, n * 4);
+        need(W.idx2, n * 4); need(W.t_a, n * 8); need(W.t_b, n * 8); need(W.keep, (n + 1) * 4); need(W.pos, (n + 1) * 4);
+        if (e != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "dictionary buffers: %s", hipGetErrorString(e)));
+        launch_wh_dict_gather(s, W.stage_lo.as<uint64_t>(), W.stage_hi.as<uint64_t>(), W.stage_flags.as<uint8_t>(), W.stage_off.as<uint64_t>(),
+                              n_wg, cap, W.loc_lo.as<uint64_t>(), W.loc_hi.as<uint64_t>(), W.loc_flags.as<uint8_t>());
+        launch_iota_u32(s, W.idx0.as<uint32_t>(), n);
+        size_t tb = 0;
+        // stable LSD sort by (hi, lo): by lo, then by hi
+        e = sort_pairs_u64_u32(s, W.loc_lo.as<uint64_t>(), W.t_a.as<uint64_t>(), W.idx0.as<uint32_t>(), W.idx1.as<uint32_t>(), n, nullptr, tb);
+        if (e == hipSuccess) e = W.tmp.ensure(tb);
+        if (e == hipSuccess) e = sort_pairs_u64_u32(s, W.loc_lo.as<uint64_t>(), W.t_a.as<uint64_t>(), W.idx0.as<uint32_t>(), W.idx1.as<uint32_t>(), n, W.tmp.p, tb);
+        launch_gather_u64(s, W.loc_hi.as<uint64_t>(), W.idx1.as<uint32_t>(), n, W.t_a.as<uint64_t>());
+        tb = 0;
+        if (e == hipSuccess) e = sort_pairs_u64_u32(s, W.t_a.as<uint64_t>(), W.t_b.as<uint64_t>(), W.idx1.as<uint32_t>(), W.idx2.as<uint32_t>(), n, nullptr, tb);
+        if (e == hipSuccess) e = W.tmp.ensure(tb);
+        if (e == hipSuccess) e = sort_pairs_u64_u32(s, W.t_a.as<uint64_t>(), W.t_b.as<uint64_t>(), W.idx1.as<uint32_t>(), W.idx2.as<uint32_t>(), n, W.tmp.p, tb);
+        launch_gather_u64(s, W.loc_lo.as<uint64_t>(), W.idx2.as<uint32_t>(), n, W.t_a.as<uint64_t>());     // sorted: hi = t_b, lo = t_a
+        if (e != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "dictionary sort: %s", hipGetErrorString(e)));
+        (void)hipMemsetAsync(W.keep.as<uint32_t>() + n, 0, 4, s);
+        launch_wh_keep_flags(s, W.loc_flags.as<uint8_t>(), W.idx2.as<uint32_t>(), n, filter_singleton, W.keep.as<uint32_t>());
+        int rc = wide_scan(c, W.tmp, false, W.keep.as<uint32_t>(), W.pos.as<uint32_t>(), n + 1);
+        if (rc) return bail(rc);
+        if (hipMemcpyAsync(&U, W.pos.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+            return bail(fail(c, GRM_ERR_HIP, "D2H"));
+    }
+    m->n_kmers = U;
+    const size_t cells = m->n_rows * (size_t)U;
+    if (m->d_data.alloc(cells * 8) != hipSuccess || m->d_kmers.alloc(((size_t)U + 1) * 16) != hipSuccess)
+        return bail(fail(c, GRM_ERR_OOM, "matrix allocation failed"));
+    if (cells) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
+    if (U) {
+        const size_t slots = (size_t)n_wg * cap;
+        if (W.col_of_slot.ensure(slots * 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
+        (void)hipMemsetAsync(W.col_of_slot.p, 0xff, slots * 4, s);
+        launch_wh_select_cols(s, W.t_b.as<uint64_t>(), W.t_a.as<uint64_t>(), W.keep.as<uint32_t>(), W.pos.as<uint32_t>(), n, bb, sb, cap_log2,
+                              W.img_lo.as<uint64_t>(), W.img_hi.as<uint64_t>(), m->d_kmers.as<uint64_t>(), W.col_of_slot.as<uint32_t>());
+        TimeScope t(c, "matrix_fill", NK);
+        launch_matrix_fill_slots(s, W.kslot.as<uint16_t>(), W.off.as<uint64_t>(), nullptr, G, bb, sb, cap_log2, W.col_of_slot.as<uint32_t>(),
+                                 m->d_data.as<uint64_t>(), U);
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "wide hash pipeline failed"));
+    *out = m;
+    return GRM_OK;
+}
+
 static int wide_matrix(grm_batch *b, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out)
 {
     grm_ctx *c = b->ctx;
@@ -1219,7 +1377,16 @@ extern "C" int grm_batch_run(grm_batch *b, int k, uint32_t abundance_min, int fi
     if (!b || !out) return GRM_ERR_ARG;
     int rc = batch_partition_impl(b, k, abundance_min, false);
     if (rc) return rc;
-    if (k > 32) return wide_matrix(b, k, abundance_min < 1 ? 1 : abundance_min, filter_singleton, out);
+    if (k > 32) {
+        // hash-partition pipeline when it applies (abundance-min 1, moderate depth); the sort-based path
+        // is the general fallback (and can be forced with the "wide_sort" option, for tests)
+        if (abundance_min <= 1 && c_opt_wide_sort(b->ctx) <= 0) {
+            bool fallback = false;
+            rc = wide_hash_matrix(b, k, filter_singleton, out, &fallback);
+            if (rc || !fallback) return rc;
+        }
+        return wide_matrix(b, k, abundance_min < 1 ? 1 : abundance_min, filter_singleton, out);
+    }
     uint64_t n_local = 0, n_kmers = 0;
     rc = grm_batch_local_dict(b, &n_local);
     if (rc) return rc;

@@ -394,7 +394,7 @@ GRM_HD void for_each_kmer_wide(uint64_t w0, uint64_t w1, uint64_t w2, int off, u
     const int top = 2 * (k - 1) - 64;                  // bit of the hi word that receives the complement
     const uint64_t mask_hi = k == 64 ? ~0ull : ((1ull << (2 * k - 64)) - 1);
     K128 fwd = {0, 0}, rc = {0, 0};
-    for (int j = 0; j < k - 1 + NPOS; j++) {
+    auto step = [&]() {
         const uint64_t sym = s0 >> 62;
         s0 = (s0 << 2) | (s1 >> 62);
         s1 = (s1 << 2) | (s2 >> 62);
@@ -403,8 +403,12 @@ GRM_HD void for_each_kmer_wide(uint64_t w0, uint64_t w1, uint64_t w2, int off, u
         fwd.lo = (fwd.lo << 2) | sym;
         rc.lo = (rc.lo >> 2) | (rc.hi << 62);
         rc.hi = (rc.hi >> 2) | ((sym ^ 2) << top);
-        const int i = j - (k - 1);
-        if (i >= 0 && ((valid >> i) & 1u)) f(i, k128_less(fwd, rc) ? fwd : rc);
+    };
+    for (int j = 0; j < k - 1; j++) step();            // warm-up: the first k-1 symbols (run-time count)
+#pragma unroll
+    for (int i = 0; i < NPOS; i++) {                     // fully unrolled: i is static, callers may index registers with it
+        step();
+        if ((valid >> i) & 1u) f(i, k128_less(fwd, rc) ? fwd : rc);
     }
 }
 

@@ -135,4 +135,19 @@ void launch_wide_emit(hipStream_t s, const uint64_t *khi, const uint64_t *klo, c
 void launch_wide_set(hipStream_t s, const uint64_t *khi, const uint64_t *klo, const uint32_t *sub_start, const uint32_t *sub_ok,
                      const uint32_t *out_pos, uint32_t n_sub, uint64_t *kmers, uint32_t *counts);
 
+// ---- two-word k-mers, hash-partition pipeline (grm_wide_hash.hip) ----
+void launch_wh_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
+void launch_wh_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, void *out);
+void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor2, const void *keys1, void *keys);
+void launch_wh_dict_build(hipStream_t s, const void *keys, const uint64_t *off, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
+                          uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint16_t *kslot,
+                          uint64_t *img_lo, uint64_t *img_hi, int *overflow);
+void launch_wh_dict_gather(hipStream_t s, const uint64_t *stage_lo, const uint64_t *stage_hi, const uint8_t *stage_flags,
+                           const uint64_t *stage_off, uint32_t n_wg, uint32_t cap, uint64_t *out_lo, uint64_t *out_hi, uint8_t *out_flags);
+void launch_wh_keep_flags(hipStream_t s, const uint8_t *flags, const uint32_t *order, uint64_t n, int filter_singleton, uint32_t *keep);
+void launch_wh_select_cols(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
+                           int bb, int sb, uint32_t cap_log2, const uint64_t *img_lo, const uint64_t *img_hi, uint64_t *dict,
+                           uint32_t *col_of_slot);
+hipError_t wh_set_max_dynamic_lds();
+
 }  // namespace grm

@@ -1,0 +1,461 @@
+// grm_wide_hash.hip -- the hash-partition pipeline for two-word k-mers (33 <= k <= 64).
+//
+// Same stages as grm_kernels.hip (histogram -> two-level LDS-staged partition -> per-bucket LDS
+// dictionary with slot ids -> slot-form fill), with 16-byte keys (hi, lo).  The fill kernel is
+// shared (it only sees slot ids).  Differences that matter:
+//   * tiles hold 4096 keys (64 KiB of LDS) instead of 8192;
+//   * LDS tables are {lo[cap], hi[cap], state[cap]} and there is no 128-bit LDS compare-and-swap:
+//     a slot is claimed with a 64-bit CAS on `lo`, then `hi` is published; a prober that meets a
+//     claimed slot whose `hi` is not published yet simply goes round its loop again.  Lanes of one
+//     wave reconverge every iteration, so the claimer always gets to publish: no spinning on a
+//     lane of the same wave.
+// Scope of this path: grm_batch_run with abundance-min 1 on one GPU (BASELINE config C5);
+// counted sets, abundance filters and anything that overflows fall back to the sort-based path
+// in grm_wide.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "grm_device_fns.h"
+#include "grm_internal.h"
+#include "grm_coop.h"
+
+namespace grm {
+
+constexpr int WH_PPT = 16;                       // start positions / keys per thread
+constexpr int WH_THREADS = 256;
+constexpr int WH_TILE = WH_THREADS * WH_PPT;     // 4096 keys staged in LDS
+constexpr int WH_LDS_BYTES = WH_TILE * 16 + 2048 + 1024 + 1024 + 64;
+constexpr uint64_t WH_EMPTY = ~0ull;             // lo == hi == ~0 is never a canonical k-mer
+constexpr uint64_t WH_PENDING = ~0ull;           // hi of a slot that is claimed but not yet published
+
+__device__ __forceinline__ uint64_t mix128(uint64_t hi, uint64_t lo)
+{
+    const uint64_t a = mix64(lo), b = mix64(hi ^ 0x5bd1e9955bd1e995ull);
+    const uint32_t top = (uint32_t)(a >> 32) + (uint32_t)(b >> 32) * 0x9E3779B1u;
+    const uint32_t low = (uint32_t)a ^ ((uint32_t)b << 7) ^ ((uint32_t)b >> 11);
+    return ((uint64_t)top << 32) | low;
+}
+
+struct WideArgs {
+    const uint64_t *sym2;
+    const uint64_t *inv;
+    uint64_t total_syms;
+    const uint64_t *genome_sym_off;
+    uint32_t n_genomes;
+    int k;
+    int bb;
+};
+
+// the 16 start positions p0 .. p0+15 of a thread; calls f(i, key) for the valid ones
+template <typename F>
+__device__ __forceinline__ uint32_t wide_positions(const WideArgs &a, uint64_t p0, F &&f)
+{
+    const int64_t nv = (int64_t)a.total_syms - a.k + 1 - (int64_t)p0;
+    if (nv <= 0) return 0;
+    const uint64_t grp = p0 >> 6;
+    uint32_t valid = (uint32_t)(valid_starts(a.inv[grp], a.inv[grp + 1], a.k) >> (p0 & 63)) & 0xffffu;
+    if (nv < WH_PPT) valid &= (1u << nv) - 1;
+    if (valid) {
+        const uint64_t wi = p0 >> 5;
+        for_each_kmer_wide<WH_PPT>(a.sym2[wi], a.sym2[wi + 1], a.sym2[wi + 2], (int)(p0 & 31), valid, a.k, f);
+    }
+    return valid;
+}
+
+// ---- histogram --------------------------------------------------------------------------
+__global__ __launch_bounds__(WH_THREADS) void wide_hist_kernel(WideArgs a, uint32_t n_tiles, uint32_t tiles_per_block,
+                                                               uint32_t *__restrict__ counts)
+{
+    extern __shared__ uint32_t lds_hist[];
+    const uint32_t B = 1u << a.bb;
+    const uint64_t t_first = (uint64_t)blockIdx.x * tiles_per_block;
+    if (t_first >= n_tiles) return;
+    const uint64_t t_last = min(t_first + tiles_per_block, (uint64_t)n_tiles) - 1;
+    const uint64_t p_first = t_first * WH_TILE;
+    const uint64_t p_last = min((t_last + 1) * WH_TILE, a.total_syms) - 1;
+    const uint32_t gen0 = genome_of(a.genome_sym_off, a.n_genomes, p_first);
+    const bool uniform = a.genome_sym_off[gen0 + 1] > p_last;
+    if (uniform) {
+        for (uint32_t i = threadIdx.x; i < B; i += WH_THREADS) lds_hist[i] = 0;
+        __syncthreads();
+        for (uint64_t t = t_first; t <= t_last; t++)
+            wide_positions(a, t * WH_TILE + (uint64_t)threadIdx.x * WH_PPT,
+                           [&](int, K128 c) { atomicAdd(&lds_hist[hash_bucket(mix128(c.hi, c.lo), a.bb)], 1u); });
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < B; i += WH_THREADS) {
+            const uint32_t c = lds_hist[i];
+            if (c) atomicAdd(&counts[(uint64_t)gen0 * B + i], c);
+        }
+    } else {
+        for (uint64_t t = t_first; t <= t_last; t++) {
+            const uint64_t p0 = t * WH_TILE + (uint64_t)threadIdx.x * WH_PPT;
+            if (p0 >= a.total_syms) continue;
+            uint32_t gen = genome_of(a.genome_sym_off, a.n_genomes, p0);
+            uint64_t gend = a.genome_sym_off[gen + 1];
+            wide_positions(a, p0, [&](int i, K128 c) {
+                while (p0 + (uint64_t)i >= gend) { gen++; gend = a.genome_sym_off[gen + 1]; }
+                atomicAdd(&counts[(uint64_t)gen * B + hash_bucket(mix128(c.hi, c.lo), a.bb)], 1u);
+            });
+        }
+    }
+}
+
+// ---- level 1: tile of 4096 positions -> coarse buckets ---------------------------------------
+__global__ __launch_bounds__(WH_THREADS) void wide_l1_kernel(WideArgs a, int b1bits, uint32_t n_tiles,
+                                                             const uint64_t *__restrict__ off, uint32_t *__restrict__ cursor1,
+                                                             ulonglong2 *__restrict__ keys1)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    ulonglong2 *skeys = reinterpret_cast<ulonglong2 *>(lds_raw);                          // [WH_TILE]
+    uint64_t *gbase = reinterpret_cast<uint64_t *>(lds_raw + (size_t)WH_TILE * 16);       // [256]
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + (size_t)WH_TILE * 16 + 2048); // [256]
+    uint32_t *start = hist + 256;
+    uint32_t *scratch = start + 256;
+    const uint64_t tile = xcd_span(blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;
+    const int b2bits = a.bb - b1bits;
+    const uint32_t B1 = 1u << b1bits;
+    const uint64_t p_first = tile * WH_TILE;
+    if (p_first >= a.total_syms) return;
+    const uint64_t p_last = min(p_first + WH_TILE, a.total_syms) - 1;
+    const uint64_t p0 = p_first + (uint64_t)threadIdx.x * WH_PPT;
+    const uint32_t gen0 = genome_of(a.genome_sym_off, a.n_genomes, p_first);
+    const bool uniform = a.genome_sym_off[gen0 + 1] > p_last;
+    if (uniform) {
+        hist[threadIdx.x] = 0;          // WH_THREADS == 256 >= B1
+        __syncthreads();
+        K128 kv[WH_PPT];
+        uint32_t bk[WH_PPT], rk[WH_PPT];
+        const uint32_t valid = wide_positions(a, p0, [&](int i, K128 c) {
+            kv[i] = c;
+            bk[i] = hash_bucket(mix128(c.hi, c.lo), b1bits);
+            rk[i] = atomicAdd(&hist[bk[i]], 1u);
+        });
+        __syncthreads();
+        const uint32_t c = threadIdx.x < B1 ? hist[threadIdx.x] : 0u;
+        uint32_t n_tile;
+        const uint32_t st = block_scan_sum(c, scratch, &n_tile);
+        start[threadIdx.x] = st;
+        if (c) {
+            const uint64_t cidx = (uint64_t)gen0 * B1 + threadIdx.x;
+            gbase[threadIdx.x] = off[(uint64_t)gen0 * (1ull << a.bb) + ((uint64_t)threadIdx.x << b2bits)] + atomicAdd(&cursor1[cidx], c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WH_PPT; i++)
+            if ((valid >> i) & 1u) skeys[start[bk[i]] + rk[i]] = make_ulonglong2(kv[i].lo, kv[i].hi);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_tile; i += WH_THREADS) {
+            const ulonglong2 key = skeys[i];
+            const uint32_t b1 = hash_bucket(mix128(key.y, key.x), b1bits);
+            keys1[gbase[b1] + (i - start[b1])] = key;
+        }
+    } else {
+        if (p0 >= a.total_syms) return;
+        uint32_t gen = genome_of(a.genome_sym_off, a.n_genomes, p0);
+        uint64_t gend = a.genome_sym_off[gen + 1];
+        wide_positions(a, p0, [&](int i, K128 c) {
+            while (p0 + (uint64_t)i >= gend) { gen++; gend = a.genome_sym_off[gen + 1]; }
+            const uint32_t b1 = hash_bucket(mix128(c.hi, c.lo), b1bits);
+            const uint64_t cidx = (uint64_t)gen * B1 + b1;
+            const uint64_t region0 = off[(uint64_t)gen * (1ull << a.bb) + ((uint64_t)b1 << b2bits)];
+            keys1[region0 + atomicAdd(&cursor1[cidx], 1u)] = make_ulonglong2(c.lo, c.hi);
+        });
+    }
+}
+
+// ---- level 2: (genome, coarse bucket) region -> fine buckets ------------------------------------
+__global__ __launch_bounds__(WH_THREADS) void wide_l2_kernel(const ulonglong2 *__restrict__ keys1, ulonglong2 *__restrict__ keys,
+                                                             const uint64_t *__restrict__ off, uint32_t *__restrict__ cursor2,
+                                                             uint64_t n_regions, int bb, int b1bits)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    ulonglong2 *skeys = reinterpret_cast<ulonglong2 *>(lds_raw);
+    uint64_t *gbase = reinterpret_cast<uint64_t *>(lds_raw + (size_t)WH_TILE * 16);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + (size_t)WH_TILE * 16 + 2048);
+    uint32_t *start = hist + 256;
+    uint32_t *scratch = start + 256;
+    const int b2bits = bb - b1bits;
+    const uint32_t B2 = 1u << b2bits;
+    for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
+        const uint64_t g = region >> b1bits, c1 = region & ((1u << b1bits) - 1);
+        const uint64_t fine0 = (g << bb) + (c1 << b2bits);
+        const uint64_t r0 = off[fine0], r1 = off[fine0 + B2];
+        for (uint64_t base = r0; base < r1; base += WH_TILE) {
+            const uint32_t n = (uint32_t)min((uint64_t)WH_TILE, r1 - base);
+            if (threadIdx.x < B2) hist[threadIdx.x] = 0;
+            __syncthreads();
+            ulonglong2 kv[WH_PPT];
+            uint32_t bk[WH_PPT], rk[WH_PPT];
+#pragma unroll
+            for (int j = 0; j < WH_PPT; j++) {
+                const uint32_t i = (uint32_t)j * WH_THREADS + threadIdx.x;
+                kv[j] = i < n ? keys1[base + i] : make_ulonglong2(WH_EMPTY, WH_EMPTY);
+            }
+#pragma unroll
+            for (int j = 0; j < WH_PPT; j++) {
+                if (!(kv[j].x == WH_EMPTY && kv[j].y == WH_EMPTY)) {
+                    bk[j] = hash_bucket(mix128(kv[j].y, kv[j].x), bb) & (B2 - 1);
+                    rk[j] = atomicAdd(&hist[bk[j]], 1u);
+                }
+            }
+            __syncthreads();
+            const uint32_t c = threadIdx.x < B2 ? hist[threadIdx.x] : 0u;
+            uint32_t n_tile;
+            const uint32_t st = block_scan_sum(c, scratch, &n_tile);
+            if (threadIdx.x < B2) {
+                start[threadIdx.x] = st;
+                if (c) gbase[threadIdx.x] = off[fine0 + threadIdx.x] + atomicAdd(&cursor2[fine0 + threadIdx.x], c);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < WH_PPT; j++)
+                if (!(kv[j].x == WH_EMPTY && kv[j].y == WH_EMPTY)) skeys[start[bk[j]] + rk[j]] = kv[j];
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += WH_THREADS) {
+                const ulonglong2 key = skeys[i];
+                const uint32_t b2 = hash_bucket(mix128(key.y, key.x), bb) & (B2 - 1);
+                keys[gbase[b2] + (i - start[b2])] = key;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- per-bucket dictionary with 16-byte keys ---------------------------------------------------
+// returns the slot of (hi, lo), inserting it if absent; 0xffffffff when the table is full
+__device__ __forceinline__ uint32_t wide_find_or_insert(uint64_t *tlo, uint64_t *thi, uint32_t cap_mask, uint64_t hi, uint64_t lo,
+                                                        uint64_t h, bool *inserted)
+{
+    uint32_t slot = hash_slot(h, cap_mask);
+    uint32_t probes = 0;
+    *inserted = false;
+    // every lane goes round this loop until it is done; a lane that meets a claimed-but-unpublished
+    // slot re-reads it next time round (the claimer published in the meantime or will soon)
+    for (uint32_t guard = 0; guard < 64u * (cap_mask + 1); guard++) {
+        uint64_t cur = *reinterpret_cast<volatile uint64_t *>(&tlo[slot]);
+        if (cur == WH_EMPTY) {
+            cur = atomicCAS((unsigned long long *)&tlo[slot], (unsigned long long)WH_EMPTY, (unsigned long long)lo);
+            if (cur == WH_EMPTY) {                                   // claimed: publish hi
+                *reinterpret_cast<volatile uint64_t *>(&thi[slot]) = hi;
+                *inserted = true;
+                return slot;
+            }
+        }
+        if (cur == lo) {
+            const uint64_t ch = *reinterpret_cast<volatile uint64_t *>(&thi[slot]);
+            if (ch == hi) return slot;
+            if (ch == WH_PENDING) continue;                          // not published yet: look again
+        }
+        slot = (slot + 1) & cap_mask;
+        if (++probes > cap_mask) return 0xffffffffu;
+    }
+    return 0xffffffffu;
+}
+
+// NOTE: hi == WH_PENDING (all ones) together with a real lo is impossible for k <= 63 (hi has
+// at most 62 significant bits); for k == 64 a canonical k-mer cannot start with 32 G's
+// (its reverse complement would start with C's and be smaller), so hi is never all ones either.
+__global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
+    const ulonglong2 *__restrict__ keys, const uint64_t *__restrict__ off, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
+    uint64_t *__restrict__ stage_lo, uint64_t *__restrict__ stage_hi, uint8_t *__restrict__ stage_flags,
+    uint32_t *__restrict__ stage_cnt, uint16_t *__restrict__ kslot, uint64_t *__restrict__ img_lo, uint64_t *__restrict__ img_hi,
+    int *__restrict__ overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
+    uint64_t *tlo = reinterpret_cast<uint64_t *>(lds_raw);
+    uint64_t *thi = reinterpret_cast<uint64_t *>(lds_raw + (size_t)cap * 8);
+    uint32_t *tstate = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 16);
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 20);
+    volatile int &full = *reinterpret_cast<volatile int *>(scratch + 16);
+    uint32_t &n_distinct = scratch[17];
+    const uint32_t wg = blockIdx.x;
+    const uint32_t B = 1u << bb;
+    const uint32_t b = wg >> sb, sub = wg & ((1u << sb) - 1);
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tlo[i] = WH_EMPTY; thi[i] = WH_PENDING; tstate[i] = 0; }
+    if (threadIdx.x == 0) { full = 0; n_distinct = 0; }
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
+    const uint32_t max_fill = cap - (cap >> 3);
+    for (uint32_t g = wave; g < n_genomes; g += nw) {
+        const uint64_t idx = (uint64_t)g * B + b;
+        const uint64_t s0 = off[idx], n = off[idx + 1] - s0;
+        for (uint64_t i0 = lane; i0 < n; i0 += 64 * 2) {
+            ulonglong2 kv[2];
+            uint64_t hv[2];
+            uint32_t sl[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint64_t i = i0 + 64u * j;
+                kv[j] = i < n ? keys[s0 + i] : make_ulonglong2(WH_EMPTY, WH_EMPTY);
+                hv[j] = mix128(kv[j].y, kv[j].x);
+                sl[j] = hash_slot(hv[j], cap_mask);
+            }
+            uint64_t cl[2], ch[2];
+            uint32_t cs[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) { cl[j] = tlo[sl[j]]; ch[j] = thi[sl[j]]; cs[j] = tstate[sl[j]]; }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const bool real = !(kv[j].x == WH_EMPTY && kv[j].y == WH_EMPTY);
+                if (!real) continue;
+                if (sb && hash_sub(hv[j], bb, sb) != sub) continue;
+                uint32_t slot = sl[j];
+                if (!(cl[j] == kv[j].x && ch[j] == kv[j].y && ((cs[j] >> 31) || cs[j] == g + 1))) {
+                    bool ins;
+                    slot = wide_find_or_insert(tlo, thi, cap_mask, kv[j].y, kv[j].x, hv[j], &ins);
+                    if (slot == 0xffffffffu) { full = 1; continue; }
+                    if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
+                    const uint32_t st = atomicCAS(&tstate[slot], 0u, g + 1);
+                    if (st != 0 && !(st >> 31) && st != g + 1) atomicOr(&tstate[slot], 0x80000000u);
+                }
+                kslot[s0 + i0 + 64u * j] = (uint16_t)((sub << cap_log2) | slot);
+            }
+        }
+        if (full) break;
+    }
+    __syncthreads();
+    if (full) {
+        if (threadIdx.x == 0) { atomicExch(overflow, 1); stage_cnt[wg] = 0; }
+        return;
+    }
+    uint32_t base = 0;
+    const uint64_t out0 = (uint64_t)wg * cap;
+    for (uint32_t s = 0; s < cap; s += blockDim.x) {
+        const uint32_t slot = s + threadIdx.x;
+        const uint64_t lo = slot < cap ? tlo[slot] : WH_EMPTY;
+        const bool keep = lo != WH_EMPTY;
+        uint32_t sweep_total;
+        const uint32_t pos = sweep_compact(keep, scratch, &sweep_total);
+        if (keep) {
+            stage_lo[out0 + base + pos] = lo;
+            stage_hi[out0 + base + pos] = thi[slot];
+            stage_flags[out0 + base + pos] = (tstate[slot] & 0x80000000u) ? 2 : 1;
+        }
+        base += sweep_total;
+    }
+    if (threadIdx.x == 0) stage_cnt[wg] = base;
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { img_lo[out0 + i] = tlo[i]; img_hi[out0 + i] = thi[i]; }
+}
+
+// dense (hi, lo, flag) lists from the staged per-workgroup dictionaries
+__global__ void wide_dict_gather_kernel(const uint64_t *__restrict__ stage_lo, const uint64_t *__restrict__ stage_hi,
+                                        const uint8_t *__restrict__ stage_flags, const uint64_t *__restrict__ stage_off, uint32_t cap,
+                                        uint64_t *__restrict__ out_lo, uint64_t *__restrict__ out_hi, uint8_t *__restrict__ out_flags)
+{
+    const uint32_t wg = blockIdx.x;
+    const uint64_t o = stage_off[wg];
+    const uint32_t n = (uint32_t)(stage_off[wg + 1] - o);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        out_lo[o + i] = stage_lo[(uint64_t)wg * cap + i];
+        out_hi[o + i] = stage_hi[(uint64_t)wg * cap + i];
+        out_flags[o + i] = stage_flags[(uint64_t)wg * cap + i];
+    }
+}
+// keep flags of the value-sorted dictionary (single GPU: keys are already unique)
+__global__ void wide_keep_flags_kernel(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ order, uint64_t n,
+                                       int filter_singleton, uint32_t *__restrict__ keep)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        keep[i] = (!filter_singleton || flags[order[i]] >= 2) ? 1u : 0u;
+}
+// final dictionary (hi, lo interleaved, ascending) + column of every table slot
+__global__ void wide_select_cols_kernel(const uint64_t *__restrict__ s_hi, const uint64_t *__restrict__ s_lo,
+                                        const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, uint64_t n, int bb, int sb,
+                                        uint32_t cap_log2, const uint64_t *__restrict__ img_lo, const uint64_t *__restrict__ img_hi,
+                                        uint64_t *__restrict__ dict, uint32_t *__restrict__ col_of_slot)
+{
+    const uint32_t cap_mask = (1u << cap_log2) - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (!keep[i]) continue;
+        const uint64_t hi = s_hi[i], lo = s_lo[i];
+        const uint32_t c = pos[i];
+        dict[2ull * c] = hi;
+        dict[2ull * c + 1] = lo;
+        const uint64_t h = mix128(hi, lo);
+        const uint64_t wg = ((uint64_t)hash_bucket(h, bb) << sb) | hash_sub(h, bb, sb);
+        uint32_t slot = hash_slot(h, cap_mask);
+        for (uint32_t probe = 0; probe <= cap_mask; probe++) {
+            const uint64_t cl = img_lo[(wg << cap_log2) + slot];
+            if (cl == lo && img_hi[(wg << cap_log2) + slot] == hi) { col_of_slot[(wg << cap_log2) + slot] = c; break; }
+            if (cl == WH_EMPTY) break;
+            slot = (slot + 1) & cap_mask;
+        }
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+static WideArgs wargs(const KmerLaunch &L)
+{
+    WideArgs a;
+    a.sym2 = L.sym2; a.inv = L.inv; a.total_syms = L.total_syms; a.genome_sym_off = L.genome_sym_off;
+    a.n_genomes = L.n_genomes; a.k = L.k; a.bb = L.bb;
+    return a;
+}
+void launch_wh_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts)
+{
+    if (!L.total_syms) return;
+    const uint32_t n_tiles = (uint32_t)((L.total_syms + WH_TILE - 1) / WH_TILE);
+    const uint32_t tpb = 16;       // 64 Ki positions per LDS histogram flush
+    hipLaunchKernelGGL(wide_hist_kernel, dim3((n_tiles + tpb - 1) / tpb), dim3(WH_THREADS), (size_t)4 << L.bb, s, wargs(L), n_tiles, tpb, counts);
+}
+void launch_wh_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, void *out)
+{
+    if (!L.total_syms) return;
+    const uint32_t n_tiles = (uint32_t)((L.total_syms + WH_TILE - 1) / WH_TILE);
+    const uint32_t grid = ((n_tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(wide_l1_kernel, dim3(grid), dim3(WH_THREADS), WH_LDS_BYTES, s, wargs(L), scatter_b1_bits(L.bb), n_tiles, off, cursor1,
+                       reinterpret_cast<ulonglong2 *>(out));
+}
+void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor2, const void *keys1, void *keys)
+{
+    const int b1 = scatter_b1_bits(L.bb);
+    if (!L.total_syms || L.bb <= b1) return;
+    const uint64_t n_regions = (uint64_t)L.n_genomes << b1;
+    const uint32_t grid = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
+    hipLaunchKernelGGL(wide_l2_kernel, dim3(grid), dim3(WH_THREADS), WH_LDS_BYTES, s, reinterpret_cast<const ulonglong2 *>(keys1),
+                       reinterpret_cast<ulonglong2 *>(keys), off, cursor2, n_regions, L.bb, b1);
+}
+void launch_wh_dict_build(hipStream_t s, const void *keys, const uint64_t *off, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
+                          uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint16_t *kslot,
+                          uint64_t *img_lo, uint64_t *img_hi, int *overflow)
+{
+    const size_t lds = (((size_t)20) << cap_log2) + TABLE_SCRATCH_BYTES;
+    hipLaunchKernelGGL(wide_dict_build_kernel, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, reinterpret_cast<const ulonglong2 *>(keys),
+                       off, n_genomes, bb, sb, cap_log2, stage_lo, stage_hi, stage_flags, stage_cnt, kslot, img_lo, img_hi, overflow);
+}
+void launch_wh_dict_gather(hipStream_t s, const uint64_t *stage_lo, const uint64_t *stage_hi, const uint8_t *stage_flags,
+                           const uint64_t *stage_off, uint32_t n_wg, uint32_t cap, uint64_t *out_lo, uint64_t *out_hi, uint8_t *out_flags)
+{
+    hipLaunchKernelGGL(wide_dict_gather_kernel, dim3(n_wg), dim3(256), 0, s, stage_lo, stage_hi, stage_flags, stage_off, cap, out_lo, out_hi,
+                       out_flags);
+}
+void launch_wh_keep_flags(hipStream_t s, const uint8_t *flags, const uint32_t *order, uint64_t n, int filter_singleton, uint32_t *keep)
+{
+    if (!n) return;
+    uint64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(wide_keep_flags_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, flags, order, n, filter_singleton, keep);
+}
+void launch_wh_select_cols(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
+                           int bb, int sb, uint32_t cap_log2, const uint64_t *img_lo, const uint64_t *img_hi, uint64_t *dict,
+                           uint32_t *col_of_slot)
+{
+    if (!n) return;
+    uint64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(wide_select_cols_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, s_hi, s_lo, keep, pos, n, bb, sb, cap_log2,
+                       img_lo, img_hi, dict, col_of_slot);
+}
+hipError_t wh_set_max_dynamic_lds()
+{
+    const int max_lds = 159 * 1024;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wide_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(wide_l1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(wide_l2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(wide_dict_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+}
+
+}  // namespace grm

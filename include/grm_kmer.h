@@ -59,7 +59,8 @@ void        grm_destroy(grm_ctx *);
 const char *grm_last_error(grm_ctx *);
 const char *grm_version(void);
 /* tuning knobs (mainly for tests): name in {"groups_per_thread","bucket_bits","cap_log2",
- * "sub_bits","no_slots"}; value < 0 restores the automatic choice. */
+ * "sub_bits","no_slots","wide_sort","keys_in_flight","table_threads"}; value < 0 restores the
+ * automatic choice. */
 int         grm_set_option(grm_ctx *, const char *name, int value);
 /* per-kernel device timings (HIP events on the engine's stream) */
 int         grm_timing_enable(grm_ctx *, int on);

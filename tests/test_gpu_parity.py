@@ -342,13 +342,21 @@ def test_two_word_kmers(ctx, k, tmp_path):
         genomes.append([cases.fasta(recs, width=70).encode()])
     genomes[3] = [b""]
     genomes[7].append(cases.fasta([("dup", core[:500] * 2)]).encode())       # repeated k-mers inside one genome
-    for amin, filt in [(1, False), (1, True), (2, False)]:
-        want = orc.build_matrix(genomes, k, amin, filt)
-        kmers, data, n_occ, colcnt = _run_batch(ctx, genomes, k, amin, filt)
-        assert n_occ == want["n_occurrences"]
-        assert kmers.shape == want["kmers"].shape and (kmers == want["kmers"]).all()
-        assert (data == want["matrix"]).all()
-        assert (colcnt == want["n_genomes_with"]).all()
+    # default: hash-partition pipeline (abundance-min 1), sort-based path otherwise / when forced
+    for opts in ({}, {"wide_sort": 1}, {"bucket_bits": 3, "cap_log2": 7}):
+        try:
+            for name, v in opts.items():
+                ctx.set_option(name, v)
+            for amin, filt in [(1, False), (1, True), (2, False)]:
+                want = orc.build_matrix(genomes, k, amin, filt)
+                kmers, data, n_occ, colcnt = _run_batch(ctx, genomes, k, amin, filt)
+                assert n_occ == want["n_occurrences"]
+                assert kmers.shape == want["kmers"].shape and (kmers == want["kmers"]).all()
+                assert (data == want["matrix"]).all()
+                assert (colcnt == want["n_genomes_with"]).all()
+        finally:
+            for name in opts:
+                ctx.set_option(name, -1)
     for g in (0, 7):
         km, ct, nocc = orc.count_genome(genomes[g], k, 1)
         s = ctx.count_genome(genomes[g], k, 1)
@@ -378,6 +386,23 @@ def test_two_word_kmers(ctx, k, tmp_path):
         with pytest.raises(grm.GrmError):
             b.partition(k, 1)                      # staged multi-GPU API: k <= 32 only, and says so
         m.free(); b.free()
+
+
+def test_two_word_medium_both_paths(ctx):
+    """300 kbp genomes at k = 63: LDS (span-uniform) paths of the two-word hash pipeline vs the sort path vs oracle"""
+    genomes = _medium_genomes(n=6, length=200_000, seed=13)
+    want = orc.build_matrix(genomes, 63, 1, False)
+    for opts in ({}, {"wide_sort": 1}, {"bucket_bits": 13}, {"sub_bits": 2}):
+        try:
+            for name, v in opts.items():
+                ctx.set_option(name, v)
+            kmers, data, n_occ, colcnt = _run_batch(ctx, genomes, 63, 1, False)
+            assert n_occ == want["n_occurrences"]
+            assert kmers.shape == want["kmers"].shape and (kmers == want["kmers"]).all()
+            assert (data == want["matrix"]).all()
+        finally:
+            for name in opts:
+                ctx.set_option(name, -1)
 
 
 def test_errors_are_loud(ctx):
