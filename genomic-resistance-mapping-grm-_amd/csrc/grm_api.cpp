@@ -7,14 +7,18 @@
 //   dsk2kover bin/kover/core/kover/dataset/tools/kmer_pack.py:28-36
 //   dsk       src/app.py:1372           Ray Surveyor  src/app.py:1310
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/grm_kmer.h"
@@ -1570,26 +1574,54 @@ extern "C" int grm_write_tsv(grm_matrix *m, const char *const *genome_ids, const
     const uint64_t *data = grm_matrix_data(m);
     if (!kmers || !data) return GRM_ERR_HIP;
     std::string tmp = std::string(path) + ".tmp";
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f) return fail(c, GRM_ERR_IO, "cannot create %s", tmp.c_str());
-    std::vector<char> obuf(1 << 22);
-    setvbuf(f, obuf.data(), _IOFBF, obuf.size());
-    fputs("kmers", f);   // first header cell is forced by dataset/create.py:241
-    for (int g = 0; g < m->n_genomes; g++) { fputc('\t', f); fputs(genome_ids[g], f); }
-    fputc('\n', f);
+    int fd = open(tmp.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (fd < 0) return fail(c, GRM_ERR_IO, "cannot create %s", tmp.c_str());
+    std::string header = "kmers";                      // first header cell is forced by dataset/create.py:241
+    for (int g = 0; g < m->n_genomes; g++) { header += '\t'; header += genome_ids[g]; }
+    header += '\n';
+    // every row has the same byte length (create.py:130-137 relies on it), so rows can be formatted
+    // and written by all host cores at computed file offsets
     const size_t line_len = (size_t)m->k + 2 * (size_t)m->n_genomes + 1;
-    std::vector<char> line(line_len);
-    for (size_t col = 0; col < m->n_kmers; col++) {
-        decode_kmer(kmers + col * (size_t)m->words, m->words, m->k, line.data());
-        size_t p = (size_t)m->k;
-        for (int g = 0; g < m->n_genomes; g++) {
-            line[p++] = '\t';
-            line[p++] = ((data[(size_t)(g >> 6) * m->n_kmers + col] >> (63 - (g & 63))) & 1) ? '1' : '0';
+    const size_t U = m->n_kmers;
+    std::atomic<int> bad(0);
+    if (pwrite(fd, header.data(), header.size(), 0) != (ssize_t)header.size()) bad = 1;
+    const size_t rows_per_block = std::max<size_t>(1, ((size_t)8 << 20) / line_len);
+    const size_t n_blocks = (U + rows_per_block - 1) / rows_per_block;
+    std::atomic<size_t> next(0);
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 32) nt = 32;
+    if (nt > n_blocks) nt = (unsigned)std::max<size_t>(1, n_blocks);
+    auto work = [&]() {
+        std::vector<char> buf(rows_per_block * line_len);
+        for (;;) {
+            const size_t blk = next.fetch_add(1);
+            if (blk >= n_blocks || bad) break;
+            const size_t c0 = blk * rows_per_block, c1 = std::min(U, c0 + rows_per_block);
+            char *p = buf.data();
+            for (size_t col = c0; col < c1; col++) {
+                decode_kmer(kmers + col * (size_t)m->words, m->words, m->k, p);
+                p += m->k;
+                for (int g = 0; g < m->n_genomes; g++) {
+                    *p++ = '\t';
+                    *p++ = ((data[(size_t)(g >> 6) * U + col] >> (63 - (g & 63))) & 1) ? '1' : '0';
+                }
+                *p++ = '\n';
+            }
+            const size_t bytes = (size_t)(p - buf.data());
+            size_t done = 0;
+            while (done < bytes) {
+                const ssize_t w = pwrite(fd, buf.data() + done, bytes - done, (off_t)(header.size() + c0 * line_len + done));
+                if (w <= 0) { bad = 1; break; }
+                done += (size_t)w;
+            }
         }
-        line[p++] = '\n';
-        if (fwrite(line.data(), 1, p, f) != p) { fclose(f); remove(tmp.c_str()); return fail(c, GRM_ERR_IO, "short write to %s", tmp.c_str()); }
-    }
-    if (fclose(f) != 0) { remove(tmp.c_str()); return fail(c, GRM_ERR_IO, "close failed on %s", tmp.c_str()); }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work);
+    for (auto &t : th) t.join();
+    if (close(fd) != 0) bad = 1;
+    if (bad) { remove(tmp.c_str()); return fail(c, GRM_ERR_IO, "write to %s failed", tmp.c_str()); }
     if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return fail(c, GRM_ERR_IO, "rename to %s failed", path); }
     return GRM_OK;
 }
