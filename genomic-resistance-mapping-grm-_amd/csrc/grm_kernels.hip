@@ -11,8 +11,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <algorithm>
-
 #include "grm_device_fns.h"
 #include "grm_internal.h"
 #include "grm_coop.h"
@@ -552,41 +550,25 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
     uint32_t *start = hist + 256;                                                        // [256]
     uint32_t *scratch = start + 256;                                                     // [16]
     uint8_t *sbkt = reinterpret_cast<uint8_t *>(scratch + 16);                           // [L1_TILE] coarse bucket of skeys[i]
-    // Persistent workgroups: each one walks a contiguous range of tiles (XCD-aware: the ranges of
-    // the workgroups of one XCD are adjacent), carries the genome index from tile to tile instead of
-    // binary-searching it, and loads the NEXT tile's packed words while the current one is sorted.
+    const uint64_t tile = xcd_span(blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;
     const int b2bits = a.bb - b1bits;
     const uint32_t B1 = 1u << b1bits;
-    const uint64_t chunk = xcd_span(blockIdx.x, gridDim.x);
-    const uint64_t t_begin = chunk * n_tiles / gridDim.x, t_end = (chunk + 1) * n_tiles / gridDim.x;
-    if (t_begin >= t_end) return;
-    uint32_t gen0 = genome_of(a.genome_sym_off, a.n_genomes, min(t_begin * L1_TILE, a.total_syms - 1));
-    auto fetch = [&](uint64_t tile, uint64_t &w0_, uint64_t &w1_, uint64_t &i0_, uint64_t &i1_) {
-        const uint64_t p = tile * L1_TILE + (uint64_t)threadIdx.x * L1_PPT;
-        w0_ = w1_ = i0_ = i1_ = 0;
-        if (tile < t_end && (int64_t)a.total_syms - a.k + 1 - (int64_t)p > 0) {
-            w0_ = a.sym2[p >> 5];
-            w1_ = a.sym2[(p >> 5) + 1];
-            i0_ = a.inv[p >> 6];
-            i1_ = a.inv[(p >> 6) + 1];
-        }
-    };
-    uint64_t w0, w1, iv0, iv1;
-    fetch(t_begin, w0, w1, iv0, iv1);
-    for (uint64_t tile = t_begin; tile < t_end; tile++) {
-    uint64_t nw0, nw1, niv0, niv1;
-    fetch(tile + 1, nw0, nw1, niv0, niv1);
     const uint64_t p0 = tile * L1_TILE + (uint64_t)threadIdx.x * L1_PPT;      // L1_PPT start positions per thread
     const uint64_t p_first = tile * L1_TILE;
-    if (p_first >= a.total_syms) break;
+    if (p_first >= a.total_syms) return;
     const uint64_t p_last = min(p_first + L1_TILE, a.total_syms) - 1;
-    while (a.genome_sym_off[gen0 + 1] <= p_first) gen0++;
+    const uint32_t gen0 = genome_of(a.genome_sym_off, a.n_genomes, p_first);
     const bool uniform = a.genome_sym_off[gen0 + 1] > p_last;
 
     uint32_t valid = 0;
+    uint64_t w0 = 0, w1 = 0;
     const int64_t nv = (int64_t)a.total_syms - a.k + 1 - (int64_t)p0;
     if (nv > 0) {
-        valid = (uint32_t)valid_starts_at(iv0, iv1, (int)(p0 & 63), a.k) & ((1u << L1_PPT) - 1);
+        const uint64_t grp = p0 >> 6;
+        w0 = a.sym2[p0 >> 5];
+        w1 = a.sym2[(p0 >> 5) + 1];
+        valid = (uint32_t)valid_starts_at(a.inv[grp], a.inv[grp + 1], (int)(p0 & 63), a.k) & ((1u << L1_PPT) - 1);
         if (nv < L1_PPT) valid &= (1u << nv) - 1;
     }
     const int off_in_word = (int)(p0 & 31);
@@ -629,7 +611,6 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
             const uint32_t b1 = sbkt[i];
             keys1[gbase[b1] + (i - start[b1])] = skeys[i];
         }
-        __syncthreads();          // skeys / start / gbase are reused by the next tile
     } else {
         uint32_t gen = genome_of(a.genome_sym_off, a.n_genomes, min(p0, a.total_syms - 1));
         uint64_t gend = a.genome_sym_off[gen + 1];
@@ -640,8 +621,6 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
             const uint64_t region0 = coarse_off ? coarse_off[cidx] : off[(uint64_t)gen * (1ull << a.bb) + ((uint64_t)b1 << b2bits)];
             keys1[region0 + atomicAdd(&cursor1[cidx], 1u)] = canon;
         });
-    }
-    w0 = nw0; w1 = nw1; iv0 = niv0; iv1 = niv1;
     }
 }
 
@@ -1299,8 +1278,7 @@ void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *
     KmerArgs a = make_args(L);
     if (a.total_syms == 0) return;
     const uint32_t n_tiles = (uint32_t)((a.total_syms + L1_TILE - 1) / L1_TILE);
-    // persistent workgroups: 2 per CU fit (LDS), a few per slot to even out the tail; multiple of 8 (XCDs)
-    const uint32_t grid = std::max(8u, std::min(((n_tiles + 7) / 8) * 8, 256u * 2u * 4u));
+    const uint32_t grid = ((n_tiles + 7) / 8) * 8;
     hipLaunchKernelGGL(kmer_scatter_l1_kernel, dim3(grid), dim3(L1_THREADS), L1_LDS_BYTES, s, a, scatter_b1_bits(L.bb), n_tiles,
                        off, coarse_off, cursor1, out);
 }
