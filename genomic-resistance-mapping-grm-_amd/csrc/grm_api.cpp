@@ -494,10 +494,21 @@ extern "C" int grm_batch_add_file(grm_batch *b, int genome_index, const char *pa
     FILE *f = fopen(path, "rb");
     if (!f) return fail(b->ctx, GRM_ERR_IO, "cannot open %s", path);
     std::vector<uint8_t> bytes;
-    uint8_t tmp[1 << 16];
+    if (fseek(f, 0, SEEK_END) == 0) {                 // regular file: one read of the whole image
+        const long sz = ftell(f);
+        rewind(f);
+        if (sz > 0) {
+            bytes.resize((size_t)sz);
+            const size_t got = fread(bytes.data(), 1, (size_t)sz, f);
+            bytes.resize(got);
+        }
+    }
+    uint8_t tmp[1 << 16];                             // pipes / anything left
     size_t got;
     while ((got = fread(tmp, 1, sizeof tmp, f)) > 0) bytes.insert(bytes.end(), tmp, tmp + got);
+    const bool err = ferror(f) != 0;
     fclose(f);
+    if (err) return fail(b->ctx, GRM_ERR_IO, "read error on %s", path);
     return grm_batch_add(b, genome_index, bytes.data(), bytes.size());
 }
 
