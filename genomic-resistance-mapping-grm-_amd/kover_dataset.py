@@ -143,7 +143,9 @@ DEFAULT_BATCH_BYTES = int(os.environ.get("GRM_BATCH_BYTES", str(6 * 10**9)))
 def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton, phenotype_description,
                  phenotype_metadata_path, gzip, progress=None, abundance_min=1, source_type="contigs"):
     """create.py:278-396 with the two tool calls replaced by one fused engine pass."""
-    progress = progress or (lambda m: None)
+    _say = progress or (lambda m: None)
+    _t0 = time.time()
+    progress = lambda m: _say("[%6.2fs] %s" % (time.time() - _t0, m))
     if (phenotype_description is None) != (phenotype_metadata_path is None):
         raise KoverError("If a phenotype is specified, it must have a description and a metadata file.")
     paths, order = parse_genome_list(contig_list_path)
@@ -173,8 +175,11 @@ def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton
         for g, fl in enumerate(files_per_genome):
             for f in fl:
                 batch.add_file(g, f)
+        progress("read %d files (%.2f GB)" % (sum(len(fl) for fl in files_per_genome), total / 1e9))
         batch.upload()
+        progress("uploaded")
         m = batch.run(kmer_size, abundance_min, bool(filter_singleton))
+        progress("device pass done: %d k-mer occurrences" % batch.n_occurrences)
         batch.free()
     elif kmer_size > 32 and total <= DEFAULT_BATCH_BYTES:
         batch = ctx.batch(len(ids))
@@ -193,6 +198,7 @@ def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton
             s_.free()
     progress("dictionary: %d k-mers; writing HDF5 (gzip %d)" % (m.n_kmers, gzip))
     m.write_kover_h5(tmp, gzip, BLOCK_SIZE)
+    progress("HDF5 written")
     n = m.n_kmers
     m.free()
     os.replace(tmp, output_path)        # never leave a plausible partial output
