@@ -56,7 +56,6 @@ PROTOTYPES = [
     ("grm_batch_create", C.c_int, [_P, C.c_int, _PP]),
     ("grm_batch_add", C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     ("grm_batch_add_file", C.c_int, [_P, C.c_int, C.c_char_p]),
-    ("grm_batch_reserve", C.c_int, [_P, C.c_int]),
     ("grm_batch_upload", C.c_int, [_P]),
     ("grm_batch_run", C.c_int, [_P, C.c_int, C.c_uint32, C.c_int, _PP]),
     ("grm_batch_partition", C.c_int, [_P, C.c_int, C.c_uint32]),

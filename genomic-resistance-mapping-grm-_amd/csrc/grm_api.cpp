@@ -407,17 +407,9 @@ static void wide_hash_free(WideHash *w);
 
 struct grm_batch {
     grm_ctx *ctx = nullptr;
-    int reserve_k = 0;               // > 0: grm_batch_reserve was called; upload pre-allocates the key buffers
-    std::thread reserve_thread;      // hipMalloc of ~100 GB takes ~1 s: it runs beside the host-to-device copy
-    hipError_t reserve_err = hipSuccess;
     WideSorted *wide = nullptr;      // two-word (k > 32) sort path buffers, created on first use
     WideHash *whash = nullptr;       // two-word hash-partition path buffers
-    ~grm_batch()
-    {
-        if (reserve_thread.joinable()) reserve_thread.join();
-        wide_free(wide);
-        wide_hash_free(whash);
-    }
+    ~grm_batch() { wide_free(wide); wide_hash_free(whash); }
     int n_genomes = 0;
     std::vector<HostFile> files;
     bool uploaded = false, partitioned = false, have_local = false, have_global = false;
@@ -473,14 +465,6 @@ extern "C" void grm_batch_free(grm_batch *b)
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     delete b;
-}
-
-extern "C" int grm_batch_reserve(grm_batch *b, int k)
-{
-    if (!b) return GRM_ERR_ARG;
-    if (b->uploaded) return fail(b->ctx, GRM_ERR_STATE, "grm_batch_reserve after upload");
-    b->reserve_k = k;
-    return GRM_OK;
 }
 
 extern "C" int grm_batch_add(grm_batch *b, int genome_index, const void *buf, size_t len)
@@ -570,19 +554,6 @@ extern "C" int grm_batch_upload(grm_batch *b)
 
     HIPCHK(c, b->d_raw_alloc.alloc(RAW_FRONT_PAD + pos + 64));
     uint8_t *d_raw = b->d_raw_alloc.as<uint8_t>();
-    if (b->reserve_k > 0 && b->reserve_k <= 32 && b->input_bytes > ((uint64_t)64 << 20)) {
-        // every input byte yields at most one k-mer occurrence: allocate the partition buffers for that
-        // bound now, on a second thread, while this one copies the image to the device
-        const uint64_t bound = b->input_bytes + 1024;
-        const int dev = c->device;
-        b->reserve_thread = std::thread([b, bound, dev]() {
-            hipError_t e = hipSetDevice(dev);
-            if (e == hipSuccess) e = b->d_keys.ensure((bound + 8) * 8);
-            if (e == hipSuccess) e = b->d_keys1.ensure((bound + 8) * 8);
-            if (e == hipSuccess) e = b->d_kslot.ensure((bound + 64) * 2);
-            b->reserve_err = e;
-        });
-    }
     // the image is assembled in pinned host memory in slabs and copied slab by slab: one
     // pageable hipMemcpy per file (thousands of 5 MB copies) is several times slower
     const size_t SLAB = (size_t)256 << 20;
@@ -647,7 +618,6 @@ static uint32_t pick_cap_log2(grm_ctx *c)
 static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, bool want_counts)
 {
     grm_ctx *c = b->ctx;
-    if (b->reserve_thread.joinable()) b->reserve_thread.join();      // buffers reserved during upload (or not: ensure() below decides)
     if (!b->uploaded) return fail(c, GRM_ERR_STATE, "grm_batch_partition before grm_batch_upload");
     if (k < 1 || k > 64) return fail(c, GRM_ERR_ARG, "k=%d out of range", k);
     if (abundance_min < 1) abundance_min = 1;

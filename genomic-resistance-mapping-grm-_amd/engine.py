@@ -240,10 +240,6 @@ class Batch:
     def add_file(self, genome_index, path):
         self.ctx._chk(self.ctx.L.grm_batch_add_file(self.h, genome_index, path.encode()))
 
-    def reserve(self, k):
-        """hint before upload(): device buffers for a run with this k are allocated beside the copy"""
-        self.ctx._chk(self.ctx.L.grm_batch_reserve(self.h, k))
-
     def upload(self):
         self.ctx._chk(self.ctx.L.grm_batch_upload(self.h))
 

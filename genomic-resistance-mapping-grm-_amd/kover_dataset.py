@@ -176,7 +176,6 @@ def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton
             for f in fl:
                 batch.add_file(g, f)
         progress("read %d files (%.2f GB)" % (sum(len(fl) for fl in files_per_genome), total / 1e9))
-        batch.reserve(kmer_size)
         batch.upload()
         progress("uploaded")
         m = batch.run(kmer_size, abundance_min, bool(filter_singleton))

@@ -122,9 +122,6 @@ int  grm_batch_create(grm_ctx *, int n_genomes, grm_batch **out);
 /* append one file image (FASTA) to genome `genome_index`; bytes are copied */
 int  grm_batch_add(grm_batch *, int genome_index, const void *buf, size_t len);
 int  grm_batch_add_file(grm_batch *, int genome_index, const char *path);
-/* optional hint, before upload: the batch will be run with this k.  For large inputs the upload then
- * allocates the partition buffers (bounded by the input size) on a second thread while it copies. */
-int  grm_batch_reserve(grm_batch *, int k);
 /* assemble + host-to-device copy; afterwards the inputs are resident in HBM */
 int  grm_batch_upload(grm_batch *);
 /* whole hot path on the resident inputs: == partition + local_dict + set_global_dict(own) + fill */
