@@ -83,6 +83,11 @@ def lib():
         "H5Aget_type": (hid_t, [hid_t]),
         "H5Aclose": (C.c_int, [hid_t]),
         "H5Lexists": (C.c_int, [hid_t, C.c_char_p, hid_t]),
+        "H5Gcreate2": (hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t]),
+        "H5Gopen2": (hid_t, [hid_t, C.c_char_p, hid_t]),
+        "H5Gclose": (C.c_int, [hid_t]),
+        "H5Gget_num_objs": (C.c_int, [hid_t, C.POINTER(hsize_t)]),
+        "H5Gget_objname_by_idx": (C.c_ssize_t, [hid_t, hsize_t, C.c_char_p, C.c_size_t]),
         "H5Eset_auto2": (C.c_int, [hid_t, C.c_void_p, C.c_void_p]),
     }
     for name, (res, args) in sig.items():
@@ -92,7 +97,7 @@ def lib():
         raise H5Error("H5open failed")
     L.H5Eset_auto2(0, None, None)
     for g in ("H5T_C_S1_g", "H5T_NATIVE_UINT8_g", "H5T_NATIVE_UINT16_g", "H5T_NATIVE_UINT32_g", "H5T_NATIVE_UINT64_g",
-              "H5T_NATIVE_DOUBLE_g", "H5P_CLS_DATASET_CREATE_ID_g"):
+              "H5T_NATIVE_DOUBLE_g", "H5T_NATIVE_INT64_g", "H5P_CLS_DATASET_CREATE_ID_g"):
         setattr(L, g[:-2], hid_t.in_dll(L, g).value)
     _lib = L
     return L
@@ -131,7 +136,11 @@ class File:
     def _set_attr_on(self, loc, name, value):
         L = self.L
         space = _chk(L.H5Screate(H5S_SCALAR), "H5Screate")
-        if isinstance(value, float):
+        if isinstance(value, (int, np.integer)) and not isinstance(value, bool):
+            a = _chk(L.H5Acreate2(loc, name.encode(), L.H5T_NATIVE_INT64, space, 0, 0), "H5Acreate2 " + name)
+            v = C.c_int64(int(value))
+            _chk(L.H5Awrite(a, L.H5T_NATIVE_INT64, C.byref(v)), "H5Awrite " + name)
+        elif isinstance(value, float):
             a = _chk(L.H5Acreate2(loc, name.encode(), L.H5T_NATIVE_DOUBLE, space, 0, 0), "H5Acreate2 " + name)
             v = C.c_double(value)
             _chk(L.H5Awrite(a, L.H5T_NATIVE_DOUBLE, C.byref(v)), "H5Awrite " + name)
@@ -160,6 +169,10 @@ class File:
                 v = C.c_double()
                 _chk(L.H5Aread(a, L.H5T_NATIVE_DOUBLE, C.byref(v)), "H5Aread")
                 return v.value
+            if cls == H5T_INTEGER:
+                v = C.c_int64()
+                _chk(L.H5Aread(a, L.H5T_NATIVE_INT64, C.byref(v)), "H5Aread")
+                return int(v.value)
             if cls == H5T_STRING:
                 if L.H5Tis_variable_str(t) > 0:
                     p = C.c_char_p()
@@ -196,7 +209,8 @@ class File:
             _chk(L.H5Tset_strpad(t, 1), "H5Tset_strpad")      # H5T_STR_NULLPAD, as h5py maps numpy 'S'
             return t, True
         m = {np.dtype(np.uint8): L.H5T_NATIVE_UINT8, np.dtype(np.uint16): L.H5T_NATIVE_UINT16,
-             np.dtype(np.uint32): L.H5T_NATIVE_UINT32, np.dtype(np.uint64): L.H5T_NATIVE_UINT64}
+             np.dtype(np.uint32): L.H5T_NATIVE_UINT32, np.dtype(np.uint64): L.H5T_NATIVE_UINT64,
+             np.dtype(np.float64): L.H5T_NATIVE_DOUBLE, np.dtype(np.int64): L.H5T_NATIVE_INT64}
         return m[arr.dtype], False
 
     def create_dataset(self, name, arr, gzip=0, chunks=None, attrs=None):
@@ -226,7 +240,44 @@ class File:
             L.H5Tclose(t)
 
     def exists(self, name):
-        return self.L.H5Lexists(self.id, name.encode(), 0) > 0
+        """link exists; every intermediate group of a path is checked first (H5Lexists requires it)"""
+        parts = [p for p in name.split("/") if p]
+        for i in range(1, len(parts) + 1):
+            if self.L.H5Lexists(self.id, "/".join(parts[:i]).encode(), 0) <= 0:
+                return False
+        return True
+
+    def create_group(self, name):
+        g = _chk(self.L.H5Gcreate2(self.id, name.encode(), 0, 0, 0), "H5Gcreate2 " + name)
+        self.L.H5Gclose(g)
+
+    def set_group_attr(self, group, name, value):
+        g = _chk(self.L.H5Gopen2(self.id, group.encode(), 0), "H5Gopen2 " + group)
+        try:
+            self._set_attr_on(g, name, value)
+        finally:
+            self.L.H5Gclose(g)
+
+    def get_group_attr(self, group, name):
+        g = _chk(self.L.H5Gopen2(self.id, group.encode(), 0), "H5Gopen2 " + group)
+        try:
+            return self._get_attr_on(g, name)
+        finally:
+            self.L.H5Gclose(g)
+
+    def list_group(self, group):
+        g = _chk(self.L.H5Gopen2(self.id, group.encode(), 0), "H5Gopen2 " + group)
+        try:
+            n = hsize_t()
+            _chk(self.L.H5Gget_num_objs(g, C.byref(n)), "H5Gget_num_objs")
+            out = []
+            for i in range(n.value):
+                buf = C.create_string_buffer(512)
+                self.L.H5Gget_objname_by_idx(g, i, buf, 512)
+                out.append(buf.value.decode())
+            return out
+        finally:
+            self.L.H5Gclose(g)
 
     def read(self, name):
         L = self.L

@@ -324,3 +324,106 @@ def _popcount64(v):
     v = (v & np.uint64(0x3333333333333333)) + ((v >> np.uint64(2)) & np.uint64(0x3333333333333333))
     v = (v + (v >> np.uint64(4))) & np.uint64(0x0F0F0F0F0F0F0F0F)
     return ((v * np.uint64(0x0101010101010101)) >> np.uint64(56)).astype(np.uint32)
+
+
+# ---- kover dataset split (bin/kover/core/kover/dataset/split.py) -----------------------------------
+def kmer_risk_tables(sum_rows, n_kmers, labels, train_idx):
+    """split.py:171-188: individual risk of the presence rule of every k-mer on the training set,
+    rounded to 5 decimals, stored as (unique values, index per k-mer, index per absence rule).
+    sum_rows(genome_indices) -> per-k-mer carrier counts (the GPU's grm_matrix_sum_rows or the
+    reader's restatement of learning/common/rules.py:201-267)."""
+    train_idx = np.asarray(train_idx, dtype=np.int64)
+    pos = train_idx[labels[train_idx] == 1]
+    neg = train_idx[labels[train_idx] == 0]
+    risks = (len(pos) - sum_rows(list(pos))[:n_kmers].astype(np.int64)).astype(np.float64)     # positive errors
+    risks += sum_rows(list(neg))[:n_kmers]                                                    # negative errors
+    risks /= len(train_idx)
+    np.round(risks, 5, out=risks)
+    anti = 1.0 - risks
+    np.round(anti, 5, out=anti)
+    unique, inverse = np.unique(np.hstack((risks, anti)), return_inverse=True)
+    dt = minimum_uint(len(unique))
+    return unique, inverse[:n_kmers].astype(dt), inverse[n_kmers:].astype(dt)
+
+
+def split(dataset_path, split_name, train_idx, test_idx, random_seed, n_folds=0, random_generator=None, sum_rows=None):
+    """split.py:110-230 (_split): writes splits/<name>/{train,test}_genome_idx, the risk tables and the
+    cross-validation folds into the dataset file."""
+    r = KoverDatasetReader(dataset_path)
+    rng = random_generator if random_generator is not None else np.random.RandomState(random_seed)
+    with h5lite.File(dataset_path, "r") as f:
+        if f.get_attr("phenotype_description") == "NA":
+            raise KoverError("A dataset must contain phenotypic metadata to be split.")
+        if f.exists("splits/" + split_name):
+            raise KoverError('A split with the identifier "%s" already exists in the dataset.' % split_name)
+        labels = f.read("phenotype")
+        n_genomes = f.read("genome_identifiers").shape[0]
+        n_kmers = f.read("kmer_by_matrix_column").shape[0]
+    train_idx = np.array(train_idx, dtype=np.int64)
+    test_idx = np.array(test_idx, dtype=np.int64)
+    if n_folds > len(train_idx):
+        raise KoverError("There cannot be more cross-validation folds (%d) than genomes in the training set (%d)." % (n_folds, len(train_idx)))
+    if n_folds == 1:
+        raise KoverError("The number of cross-validation folds must be greater than 1.")
+    if len(set(train_idx.tolist())) < len(train_idx):
+        raise KoverError("The training set contains duplicate genomes.")
+    if len(set(test_idx.tolist())) < len(test_idx):
+        raise KoverError("The testing set contains duplicate genomes.")
+    if len(set(train_idx.tolist()) | set(test_idx.tolist())) < len(train_idx) + len(test_idx):
+        raise KoverError("The training and testing sets overlap.")
+    sum_rows = sum_rows or r.sum_rows
+    idx_dt = minimum_uint(n_genomes)
+
+    def write_part(f, group, tr, te):
+        f.create_dataset(group + "/train_genome_idx", np.sort(tr).astype(idx_dt))
+        f.create_dataset(group + "/test_genome_idx", np.sort(te).astype(idx_dt))
+        unique, by_kmer, by_anti = kmer_risk_tables(sum_rows, n_kmers, labels, tr)
+        f.create_dataset(group + "/unique_risks", unique)
+        f.create_dataset(group + "/unique_risk_by_kmer", by_kmer)
+        f.create_dataset(group + "/unique_risk_by_anti_kmer", by_anti)
+
+    with h5lite.File(dataset_path, "r+") as f:
+        if not f.exists("splits"):
+            f.create_group("splits")
+        g = "splits/" + split_name
+        f.create_group(g)
+        f.set_group_attr(g, "random_seed", int(random_seed))
+        f.set_group_attr(g, "n_folds", int(n_folds))
+        f.set_group_attr(g, "train_proportion", 1.0 * len(train_idx) / n_genomes)
+        f.set_group_attr(g, "test_proportion", 1.0 * len(test_idx) / n_genomes)
+        write_part(f, g, train_idx, test_idx)
+        if n_folds > 0:
+            f.create_group(g + "/folds")
+            fold_of = np.arange(len(train_idx)) % n_folds          # split.py:197-198
+            rng.shuffle(fold_of)
+            for fold in range(n_folds):
+                fg = "%s/folds/fold_%d" % (g, fold + 1)
+                f.create_group(fg)
+                write_part(f, fg, train_idx[fold_of != fold], train_idx[fold_of == fold])
+
+
+def split_with_proportion(dataset_path, split_name, train_prop, random_seed, n_folds=0, sum_rows=None):
+    """split.py:86-107: the same RandomState stream as the reference (shuffle of arange, then the folds)"""
+    rng = np.random.RandomState(random_seed)
+    with h5lite.File(dataset_path, "r") as f:
+        n = f.read("genome_identifiers").shape[0]
+    n_train = int(np.ceil(train_prop * n))
+    idx = np.arange(n)
+    rng.shuffle(idx)
+    split(dataset_path, split_name, idx[:n_train], idx[n_train:], random_seed, n_folds, rng, sum_rows)
+
+
+def split_with_ids(dataset_path, split_name, train_ids_file, test_ids_file, random_seed, n_folds=0, sum_rows=None):
+    """split.py:31-83"""
+    rng = np.random.RandomState(random_seed)
+    ids = KoverDatasetReader(dataset_path).genome_identifiers
+    index = {g: i for i, g in enumerate(ids)}
+
+    def parse(path, step):
+        got = [l.strip() for l in open(path).read().split("\n") if l.strip()]
+        missing = [g for g in got if g not in index]
+        if missing:
+            raise KoverError("The %s genome identifiers contain IDs that are not in the dataset: %s" % (step, ", ".join(missing)))
+        return [index[g] for g in got]
+
+    split(dataset_path, split_name, parse(train_ids_file, "training"), parse(test_ids_file, "testing"), random_seed, n_folds, rng, sum_rows)

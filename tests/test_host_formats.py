@@ -187,3 +187,57 @@ def test_chunk_plan(kd, tmp_path):
     assert kd.plan_chunks(files, 400) == [[0, 1], [2], [3], [4, 5], [6]]
     assert kd.plan_chunks(files, 10**9) == [list(range(7))]
     assert kd.plan_chunks([], 10) == []
+
+
+def test_split_risk_tables_and_file_layout(kd, small_matrix, tmp_path):
+    """kover dataset split restatement (split.py:110-230): risk tables vs a dense recomputation,
+    folds partition the training set, same seed => same split"""
+    import grm_amd
+    h5 = import_module(PKG + ".h5lite")
+    k, bg, want = small_matrix
+    n = len(bg)
+    U = want["kmers"].shape[0]
+    ids = ["gen%d" % i for i in range(n)]
+    labels = np.array([i % 2 for i in range(n)], dtype=np.uint8)
+    path = str(tmp_path / "s.kover")
+    kd.write_header(path, "contigs", "l", "pheno", "md.tsv", 4, ids, labels, ["0", "1"], "binary", "nothing")
+    m = grm_amd.HostMatrix(want["kmers"][:, 0], want["matrix"], n, k)
+    m.write_kover_h5(path, 4, 100000)
+    kd.split_with_proportion(path, "s1", 0.75, 42, n_folds=2)
+    dense = np.array([[(int(want["matrix"][g // 64, c]) >> (63 - g % 64)) & 1 for c in range(U)] for g in range(n)])
+    with h5.File(path) as f:
+        assert f.list_group("splits") == ["s1"]
+        tr, te = f.read("splits/s1/train_genome_idx"), f.read("splits/s1/test_genome_idx")
+        assert len(tr) == int(np.ceil(0.75 * n)) and sorted(tr.tolist() + te.tolist()) == list(range(n))
+        assert f.get_group_attr("splits/s1", "random_seed") == 42 and f.get_group_attr("splits/s1", "n_folds") == 2
+        assert abs(f.get_group_attr("splits/s1", "train_proportion") - len(tr) / n) < 1e-12
+
+        def check(group, tr_idx):
+            tr_idx = np.asarray(tr_idx, dtype=np.int64)
+            pos, neg = tr_idx[labels[tr_idx] == 1], tr_idx[labels[tr_idx] == 0]
+            risk = np.round(((len(pos) - dense[pos].sum(axis=0)) + dense[neg].sum(axis=0)) / len(tr_idx), 5)
+            uniq = f.read(group + "/unique_risks")
+            assert (np.diff(uniq) > 0).all()
+            assert np.allclose(uniq[f.read(group + "/unique_risk_by_kmer")], risk)
+            assert np.allclose(uniq[f.read(group + "/unique_risk_by_anti_kmer")], np.round(1.0 - risk, 5))
+
+        check("splits/s1", tr)
+        folds = f.list_group("splits/s1/folds")
+        assert sorted(folds) == ["fold_1", "fold_2"]
+        held = []
+        for fo in folds:
+            ftr, fte = f.read("splits/s1/folds/%s/train_genome_idx" % fo), f.read("splits/s1/folds/%s/test_genome_idx" % fo)
+            assert sorted(ftr.tolist() + fte.tolist()) == sorted(tr.tolist())
+            held += fte.tolist()
+            check("splits/s1/folds/" + fo, ftr)
+        assert sorted(held) == sorted(tr.tolist())
+    # determinism of the RandomState stream + duplicate id / overlap errors
+    kd.split_with_proportion(path, "s2", 0.75, 42, n_folds=2)
+    with h5.File(path) as f:
+        assert (f.read("splits/s2/train_genome_idx") == f.read("splits/s1/train_genome_idx")).all()
+        assert (f.read("splits/s2/folds/fold_1/test_genome_idx") == f.read("splits/s1/folds/fold_1/test_genome_idx")).all()
+    with pytest.raises(kd.KoverError):
+        kd.split_with_proportion(path, "s1", 0.5, 1)
+    with pytest.raises(kd.KoverError):
+        kd.split(path, "bad", [0, 1], [1, 2], 1)
+    m.free()
