@@ -52,12 +52,17 @@ def die(msg, code=1):
 def write_kset(path, k, abundance_min, kmers, counts, n_occ):
     """per-genome solid k-mer set, the artefact multidsk leaves under the name Kover expects
     (<out-dir>/<stem>.h5, dataset/create.py:375,488).  The pair multidsk/dsk2kover is opaque
-    to Kover, so the container is our own: magic, header, uint64 k-mers, uint32 counts."""
+    to Kover, so the container is our own: magic, header, uint64 k-mers (two words each, most
+    significant first, when k > 32), uint32 counts."""
     tmp = path + ".tmp"
+    words = 2 if k > 32 else 1
+    kmers = np.ascontiguousarray(kmers, dtype="<u8").reshape(-1)
+    if len(kmers) != words * len(counts):
+        raise ValueError("k-mer array does not match k=%d (%d words per k-mer)" % (k, words))
     with open(tmp, "wb") as f:
         f.write(MAGIC)
         f.write(struct.pack("<IIQQ", k, abundance_min, len(counts), n_occ))
-        f.write(np.ascontiguousarray(kmers, dtype="<u8").tobytes())
+        f.write(kmers.tobytes())
         f.write(np.ascontiguousarray(counts, dtype="<u4").tobytes())
     os.replace(tmp, path)
 
@@ -67,9 +72,10 @@ def read_kset(path):
         if f.read(8) != MAGIC:
             raise ValueError("%s is not a k-mer set written by this multidsk" % path)
         k, amin, n, n_occ = struct.unpack("<IIQQ", f.read(24))
-        kmers = np.frombuffer(f.read(8 * n), dtype="<u8")
+        words = 2 if k > 32 else 1
+        kmers = np.frombuffer(f.read(8 * n * words), dtype="<u8")
         counts = np.frombuffer(f.read(4 * n), dtype="<u4")
-    if len(kmers) != n or len(counts) != n:
+    if len(kmers) != n * words or len(counts) != n:
         raise ValueError("%s is truncated" % path)
     return k, amin, kmers, counts, n_occ
 

@@ -225,10 +225,11 @@ extern "C" int grm_kmer_set_from_host(grm_ctx *c, const uint64_t *kmers, const u
                                       grm_kmer_set **out)
 {
     if (!c || !out || (n && !kmers)) return fail(c, GRM_ERR_ARG, "grm_kmer_set_from_host: bad argument");
-    if (k < 1 || k > 32) return fail(c, k > 32 && k <= 64 ? GRM_ERR_UNSUPPORTED : GRM_ERR_ARG, "k=%d unsupported (1..32 in this build)", k);
+    if (k < 1 || k > 64) return fail(c, GRM_ERR_ARG, "k=%d unsupported (1..64)", k);
     grm_kmer_set *s = new grm_kmer_set();
     s->k = k;
-    s->kmers.assign(kmers, kmers + n);
+    s->words = k > 32 ? 2 : 1;                     // two words per k-mer, most significant first
+    s->kmers.assign(kmers, kmers + n * (size_t)s->words);
     if (counts) s->counts.assign(counts, counts + n);
     else s->counts.assign(n, 1u);
     *out = s;
@@ -1082,7 +1083,9 @@ static int wide_scan(grm_ctx *c, DevBuf &tmp, bool inclusive, const uint32_t *in
 }
 
 // parse must have run (batch_partition_impl with k > 32).  Extract, sort, mark runs.
-static int wide_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, WideSorted &W)
+// preloaded: A[0] / A[1] already hold total_syms (hi, lo) keys, all valid, and d_genome_sym_off
+// their per-genome offsets (grm_build_matrix on two-word sets).
+static int wide_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, WideSorted &W, bool preloaded = false)
 {
     grm_ctx *c = b->ctx;
     hipStream_t s = c->stream;
@@ -1097,13 +1100,15 @@ static int wide_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, WideS
     uint64_t *hi0 = W.A[0].as<uint64_t>(), *lo0 = W.A[1].as<uint64_t>(), *t2 = W.A[2].as<uint64_t>(), *t3 = W.A[3].as<uint64_t>();
     uint32_t *i0 = W.I[0].as<uint32_t>(), *i1 = W.I[1].as<uint32_t>();
     HIPCHK(c, hipMemsetAsync(W.n_valid.p, 0, 8, s));
-    {
-        TimeScope t(c, "wide_extract", N);
-        launch_wide_extract(s, b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>(), N, k, hi0, lo0, W.n_valid.as<unsigned long long>());
+    unsigned long long nv = N;
+    if (!preloaded) {
+        {
+            TimeScope t(c, "wide_extract", N);
+            launch_wide_extract(s, b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>(), N, k, hi0, lo0, W.n_valid.as<unsigned long long>());
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&nv, W.n_valid.p, 8, hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(c, hipGetLastError());
-    unsigned long long nv = 0;
-    HIPCHK(c, hipMemcpyAsync(&nv, W.n_valid.p, 8, hipMemcpyDeviceToHost, s));
     {
         TimeScope t(c, "wide_sort", N);
         launch_iota_u32(s, i0, N);
@@ -1299,13 +1304,13 @@ static int wide_hash_matrix(grm_batch *b, int k, int filter_singleton, grm_matri
     return GRM_OK;
 }
 
-static int wide_matrix(grm_batch *b, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out)
+static int wide_matrix(grm_batch *b, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out, bool preloaded = false)
 {
     grm_ctx *c = b->ctx;
     hipStream_t s = c->stream;
     if (!b->wide) b->wide = new WideSorted();
     WideSorted &W = *b->wide;
-    int rc = wide_sort_and_mark(b, k, abundance_min, W);
+    int rc = wide_sort_and_mark(b, k, abundance_min, W, preloaded);
     if (rc) return rc;
     grm_matrix *m = new grm_matrix();
     m->ctx = c; m->k = k; m->words = 2; m->n_genomes = b->n_genomes;
@@ -1501,6 +1506,49 @@ extern "C" int grm_count_genome(grm_ctx *c, const char *const *paths, int n_path
     return rc;
 }
 
+// dsk2kover's merge for two-word k-mers: the sets' keys are laid out genome after genome and go
+// through the sort-based reduction (sort by 128-bit key, runs -> columns, carriers -> filter).
+static int build_matrix_wide(grm_ctx *c, grm_kmer_set *const *sets, int n_genomes, int filter_singleton, grm_matrix **out)
+{
+    const int k = sets[0]->k;
+    std::vector<uint64_t> gko(n_genomes + 1, 0);
+    size_t max_g = 0;
+    for (int g = 0; g < n_genomes; g++) {
+        if (!sets[g] || sets[g]->k != k || sets[g]->words != 2) return fail(c, GRM_ERR_ARG, "grm_build_matrix: sets with different k");
+        gko[g + 1] = gko[g] + sets[g]->counts.size();
+        max_g = std::max(max_g, sets[g]->counts.size());
+    }
+    const uint64_t n = gko[n_genomes];
+    grm_batch *b = nullptr;
+    int rc = grm_batch_create(c, n_genomes, &b);
+    if (rc) return rc;
+    auto body = [&]() -> int {
+        b->uploaded = true;
+        b->k = k;
+        b->abundance_min = 1;
+        b->total_syms = n;
+        b->wide = new WideSorted();
+        WideSorted &W = *b->wide;
+        if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "k > 32 merge is limited to 2^32-1 set entries (got %llu)", (unsigned long long)n);
+        for (int i = 0; i < 2; i++) HIPCHK(c, W.A[i].ensure((n + 2) * 8));
+        HIPCHK(c, b->d_genome_sym_off.ensure(((size_t)n_genomes + 1) * 8));
+        HIPCHK(c, hipMemcpy(b->d_genome_sym_off.p, gko.data(), ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice));
+        std::vector<uint64_t> hi(max_g), lo(max_g);
+        for (int g = 0; g < n_genomes; g++) {
+            const size_t m = sets[g]->counts.size();
+            if (!m) continue;
+            const uint64_t *w = sets[g]->kmers.data();
+            for (size_t i = 0; i < m; i++) { hi[i] = w[2 * i]; lo[i] = w[2 * i + 1]; }
+            HIPCHK(c, hipMemcpy(W.A[0].as<uint64_t>() + gko[g], hi.data(), m * 8, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(W.A[1].as<uint64_t>() + gko[g], lo.data(), m * 8, hipMemcpyHostToDevice));
+        }
+        return wide_matrix(b, k, 1, filter_singleton, out, true);
+    };
+    rc = body();
+    grm_batch_free(b);
+    return rc;
+}
+
 // dsk2kover's merge: per-genome sets (host) -> partition the explicit key lists -> same
 // dictionary / fill kernels as the fused path.
 extern "C" int grm_build_matrix(grm_ctx *c, grm_kmer_set *const *sets, int n_genomes, int filter_singleton,
@@ -1510,11 +1558,12 @@ extern "C" int grm_build_matrix(grm_ctx *c, grm_kmer_set *const *sets, int n_gen
     if (!out || n_genomes < 0 || (n_genomes && !sets)) return fail(c, GRM_ERR_ARG, "grm_build_matrix: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    if (n_genomes && sets[0] && sets[0]->words == 2) return build_matrix_wide(c, sets, n_genomes, filter_singleton, out);
     int k = n_genomes ? sets[0]->k : 1;
     std::vector<uint64_t> gko(n_genomes + 1, 0);
     uint64_t max_g = 0;
     for (int g = 0; g < n_genomes; g++) {
-        if (!sets[g] || sets[g]->k != k) return fail(c, GRM_ERR_ARG, "grm_build_matrix: sets with different k");
+        if (!sets[g] || sets[g]->k != k || sets[g]->words != 1) return fail(c, GRM_ERR_ARG, "grm_build_matrix: sets with different k");
         gko[g + 1] = gko[g] + sets[g]->counts.size();
         max_g = std::max<uint64_t>(max_g, sets[g]->counts.size());
     }

@@ -50,14 +50,47 @@ def parse_metadata(metadata_path, matrix_genome_ids, warn=None):
     return ids, labels, uniq, ctype
 
 
+def contigs_path_table(genome_contigs_dir):
+    """rows of GRM's `<genome>_paths.tsv` (src/kover.py:40-49): `<file stem>`, `<path>` for every
+    `*.fna` of `contigs/<genome name>/` (the tree src/app.py:576-583 downloads into).  Sorted by
+    file name so the table does not depend on directory order."""
+    names = sorted(f for f in os.listdir(genome_contigs_dir) if f.endswith(".fna"))
+    return [(os.path.splitext(f)[0], os.path.abspath(os.path.join(genome_contigs_dir, f))) for f in names]
+
+
+def create_contigs_path_tsv(contigs_path, genome_name):
+    """src/kover.py:40-49: writes `<contigs_path>/<genome_name>_paths.tsv`, returns its path"""
+    out = os.path.join(contigs_path, genome_name) + "_paths.tsv"
+    with open(out, "w", newline="", encoding="utf-8") as f:
+        for stem, p in contigs_path_table(os.path.join(contigs_path, genome_name)):
+            f.write("%s\t%s\n" % (stem, p))
+    return out
+
+
 def parse_genome_list(path):
-    """`GENOME_ID<ws>PATH` per line (create.py:302); duplicates are an error (:308-309)"""
+    """`GENOME_ID<ws>PATH` per line (create.py:302); duplicates are an error (:308-309).  A
+    directory is read as GRM's contig tree directly (contigs_path_table), without the TSV.
+    GRM quotes paths that contain blanks (src/util.py:111-112): the quotes are dropped."""
     out = {}
     order = []
+    if os.path.isdir(path):
+        for gid, p in contigs_path_table(path):
+            out[gid] = p
+            order.append(gid)
+        if not order:
+            raise KoverError("No *.fna file under %s" % path)
+        return out, order
     for l in open(path):
         if not l.strip():
             continue
-        gid, p = l.split()[:2]
+        parts = l.split(None, 1)
+        if len(parts) != 2:
+            raise KoverError("The genomic data file must hold `GENOME_ID<tab>PATH` lines (got %r)" % l.strip())
+        gid, rest = parts[0], parts[1].strip()
+        if len(rest) >= 2 and rest[0] == rest[-1] == '"':
+            p = rest[1:-1]
+        else:
+            p = rest.split()[0]
         if gid in out:
             raise KoverError("The genomic data contains genomes with the same identifier.")
         out[gid] = p
@@ -190,8 +223,6 @@ def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton
         m = batch.run(kmer_size, abundance_min, bool(filter_singleton))
         batch.free()
     else:                                           # the reference's own two steps: multidsk, then dsk2kover
-        if kmer_size > 32:
-            raise KoverError("k > 32 with inputs beyond one device batch is not supported yet")
         sets = counted_sets(ctx, files_per_genome, kmer_size, abundance_min, DEFAULT_BATCH_BYTES, progress)
         m = ctx.build_matrix(sets, bool(filter_singleton))
         for s_ in sets:

@@ -42,10 +42,11 @@ def genomes(tmp_path_factory):
     return out
 
 
-def test_multidsk_then_dsk2kover(genomes, tmp_path):
+@pytest.mark.parametrize("k", [31, 47])
+def test_multidsk_then_dsk2kover(genomes, tmp_path, k):
+    """k = 47: the pair carries two-word k-mers (counting and merge on the sort-based two-word path)"""
     import grm_amd  # noqa: F401
     kd = import_module(PKG + ".kover_dataset")
-    k = 31
     tmp = str(tmp_path)
     lst = os.path.join(tmp, "list_contigs_files")
     open(lst, "w").writelines(p + "\n" for p in genomes)
@@ -124,6 +125,28 @@ def test_kover_create_from_contigs(genomes, tmp_path):
     assert (r.kmer_matrix == want["matrix"]).all()
     assert r.attr("filter") == "singleton" and r.attr("genome_source_type") == "contigs"
     assert r.phenotype[1] == ["R", "S"]
+
+
+def test_kover_create_from_contig_tree(genomes, tmp_path):
+    """`--genomic-data` may name GRM's contigs/<genome name>/ directory itself (src/app.py:576-583):
+    same dataset as through the `<genome>_paths.tsv` of src/kover.py:40-49"""
+    import grm_amd  # noqa: F401
+    kd = import_module(PKG + ".kover_dataset")
+    tree = os.path.dirname(genomes[0])
+    tsv = kd.create_contigs_path_tsv(os.path.dirname(tree), os.path.basename(tree))
+    assert [l.split("\t")[0] for l in open(tsv)] == sorted(os.path.basename(p)[:-4] for p in genomes)
+    outs = []
+    for n, data in enumerate((tree, tsv)):
+        out = str(tmp_path / ("d%d.kover" % n))
+        _run([os.path.join(CLI, "kover"), "dataset", "create", "from-contigs", "--genomic-data", data, "--output", out,
+              "--kmer-size", "31", "--singleton-kmers", "--compression", "1"])
+        outs.append(kd.KoverDatasetReader(out))
+    a, b = outs
+    assert a.genome_identifiers == b.genome_identifiers == sorted(os.path.basename(p)[:-4] for p in genomes)
+    assert a.kmer_sequences == b.kmer_sequences and (a.kmer_matrix == b.kmer_matrix).all()
+    want = orc.build_matrix([[open(p, "rb").read()] for p in sorted(genomes)], 31, 1, False)
+    assert (a.kmer_matrix == want["matrix"]).all()
+    os.remove(tsv)
 
 
 def test_kover_create_from_reads_chunked(tmp_path):

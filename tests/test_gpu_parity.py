@@ -388,6 +388,34 @@ def test_two_word_kmers(ctx, k, tmp_path):
         m.free(); b.free()
 
 
+@pytest.mark.parametrize("k", [33, 63])
+def test_two_word_sets_merge(ctx, k):
+    """dsk2kover's job at k > 32: per-genome counted sets (abundance-min 2 applied per genome) ->
+    grm_build_matrix, incl. sets that travelled through host arrays"""
+    rng = np.random.RandomState(100 + k)
+    core = cases.rand_seq(rng, 3000)
+    genomes = []
+    for g in range(67):
+        s = list(core)
+        for p in rng.randint(0, len(core), size=5):
+            s[p] = "ACGT"[rng.randint(4)]
+        t = "".join(s)
+        genomes.append([cases.fasta([("a", t), ("b", t[: int(rng.randint(0, 2500))])], width=60).encode()])
+    genomes[5] = [b">e\n"]
+    for amin, filt in [(1, True), (2, False), (2, True)]:
+        want = orc.build_matrix(genomes, k, amin, filt)
+        sets = [ctx.count_genome(g, k, amin) for g in genomes]
+        # half of them re-created from host arrays, as dsk2kover does after reading multidsk's files
+        sets = [ctx.kmer_set_from_arrays(s.kmers(), s.counts(), k) if i % 2 else s for i, s in enumerate(sets)]
+        m = ctx.build_matrix(sets, filt)
+        assert m.kmers().shape == want["kmers"].shape and (m.kmers() == want["kmers"]).all()
+        assert (m.data() == want["matrix"]).all()
+        assert (m.column_counts() == want["n_genomes_with"]).all()
+        m.free()
+    with pytest.raises(grm.GrmError):
+        ctx.build_matrix([ctx.count_genome(genomes[0], 31, 1), ctx.count_genome(genomes[1], k, 1)], False)
+
+
 def test_two_word_medium_both_paths(ctx):
     """300 kbp genomes at k = 63: LDS (span-uniform) paths of the two-word hash pipeline vs the sort path vs oracle"""
     genomes = _medium_genomes(n=6, length=200_000, seed=13)

@@ -143,6 +143,33 @@ def test_tsv_writer_and_from_tsv_roundtrip(kd, small_matrix, tmp_path):
     m.free()
 
 
+def test_genome_list_and_contig_tree(kd, tmp_path):
+    """create.py:302 list parsing; src/kover.py:40-49 table of contigs/<genome name>/*.fna"""
+    tree = tmp_path / "contigs" / "Escherichia coli"
+    tree.mkdir(parents=True)
+    for n in ("562.20.fna", "562.3.fna", "notes.txt"):
+        (tree / n).write_text(">x\nACGT\n")
+    rows = kd.contigs_path_table(str(tree))
+    assert [r[0] for r in rows] == ["562.20", "562.3"] and all(os.path.isabs(r[1]) and os.path.exists(r[1]) for r in rows)
+    tsv = kd.create_contigs_path_tsv(str(tmp_path / "contigs"), "Escherichia coli")
+    assert tsv == str(tmp_path / "contigs" / "Escherichia coli_paths.tsv")
+    assert open(tsv).read() == "".join("%s\t%s\n" % r for r in rows)
+    paths, order = kd.parse_genome_list(str(tree))                 # the directory itself
+    assert order == ["562.20", "562.3"] and paths["562.3"] == rows[1][1]
+    quoted = tmp_path / "q.tsv"                                     # GRM quotes paths with blanks (src/util.py:111)
+    quoted.write_text('a\t"%s"\nb\t/x/y.fna\n\n' % rows[0][1])
+    paths, order = kd.parse_genome_list(str(quoted))
+    assert order == ["a", "b"] and paths["a"] == rows[0][1] and paths["b"] == "/x/y.fna"
+    quoted.write_text("a\t/x\na\t/y\n")
+    with pytest.raises(kd.KoverError):
+        kd.parse_genome_list(str(quoted))
+    quoted.write_text("only_id\n")
+    with pytest.raises(kd.KoverError):
+        kd.parse_genome_list(str(quoted))
+    with pytest.raises(kd.KoverError):
+        kd.parse_genome_list(str(tmp_path))                        # a directory without *.fna
+
+
 def test_kset_container_and_names(tmp_path):
     C = _load_cli("_common.py")
     p = str(tmp_path / "x.h5")
