@@ -8,6 +8,7 @@
 //   dsk       src/app.py:1372           Ray Surveyor  src/app.py:1310
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -17,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -49,6 +51,7 @@ struct grm_ctx {
     int opt_no_slots = -1;      // > 0: force the probing form of the fill (tests)
     int opt_keys_in_flight = -1, opt_table_threads = -1;
     int opt_wide_sort = -1;     // > 0: k > 32 always through the sort-based path (tests)
+    int opt_upload_slab_kb = -1; // pinned upload slab size in KiB (tests; default 128 MiB)
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
 
@@ -161,6 +164,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "sub_bits") c->opt_sub_bits = value;
     else if (n == "no_slots") c->opt_no_slots = value;
     else if (n == "wide_sort") c->opt_wide_sort = value;
+    else if (n == "upload_slab_kb") c->opt_upload_slab_kb = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
@@ -197,11 +201,19 @@ extern "C" int grm_timing_get(grm_ctx *c, int i, char *name, size_t name_cap, do
 // --------------------------------------------------------------------------------------
 // result objects
 // --------------------------------------------------------------------------------------
+// A counted set lives where it was produced: sets that come out of a device batch stay in HBM
+// (grm_build_matrix consumes them there) and reach the host only when the caller asks for the
+// arrays; sets built from host arrays stay on the host.
 struct grm_kmer_set {
+    grm_ctx *ctx = nullptr;
     int k = 0, words = 1;
     uint64_t occurrences = 0;
+    size_t n = 0;
+    bool on_device = false, on_host = true;
+    DevBuf d_kmers, d_counts;
     std::vector<uint64_t> kmers;
     std::vector<uint32_t> counts;
+    bool to_host();
 };
 
 struct grm_matrix {
@@ -213,12 +225,30 @@ struct grm_matrix {
     bool have_kmers = false, have_data = false;
 };
 
-extern "C" size_t grm_kmer_set_size(const grm_kmer_set *s) { return s ? s->counts.size() : 0; }
+bool grm_kmer_set::to_host()
+{
+    if (on_host) return true;
+    kmers.resize(n * (size_t)words);
+    counts.resize(n);
+    if (n) {
+        if (hipSetDevice(ctx->device) != hipSuccess) return false;
+        if (hipMemcpy(kmers.data(), d_kmers.p, n * 8 * (size_t)words, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(counts.data(), d_counts.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)fail(ctx, GRM_ERR_HIP, "k-mer set download failed");
+            kmers.clear(); counts.clear();
+            return false;
+        }
+    }
+    on_host = true;
+    return true;
+}
+
+extern "C" size_t grm_kmer_set_size(const grm_kmer_set *s) { return s ? s->n : 0; }
 extern "C" int grm_kmer_set_k(const grm_kmer_set *s) { return s ? s->k : 0; }
 extern "C" int grm_kmer_set_words(const grm_kmer_set *s) { return s ? s->words : 0; }
 extern "C" uint64_t grm_kmer_set_occurrences(const grm_kmer_set *s) { return s ? s->occurrences : 0; }
-extern "C" const uint64_t *grm_kmer_set_kmers(const grm_kmer_set *s) { return s ? s->kmers.data() : nullptr; }
-extern "C" const uint32_t *grm_kmer_set_counts(const grm_kmer_set *s) { return s ? s->counts.data() : nullptr; }
+extern "C" const uint64_t *grm_kmer_set_kmers(grm_kmer_set *s) { return s && s->to_host() ? s->kmers.data() : nullptr; }
+extern "C" const uint32_t *grm_kmer_set_counts(grm_kmer_set *s) { return s && s->to_host() ? s->counts.data() : nullptr; }
 extern "C" void grm_kmer_set_free(grm_kmer_set *s) { delete s; }
 
 extern "C" int grm_kmer_set_from_host(grm_ctx *c, const uint64_t *kmers, const uint32_t *counts, size_t n, int k,
@@ -228,6 +258,8 @@ extern "C" int grm_kmer_set_from_host(grm_ctx *c, const uint64_t *kmers, const u
     if (k < 1 || k > 64) return fail(c, GRM_ERR_ARG, "k=%d unsupported (1..64)", k);
     grm_kmer_set *s = new grm_kmer_set();
     s->k = k;
+    s->ctx = c;
+    s->n = n;
     s->words = k > 32 ? 2 : 1;                     // two words per k-mer, most significant first
     s->kmers.assign(kmers, kmers + n * (size_t)s->words);
     if (counts) s->counts.assign(counts, counts + n);
@@ -362,7 +394,10 @@ extern "C" const char *grm_matrix_last_error(const grm_matrix *m)
 struct HostFile {
     int genome;
     bool fastq = false;           // 4-line FASTQ (first non-blank byte '@'), else FASTA
-    std::vector<uint8_t> bytes;   // inflated image
+    std::vector<uint8_t> bytes;   // inflated image (memory buffers, gzip members, pipes)
+    std::string path;             // plain regular file: read straight into the pinned slab at upload
+    uint64_t size = 0;            // image bytes (bytes.size() or the file size)
+    bool deferred() const { return !path.empty(); }
 };
 
 // gzip / zlib streams (magic 1f 8b) are inflated on the host: Kover's from-reads accepts
@@ -447,6 +482,7 @@ struct grm_batch {
     // scratch that survives between steps (grow-only)
     DevBuf t_flag, t_stage_keys, t_stage_flags, t_stage_cnt, t_stage_off;
     DevBuf t_sk, t_sf, t_keep, t_pos, t_tmp, t_bid, t_col, t_bid_sorted;
+    DevBuf t_set_off, t_set_len, t_set_k, t_set_c, t_set_tmp;     // grm_batch_genome_set
 };
 
 extern "C" int grm_batch_create(grm_ctx *c, int n_genomes, grm_batch **out)
@@ -485,6 +521,7 @@ extern "C" int grm_batch_add(grm_batch *b, int genome_index, const void *buf, si
     size_t i = 0;
     while (i < f.bytes.size() && (f.bytes[i] == '\n' || f.bytes[i] == '\r' || f.bytes[i] == ' ' || f.bytes[i] == '\t')) i++;
     f.fastq = i < f.bytes.size() && f.bytes[i] == '@';
+    f.size = f.bytes.size();
     b->files.push_back(std::move(f));
     return GRM_OK;
 }
@@ -492,8 +529,32 @@ extern "C" int grm_batch_add(grm_batch *b, int genome_index, const void *buf, si
 extern "C" int grm_batch_add_file(grm_batch *b, int genome_index, const char *path)
 {
     if (!b || !path) return GRM_ERR_ARG;
+    if (genome_index < 0 || genome_index >= b->n_genomes)
+        return fail(b->ctx, GRM_ERR_ARG, "grm_batch_add_file: bad genome index %d", genome_index);
+    if (b->uploaded) return fail(b->ctx, GRM_ERR_STATE, "grm_batch_add_file after upload");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(b->ctx, GRM_ERR_IO, "cannot open %s", path);
+    // a plain regular file is only looked at here (format, size); its bytes go from the page
+    // cache straight into the pinned upload slab, in parallel, at grm_batch_upload
+    struct stat st;
+    uint8_t head[4096];
+    if (fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        const size_t got = fread(head, 1, sizeof head, f);
+        const bool gz = got >= 2 && head[0] == 0x1f && head[1] == 0x8b;
+        size_t i = 0;
+        while (i < got && (head[i] == '\n' || head[i] == '\r' || head[i] == ' ' || head[i] == '\t')) i++;
+        if (!gz && (i < got || got == (size_t)st.st_size)) {
+            HostFile hf;
+            hf.genome = genome_index;
+            hf.fastq = i < got && head[i] == '@';
+            hf.path = path;
+            hf.size = (uint64_t)st.st_size;
+            fclose(f);
+            b->files.push_back(std::move(hf));
+            return GRM_OK;
+        }
+        rewind(f);
+    }
     std::vector<uint8_t> bytes;
     if (fseek(f, 0, SEEK_END) == 0) {                 // regular file: one read of the whole image
         const long sz = ftell(f);
@@ -538,11 +599,11 @@ extern "C" int grm_batch_upload(grm_batch *b)
         bool any = false;
         while (fi < b->files.size() && b->files[fi].genome == g) {
             file_pos[fi] = pos;
-            const uint64_t end = round_up(pos + (b->files[fi].fastq ? 0 : 2) + b->files[fi].bytes.size() + 1, TILE_BYTES);
+            const uint64_t end = round_up(pos + (b->files[fi].fastq ? 0 : 2) + b->files[fi].size + 1, TILE_BYTES);
             const uint8_t fmt = b->files[fi].fastq ? TILE_META_FASTQ : 0;
             for (uint64_t t = pos; t < end; t += TILE_BYTES) tile_meta.push_back(fmt | (t == pos ? TILE_META_FIRST : 0));
             pos = end;
-            b->input_bytes += b->files[fi].bytes.size();
+            b->input_bytes += b->files[fi].size;
             fi++;
             any = true;
         }
@@ -555,38 +616,101 @@ extern "C" int grm_batch_upload(grm_batch *b)
 
     HIPCHK(c, b->d_raw_alloc.alloc(RAW_FRONT_PAD + pos + 64));
     uint8_t *d_raw = b->d_raw_alloc.as<uint8_t>();
-    // the image is assembled in pinned host memory in slabs and copied slab by slab: one
-    // pageable hipMemcpy per file (thousands of 5 MB copies) is several times slower
-    const size_t SLAB = (size_t)256 << 20;
-    uint8_t *pinned = nullptr;
-    const size_t slab_bytes = std::min<size_t>(SLAB, RAW_FRONT_PAD + pos + 64);
-    HIPCHK(c, hipHostMalloc((void **)&pinned, slab_bytes, hipHostMallocDefault));
+    // The image is assembled in two pinned slabs: host threads fill one (memory buffers by memcpy,
+    // plain files by pread from the page cache) while the other is on its way over PCIe.
     {
-        size_t next_file = 0;
         const uint64_t total = RAW_FRONT_PAD + pos + 64;
-        for (uint64_t s0 = 0; s0 < total; s0 += slab_bytes) {
-            const uint64_t s1 = std::min<uint64_t>(s0 + slab_bytes, total);
-            memset(pinned, '\n', (size_t)(s1 - s0));
-            // every file that overlaps [s0, s1) contributes its overlapping part
-            for (size_t i = next_file; i < b->files.size(); i++) {
-                const size_t head = b->files[i].fastq ? 0 : 2;
-                const uint64_t f0 = RAW_FRONT_PAD + file_pos[i];                        // image start (header included)
-                const uint64_t f1 = f0 + head + b->files[i].bytes.size();               // image end (the trailing \n is padding)
-                if (f0 >= s1) break;
-                if (f1 <= s0) { next_file = i + 1; continue; }
-                if (head) {
-                    if (f0 >= s0 && f0 < s1) pinned[f0 - s0] = '>';
-                    if (f0 + 1 >= s0 && f0 + 1 < s1) pinned[f0 + 1 - s0] = '\n';
-                }
-                const uint64_t d0 = f0 + head;                                          // data start
-                const uint64_t lo = std::max(d0, s0), hi = std::min(f1, s1);
-                if (hi > lo) memcpy(pinned + (lo - s0), b->files[i].bytes.data() + (lo - d0), (size_t)(hi - lo));
+        const uint64_t slab_want = c->opt_upload_slab_kb > 0 ? (uint64_t)c->opt_upload_slab_kb << 10 : (uint64_t)128 << 20;
+        const size_t slab_bytes = (size_t)std::min<uint64_t>(slab_want, total);
+        uint8_t *pinned[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        bool in_flight[2] = {false, false};
+        std::string io_err;
+        std::mutex io_mu;
+        auto cleanup = [&]() {
+            (void)hipStreamSynchronize(c->stream);
+            for (int i = 0; i < 2; i++) {
+                if (pinned[i]) (void)hipHostFree(pinned[i]);
+                if (done[i]) (void)hipEventDestroy(done[i]);
             }
-            hipError_t e = hipMemcpy(d_raw + s0, pinned, (size_t)(s1 - s0), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { (void)hipHostFree(pinned); return fail(c, GRM_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
+        };
+        const int n_slabs = total > slab_bytes ? 2 : 1;
+        for (int i = 0; i < n_slabs; i++) {
+            hipError_t e = hipHostMalloc((void **)&pinned[i], slab_bytes, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+            if (e != hipSuccess) { cleanup(); return fail(c, GRM_ERR_HIP, "upload: pinned slab: %s", hipGetErrorString(e)); }
         }
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int n_thr = (int)std::min<unsigned>(16u, std::max(1u, hw));
+        // fills image bytes [a, b) (absolute image offsets) into dst (which maps offset a)
+        auto fill_range = [&](uint8_t *dst, uint64_t a, uint64_t bnd) {
+            memset(dst, '\n', (size_t)(bnd - a));
+            // first file whose image may reach a: file_pos is ascending
+            size_t lo_i = 0, hi_i = b->files.size();
+            while (lo_i < hi_i) {
+                const size_t mid = (lo_i + hi_i) / 2;
+                const uint64_t f1 = RAW_FRONT_PAD + file_pos[mid] + (b->files[mid].fastq ? 0 : 2) + b->files[mid].size;
+                if (f1 <= a) lo_i = mid + 1; else hi_i = mid;
+            }
+            for (size_t i = lo_i; i < b->files.size(); i++) {
+                const HostFile &hf = b->files[i];
+                const size_t head = hf.fastq ? 0 : 2;
+                const uint64_t f0 = RAW_FRONT_PAD + file_pos[i];                 // image start (header included)
+                const uint64_t f1 = f0 + head + hf.size;                         // image end (the trailing \n is padding)
+                if (f0 >= bnd) break;
+                if (f1 <= a) continue;
+                if (head) {
+                    if (f0 >= a && f0 < bnd) dst[f0 - a] = '>';
+                    if (f0 + 1 >= a && f0 + 1 < bnd) dst[f0 + 1 - a] = '\n';
+                }
+                const uint64_t d0 = f0 + head;                                   // data start
+                const uint64_t lo = std::max(d0, a), hi = std::min(f1, bnd);
+                if (hi <= lo) continue;
+                if (!hf.deferred()) {
+                    memcpy(dst + (lo - a), hf.bytes.data() + (lo - d0), (size_t)(hi - lo));
+                    continue;
+                }
+                const int fd = open(hf.path.c_str(), O_RDONLY);
+                bool ok = fd >= 0;
+                uint64_t at = lo;
+                while (ok && at < hi) {
+                    const ssize_t r = pread(fd, dst + (at - a), (size_t)(hi - at), (off_t)(at - d0));
+                    if (r <= 0) ok = false; else at += (uint64_t)r;
+                }
+                if (fd >= 0) close(fd);
+                if (!ok) {
+                    std::lock_guard<std::mutex> g(io_mu);
+                    if (io_err.empty()) io_err = "read error on " + hf.path + " (changed since it was added?)";
+                }
+            }
+        };
+        int which = 0;
+        for (uint64_t s0 = 0; s0 < total; s0 += slab_bytes, which ^= 1) {
+            const uint64_t s1 = std::min<uint64_t>(s0 + slab_bytes, total);
+            if (in_flight[which]) {
+                hipError_t e = hipEventSynchronize(done[which]);
+                if (e != hipSuccess) { cleanup(); return fail(c, GRM_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
+                in_flight[which] = false;
+            }
+            uint8_t *slab = pinned[which];
+            const uint64_t len = s1 - s0, piece = round_up((len + n_thr - 1) / n_thr, 4096);
+            std::vector<std::thread> pool;
+            for (int t = 1; t < n_thr; t++) {
+                const uint64_t a = s0 + (uint64_t)t * piece, bnd = std::min(s1, a + piece);
+                if (a < bnd) pool.emplace_back(fill_range, slab + (a - s0), a, bnd);
+            }
+            fill_range(slab, s0, std::min(s1, s0 + piece));
+            for (auto &t : pool) t.join();
+            if (!io_err.empty()) { cleanup(); return fail(c, GRM_ERR_IO, "%s", io_err.c_str()); }
+            hipError_t e = hipMemcpyAsync(d_raw + s0, slab, (size_t)len, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(done[which], c->stream);
+            if (e != hipSuccess) { cleanup(); return fail(c, GRM_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
+            in_flight[which] = true;
+        }
+        hipError_t e = hipStreamSynchronize(c->stream);
+        cleanup();
+        if (e != hipSuccess) return fail(c, GRM_ERR_HIP, "upload: %s", hipGetErrorString(e));
     }
-    (void)hipHostFree(pinned);
     for (auto &f : b->files) std::vector<uint8_t>().swap(f.bytes);
     HIPCHK(c, b->d_tile_meta.alloc(tile_meta.size() + 16));
     if (!tile_meta.empty()) HIPCHK(c, hipMemcpy(b->d_tile_meta.p, tile_meta.data(), tile_meta.size(), hipMemcpyHostToDevice));
@@ -1366,11 +1490,11 @@ static int wide_set(grm_batch *b, int k, uint32_t abundance_min, grm_kmer_set **
     int rc = wide_sort_and_mark(b, k, abundance_min, W);
     if (rc) return rc;
     grm_kmer_set *set = new grm_kmer_set();
-    set->k = k; set->words = 2; set->occurrences = b->total_keys;
+    set->ctx = c; set->k = k; set->words = 2; set->occurrences = b->total_keys;
     *out = set;
     if (!W.n_sub) return GRM_OK;
     DevBuf &opos = W.opos;
-    DevBuf dk, dc;
+    DevBuf &dk = set->d_kmers, &dc = set->d_counts;
     HIPCHK(c, opos.ensure((size_t)W.n_sub * 4));
     rc = wide_scan(c, W.tmp, false, W.sub_ok.as<uint32_t>(), opos.as<uint32_t>(), W.n_sub);
     if (rc) return rc;
@@ -1384,11 +1508,10 @@ static int wide_set(grm_batch *b, int k, uint32_t abundance_min, grm_kmer_set **
     launch_wide_set(s, W.khi(), W.klo(), W.sub_start.as<uint32_t>(), W.sub_ok.as<uint32_t>(),
                     opos.as<uint32_t>(), W.n_sub, dk.as<uint64_t>(), dc.as<uint32_t>());
     HIPCHK(c, hipGetLastError());
-    set->kmers.resize(n_out * 2);
-    set->counts.resize(n_out);
-    HIPCHK(c, hipMemcpyAsync(set->kmers.data(), dk.p, n_out * 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(set->counts.data(), dc.p, n_out * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    set->n = n_out;
+    set->on_device = true;
+    set->on_host = false;
     return GRM_OK;
 }
 
@@ -1422,6 +1545,7 @@ static int genome_set_impl(grm_batch *b, int g, bool have_counts, grm_kmer_set *
     hipStream_t s = c->stream;
     const uint64_t B = 1ull << b->bb;
     grm_kmer_set *set = new grm_kmer_set();
+    set->ctx = c;
     set->k = b->k;
     set->words = 1;
     *out = set;
@@ -1435,10 +1559,12 @@ static int genome_set_impl(grm_batch *b, int g, bool have_counts, grm_kmer_set *
     uint64_t n = 0;
     for (uint64_t i = 0; i < B; i++) { dst[i] = n; n += len[i]; }
     if (n == 0) return GRM_OK;
-    DevBuf d_dst_off, d_len, d_k, d_c, d_k2, d_c2, d_tmp;
-    HIPCHK(c, d_dst_off.alloc(B * 8));
-    HIPCHK(c, d_len.alloc(B * 4));
-    HIPCHK(c, d_k.alloc(n * 8)); HIPCHK(c, d_c.alloc(n * 4));
+    // scratch is the batch's (grow-only); the sorted result goes straight into the set's own buffers
+    DevBuf &d_dst_off = b->t_set_off, &d_len = b->t_set_len, &d_k = b->t_set_k, &d_c = b->t_set_c, &d_tmp = b->t_set_tmp;
+    DevBuf &d_k2 = set->d_kmers, &d_c2 = set->d_counts;
+    HIPCHK(c, d_dst_off.ensure(B * 8));
+    HIPCHK(c, d_len.ensure(B * 4));
+    HIPCHK(c, d_k.ensure(n * 8)); HIPCHK(c, d_c.ensure(n * 4));
     HIPCHK(c, d_k2.alloc(n * 8)); HIPCHK(c, d_c2.alloc(n * 4));
     HIPCHK(c, hipMemcpy(d_dst_off.p, dst.data(), B * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(d_len.p, len.data(), B * 4, hipMemcpyHostToDevice));
@@ -1447,14 +1573,13 @@ static int genome_set_impl(grm_batch *b, int g, bool have_counts, grm_kmer_set *
                             (uint32_t)B, d_k.as<uint64_t>(), d_c.as<uint32_t>());
     size_t tb = 0;
     HIPCHK(c, sort_pairs_u64_u32(s, d_k.as<uint64_t>(), d_k2.as<uint64_t>(), d_c.as<uint32_t>(), d_c2.as<uint32_t>(), n, nullptr, tb));
-    HIPCHK(c, d_tmp.alloc(tb));
+    HIPCHK(c, d_tmp.ensure(tb));
     HIPCHK(c, sort_pairs_u64_u32(s, d_k.as<uint64_t>(), d_k2.as<uint64_t>(), d_c.as<uint32_t>(), d_c2.as<uint32_t>(), n, d_tmp.p, tb));
     HIPCHK(c, hipGetLastError());
-    set->kmers.resize(n);
-    set->counts.resize(n);
-    HIPCHK(c, hipMemcpyAsync(set->kmers.data(), d_k2.p, n * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(set->counts.data(), d_c2.p, n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    set->n = n;
+    set->on_device = true;
+    set->on_host = false;
     return GRM_OK;
 }
 
@@ -1515,8 +1640,8 @@ static int build_matrix_wide(grm_ctx *c, grm_kmer_set *const *sets, int n_genome
     size_t max_g = 0;
     for (int g = 0; g < n_genomes; g++) {
         if (!sets[g] || sets[g]->k != k || sets[g]->words != 2) return fail(c, GRM_ERR_ARG, "grm_build_matrix: sets with different k");
-        gko[g + 1] = gko[g] + sets[g]->counts.size();
-        max_g = std::max(max_g, sets[g]->counts.size());
+        gko[g + 1] = gko[g] + sets[g]->n;
+        if (!sets[g]->on_device) max_g = std::max(max_g, sets[g]->n);
     }
     const uint64_t n = gko[n_genomes];
     grm_batch *b = nullptr;
@@ -1535,13 +1660,19 @@ static int build_matrix_wide(grm_ctx *c, grm_kmer_set *const *sets, int n_genome
         HIPCHK(c, hipMemcpy(b->d_genome_sym_off.p, gko.data(), ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice));
         std::vector<uint64_t> hi(max_g), lo(max_g);
         for (int g = 0; g < n_genomes; g++) {
-            const size_t m = sets[g]->counts.size();
+            const size_t m = sets[g]->n;
             if (!m) continue;
+            if (sets[g]->on_device) {          // (hi, lo) pairs in HBM: split on the device
+                launch_split_pairs_u64(c->stream, sets[g]->d_kmers.as<uint64_t>(), m, W.A[0].as<uint64_t>() + gko[g], W.A[1].as<uint64_t>() + gko[g]);
+                continue;
+            }
             const uint64_t *w = sets[g]->kmers.data();
             for (size_t i = 0; i < m; i++) { hi[i] = w[2 * i]; lo[i] = w[2 * i + 1]; }
             HIPCHK(c, hipMemcpy(W.A[0].as<uint64_t>() + gko[g], hi.data(), m * 8, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(W.A[1].as<uint64_t>() + gko[g], lo.data(), m * 8, hipMemcpyHostToDevice));
         }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         return wide_matrix(b, k, 1, filter_singleton, out, true);
     };
     rc = body();
@@ -1564,8 +1695,8 @@ extern "C" int grm_build_matrix(grm_ctx *c, grm_kmer_set *const *sets, int n_gen
     uint64_t max_g = 0;
     for (int g = 0; g < n_genomes; g++) {
         if (!sets[g] || sets[g]->k != k || sets[g]->words != 1) return fail(c, GRM_ERR_ARG, "grm_build_matrix: sets with different k");
-        gko[g + 1] = gko[g] + sets[g]->counts.size();
-        max_g = std::max<uint64_t>(max_g, sets[g]->counts.size());
+        gko[g + 1] = gko[g] + sets[g]->n;
+        max_g = std::max<uint64_t>(max_g, sets[g]->n);
     }
     const uint64_t n = gko[n_genomes];
     grm_batch *b = nullptr;
@@ -1584,8 +1715,10 @@ extern "C" int grm_build_matrix(grm_ctx *c, grm_kmer_set *const *sets, int n_gen
         HIPCHK(c, d_in.alloc((n + 2) * 8));
         HIPCHK(c, d_gko.alloc((n_genomes + 1) * 8));
         for (int g = 0; g < n_genomes; g++)
-            if (!sets[g]->kmers.empty())
-                HIPCHK(c, hipMemcpy(d_in.as<uint64_t>() + gko[g], sets[g]->kmers.data(), sets[g]->kmers.size() * 8, hipMemcpyHostToDevice));
+            if (sets[g]->n)
+                HIPCHK(c, sets[g]->on_device
+                              ? hipMemcpyAsync(d_in.as<uint64_t>() + gko[g], sets[g]->d_kmers.p, sets[g]->n * 8, hipMemcpyDeviceToDevice, s)
+                              : hipMemcpy(d_in.as<uint64_t>() + gko[g], sets[g]->kmers.data(), sets[g]->n * 8, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(d_gko.p, gko.data(), (n_genomes + 1) * 8, hipMemcpyHostToDevice));
         HIPCHK(c, b->d_counts.ensure((n_seg + 1) * 4));
         HIPCHK(c, b->d_cursor.ensure((n_seg + 1) * 4));

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -123,6 +124,24 @@ hid_t make_dcpl(H5 &H, int rank, const hsize_t *chunk, int gzip)
     return p;
 }
 
+// body(i0, i1) over [0, n) split across the host cores
+template <typename Body>
+void parallel_for(size_t n, Body &&body)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 64) nt = 64;
+    if (n < (size_t)1 << 16) nt = 1;
+    const size_t per = (n + nt - 1) / nt;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) {
+        const size_t a = std::min(n, t * per), b = std::min(n, a + per);
+        if (a < b) th.emplace_back([&body, a, b]() { body(a, b); });
+    }
+    body(0, std::min(n, per));
+    for (auto &t : th) t.join();
+}
+
 // deflate `n_chunks` equally sized raw chunks on the host cores; get_chunk(i, buf) must leave the
 // (padded) chunk bytes in buf and return a pointer to them
 template <typename GetChunk>
@@ -207,9 +226,20 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
     if (chunk_cols <= 0) chunk_cols = 100000;                        // BLOCK_SIZE, dataset/create.py:41
     H5 &H = g_h5;
     if (!H.load()) return grm_internal_fail(m, GRM_ERR_HDF5, H.err.c_str());
+    // GRM_TRACE=1: phase timings on stderr
+    const bool trace = getenv("GRM_TRACE") && atoi(getenv("GRM_TRACE")) > 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const double t = now();
+        fprintf(stderr, "[grm_write_kover_h5] %-28s %8.1f ms\n", what, (t - t_last) * 1e3);
+        t_last = t;
+    };
     const uint64_t *kmers = grm_matrix_kmers(m);
     const uint64_t *data = grm_matrix_data(m);
     if (!kmers || !data) return GRM_ERR_HIP;
+    lap("device -> host");
     const size_t U = grm_matrix_n_kmers(m), R = grm_matrix_n_rows(m);
     const int k = grm_matrix_k(m);
 
@@ -223,12 +253,16 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
     {
         std::vector<char> seq(U * (size_t)k + 1);
         const int words = grm_matrix_words(m);
-        for (size_t c = 0; c < U; c++) decode_kmer(kmers + c * (size_t)words, words, k, seq.data() + c * (size_t)k);
+        parallel_for(U, [&](size_t c0, size_t c1) {
+            for (size_t c = c0; c < c1; c++) decode_kmer(kmers + c * (size_t)words, words, k, seq.data() + c * (size_t)k);
+        });
+        lap("decode k-mer strings");
         hid_t st = H.Tcopy(H.C_S1);
         H.Tset_size(st, (size_t)k);
         H.Tset_strpad(st, 1);   // H5T_STR_NULLPAD
         rc = write_1d(H, file, "kmer_sequences", st, (size_t)k, seq.data(), U, gzip_level, err);
         H.Tclose(st);
+        lap("kmer_sequences");
     }
     // kmer_by_matrix_column: identity map in the minimum unsigned width (utils.py:117-130)
     if (!rc) {
@@ -237,6 +271,7 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
         else if (U <= 0xffffffffull) { std::vector<uint32_t> v(U); for (size_t i = 0; i < U; i++) v[i] = (uint32_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U32, 4, v.data(), U, gzip_level, err); }
         else { std::vector<uint64_t> v(U); for (size_t i = 0; i < U; i++) v[i] = i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U64, 8, v.data(), U, gzip_level, err); }
     }
+    lap("kmer_by_matrix_column");
     // kmer_matrix: chunks (1, min(U, chunk_cols)) as from_tsv does (create.py:160,230)
     if (!rc) {
         if (H.Lexists(file, "kmer_matrix", 0) > 0) H.Ldelete(file, "kmer_matrix", 0);
@@ -266,6 +301,7 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
                     return buf;
                 }, z);
                 if (!ok) { err = "zlib compress2 failed"; rc = -1; }
+                lap("kmer_matrix deflate");
                 for (size_t i = 0; i < n_chunks && !rc; i++) {
                     hsize_t off[2] = {i / chunks_per_row, (i % chunks_per_row) * cw};
                     if (H.Dwrite_chunk(ds, 0, 0, off, z[i].size(), z[i].data()) < 0) { err = "H5Dwrite_chunk kmer_matrix"; rc = -1; }
@@ -276,7 +312,9 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
         if (dcpl > 0) H.Pclose(dcpl);
         H.Sclose(space);
     }
+    lap("kmer_matrix write");
     if (H.Fclose(file) < 0 && !rc) { err = "H5Fclose"; rc = -1; }
+    lap("H5Fclose");
     if (rc) return grm_internal_fail(m, GRM_ERR_HDF5, err.c_str());
     return GRM_OK;
 }

@@ -101,6 +101,7 @@ void launch_matrix_fill(hipStream_t s, const uint64_t *keys, const uint64_t *off
 void launch_column_popcount(hipStream_t s, const uint64_t *matrix, uint64_t n_rows, uint64_t n_cols,
                             const uint64_t *row_mask, uint32_t *out);
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint64_t n);
+void launch_split_pairs_u64(hipStream_t s, const uint64_t *pairs, uint64_t n, uint64_t *hi, uint64_t *lo);
 hipError_t set_max_dynamic_lds();
 void set_table_tuning(int keys_in_flight, int threads);
 

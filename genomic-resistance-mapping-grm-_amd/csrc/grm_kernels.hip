@@ -1420,6 +1420,21 @@ void launch_column_popcount(hipStream_t s, const uint64_t *matrix, uint64_t n_ro
     hipLaunchKernelGGL(column_popcount_kernel, dim3(grid_for(n_cols, 256)), dim3(256), 0, s, matrix, n_rows, n_cols,
                        row_mask, out);
 }
+// (hi, lo) pairs of a two-word k-mer set -> separate hi / lo arrays
+__global__ void split_pairs_u64_kernel(const uint64_t *__restrict__ pairs, uint64_t n, uint64_t *__restrict__ hi,
+                                       uint64_t *__restrict__ lo)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(pairs)[i];
+    hi[i] = v.x;
+    lo[i] = v.y;
+}
+void launch_split_pairs_u64(hipStream_t s, const uint64_t *pairs, uint64_t n, uint64_t *hi, uint64_t *lo)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(split_pairs_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, pairs, n, hi, lo);
+}
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint64_t n)
 {
     if (!n) return;

@@ -122,13 +122,19 @@ class KmerSet:
         n, w = len(self), self.ctx.L.grm_kmer_set_words(self.h)
         if n == 0:
             return np.zeros((0, w), np.uint64)
-        return np.ctypeslib.as_array(self.ctx.L.grm_kmer_set_kmers(self.h), shape=(n * w,)).copy().reshape(n, w)
+        p = self.ctx.L.grm_kmer_set_kmers(self.h)          # downloads a device-resident set on first use
+        if not p:
+            self.ctx._chk(-3)
+        return np.ctypeslib.as_array(p, shape=(n * w,)).copy().reshape(n, w)
 
     def counts(self):
         n = len(self)
         if n == 0:
             return np.zeros(0, np.uint32)
-        return np.ctypeslib.as_array(self.ctx.L.grm_kmer_set_counts(self.h), shape=(n,)).copy()
+        p = self.ctx.L.grm_kmer_set_counts(self.h)
+        if not p:
+            self.ctx._chk(-3)
+        return np.ctypeslib.as_array(p, shape=(n,)).copy()
 
     def free(self):
         if self.h:

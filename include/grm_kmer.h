@@ -59,7 +59,7 @@ void        grm_destroy(grm_ctx *);
 const char *grm_last_error(grm_ctx *);
 const char *grm_version(void);
 /* tuning knobs (mainly for tests): name in {"groups_per_thread","bucket_bits","cap_log2",
- * "sub_bits","no_slots","wide_sort","keys_in_flight","table_threads"}; value < 0 restores the
+ * "sub_bits","no_slots","wide_sort","keys_in_flight","table_threads","upload_slab_kb"}; value < 0 restores the
  * automatic choice. */
 int         grm_set_option(grm_ctx *, const char *name, int value);
 /* per-kernel device timings (HIP events on the engine's stream) */
@@ -83,8 +83,10 @@ size_t          grm_kmer_set_size(const grm_kmer_set *);
 int             grm_kmer_set_k(const grm_kmer_set *);
 int             grm_kmer_set_words(const grm_kmer_set *);
 uint64_t        grm_kmer_set_occurrences(const grm_kmer_set *);
-const uint64_t *grm_kmer_set_kmers(const grm_kmer_set *);    /* host, size*words */
-const uint32_t *grm_kmer_set_counts(const grm_kmer_set *);   /* host, size */
+/* host arrays (size*words / size).  A set counted on the device stays in HBM, where
+ * grm_build_matrix consumes it; the first call of either accessor downloads it (NULL on failure). */
+const uint64_t *grm_kmer_set_kmers(grm_kmer_set *);
+const uint32_t *grm_kmer_set_counts(grm_kmer_set *);
 void            grm_kmer_set_free(grm_kmer_set *);
 
 /* replaces dsk2kover's merge (kmer_pack.py:28-36): N per-genome sets -> dictionary + matrix */

@@ -433,6 +433,50 @@ def test_two_word_medium_both_paths(ctx):
                 ctx.set_option(name, -1)
 
 
+def test_upload_sources_and_slabs(ctx, tmp_path):
+    """the host image: files read at upload time straight into the pinned slabs (plain), inflated
+    (.gz) or copied (memory buffers), mixed inside one genome, with slabs far smaller than a file so
+    that files straddle slab and thread boundaries"""
+    import gzip
+    genomes = _medium_genomes(n=5, length=150_000, seed=31)
+    fq = cases.fastq([cases.rand_seq(np.random.RandomState(i), 120) for i in range(300)]).encode()
+    genomes[1] = [genomes[1][0], fq]
+    genomes[3] = [b"", genomes[3][0]]
+    want = orc.build_matrix(genomes, 25, 1, False)
+    for slab_kb in (16, 100, -1):
+        ctx.set_option("upload_slab_kb", slab_kb)
+        try:
+            b = ctx.batch(len(genomes))
+            for g, files in enumerate(genomes):
+                for n, f in enumerate(files):
+                    path = str(tmp_path / ("g%d_%d_%d" % (g, n, slab_kb)))
+                    if (g + n) % 3 == 0:
+                        open(path, "wb").write(f)
+                        b.add_file(g, path)
+                    elif (g + n) % 3 == 1:
+                        open(path + ".gz", "wb").write(gzip.compress(f))
+                        b.add_file(g, path + ".gz")
+                    else:
+                        b.add(g, f)
+            b.upload()
+            m = b.run(25, 1, False)
+            assert b.n_occurrences == want["n_occurrences"]
+            assert (m.kmers() == want["kmers"]).all() and (m.data() == want["matrix"]).all()
+            m.free(); b.free()
+        finally:
+            ctx.set_option("upload_slab_kb", -1)
+    b = ctx.batch(1)
+    path = str(tmp_path / "vanishing.fna")
+    open(path, "wb").write(genomes[0][0])
+    b.add_file(0, path)
+    open(path, "wb").write(b">x\nACGT\n")           # shrinks between add and upload
+    with pytest.raises(grm.GrmError):
+        b.upload()
+    b.free()
+    with pytest.raises(grm.GrmError):
+        ctx.batch(1).add_file(0, str(tmp_path / "missing.fna"))
+
+
 def test_errors_are_loud(ctx):
     b = ctx.batch(1)
     b.add(0, b">x\nACGT\n")
