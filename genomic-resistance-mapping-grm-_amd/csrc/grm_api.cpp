@@ -824,11 +824,9 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     const bool deep = b->bb > MAX_HIST_BITS;
     const uint64_t n_coarse = (uint64_t)G << b1;
     HIPCHK(c, b->d_counts.ensure((n_seg + 1) * 4));
-    HIPCHK(c, b->d_cursor.ensure(n_seg * 4));
     HIPCHK(c, b->d_off.ensure((n_seg + 1) * 8));
     HIPCHK(c, b->d_cursor1.ensure(n_coarse * 4));
     HIPCHK(c, hipMemsetAsync(b->d_counts.p, 0, (n_seg + 1) * 4, s));
-    HIPCHK(c, hipMemsetAsync(b->d_cursor.p, 0, n_seg * 4, s));
     HIPCHK(c, hipMemsetAsync(b->d_cursor1.p, 0, n_coarse * 4, s));
     auto scan_counts = [&](DevBuf &counts, DevBuf &off, uint64_t n) -> int {
         // exclusive scan over n+1 entries (the extra, zeroed entry yields the total)
@@ -882,7 +880,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     }
     if (b->bb > b1) {
         TimeScope t(c, "kmer_scatter_l2", b->total_keys);
-        launch_kmer_scatter_l2(s, L, b->d_off.as<uint64_t>(), b->d_cursor.as<uint32_t>(), b->d_keys1.as<uint64_t>(),
+        launch_kmer_scatter_l2(s, L, b->d_off.as<uint64_t>(), b->d_keys1.as<uint64_t>(),
                                b->d_keys.as<uint64_t>());
     }
     HIPCHK(c, hipGetLastError());
@@ -1278,7 +1276,7 @@ static void wide_free(WideSorted *w) { delete w; }
 
 // ---- two-word k-mers: hash-partition pipeline (grm_wide_hash.hip) ------------------------------
 struct WideHash {
-    DevBuf counts, off, cursor1, cursor2, keys, keys1, kslot;
+    DevBuf counts, off, cursor1, keys, keys1, kslot;
     DevBuf stage_lo, stage_hi, stage_flags, stage_cnt, stage_off, img_lo, img_hi, col_of_slot, flag;
     DevBuf loc_lo, loc_hi, loc_flags, idx0, idx1, idx2, t_a, t_b, keep, pos, tmp;
 };
@@ -1315,9 +1313,8 @@ static int wide_hash_matrix(grm_batch *b, int k, int filter_singleton, grm_matri
     L.genome_sym_off = b->d_genome_sym_off.as<uint64_t>(); L.n_genomes = G; L.k = k; L.bb = bb; L.groups_per_thread = 1;
 
     HIPCHK(c, W.counts.ensure((n_seg + 1) * 4)); HIPCHK(c, W.off.ensure((n_seg + 1) * 8));
-    HIPCHK(c, W.cursor2.ensure(n_seg * 4)); HIPCHK(c, W.cursor1.ensure(n_coarse * 4)); HIPCHK(c, W.flag.ensure(4));
+    HIPCHK(c, W.cursor1.ensure(n_coarse * 4)); HIPCHK(c, W.flag.ensure(4));
     HIPCHK(c, hipMemsetAsync(W.counts.p, 0, (n_seg + 1) * 4, s));
-    HIPCHK(c, hipMemsetAsync(W.cursor2.p, 0, n_seg * 4, s));
     HIPCHK(c, hipMemsetAsync(W.cursor1.p, 0, n_coarse * 4, s));
     {
         TimeScope t(c, "wh_hist", b->total_syms);
@@ -1341,7 +1338,7 @@ static int wide_hash_matrix(grm_batch *b, int k, int filter_singleton, grm_matri
     }
     if (bb > b1) {
         TimeScope t(c, "wh_scatter_l2", NK);
-        launch_wh_l2(s, L, W.off.as<uint64_t>(), W.cursor2.as<uint32_t>(), W.keys1.p, W.keys.p);
+        launch_wh_l2(s, L, W.off.as<uint64_t>(), W.keys1.p, W.keys.p);
     }
     HIPCHK(c, hipGetLastError());
 

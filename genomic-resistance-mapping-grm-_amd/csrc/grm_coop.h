@@ -9,6 +9,31 @@ namespace grm {
 // ------------------------------------------------------------------------------------
 // small cooperative helpers (256- or 1024-thread blocks, wave64)
 // ------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only: waits for this wave's outstanding LDS operations
+// (lgkmcnt) but not for global memory (vmcnt), so a returning global atomic or a load issued before
+// the barrier stays in flight across it.  s_waitcnt simm16 (gfx9): vmcnt = 63 (no wait), expcnt = 7,
+// lgkmcnt = 0.
+__device__ __forceinline__ void lds_barrier()
+{
+    __asm__ volatile("" ::: "memory");      // compiler: no memory access moves across (no instruction emitted)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    __asm__ volatile("" ::: "memory");
+}
+
+// exclusive prefix sum of one value per lane inside a wave (DPP-free shuffle form)
+__device__ __forceinline__ uint32_t wave_scan_excl(uint32_t v)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    return inc - v;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

@@ -105,10 +105,12 @@ GRM_HD uint64_t mix64(uint64_t x)
     return ((uint64_t)h32 << 32) | low;
 }
 // radix bucket: top `bb` bits; sub-bucket: the next `sb` bits (bb + sb <= 24); slot: low word
-GRM_HD uint32_t hash_bucket(uint64_t h, int bb) { return bb ? (uint32_t)(h >> (64 - bb)) : 0u; }
+// Both read h32 only (bb + sb <= 24), so a caller that needs no slot never computes the low word;
+// (x >> 1) >> (31 - n) is x >> (32 - n) that also holds for n = 0, without a select.
+GRM_HD uint32_t hash_bucket(uint64_t h, int bb) { return ((uint32_t)(h >> 32) >> 1) >> (31 - bb); }
 GRM_HD uint32_t hash_sub(uint64_t h, int bb, int sb)
 {
-    return sb ? (uint32_t)((h << bb) >> (64 - sb)) : 0u;
+    return (((uint32_t)(h >> 32) << bb) >> 1) >> (31 - sb);
 }
 GRM_HD uint32_t hash_slot(uint64_t h, uint32_t cap_mask) { return (uint32_t)h & cap_mask; }
 
@@ -356,6 +358,22 @@ GRM_HD void for_each_kmer_n(uint64_t w0, uint64_t w1, int off, uint32_t valid, i
     // always the top 2 bits of hi
     uint64_t hi = m ? ((a << (2 * m)) | (b >> (64 - 2 * m))) : a;
     uint64_t lo = m ? (b << (2 * m)) : b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // almost every wave sees nothing but valid starts (no contig end, no N nearby): a wave-uniform
+    // branch then runs the positions without the per-position exec masking
+    if (__all(valid == (NPOS == 32 ? ~0u : (1u << (NPOS & 31)) - 1u))) {
+#pragma unroll
+        for (int i = 0; i < NPOS; i++) {
+            const uint64_t s = hi >> 62;
+            hi = (hi << 2) | (lo >> 62);
+            lo <<= 2;
+            fwd = ((fwd << 2) | s) & mask;
+            rc = (rc >> 2) | ((s ^ 2) << rcshift);
+            f(i, fwd < rc ? fwd : rc);
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < NPOS; i++) {
         const uint64_t s = hi >> 62;

@@ -20,7 +20,10 @@ constexpr int MAX_HIST_BITS = 13;                          // largest LDS histog
 constexpr int L1_PPT = 16;                                 // start positions per thread in level 1
 constexpr int L1_THREADS = 512;                            // 8 waves per tile: 2 tiles (16 waves) per CU
 constexpr int L1_TILE = L1_THREADS * L1_PPT;               // 8192 k-mers staged in LDS per tile
-constexpr int L2_THREADS = 256;                            // level 2: 32 keys per thread, same tile size
+constexpr int L2_THREADS = 256;                            // level 2: L2_PPT keys per thread
+constexpr int L2_PPT = 32;
+constexpr int L2_TILE = L2_THREADS * L2_PPT;
+constexpr int L2_LDS_BYTES = L2_TILE * 8 + 2048 + 1024 + 1024 + 64;   // keys, gbase[256], hist[256], start[256], scratch[16]
 constexpr int L1_MAX_BITS = 8;                             // coarse fan-out 256: ~32 keys (256 B) per run
 constexpr int L1_LDS_BYTES = L1_TILE * 8 + 2048 + 1024 + 1024 + 64 + L1_TILE;   // keys, gbase[256], hist[256], start[256], scratch[16], bucket bytes
 
@@ -64,7 +67,7 @@ void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *
                             uint32_t *cursor1, uint64_t *out);
 void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *coarse_off, uint64_t n_regions, int bb,
                         uint32_t *counts);
-void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor2, const uint64_t *keys1,
+void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *keys1,
                             uint64_t *keys);
 void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
                                 uint32_t n_genomes, int bb, uint32_t *counts);
@@ -139,7 +142,7 @@ void launch_wide_set(hipStream_t s, const uint64_t *khi, const uint64_t *klo, co
 // ---- two-word k-mers, hash-partition pipeline (grm_wide_hash.hip) ----
 void launch_wh_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
 void launch_wh_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, void *out);
-void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor2, const void *keys1, void *keys);
+void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const void *keys1, void *keys);
 void launch_wh_dict_build(hipStream_t s, const void *keys, const uint64_t *off, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
                           uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint16_t *kslot,
                           uint64_t *img_lo, uint64_t *img_hi, int *overflow);

@@ -591,14 +591,16 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
         uint32_t n_tile;
         const uint32_t st = block_scan_sum(c, scratch, &n_tile);
         if (threadIdx.x < 256) start[threadIdx.x] = st;
+        uint64_t region0 = 0;
+        uint32_t reserved = 0;      // not touched before the placement is done: see lds_barrier()
         if (c) {
             // start of the coarse region: from the coarse scan (deep mode: fine offsets do not exist
             // yet) or from the fine scan (fine ids are nested inside the coarse bucket)
             const uint64_t cidx = (uint64_t)gen0 * B1 + threadIdx.x;
-            const uint64_t region0 = coarse_off ? coarse_off[cidx] : off[(uint64_t)gen0 * (1ull << a.bb) + ((uint64_t)threadIdx.x << b2bits)];
-            gbase[threadIdx.x] = region0 + atomicAdd(&cursor1[cidx], c);
+            region0 = coarse_off ? coarse_off[cidx] : off[(uint64_t)gen0 * (1ull << a.bb) + ((uint64_t)threadIdx.x << b2bits)];
+            reserved = atomicAdd(&cursor1[cidx], c);
         }
-        __syncthreads();
+        lds_barrier();      // start[] is visible; the reservation (a global round trip) lands during the placement
 #pragma unroll
         for (int i = 0; i < L1_PPT; i++)
             if ((valid >> i) & 1u) {
@@ -606,6 +608,7 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
                 skeys[at] = kv[i];
                 sbkt[at] = (uint8_t)bk[i];        // the copy-out then needs no hash
             }
+        if (c) gbase[threadIdx.x] = region0 + reserved;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n_tile; i += L1_THREADS) {
             const uint32_t b1 = sbkt[i];
@@ -646,33 +649,36 @@ __global__ __launch_bounds__(256) void region_hist_kernel(const uint64_t *__rest
 
 __global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
     const uint64_t *__restrict__ keys1, uint64_t *__restrict__ keys, const uint64_t *__restrict__ off,
-    uint32_t *__restrict__ cursor2, uint64_t n_regions, int bb, int b1bits)
+    uint64_t n_regions, int bb, int b1bits)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint64_t *skeys = reinterpret_cast<uint64_t *>(lds_raw);
-    uint64_t *gbase = reinterpret_cast<uint64_t *>(lds_raw + (size_t)L1_TILE * 8);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + (size_t)L1_TILE * 8 + 2048);
+    uint64_t *gbase = reinterpret_cast<uint64_t *>(lds_raw + (size_t)L2_TILE * 8);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + (size_t)L2_TILE * 8 + 2048);
     uint32_t *start = hist + 256;
     uint32_t *scratch = start + 256;
     const int b2bits = bb - b1bits;
-    const uint32_t B2 = 1u << b2bits;
+    const uint32_t B2 = 1u << b2bits;          // <= 32 normally, up to 256 in deep mode
     for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
         const uint64_t g = region >> b1bits, c1 = region & ((1u << b1bits) - 1);
         const uint64_t fine0 = (g << bb) + (c1 << b2bits);
         const uint64_t r0 = off[fine0], r1 = off[fine0 + B2];
-        for (uint64_t base = r0; base < r1; base += L1_TILE) {
-            const uint32_t n = (uint32_t)min((uint64_t)L1_TILE, r1 - base);
+        // a region is written by this workgroup alone, tile after tile: thread t keeps the running
+        // output position of fine bucket t in a register (no global cursor, no atomic round trip)
+        uint64_t my_next = threadIdx.x < B2 ? off[fine0 + threadIdx.x] : 0;
+        for (uint64_t base = r0; base < r1; base += L2_TILE) {
+            const uint32_t n = (uint32_t)min((uint64_t)L2_TILE, r1 - base);
             if (threadIdx.x < B2) hist[threadIdx.x] = 0;
             __syncthreads();
-            uint64_t kv[32];
-            uint32_t bk[32], rk[32];      // fine sub-bucket, returned rank (left in flight, see level 1)
+            uint64_t kv[L2_PPT];
+            uint32_t bk[L2_PPT], rk[L2_PPT];      // fine sub-bucket, returned rank (left in flight, see level 1)
 #pragma unroll
-            for (int j = 0; j < 32; j++) {
+            for (int j = 0; j < L2_PPT; j++) {
                 const uint32_t i = (uint32_t)j * L2_THREADS + threadIdx.x;
                 kv[j] = i < n ? keys1[base + i] : EMPTY_KEY;
             }
 #pragma unroll
-            for (int j = 0; j < 32; j++) {
+            for (int j = 0; j < L2_PPT; j++) {
                 if (kv[j] != EMPTY_KEY) {
                     bk[j] = hash_bucket(mix64(kv[j]), bb) & (B2 - 1);
                     rk[j] = atomicAdd(&hist[bk[j]], 1u);
@@ -684,11 +690,12 @@ __global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
             const uint32_t st = block_scan_sum(c, scratch, &n_tile);
             if (threadIdx.x < B2) {
                 start[threadIdx.x] = st;
-                if (c) gbase[threadIdx.x] = off[fine0 + threadIdx.x] + atomicAdd(&cursor2[fine0 + threadIdx.x], c);
+                gbase[threadIdx.x] = my_next;
+                my_next += c;
             }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 32; j++)
+            for (int j = 0; j < L2_PPT; j++)
                 if (kv[j] != EMPTY_KEY) skeys[start[bk[j]] + rk[j]] = kv[j];
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n; i += L2_THREADS) {
@@ -1289,14 +1296,14 @@ void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *co
     const uint32_t grid = (uint32_t)(n_regions < 256u * 32u ? n_regions : 256u * 32u);
     hipLaunchKernelGGL(region_hist_kernel, dim3(grid), dim3(256), 0, s, keys1, coarse_off, n_regions, bb, scatter_b1_bits(bb), counts);
 }
-void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor2, const uint64_t *keys1,
+void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *keys1,
                             uint64_t *keys)
 {
     const int b1 = scatter_b1_bits(L.bb);
     if (L.total_syms == 0 || L.bb <= b1) return;
     const uint64_t n_regions = (uint64_t)L.n_genomes << b1;
     const uint32_t grid2 = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
-    hipLaunchKernelGGL(kmer_scatter_l2_kernel, dim3(grid2), dim3(L2_THREADS), L1_LDS_BYTES, s, keys1, keys, off, cursor2,
+    hipLaunchKernelGGL(kmer_scatter_l2_kernel, dim3(grid2), dim3(L2_THREADS), L2_LDS_BYTES, s, keys1, keys, off,
                        n_regions, L.bb, b1);
 }
 void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,

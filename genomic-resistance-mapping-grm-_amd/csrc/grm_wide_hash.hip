@@ -166,8 +166,7 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l1_kernel(WideArgs a, int b1b
 
 // ---- level 2: (genome, coarse bucket) region -> fine buckets ------------------------------------
 __global__ __launch_bounds__(WH_THREADS) void wide_l2_kernel(const ulonglong2 *__restrict__ keys1, ulonglong2 *__restrict__ keys,
-                                                             const uint64_t *__restrict__ off, uint32_t *__restrict__ cursor2,
-                                                             uint64_t n_regions, int bb, int b1bits)
+                                                             const uint64_t *__restrict__ off, uint64_t n_regions, int bb, int b1bits)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     ulonglong2 *skeys = reinterpret_cast<ulonglong2 *>(lds_raw);
@@ -181,6 +180,7 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l2_kernel(const ulonglong2 *_
         const uint64_t g = region >> b1bits, c1 = region & ((1u << b1bits) - 1);
         const uint64_t fine0 = (g << bb) + (c1 << b2bits);
         const uint64_t r0 = off[fine0], r1 = off[fine0 + B2];
+        uint64_t my_next = threadIdx.x < B2 ? off[fine0 + threadIdx.x] : 0;   // running output position of fine bucket t
         for (uint64_t base = r0; base < r1; base += WH_TILE) {
             const uint32_t n = (uint32_t)min((uint64_t)WH_TILE, r1 - base);
             if (threadIdx.x < B2) hist[threadIdx.x] = 0;
@@ -205,7 +205,8 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l2_kernel(const ulonglong2 *_
             const uint32_t st = block_scan_sum(c, scratch, &n_tile);
             if (threadIdx.x < B2) {
                 start[threadIdx.x] = st;
-                if (c) gbase[threadIdx.x] = off[fine0 + threadIdx.x] + atomicAdd(&cursor2[fine0 + threadIdx.x], c);
+                gbase[threadIdx.x] = my_next;
+                my_next += c;
             }
             __syncthreads();
 #pragma unroll
@@ -408,14 +409,14 @@ void launch_wh_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint3
     hipLaunchKernelGGL(wide_l1_kernel, dim3(grid), dim3(WH_THREADS), WH_LDS_BYTES, s, wargs(L), scatter_b1_bits(L.bb), n_tiles, off, cursor1,
                        reinterpret_cast<ulonglong2 *>(out));
 }
-void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor2, const void *keys1, void *keys)
+void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const void *keys1, void *keys)
 {
     const int b1 = scatter_b1_bits(L.bb);
     if (!L.total_syms || L.bb <= b1) return;
     const uint64_t n_regions = (uint64_t)L.n_genomes << b1;
     const uint32_t grid = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
     hipLaunchKernelGGL(wide_l2_kernel, dim3(grid), dim3(WH_THREADS), WH_LDS_BYTES, s, reinterpret_cast<const ulonglong2 *>(keys1),
-                       reinterpret_cast<ulonglong2 *>(keys), off, cursor2, n_regions, L.bb, b1);
+                       reinterpret_cast<ulonglong2 *>(keys), off, n_regions, L.bb, b1);
 }
 void launch_wh_dict_build(hipStream_t s, const void *keys, const uint64_t *off, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
                           uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint16_t *kslot,

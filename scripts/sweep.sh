@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-for o in "keys_in_flight=4" "no_slots=1"; do
+for o in "groups_per_thread=4"; do
   timeout -k 10 300 python bench.py --genomes 400 --steps 3 --warmup 1 --cpu-sample 0 --opt $o > gpurun_out/sweep_$o.log 2>&1
   tail -1 gpurun_out/sweep_$o.log | python -c "
 import json,sys
