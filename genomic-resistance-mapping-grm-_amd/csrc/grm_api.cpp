@@ -440,6 +440,12 @@ struct WideSorted;
 static void wide_free(WideSorted *w);
 struct WideHash;
 static void wide_hash_free(WideHash *w);
+// staged (multi-GPU) entry points of the two-word hash pipeline, defined next to it
+static int wide_stage_local(grm_batch *b, int k);
+static int wide_stage_n_local(grm_batch *b, uint64_t *n_local);
+static int wide_stage_export(grm_batch *b, void *dev_keys_out, void *dev_flags_out);
+static int wide_stage_global(grm_batch *b, const void *dev_keys, const void *dev_flags, uint64_t n, int filter_singleton, uint64_t *n_kmers);
+static int wide_stage_fill(grm_batch *b, grm_matrix **out);
 
 struct grm_batch {
     grm_ctx *ctx = nullptr;
@@ -913,7 +919,13 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
 extern "C" int grm_batch_partition(grm_batch *b, int k, uint32_t abundance_min)
 {
     if (!b) return GRM_ERR_ARG;
-    if (k > 32 && k <= 64) return fail(b->ctx, GRM_ERR_UNSUPPORTED, "k=%d: the staged (multi-GPU) API handles k <= 32; use grm_batch_run", k);
+    if (k > 32 && k <= 64) {
+        // two-word k-mers: the hash-partition pipeline, which also leaves the local dictionary behind
+        if (abundance_min > 1) return fail(b->ctx, GRM_ERR_UNSUPPORTED, "k=%d: the staged (multi-GPU) API takes abundance-min 1 for k > 32", k);
+        int rc = batch_partition_impl(b, k, abundance_min, false);
+        if (rc) return rc;
+        return wide_stage_local(b, k);
+    }
     return batch_partition_impl(b, k, abundance_min, false);
 }
 
@@ -934,6 +946,7 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
     if (!b) return GRM_ERR_ARG;
     grm_ctx *c = b->ctx;
     if (!b->partitioned) return fail(c, GRM_ERR_STATE, "grm_batch_local_dict before grm_batch_partition");
+    if (b->k > 32) return wide_stage_n_local(b, n_local);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     b->have_local = b->have_global = false;
@@ -1008,6 +1021,7 @@ extern "C" int grm_batch_export_dict(grm_batch *b, void *dev_keys_out, void *dev
     grm_ctx *c = b->ctx;
     if (!b->have_local) return fail(c, GRM_ERR_STATE, "grm_batch_export_dict before grm_batch_local_dict");
     HIPCHK(c, hipSetDevice(c->device));
+    if (b->k > 32) return wide_stage_export(b, dev_keys_out, dev_flags_out);
     if (b->n_local) {
         HIPCHK(c, hipMemcpyAsync(dev_keys_out, b->d_local_keys.p, b->n_local * 8, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(dev_flags_out, b->d_local_flags.p, b->n_local, hipMemcpyDeviceToDevice, c->stream));
@@ -1060,6 +1074,7 @@ extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, con
     if (n && (!dev_keys || !dev_flags)) return fail(c, GRM_ERR_ARG, "grm_batch_set_global_dict: NULL buffers");
     if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "dictionary of %llu k-mers exceeds 2^32-1 columns", (unsigned long long)n);
     HIPCHK(c, hipSetDevice(c->device));
+    if (b->k > 32) return wide_stage_global(b, dev_keys, dev_flags, n, filter_singleton, n_kmers);
     hipStream_t s = c->stream;
     b->have_global = false;
     b->filter_singleton = filter_singleton;
@@ -1129,6 +1144,7 @@ extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
     grm_ctx *c = b->ctx;
     if (!b->have_global) return fail(c, GRM_ERR_STATE, "grm_batch_fill before grm_batch_set_global_dict");
     HIPCHK(c, hipSetDevice(c->device));
+    if (b->k > 32) return wide_stage_fill(b, out);
     hipStream_t s = c->stream;
     grm_matrix *m = new grm_matrix();
     m->ctx = c;
@@ -1275,26 +1291,33 @@ static int wide_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, WideS
 static void wide_free(WideSorted *w) { delete w; }
 
 // ---- two-word k-mers: hash-partition pipeline (grm_wide_hash.hip) ------------------------------
+// Three stages, as for one-word k-mers: local (partition + per-bucket dictionary of this batch's
+// genomes), global (sort / merge / filter of the k-mers of every rank), fill.
 struct WideHash {
     DevBuf counts, off, cursor1, keys, keys1, kslot;
     DevBuf stage_lo, stage_hi, stage_flags, stage_cnt, stage_off, img_lo, img_hi, col_of_slot, flag;
-    DevBuf loc_lo, loc_hi, loc_flags, idx0, idx1, idx2, t_a, t_b, keep, pos, tmp;
+    DevBuf loc_lo, loc_hi, loc_flags, idx0, idx1, idx2, t_a, t_b, keep, pos, tmp, g_hi, g_lo;
+    int sb = 0;
+    uint32_t cap_log2 = 0, n_wg = 0, U = 0;
+    uint64_t n_local = 0, n_sorted = 0;
+    bool have_local = false, have_global = false;
 };
 static void wide_hash_free(WideHash *w) { delete w; }
 
 // returns GRM_OK with *fallback = true when the input does not suit this path (the caller then
 // uses the sort-based path); parse must have run.
-static int wide_hash_matrix(grm_batch *b, int k, int filter_singleton, grm_matrix **out, bool *fallback)
+static int wide_hash_local(grm_batch *b, int k, bool *fallback)
 {
     grm_ctx *c = b->ctx;
     hipStream_t s = c->stream;
     *fallback = false;
     const uint32_t G = (uint32_t)b->n_genomes;
+    if (!b->whash) b->whash = new WideHash();
+    WideHash &W = *b->whash;
+    W.have_local = W.have_global = false;
     if (b->total_syms == 0 || G == 0) { *fallback = true; return GRM_OK; }
     static bool lds_attr_set = false;
     if (!lds_attr_set) { HIPCHK(c, wh_set_max_dynamic_lds()); lds_attr_set = true; }
-    if (!b->whash) b->whash = new WideHash();
-    WideHash &W = *b->whash;
     uint64_t max_g = 0;
     for (uint32_t g = 0; g < G; g++) max_g = std::max(max_g, b->h_genome_sym_off[g + 1] - b->h_genome_sym_off[g]);
     int bb = 0;
@@ -1307,6 +1330,8 @@ static int wide_hash_matrix(grm_batch *b, int k, int filter_singleton, grm_matri
     const int b1 = scatter_b1_bits(bb);
     const uint64_t n_coarse = (uint64_t)G << b1;
     b->bb = bb;
+    b->k = k;
+    W.cap_log2 = cap_log2;
 
     KmerLaunch L;
     L.sym2 = b->d_sym2.as<uint64_t>(); L.inv = b->d_inv.as<uint64_t>(); L.total_syms = b->total_syms;
@@ -1371,58 +1396,177 @@ static int wide_hash_matrix(grm_batch *b, int k, int filter_singleton, grm_matri
     HIPCHK(c, hipMemcpyAsync(&n_local, W.stage_off.as<uint64_t>() + n_wg, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (n_local >= 0xffffffffull) { *fallback = true; return GRM_OK; }
-    const uint64_t n = n_local;
-    uint32_t U = 0;
-    grm_matrix *m = new grm_matrix();
-    m->ctx = c; m->k = k; m->words = 2; m->n_genomes = b->n_genomes; m->n_rows = ((size_t)b->n_genomes + 63) / 64;
-    auto bail = [&](int code) { delete m; return code; };
+    W.sb = sb;
+    W.n_wg = n_wg;
+    W.n_local = n_local;
+    HIPCHK(c, W.loc_lo.ensure((n_local + 2) * 8)); HIPCHK(c, W.loc_hi.ensure((n_local + 2) * 8)); HIPCHK(c, W.loc_flags.ensure(n_local + 16));
+    if (n_local) {
+        TimeScope t(c, "wh_dict_gather", n_local);
+        launch_wh_dict_gather(s, W.stage_lo.as<uint64_t>(), W.stage_hi.as<uint64_t>(), W.stage_flags.as<uint8_t>(), W.stage_off.as<uint64_t>(),
+                              n_wg, cap, W.loc_lo.as<uint64_t>(), W.loc_hi.as<uint64_t>(), W.loc_flags.as<uint8_t>());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    W.have_local = true;
+    return GRM_OK;
+}
+
+// (hi, lo, flag) of every rank (or of this batch alone) -> sorted, merged, filtered dictionary:
+// sorted keys stay in t_b (hi) / t_a (lo), keep / pos give the columns, W.U their number.
+static int wide_hash_global(grm_batch *b, const uint64_t *hi, const uint64_t *lo, const uint8_t *flags, uint64_t n, int filter_singleton)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    WideHash &W = *b->whash;
+    W.have_global = false;
+    W.U = 0;
+    W.n_sorted = n;
+    if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "dictionary of %llu k-mers exceeds 2^32-1 entries", (unsigned long long)n);
     if (n) {
         TimeScope t(c, "wh_dict_sort", n);
         hipError_t e = hipSuccess;
         auto need = [&](DevBuf &d, size_t bytes) { if (e == hipSuccess) e = d.ensure(bytes); };
-        need(W.loc_lo, n * 8); need(W.loc_hi, n * 8); need(W.loc_flags, n + 16); need(W.idx0, n * 4); need(W.idx1, n * 4);
-        need(W.idx2, n * 4); need(W.t_a, n * 8); need(W.t_b, n * 8); need(W.keep, (n + 1) * 4); need(W.pos, (n + 1) * 4);
-        if (e != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "dictionary buffers: %s", hipGetErrorString(e)));
-        launch_wh_dict_gather(s, W.stage_lo.as<uint64_t>(), W.stage_hi.as<uint64_t>(), W.stage_flags.as<uint8_t>(), W.stage_off.as<uint64_t>(),
-                              n_wg, cap, W.loc_lo.as<uint64_t>(), W.loc_hi.as<uint64_t>(), W.loc_flags.as<uint8_t>());
+        need(W.idx0, n * 4); need(W.idx1, n * 4); need(W.idx2, n * 4); need(W.t_a, n * 8); need(W.t_b, n * 8);
+        need(W.keep, (n + 1) * 4); need(W.pos, (n + 1) * 4);
+        if (e != hipSuccess) return fail(c, GRM_ERR_OOM, "dictionary buffers: %s", hipGetErrorString(e));
         launch_iota_u32(s, W.idx0.as<uint32_t>(), n);
         size_t tb = 0;
         // stable LSD sort by (hi, lo): by lo, then by hi
-        e = sort_pairs_u64_u32(s, W.loc_lo.as<uint64_t>(), W.t_a.as<uint64_t>(), W.idx0.as<uint32_t>(), W.idx1.as<uint32_t>(), n, nullptr, tb);
+        e = sort_pairs_u64_u32(s, lo, W.t_a.as<uint64_t>(), W.idx0.as<uint32_t>(), W.idx1.as<uint32_t>(), n, nullptr, tb);
         if (e == hipSuccess) e = W.tmp.ensure(tb);
-        if (e == hipSuccess) e = sort_pairs_u64_u32(s, W.loc_lo.as<uint64_t>(), W.t_a.as<uint64_t>(), W.idx0.as<uint32_t>(), W.idx1.as<uint32_t>(), n, W.tmp.p, tb);
-        launch_gather_u64(s, W.loc_hi.as<uint64_t>(), W.idx1.as<uint32_t>(), n, W.t_a.as<uint64_t>());
+        if (e == hipSuccess) e = sort_pairs_u64_u32(s, lo, W.t_a.as<uint64_t>(), W.idx0.as<uint32_t>(), W.idx1.as<uint32_t>(), n, W.tmp.p, tb);
+        launch_gather_u64(s, hi, W.idx1.as<uint32_t>(), n, W.t_a.as<uint64_t>());
         tb = 0;
         if (e == hipSuccess) e = sort_pairs_u64_u32(s, W.t_a.as<uint64_t>(), W.t_b.as<uint64_t>(), W.idx1.as<uint32_t>(), W.idx2.as<uint32_t>(), n, nullptr, tb);
         if (e == hipSuccess) e = W.tmp.ensure(tb);
         if (e == hipSuccess) e = sort_pairs_u64_u32(s, W.t_a.as<uint64_t>(), W.t_b.as<uint64_t>(), W.idx1.as<uint32_t>(), W.idx2.as<uint32_t>(), n, W.tmp.p, tb);
-        launch_gather_u64(s, W.loc_lo.as<uint64_t>(), W.idx2.as<uint32_t>(), n, W.t_a.as<uint64_t>());     // sorted: hi = t_b, lo = t_a
-        if (e != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "dictionary sort: %s", hipGetErrorString(e)));
-        (void)hipMemsetAsync(W.keep.as<uint32_t>() + n, 0, 4, s);
-        launch_wh_keep_flags(s, W.loc_flags.as<uint8_t>(), W.idx2.as<uint32_t>(), n, filter_singleton, W.keep.as<uint32_t>());
+        launch_gather_u64(s, lo, W.idx2.as<uint32_t>(), n, W.t_a.as<uint64_t>());     // sorted: hi = t_b, lo = t_a
+        if (e != hipSuccess) return fail(c, GRM_ERR_HIP, "dictionary sort: %s", hipGetErrorString(e));
+        HIPCHK(c, hipMemsetAsync(W.keep.as<uint32_t>() + n, 0, 4, s));
+        // a k-mer held by several ranks shows up as a run of equal keys: one column, carried by >= 2 genomes
+        launch_wh_mark(s, W.t_b.as<uint64_t>(), W.t_a.as<uint64_t>(), flags, W.idx2.as<uint32_t>(), n, filter_singleton, W.keep.as<uint32_t>());
         int rc = wide_scan(c, W.tmp, false, W.keep.as<uint32_t>(), W.pos.as<uint32_t>(), n + 1);
-        if (rc) return bail(rc);
-        if (hipMemcpyAsync(&U, W.pos.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-            return bail(fail(c, GRM_ERR_HIP, "D2H"));
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(&W.U, W.pos.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
     }
+    W.have_global = true;
+    return GRM_OK;
+}
+
+static int wide_hash_fill(grm_batch *b, grm_matrix **out)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    WideHash &W = *b->whash;
+    const uint32_t G = (uint32_t)b->n_genomes, cap = 1u << W.cap_log2;
+    grm_matrix *m = new grm_matrix();
+    m->ctx = c; m->k = b->k; m->words = 2; m->n_genomes = b->n_genomes; m->n_rows = ((size_t)b->n_genomes + 63) / 64;
+    auto bail = [&](int code) { delete m; return code; };
+    const uint32_t U = W.U;
     m->n_kmers = U;
     const size_t cells = m->n_rows * (size_t)U;
     if (m->d_data.alloc(cells * 8) != hipSuccess || m->d_kmers.alloc(((size_t)U + 1) * 16) != hipSuccess)
         return bail(fail(c, GRM_ERR_OOM, "matrix allocation failed"));
     if (cells) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
     if (U) {
-        const size_t slots = (size_t)n_wg * cap;
+        const size_t slots = (size_t)W.n_wg * cap;
         if (W.col_of_slot.ensure(slots * 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
         (void)hipMemsetAsync(W.col_of_slot.p, 0xff, slots * 4, s);
-        launch_wh_select_cols(s, W.t_b.as<uint64_t>(), W.t_a.as<uint64_t>(), W.keep.as<uint32_t>(), W.pos.as<uint32_t>(), n, bb, sb, cap_log2,
-                              W.img_lo.as<uint64_t>(), W.img_hi.as<uint64_t>(), m->d_kmers.as<uint64_t>(), W.col_of_slot.as<uint32_t>());
-        TimeScope t(c, "matrix_fill", NK);
-        launch_matrix_fill_slots(s, W.kslot.as<uint16_t>(), W.off.as<uint64_t>(), nullptr, G, bb, sb, cap_log2, W.col_of_slot.as<uint32_t>(),
-                                 m->d_data.as<uint64_t>(), U);
+        launch_wh_select_cols(s, W.t_b.as<uint64_t>(), W.t_a.as<uint64_t>(), W.keep.as<uint32_t>(), W.pos.as<uint32_t>(), W.n_sorted, b->bb, W.sb,
+                              W.cap_log2, W.img_lo.as<uint64_t>(), W.img_hi.as<uint64_t>(), m->d_kmers.as<uint64_t>(), W.col_of_slot.as<uint32_t>());
+        if (cells && b->total_keys) {
+            TimeScope t(c, "matrix_fill", b->total_keys);
+            launch_matrix_fill_slots(s, W.kslot.as<uint16_t>(), W.off.as<uint64_t>(), nullptr, G, b->bb, W.sb, W.cap_log2, W.col_of_slot.as<uint32_t>(),
+                                     m->d_data.as<uint64_t>(), U);
+        }
     }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "wide hash pipeline failed"));
     *out = m;
     return GRM_OK;
+}
+
+static int wide_hash_matrix(grm_batch *b, int k, int filter_singleton, grm_matrix **out, bool *fallback)
+{
+    int rc = wide_hash_local(b, k, fallback);
+    if (rc || *fallback) return rc;
+    WideHash &W = *b->whash;
+    rc = wide_hash_global(b, W.loc_hi.as<uint64_t>(), W.loc_lo.as<uint64_t>(), W.loc_flags.as<uint8_t>(), W.n_local, filter_singleton);
+    if (rc) return rc;
+    return wide_hash_fill(b, out);
+}
+
+// ---- staged form (grm_batch_partition / local_dict / export_dict / set_global_dict / fill) ----
+static int wide_stage_local(grm_batch *b, int k)
+{
+    grm_ctx *c = b->ctx;
+    bool fallback = false;
+    b->partitioned = b->have_local = b->have_global = false;
+    int rc = wide_hash_local(b, k, &fallback);
+    if (rc) return rc;
+    if (fallback && (b->total_syms == 0 || b->n_genomes == 0)) {       // nothing to count: an empty local dictionary
+        WideHash &W = *b->whash;
+        // one all-empty table image, so that the column pass of the fill has something to probe
+        W.n_local = 0; W.n_wg = 1; W.sb = 0; W.cap_log2 = 6;
+        b->total_keys = 0;
+        b->k = k;
+        b->bb = 0;
+        HIPCHK(c, W.loc_lo.ensure(16)); HIPCHK(c, W.loc_hi.ensure(16)); HIPCHK(c, W.loc_flags.ensure(16));
+        HIPCHK(c, W.img_lo.ensure(64 * 8)); HIPCHK(c, W.img_hi.ensure(64 * 8));
+        HIPCHK(c, hipMemsetAsync(W.img_lo.p, 0xff, 64 * 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(W.img_hi.p, 0xff, 64 * 8, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        W.have_local = true;
+    } else if (fallback) {
+        return fail(c, GRM_ERR_UNSUPPORTED, "k=%d: this input is too deep for the staged two-word pipeline (use grm_batch_run)", k);
+    }
+    b->partitioned = true;
+    b->have_local = true;
+    return GRM_OK;
+}
+static int wide_stage_n_local(grm_batch *b, uint64_t *n_local)
+{
+    if (!b->whash || !b->whash->have_local) return fail(b->ctx, GRM_ERR_STATE, "grm_batch_local_dict before grm_batch_partition");
+    b->n_local = b->whash->n_local;
+    if (n_local) *n_local = b->n_local;
+    return GRM_OK;
+}
+// keys leave as (hi, lo) pairs, 16 bytes per k-mer
+static int wide_stage_export(grm_batch *b, void *dev_keys_out, void *dev_flags_out)
+{
+    grm_ctx *c = b->ctx;
+    WideHash &W = *b->whash;
+    if (W.n_local) {
+        launch_join_pairs_u64(c->stream, W.loc_hi.as<uint64_t>(), W.loc_lo.as<uint64_t>(), W.n_local, (uint64_t *)dev_keys_out);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(dev_flags_out, W.loc_flags.p, W.n_local, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GRM_OK;
+}
+static int wide_stage_global(grm_batch *b, const void *dev_keys, const void *dev_flags, uint64_t n, int filter_singleton, uint64_t *n_kmers)
+{
+    grm_ctx *c = b->ctx;
+    if (!b->whash || !b->whash->have_local) return fail(c, GRM_ERR_STATE, "grm_batch_set_global_dict before grm_batch_partition");
+    WideHash &W = *b->whash;
+    b->have_global = false;
+    b->filter_singleton = filter_singleton;
+    HIPCHK(c, W.g_hi.ensure((n + 2) * 8)); HIPCHK(c, W.g_lo.ensure((n + 2) * 8));
+    if (n) {
+        launch_split_pairs_u64(c->stream, (const uint64_t *)dev_keys, n, W.g_hi.as<uint64_t>(), W.g_lo.as<uint64_t>());
+        HIPCHK(c, hipGetLastError());
+    }
+    int rc = wide_hash_global(b, W.g_hi.as<uint64_t>(), W.g_lo.as<uint64_t>(), (const uint8_t *)dev_flags, n, filter_singleton);
+    if (rc) return rc;
+    b->n_dict = W.U;
+    b->have_global = true;
+    if (n_kmers) *n_kmers = W.U;
+    return GRM_OK;
+}
+static int wide_stage_fill(grm_batch *b, grm_matrix **out)
+{
+    if (!b->whash || !b->whash->have_global) return fail(b->ctx, GRM_ERR_STATE, "grm_batch_fill before grm_batch_set_global_dict");
+    return wide_hash_fill(b, out);
 }
 
 static int wide_matrix(grm_batch *b, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out, bool preloaded = false)

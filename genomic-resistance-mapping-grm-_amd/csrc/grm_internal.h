@@ -105,6 +105,7 @@ void launch_column_popcount(hipStream_t s, const uint64_t *matrix, uint64_t n_ro
                             const uint64_t *row_mask, uint32_t *out);
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint64_t n);
 void launch_split_pairs_u64(hipStream_t s, const uint64_t *pairs, uint64_t n, uint64_t *hi, uint64_t *lo);
+void launch_join_pairs_u64(hipStream_t s, const uint64_t *hi, const uint64_t *lo, uint64_t n, uint64_t *pairs);
 hipError_t set_max_dynamic_lds();
 void set_table_tuning(int keys_in_flight, int threads);
 
@@ -148,7 +149,8 @@ void launch_wh_dict_build(hipStream_t s, const void *keys, const uint64_t *off, 
                           uint64_t *img_lo, uint64_t *img_hi, int *overflow);
 void launch_wh_dict_gather(hipStream_t s, const uint64_t *stage_lo, const uint64_t *stage_hi, const uint8_t *stage_flags,
                            const uint64_t *stage_off, uint32_t n_wg, uint32_t cap, uint64_t *out_lo, uint64_t *out_hi, uint8_t *out_flags);
-void launch_wh_keep_flags(hipStream_t s, const uint8_t *flags, const uint32_t *order, uint64_t n, int filter_singleton, uint32_t *keep);
+void launch_wh_mark(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint8_t *flags, const uint32_t *order, uint64_t n,
+                    int filter_singleton, uint32_t *keep);
 void launch_wh_select_cols(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
                            int bb, int sb, uint32_t cap_log2, const uint64_t *img_lo, const uint64_t *img_hi, uint64_t *dict,
                            uint32_t *col_of_slot);

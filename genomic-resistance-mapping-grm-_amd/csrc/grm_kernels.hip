@@ -1006,11 +1006,22 @@ __global__ __launch_bounds__(1024) void matrix_fill_slots_kernel(
         for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) words[i] = 0;
         __syncthreads();
         const uint32_t g_end = min(r * 64 + 64, n_genomes);
+        // the segment bounds of the NEXT genome are requested while the current one is processed
+        // (offsets, then slots: two dependent global round trips per genome otherwise)
+        uint64_t s0 = 0, n = 0;
+        if (r * 64 + wave < g_end) {
+            const uint64_t idx = (uint64_t)(r * 64 + wave) * B + b;
+            s0 = off[idx];
+            n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
+        }
         for (uint32_t g = r * 64 + wave; g < g_end; g += nw) {
             const unsigned long long bit = 1ull << (63 - (g & 63));
-            const uint64_t idx = (uint64_t)g * B + b;
-            const uint64_t s0 = off[idx];
-            const uint64_t n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
+            uint64_t s0_next = 0, n_next = 0;
+            if (g + nw < g_end) {
+                const uint64_t idx = (uint64_t)(g + nw) * B + b;
+                s0_next = off[idx];
+                n_next = len ? (uint64_t)len[idx] : off[idx + 1] - s0_next;
+            }
             for (uint64_t i0 = lane; i0 < n; i0 += 64 * SLOTS_IN_FLIGHT) {
                 uint32_t sv[SLOTS_IN_FLIGHT];
 #pragma unroll
@@ -1025,6 +1036,8 @@ __global__ __launch_bounds__(1024) void matrix_fill_slots_kernel(
                     atomicOr((unsigned long long *)&words[sv[j] & cap_mask], bit);
                 }
             }
+            s0 = s0_next;
+            n = n_next;
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) {
@@ -1441,6 +1454,18 @@ void launch_split_pairs_u64(hipStream_t s, const uint64_t *pairs, uint64_t n, ui
 {
     if (!n) return;
     hipLaunchKernelGGL(split_pairs_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, pairs, n, hi, lo);
+}
+__global__ void join_pairs_u64_kernel(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n,
+                                      uint64_t *__restrict__ pairs)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    reinterpret_cast<ulonglong2 *>(pairs)[i] = make_ulonglong2(hi[i], lo[i]);
+}
+void launch_join_pairs_u64(hipStream_t s, const uint64_t *hi, const uint64_t *lo, uint64_t n, uint64_t *pairs)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(join_pairs_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, hi, lo, n, pairs);
 }
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint64_t n)
 {

@@ -355,11 +355,18 @@ __global__ void wide_dict_gather_kernel(const uint64_t *__restrict__ stage_lo, c
     }
 }
 // keep flags of the value-sorted dictionary (single GPU: keys are already unique)
-__global__ void wide_keep_flags_kernel(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ order, uint64_t n,
-                                       int filter_singleton, uint32_t *__restrict__ keep)
+// sorted (hi, lo) with the flag of entry i at flags[order[i]].  A run of equal keys (the same k-mer
+// reported by several ranks, whose genomes are disjoint) is ONE column carried by several genomes;
+// keep[i] = 1 on the first entry of every run that survives the singleton filter.
+__global__ void wide_mark_kernel(const uint64_t *__restrict__ s_hi, const uint64_t *__restrict__ s_lo, const uint8_t *__restrict__ flags,
+                                 const uint32_t *__restrict__ order, uint64_t n, int filter_singleton, uint32_t *__restrict__ keep)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        keep[i] = (!filter_singleton || flags[order[i]] >= 2) ? 1u : 0u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t hi = s_hi[i], lo = s_lo[i];
+        const bool head = i == 0 || s_hi[i - 1] != hi || s_lo[i - 1] != lo;
+        const bool several = flags[order[i]] >= 2 || (i + 1 < n && s_hi[i + 1] == hi && s_lo[i + 1] == lo);
+        keep[i] = (head && (!filter_singleton || several)) ? 1u : 0u;
+    }
 }
 // final dictionary (hi, lo interleaved, ascending) + column of every table slot
 __global__ void wide_select_cols_kernel(const uint64_t *__restrict__ s_hi, const uint64_t *__restrict__ s_lo,
@@ -432,11 +439,12 @@ void launch_wh_dict_gather(hipStream_t s, const uint64_t *stage_lo, const uint64
     hipLaunchKernelGGL(wide_dict_gather_kernel, dim3(n_wg), dim3(256), 0, s, stage_lo, stage_hi, stage_flags, stage_off, cap, out_lo, out_hi,
                        out_flags);
 }
-void launch_wh_keep_flags(hipStream_t s, const uint8_t *flags, const uint32_t *order, uint64_t n, int filter_singleton, uint32_t *keep)
+void launch_wh_mark(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint8_t *flags, const uint32_t *order, uint64_t n,
+                    int filter_singleton, uint32_t *keep)
 {
     if (!n) return;
-    uint64_t g = (n + 255) / 256;
-    hipLaunchKernelGGL(wide_keep_flags_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, flags, order, n, filter_singleton, keep);
+    const uint64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(wide_mark_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, s_hi, s_lo, flags, order, n, filter_singleton, keep);
 }
 void launch_wh_select_cols(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
                            int bb, int sb, uint32_t cap_log2, const uint64_t *img_lo, const uint64_t *img_hi, uint64_t *dict,

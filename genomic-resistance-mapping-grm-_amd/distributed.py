@@ -4,8 +4,8 @@ torch.distributed over RCCL ("nccl" backend on ROCm) / xGMI.
 Genomes are independent through parse / partition / local dictionary, and again through
 the presence-bit fill; the ONE exchange step is the union of the per-rank dictionaries:
 
-    rank r:  local distinct k-mers (uint64) + flag (1 = carried by one local genome,
-             2 = by several)                                   n_r entries
+    rank r:  local distinct k-mers (uint64; (hi, lo) pairs for 33 <= k <= 64) + flag
+             (1 = carried by one local genome, 2 = by several)  n_r entries
     all-gather(n_r)  ->  all-gather of max-padded (keys, flags) buffers
     every rank: same deterministic sort / merge / singleton filter  ->  identical global
              dictionary and column order, no second collective
@@ -47,13 +47,14 @@ def _all_gather(out, inp, group):
         dist.all_gather_into_tensor(out, inp, group=group)
 
 
-def allgather_dict(batch, n_local, device, group=None):
+def allgather_dict(batch, n_local, device, group=None, words=1):
     """the single data-path collective.  batch: object with export_dict(keys_ptr, flags_ptr).
-    -> (keys int64 tensor [n_total], flags uint8 tensor [n_total]) on `device`."""
+    -> (keys int64 tensor [n_total, words], flags uint8 tensor [n_total]) on `device`;
+    words = 2 for 33 <= k <= 64: (hi, lo) pairs, 16 bytes per k-mer."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    keys = torch.empty(max(1, n_local), dtype=torch.int64, device=device)
+    keys = torch.empty((max(1, n_local), words), dtype=torch.int64, device=device)
     flags = torch.empty(max(1, n_local), dtype=torch.uint8, device=device)
     batch.export_dict(keys.data_ptr(), flags.data_ptr())
     if world == 1:
@@ -63,11 +64,11 @@ def allgather_dict(batch, n_local, device, group=None):
     _all_gather(counts, mine, group)
     counts_h = counts.cpu().tolist()
     n_max = max(1, max(counts_h))
-    kpad = torch.zeros(n_max, dtype=torch.int64, device=device)
+    kpad = torch.zeros((n_max, words), dtype=torch.int64, device=device)
     fpad = torch.zeros(n_max, dtype=torch.uint8, device=device)
     kpad[:n_local] = keys[:n_local]
     fpad[:n_local] = flags[:n_local]
-    kall = torch.empty(world * n_max, dtype=torch.int64, device=device)
+    kall = torch.empty((world * n_max, words), dtype=torch.int64, device=device)
     fall = torch.empty(world * n_max, dtype=torch.uint8, device=device)
     _all_gather(kall, kpad, group)
     _all_gather(fall, fpad, group)
@@ -87,8 +88,8 @@ def sharded_step(batch, k, abundance_min, filter_singleton, device, group=None):
     (its word-rows against the GLOBAL dictionary)."""
     batch.partition(k, abundance_min)
     n_local = batch.local_dict()
-    keys, flags = allgather_dict(batch, n_local, device, group)
-    batch.set_global_dict(keys.data_ptr(), flags.data_ptr(), int(keys.numel()), filter_singleton)
+    keys, flags = allgather_dict(batch, n_local, device, group, words=2 if k > 32 else 1)
+    batch.set_global_dict(keys.data_ptr(), flags.data_ptr(), int(keys.shape[0]), filter_singleton)
     return batch.fill()
 
 

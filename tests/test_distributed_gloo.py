@@ -34,7 +34,7 @@ class FakeMatrix:
         self._k, self._d = kmers, data
 
     def kmers(self):
-        return self._k.reshape(-1, 1)
+        return self._k
 
     def data(self):
         return self._d
@@ -44,19 +44,21 @@ class FakeMatrix:
 
 
 class OracleBatch:
-    """same staged interface as engine.Batch, host memory instead of HBM"""
+    """same staged interface as engine.Batch, host memory instead of HBM; keys are rows of
+    `words` uint64 (most significant first), 2 words for 33 <= k <= 64"""
 
     def __init__(self, genomes):
         self.genomes = genomes
 
     def partition(self, k, abundance_min):
-        self.sets = [orc.count_genome(g, k, abundance_min)[0][:, 0] for g in self.genomes]
+        self.w = 2 if k > 32 else 1
+        self.sets = [orc.count_genome(g, k, abundance_min)[0].reshape(-1, self.w) for g in self.genomes]
 
     def local_dict(self):
-        allk = np.concatenate(self.sets) if self.sets else np.zeros(0, np.uint64)
-        vals, counts = np.unique(allk, return_counts=True)
+        allk = np.concatenate(self.sets) if self.sets else np.zeros((0, self.w), np.uint64)
+        vals, counts = np.unique(allk, axis=0, return_counts=True)
         perm = np.random.RandomState(len(vals)).permutation(len(vals))      # order must not matter
-        self.lk = vals[perm].astype(np.uint64)
+        self.lk = np.ascontiguousarray(vals[perm].astype(np.uint64))
         self.lf = np.where(counts[perm] > 1, 2, 1).astype(np.uint8)
         return len(self.lk)
 
@@ -65,23 +67,23 @@ class OracleBatch:
         C.memmove(flags_ptr, self.lf.ctypes.data, self.lf.nbytes)
 
     def set_global_dict(self, keys_ptr, flags_ptr, n, filter_singleton):
-        keys = np.ctypeslib.as_array(C.cast(keys_ptr, C.POINTER(C.c_uint64)), shape=(max(n, 1),))[:n].copy()
+        keys = np.ctypeslib.as_array(C.cast(keys_ptr, C.POINTER(C.c_uint64)), shape=(max(n, 1) * self.w,))[:n * self.w].copy().reshape(n, self.w)
         flags = np.ctypeslib.as_array(C.cast(flags_ptr, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()
-        order = np.argsort(keys, kind="stable")
-        keys, flags = keys[order], flags[order]
-        vals, first, counts = np.unique(keys, return_index=True, return_counts=True)
-        multi = (counts > 1) | (np.maximum.reduceat(flags, first) >= 2 if len(keys) else np.zeros(0, bool))
-        self.dict = vals[multi] if filter_singleton else vals
+        vals, inv, counts = np.unique(keys, axis=0, return_inverse=True, return_counts=True)
+        top = np.zeros(len(vals), dtype=np.uint8)
+        np.maximum.at(top, inv.reshape(-1), flags)
+        multi = (counts > 1) | (top >= 2)
+        self.dict = vals[multi] if filter_singleton else vals          # rows sorted (hi, lo): the column order
         return len(self.dict)
 
     def fill(self):
         rows = (len(self.genomes) + 63) // 64
         out = np.zeros((rows, len(self.dict)), dtype=np.uint64)
+        col = {r.tobytes(): i for i, r in enumerate(self.dict)}
         for g, s in enumerate(self.sets):
-            idx = np.searchsorted(self.dict, s)
-            ok = (idx < len(self.dict))
-            ok[ok] &= self.dict[idx[ok]] == s[ok]
-            out[g // 64, idx[ok]] |= np.uint64(1) << np.uint64(63 - g % 64)
+            idx = np.array([col.get(r.tobytes(), -1) for r in s], dtype=np.int64)
+            idx = idx[idx >= 0]
+            out[g // 64, idx] |= np.uint64(1) << np.uint64(63 - g % 64)
         return FakeMatrix(self.dict, out)
 
 
@@ -111,16 +113,16 @@ def _worker(rank, world, port, n_genomes, k, filt, q):
         m = D.sharded_step(batch, k, 1, filt, torch.device("cpu"))
         rows = D.gather_rows(m.data(), torch.device("cpu"))
         if rank == 0:
-            q.put((m.kmers()[:, 0].copy(), rows))
+            q.put((m.kmers().copy(), rows))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_genomes,filt", [(100, True), (70, False), (130, True)])
-def test_two_rank_gloo_matches_single_process_oracle(n_genomes, filt):
+@pytest.mark.parametrize("n_genomes,filt,k", [(100, True, 15), (70, False, 15), (130, True, 15), (130, True, 40)])
+def test_two_rank_gloo_matches_single_process_oracle(n_genomes, filt, k):
+    """k = 40: two-word k-mers, the dictionary travels as (hi, lo) pairs"""
     import torch.multiprocessing as mp
-    k = 15
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -135,5 +137,5 @@ def test_two_rank_gloo_matches_single_process_oracle(n_genomes, filt):
         p.join(timeout=60)
         assert p.exitcode == 0
     want = orc.build_matrix(_genomes(n_genomes), k, 1, filt)
-    assert (kmers == want["kmers"][:, 0]).all()
+    assert kmers.shape == want["kmers"].shape and (kmers == want["kmers"]).all()
     assert rows.shape == want["matrix"].shape and (rows == want["matrix"]).all()

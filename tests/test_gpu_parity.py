@@ -221,26 +221,29 @@ def test_deep_read_set_counts(ctx):
                 ctx.set_option(name, -1)
 
 
-def test_staged_equals_fused(ctx):
+@pytest.mark.parametrize("k", [31, 63])
+def test_staged_equals_fused(ctx, k):
+    """the staged (multi-GPU) API on one device; k = 63: keys travel as (hi, lo) pairs"""
     import torch
+    w = 2 if k > 32 else 1
     genomes = _medium_genomes(n=4, length=100_000, seed=3)
-    want = orc.build_matrix(genomes, 31, 1, True)
+    want = orc.build_matrix(genomes, k, 1, True)
     b = ctx.batch(len(genomes))
     for g, files in enumerate(genomes):
         b.add(g, files[0])
     b.upload()
-    b.partition(31, 1)
+    b.partition(k, 1)
     n_local = b.local_dict()
-    keys = torch.empty(max(1, n_local), dtype=torch.int64, device="cuda:0")
+    keys = torch.empty((max(1, n_local), w), dtype=torch.int64, device="cuda:0")
     flags = torch.empty(max(1, n_local), dtype=torch.uint8, device="cuda:0")
     b.export_dict(keys.data_ptr(), flags.data_ptr())
     torch.cuda.synchronize()
     # local dictionary = every distinct k-mer of the union, flag 2 where >1 genome carries it
-    allm = orc.build_matrix(genomes, 31, 1, False)
-    k_host = keys.cpu().numpy().view(np.uint64)
-    order = np.argsort(k_host)
-    assert (k_host[order] == allm["kmers"][:, 0]).all()
-    assert ((flags.cpu().numpy()[order] == 2) == (allm["n_genomes_with"] > 1)).all()
+    allm = orc.build_matrix(genomes, k, 1, False)
+    k_host = keys.cpu().numpy().view(np.uint64)[:n_local]
+    order = np.lexsort(tuple(k_host[:, j] for j in reversed(range(w))))
+    assert (k_host[order] == allm["kmers"]).all()
+    assert ((flags.cpu().numpy()[:n_local][order] == 2) == (allm["n_genomes_with"] > 1)).all()
     u = b.set_global_dict(keys.data_ptr(), flags.data_ptr(), n_local, True)
     assert u == want["kmers"].shape[0]
     m = b.fill()
@@ -249,7 +252,7 @@ def test_staged_equals_fused(ctx):
     b.free()
 
 
-def _rank_worker(rank, world, port, n_genomes, q):
+def _rank_worker(rank, world, port, n_genomes, k, q):
     """one rank of the sharded path with the REAL engine; both ranks share cuda:0 (gloo, host-staged)"""
     import torch
     import torch.distributed as dist
@@ -266,10 +269,10 @@ def _rank_worker(rank, world, port, n_genomes, q):
                 batch.add_array(g - a, pg.genome(g))
             batch.upload()
             dev = torch.device("cuda", 0)
-            m = D.sharded_step(batch, 31, 1, True, dev)
+            m = D.sharded_step(batch, k, 1, True, dev)
             rows = D.gather_rows(m.data(), dev)
             if rank == 0:
-                q.put((m.kmers()[:, 0].copy(), rows))
+                q.put((m.kmers().copy(), rows))
             m.free()
             batch.free()
         dist.barrier()
@@ -277,7 +280,8 @@ def _rank_worker(rank, world, port, n_genomes, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_real_engine_one_gpu(ctx):
+@pytest.mark.parametrize("k", [31, 47])
+def test_two_ranks_real_engine_one_gpu(ctx, k):
     """N>1 path end to end with the HIP engine: 2 processes, genomes sharded 64 + 36, dictionary
     all-gather, identical global dictionary, rows stacked == single-process oracle matrix"""
     import socket
@@ -286,7 +290,7 @@ def test_two_ranks_real_engine_one_gpu(ctx):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_rank_worker, args=(r, 2, port, n_genomes, q)) for r in range(2)]
+    procs = [mpc.Process(target=_rank_worker, args=(r, 2, port, n_genomes, k, q)) for r in range(2)]
     for p in procs:
         p.start()
     kmers, rows = q.get(timeout=240)
@@ -294,8 +298,8 @@ def test_two_ranks_real_engine_one_gpu(ctx):
         p.join(timeout=120)
         assert p.exitcode == 0
     pg = synth.PanGenome(genome_len=60_000, n_snps=600, n_accessory=6, accessory_len=1500, seed=21, n_contigs=2)
-    want = orc.build_matrix([[pg.genome(g).tobytes()] for g in range(n_genomes)], 31, 1, True)
-    assert (kmers == want["kmers"][:, 0]).all() and kmers.shape[0] == want["kmers"].shape[0]
+    want = orc.build_matrix([[pg.genome(g).tobytes()] for g in range(n_genomes)], k, 1, True)
+    assert kmers.shape == want["kmers"].shape and (kmers == want["kmers"]).all()
     assert rows.shape == want["matrix"].shape and (rows == want["matrix"]).all()
 
 
@@ -384,7 +388,7 @@ def test_two_word_kmers(ctx, k, tmp_path):
         m.write_tsv(ids, tsv)
         assert [l.split("\t")[0] for l in open(tsv).read().split("\n")[1:] if l] == orc.decode_kmers(want["kmers"], k)
         with pytest.raises(grm.GrmError):
-            b.partition(k, 1)                      # staged multi-GPU API: k <= 32 only, and says so
+            b.partition(k, 2)                      # staged multi-GPU API at k > 32: abundance-min 1 only, and says so
         m.free(); b.free()
 
 
