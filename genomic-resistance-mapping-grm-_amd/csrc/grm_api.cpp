@@ -40,6 +40,10 @@ struct TimingRec {
 struct grm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // uploads run on their own stream: grm_batch_upload of the NEXT batch may be called from a
+    // second host thread while this context computes on `stream` (kover_dataset.counted_sets)
+    hipStream_t copy_stream = nullptr;
+    std::mutex err_mu;
     std::string err;
     bool timing = false;
     std::vector<TimingRec> recs;
@@ -62,7 +66,10 @@ static int fail(grm_ctx *c, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf;
+    if (c) {
+        std::lock_guard<std::mutex> g(c->err_mu);
+        c->err = buf;
+    }
     return code;
 }
 
@@ -139,7 +146,13 @@ extern "C" grm_ctx *grm_create(int device_ordinal, int n_streams)
     grm_ctx *c = new grm_ctx();
     c->device = device_ordinal;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
-    if (set_max_dynamic_lds() != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        set_max_dynamic_lds() != hipSuccess) {
+        if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return nullptr;
+    }
     return c;
 }
 
@@ -148,6 +161,7 @@ extern "C" void grm_destroy(grm_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (auto &r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -634,7 +648,7 @@ extern "C" int grm_batch_upload(grm_batch *b)
         std::string io_err;
         std::mutex io_mu;
         auto cleanup = [&]() {
-            (void)hipStreamSynchronize(c->stream);
+            (void)hipStreamSynchronize(c->copy_stream);
             for (int i = 0; i < 2; i++) {
                 if (pinned[i]) (void)hipHostFree(pinned[i]);
                 if (done[i]) (void)hipEventDestroy(done[i]);
@@ -708,20 +722,21 @@ extern "C" int grm_batch_upload(grm_batch *b)
             fill_range(slab, s0, std::min(s1, s0 + piece));
             for (auto &t : pool) t.join();
             if (!io_err.empty()) { cleanup(); return fail(c, GRM_ERR_IO, "%s", io_err.c_str()); }
-            hipError_t e = hipMemcpyAsync(d_raw + s0, slab, (size_t)len, hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess) e = hipEventRecord(done[which], c->stream);
+            hipError_t e = hipMemcpyAsync(d_raw + s0, slab, (size_t)len, hipMemcpyHostToDevice, c->copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(done[which], c->copy_stream);
             if (e != hipSuccess) { cleanup(); return fail(c, GRM_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
             in_flight[which] = true;
         }
-        hipError_t e = hipStreamSynchronize(c->stream);
+        hipError_t e = hipStreamSynchronize(c->copy_stream);
         cleanup();
         if (e != hipSuccess) return fail(c, GRM_ERR_HIP, "upload: %s", hipGetErrorString(e));
     }
     for (auto &f : b->files) std::vector<uint8_t>().swap(f.bytes);
     HIPCHK(c, b->d_tile_meta.alloc(tile_meta.size() + 16));
-    if (!tile_meta.empty()) HIPCHK(c, hipMemcpy(b->d_tile_meta.p, tile_meta.data(), tile_meta.size(), hipMemcpyHostToDevice));
+    if (!tile_meta.empty()) HIPCHK(c, hipMemcpyAsync(b->d_tile_meta.p, tile_meta.data(), tile_meta.size(), hipMemcpyHostToDevice, c->copy_stream));
     HIPCHK(c, b->d_genome_tile_off.alloc((b->n_genomes + 1) * 4));
-    HIPCHK(c, hipMemcpy(b->d_genome_tile_off.p, genome_tile_off.data(), (b->n_genomes + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpyAsync(b->d_genome_tile_off.p, genome_tile_off.data(), (b->n_genomes + 1) * 4, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     b->uploaded = true;
     return GRM_OK;
 }

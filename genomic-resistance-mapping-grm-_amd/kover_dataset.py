@@ -152,21 +152,47 @@ def counted_sets(ctx, files_per_genome, kmer_size, abundance_min, budget_bytes, 
     the byte budget (deep read sets do not fit one batch: 100x coverage = 100x the k-mers)"""
     progress = progress or (lambda m: None)
     sets = [None] * len(files_per_genome)
-    for chunk in plan_chunks(files_per_genome, budget_bytes):
-        if kmer_size > 32:                                  # two-word k-mers: per-genome counting path
+    chunks = plan_chunks(files_per_genome, budget_bytes)
+    if kmer_size > 32:                                      # two-word k-mers: per-genome counting path
+        for chunk in chunks:
             for g in chunk:
                 sets[g] = ctx.count_genome_files(files_per_genome[g], kmer_size, abundance_min)
-            continue
+        return sets
+
+    def load(chunk):
+        """read + assemble + upload one chunk (host threads and the copy stream: it runs beside the
+        device pass of the previous chunk)"""
         b = ctx.batch(len(chunk))
-        for j, g in enumerate(chunk):
-            for f in files_per_genome[g]:
-                b.add_file(j, f)
-        b.upload()
-        b.partition_counts(kmer_size, abundance_min)
-        for j, g in enumerate(chunk):
-            sets[g] = b.genome_set(j)
-        progress("counted genomes %d..%d (%d k-mer occurrences)" % (chunk[0], chunk[-1], b.n_occurrences))
-        b.free()
+        try:
+            for j, g in enumerate(chunk):
+                for f in files_per_genome[g]:
+                    b.add_file(j, f)
+            b.upload()
+        except BaseException:
+            b.free()
+            raise
+        return b
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        nxt = pool.submit(load, chunks[0]) if chunks else None
+        for i, chunk in enumerate(chunks):
+            b = nxt.result()
+            nxt = pool.submit(load, chunks[i + 1]) if i + 1 < len(chunks) else None
+            try:
+                b.partition_counts(kmer_size, abundance_min)
+                for j, g in enumerate(chunk):
+                    sets[g] = b.genome_set(j)
+                progress("counted genomes %d..%d (%d k-mer occurrences)" % (chunk[0], chunk[-1], b.n_occurrences))
+            except BaseException:
+                if nxt is not None:
+                    try:
+                        nxt.result().free()
+                    except Exception:       # noqa: BLE001 - the first error is the one to report
+                        pass
+                raise
+            finally:
+                b.free()
     return sets
 
 
