@@ -50,7 +50,7 @@ def micro_cases():
     # two files for one genome (k-mers must not span files)
     g7 = [fasta([("p1", a[:75])], width=80), fasta([("p2", a[75:])], width=80)]
     genomes = [[g0], [g1], [g2], [g3], [g4], [g5], [g6], g7]
-    for k in (5, 11, 21, 31, 32):
+    for k in (1, 2, 3, 5, 11, 16, 17, 21, 31, 32):
         cases.append(("micro_k%d" % k, k, genomes))
     # low-complexity: heavy duplicates
     poly = fasta([("polyA", "A" * 300), ("at", "AT" * 150), ("mix", "ACG" * 100)], width=80)
