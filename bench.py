@@ -5,8 +5,10 @@ A "step" = one pass of the hot path (FASTA bytes resident in HBM -> packed symbo
 hash-partitioned canonical k-mers -> dictionary -> genome x k-mer presence matrix) over one
 batch of synthetic genomes.  Workload at N=1: BASELINE.json configs[1]
 (1000 x 5 Mbp synthetic contig genomes, k=31, pan-genome mode, singleton filter on).
-N>1: one process per GPU, each with its own 1000-genome shard (weak scaling) and the one
-dictionary all-gather over RCCL between the local-dictionary and fill stages.
+N>1: one process per GPU, each with its own 1000-genome shard (weak scaling: per-GPU work fixed; a
+rank's block is padded to whole word-rows) and the one dictionary all-gather over RCCL between the
+local-dictionary and fill stages.  `--total-genomes T` is the strong-scaling form of BASELINE C3:
+one T-genome set split over the ranks in blocks of whole word-rows.
 
 Prints ONE JSON line on rank 0.
 """
@@ -40,7 +42,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genomes", type=int, default=1000, help="genomes per GPU")
+    ap.add_argument("--genomes", type=int, default=1000, help="genomes per GPU (weak scaling, the default)")
+    ap.add_argument("--total-genomes", type=int, default=0,
+                    help="strong-scaling form (BASELINE C3): ONE set of this many genomes split over the ranks in "
+                         "blocks of whole word-rows (1000 over 8 GPUs = 128,...,104); overrides --genomes")
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("--mode", default="P", choices=["P", "R"])
     ap.add_argument("--k", type=int, default=31)
@@ -82,8 +87,13 @@ def main():
     for kv in args.opt:
         name, val = kv.split("=")
         ctx.set_option(name, int(val))
+    strong = args.total_genomes > 0
+    if strong:
+        base, stop = D.shard_genomes(args.total_genomes, world)[rank]
+        args.genomes = stop - base
+    else:
+        base = rank * args.genomes
     batch = ctx.batch(args.genomes)
-    base = rank * args.genomes
     if args.mode == "P":
         pg = synth.PanGenome(genome_len=args.genome_len, seed=1234)
         gen = lambda i: pg.genome(base + i)
@@ -132,8 +142,13 @@ def main():
         t = torch.tensor([occ], dtype=torch.int64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         occ_total = int(t.item())
+        t = torch.tensor([batch.input_bytes], dtype=torch.int64, device="cpu" if rehearsal else device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        bytes_total = int(t.item())
     else:
         occ_total = occ
+        bytes_total = batch.input_bytes
+    genomes_total = args.total_genomes if strong else args.genomes * world
 
     # ---- per-kernel device times (HIP events on the engine's stream, timed region only) ----
     per = {}
@@ -190,15 +205,16 @@ def main():
             "value": round(value, 1), "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%d x %d bp synthetic contig genomes per GPU (mode %s, seed 1234), k=%d, abundance-min %d, %s"
-                                   % (args.genomes, args.genome_len, args.mode, args.k, args.abundance_min,
+            "config": {"workload": "%s x %d bp synthetic contig genomes (mode %s, seed 1234), k=%d, abundance-min %d, %s"
+                                   % ("%d in total, split in word-row blocks" % args.total_genomes if strong else "%d per GPU" % args.genomes,
+                                      args.genome_len, args.mode, args.k, args.abundance_min,
                                       "singleton filter" if filt else "singletons kept"),
-                       "genomes_total": args.genomes * world, "columns": int(n_cols), "word_rows_per_gpu": int(n_rows),
+                       "genomes_total": genomes_total, "columns": int(n_cols), "word_rows_per_gpu": int(n_rows),
                        "input_bytes_per_gpu": batch.input_bytes, "parallelism": "genome-sharded x%d" % world},
-            "genomes_per_min": round(args.genomes * world * args.steps / elapsed * 60, 1),
-            "bases_per_s": round(batch.input_bytes * world * args.steps / elapsed, 1),
+            "genomes_per_min": round(genomes_total * args.steps / elapsed * 60, 1),
+            "bases_per_s": round(bytes_total * args.steps / elapsed, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
             "setup_s": round(setup_s, 1),
         }

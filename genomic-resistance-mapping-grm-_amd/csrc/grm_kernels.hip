@@ -1444,11 +1444,12 @@ void launch_column_popcount(hipStream_t s, const uint64_t *matrix, uint64_t n_ro
 __global__ void split_pairs_u64_kernel(const uint64_t *__restrict__ pairs, uint64_t n, uint64_t *__restrict__ hi,
                                        uint64_t *__restrict__ lo)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(pairs)[i];
-    hi[i] = v.x;
-    lo[i] = v.y;
+    // grid_for() caps the grid: stride over the rest
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(pairs)[i];
+        hi[i] = v.x;
+        lo[i] = v.y;
+    }
 }
 void launch_split_pairs_u64(hipStream_t s, const uint64_t *pairs, uint64_t n, uint64_t *hi, uint64_t *lo)
 {
@@ -1458,9 +1459,8 @@ void launch_split_pairs_u64(hipStream_t s, const uint64_t *pairs, uint64_t n, ui
 __global__ void join_pairs_u64_kernel(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n,
                                       uint64_t *__restrict__ pairs)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    reinterpret_cast<ulonglong2 *>(pairs)[i] = make_ulonglong2(hi[i], lo[i]);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<ulonglong2 *>(pairs)[i] = make_ulonglong2(hi[i], lo[i]);
 }
 void launch_join_pairs_u64(hipStream_t s, const uint64_t *hi, const uint64_t *lo, uint64_t n, uint64_t *pairs)
 {

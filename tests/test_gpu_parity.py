@@ -420,6 +420,43 @@ def test_two_word_sets_merge(ctx, k):
         ctx.build_matrix([ctx.count_genome(genomes[0], 31, 1), ctx.count_genome(genomes[1], k, 1)], False)
 
 
+def test_two_word_large_dictionaries(ctx):
+    """more than 2^19 two-word dictionary entries / set entries: the helper kernels that split and
+    join (hi, lo) pairs run on a capped grid and must stride over the rest"""
+    import torch
+    k = 41
+    genomes = [[synth.random_genome(i, genome_len=n, seed=77).tobytes()] for i, n in enumerate((600_000, 200_000, 200_000))]
+    genomes.append(genomes[1])                                   # one shared genome: flags 2
+    want = orc.build_matrix(genomes, k, 1, True)
+    allm = orc.build_matrix(genomes, k, 1, False)
+    assert allm["kmers"].shape[0] > (1 << 19)
+    # staged API: export (join) -> set_global_dict (split)
+    b = ctx.batch(len(genomes))
+    for g, files in enumerate(genomes):
+        b.add(g, files[0])
+    b.upload()
+    b.partition(k, 1)
+    n_local = b.local_dict()
+    assert n_local == allm["kmers"].shape[0]
+    keys = torch.empty((n_local, 2), dtype=torch.int64, device="cuda:0")
+    flags = torch.empty(n_local, dtype=torch.uint8, device="cuda:0")
+    b.export_dict(keys.data_ptr(), flags.data_ptr())
+    torch.cuda.synchronize()
+    k_host = keys.cpu().numpy().view(np.uint64)
+    order = np.lexsort((k_host[:, 1], k_host[:, 0]))
+    assert (k_host[order] == allm["kmers"]).all()
+    assert b.set_global_dict(keys.data_ptr(), flags.data_ptr(), n_local, True) == want["kmers"].shape[0]
+    m = b.fill()
+    assert (m.kmers() == want["kmers"]).all() and (m.data() == want["matrix"]).all()
+    m.free(); b.free()
+    # merge of device-resident counted sets (split on the device)
+    sets = [ctx.count_genome(g, k, 1) for g in genomes]
+    assert max(len(s_) for s_ in sets) > (1 << 19)
+    m = ctx.build_matrix(sets, True)
+    assert (m.kmers() == want["kmers"]).all() and (m.data() == want["matrix"]).all()
+    m.free()
+
+
 def test_two_word_medium_both_paths(ctx):
     """300 kbp genomes at k = 63: LDS (span-uniform) paths of the two-word hash pipeline vs the sort path vs oracle"""
     genomes = _medium_genomes(n=6, length=200_000, seed=13)
