@@ -252,7 +252,7 @@ def test_staged_equals_fused(ctx, k):
     b.free()
 
 
-def _rank_worker(rank, world, port, n_genomes, k, q):
+def _rank_worker(rank, world, port, n_genomes, k, genome_len, q):
     """one rank of the sharded path with the REAL engine; both ranks share cuda:0 (gloo, host-staged)"""
     import torch
     import torch.distributed as dist
@@ -261,7 +261,7 @@ def _rank_worker(rank, world, port, n_genomes, k, q):
     S = import_module("genomic-resistance-mapping-grm-_amd.synth")
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
-        pg = S.PanGenome(genome_len=60_000, n_snps=600, n_accessory=6, accessory_len=1500, seed=21, n_contigs=2)
+        pg = S.PanGenome(genome_len=genome_len, n_snps=genome_len // 100, n_accessory=6, accessory_len=1500, seed=21, n_contigs=2)
         a, b_ = D.shard_genomes(n_genomes, world)[rank]
         with grm_amd.Context(0) as c:
             batch = c.batch(b_ - a)
@@ -280,25 +280,26 @@ def _rank_worker(rank, world, port, n_genomes, k, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k", [31, 47])
-def test_two_ranks_real_engine_one_gpu(ctx, k):
+@pytest.mark.parametrize("k,genome_len", [(31, 60_000), (47, 60_000), (31, 1_500_000), (63, 1_500_000)])
+def test_two_ranks_real_engine_one_gpu(ctx, k, genome_len):
     """N>1 path end to end with the HIP engine: 2 processes, genomes sharded 64 + 36, dictionary
-    all-gather, identical global dictionary, rows stacked == single-process oracle matrix"""
+    all-gather, identical global dictionary, rows stacked == single-process oracle matrix
+    (1.5 Mbp genomes: millions of dictionary entries per rank)"""
     import socket
     import torch.multiprocessing as mp
     n_genomes = 100
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_rank_worker, args=(r, 2, port, n_genomes, k, q)) for r in range(2)]
+    procs = [mpc.Process(target=_rank_worker, args=(r, 2, port, n_genomes, k, genome_len, q)) for r in range(2)]
     for p in procs:
         p.start()
     kmers, rows = q.get(timeout=240)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    pg = synth.PanGenome(genome_len=60_000, n_snps=600, n_accessory=6, accessory_len=1500, seed=21, n_contigs=2)
-    want = orc.build_matrix([[pg.genome(g).tobytes()] for g in range(n_genomes)], k, 1, True)
+    pg = synth.PanGenome(genome_len=genome_len, n_snps=genome_len // 100, n_accessory=6, accessory_len=1500, seed=21, n_contigs=2)
+    want = orc.pipeline([pg.genome(g).tobytes() for g in range(n_genomes)], k, 1, True, min(os.cpu_count() or 1, 32))[0]
     assert kmers.shape == want["kmers"].shape and (kmers == want["kmers"]).all()
     assert rows.shape == want["matrix"].shape and (rows == want["matrix"]).all()
 
@@ -572,6 +573,70 @@ def test_scale_properties(ctx):
     both = ((d_all[0] >> np.uint64(63 - 3)) & np.uint64(1)).astype(bool) | ((d_all[0] >> np.uint64(63 - 4)) & np.uint64(1)).astype(bool)
     assert (k_all[both] == sub["kmers"][:, 0]).all()
     m_all.free(); m_f.free(); b.free()
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_all_paths_agree_at_scale(ctx, k, tmp_path):
+    """120 x 1.5 Mbp pan-genome: large enough for millions of dictionary entries and multi-tile regions,
+    small enough for the threaded oracle.  The fused pass must equal the oracle; every other route to
+    the matrix (staged API, counted sets -> merge, forced sub-buckets, probing fill / sort-based
+    two-word path) must equal the fused pass."""
+    import torch
+    n = 120
+    pg = synth.PanGenome(genome_len=1_500_000, n_snps=15000, n_accessory=60, accessory_len=5000, seed=5)
+    arrays = [pg.genome(g) for g in range(n)]
+    want, _, _, occ = orc.pipeline([a.tobytes() for a in arrays], k, 1, True, min(os.cpu_count() or 1, 32))
+    w = 2 if k > 32 else 1
+
+    def batch():
+        b = ctx.batch(n)
+        for g in range(n):
+            b.add_array(g, arrays[g])
+        b.upload()
+        return b
+
+    def same(m, what):
+        assert m.kmers().shape == want["kmers"].shape, what
+        assert (m.kmers() == want["kmers"]).all(), what
+        assert (m.data() == want["matrix"]).all(), what
+        m.free()
+
+    b = batch()
+    m = b.run(k, 1, True)
+    assert b.n_occurrences == occ
+    assert want["kmers"].shape[0] > 1_000_000
+    same(m, "fused")
+    # staged API on one rank
+    b.partition(k, 1)
+    n_local = b.local_dict()
+    keys = torch.empty((max(1, n_local), w), dtype=torch.int64, device="cuda:0")
+    flags = torch.empty(max(1, n_local), dtype=torch.uint8, device="cuda:0")
+    b.export_dict(keys.data_ptr(), flags.data_ptr())
+    torch.cuda.synchronize()
+    b.set_global_dict(keys.data_ptr(), flags.data_ptr(), n_local, True)
+    same(b.fill(), "staged")
+    # forced geometry / alternative kernels
+    alts = [{"sub_bits": 1}, {"bucket_bits": 12}] + ([{"no_slots": 1}] if k <= 32 else [{"wide_sort": 1}])
+    for opts in alts:
+        try:
+            for name, v in opts.items():
+                ctx.set_option(name, v)
+            same(b.run(k, 1, True), str(opts))
+        finally:
+            for name in opts:
+                ctx.set_option(name, -1)
+    b.free()
+    # multidsk -> dsk2kover: counted sets (device-resident), merged
+    if k <= 32:
+        b = batch()
+        b.partition_counts(k, 1)
+        sets = [b.genome_set(g) for g in range(n)]
+        b.free()
+    else:
+        sets = [ctx.count_genome([arrays[g].tobytes()], k, 1) for g in range(0, n)]
+    same(ctx.build_matrix(sets, True), "sets -> merge")
+    for s_ in sets:
+        s_.free()
 
 
 def test_full_size_properties(ctx):
