@@ -262,36 +262,97 @@ def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton
     return n
 
 
-def from_tsv(tsv_path, output_path, phenotype_description, phenotype_metadata_path, gzip):
-    """create.py:119-275: TSV matrix -> Kover HDF5 (pure host code; packs with the MSB-first
-    layout of utils.py:133-156)."""
+def _read_tsv_uniform(tsv_path):
+    """fast path for the layout the reference itself assumes (create.py:127-137: every row
+    `kmer\tV\tV...V\n` of the same byte length, V one binary digit): the body is viewed as a
+    [U][row_len] byte array and sliced -- no per-line Python.  -> (genome_ids, kmers S<k>[U],
+    cells uint8 [U][n] of 0/1) or None when the file does not have that layout."""
+    raw = np.fromfile(tsv_path, dtype=np.uint8)
+    nl = np.flatnonzero(raw[:1 << 22] == 10)
+    if nl.size == 0:
+        return None
+    header = raw[:nl[0]].tobytes().decode().rstrip("\r").split("\t")
+    genome_ids = header[1:]
+    n = len(genome_ids)
+    body = raw[nl[0] + 1:]
+    while body.size and body[-1] == 10 and body.size >= 2 and body[-2] == 10:
+        body = body[:-1]                                   # trailing blank lines
+    if body.size == 0:
+        return genome_ids, np.zeros(0, dtype="S1"), np.zeros((0, n), np.uint8)
+    if body[-1] != 10:
+        body = np.concatenate([body, np.array([10], np.uint8)])
+    first = np.flatnonzero(body[:1 << 22] == 10)
+    if first.size == 0:
+        return None
+    row_len = int(first[0]) + 1
+    klen = row_len - 1 - 2 * n
+    if klen < 1 or body.size % row_len:
+        return None
+    rows = body.reshape(-1, row_len)
+    if not ((rows[:, -1] == 10).all() and (rows[:, klen::2][:, :n] == 9).all()):
+        return None
+    cells = rows[:, klen + 1::2][:, :n] - np.uint8(48)
+    if cells.size and cells.max() > 1:
+        return None
+    kmers = np.ascontiguousarray(rows[:, :klen]).view("S%d" % klen).reshape(-1)
+    return genome_ids, kmers, cells
+
+
+def _read_tsv_lines(tsv_path):
+    """general parser (any row lengths, blank lines, CRLF)"""
     with open(tsv_path) as f:
-        header = f.readline().rstrip("\n").split("\t")
+        header = f.readline().rstrip("\r\n").split("\t")
         genome_ids = header[1:]
         kmers, cols = [], []
         for line in f:
             if not line.strip():
                 continue
-            cells = line.rstrip("\n").split("\t")
+            cells = line.rstrip("\r\n").split("\t")
             kmers.append(cells[0].encode())
             cols.append(np.array(cells[1:], dtype=np.uint8))
+    klen = len(kmers[0]) if kmers else 1
+    cells = np.array(cols, dtype=np.uint8) if cols else np.zeros((0, len(genome_ids)), np.uint8)
+    return genome_ids, np.array(kmers, dtype="S%d" % klen), cells
+
+
+def pack_cells(cells, order):
+    """cells uint8 [U][n] (k-mer major, as a TSV stores them), order = genome row permutation ->
+    uint64 [ceil(len(order)/64)][U], genome i of `order` at word-row i//64, bit 63 - i%64
+    (utils.py:133-156), built block-wise without a [n][U] dense intermediate"""
+    U, rows = cells.shape[0], (len(order) + 63) // 64
+    out = np.zeros((rows, U), dtype=np.uint64)
+    idx = np.asarray(order, dtype=np.int64)
+    for a in range(0, U, 1 << 20):
+        blk = cells[a:a + (1 << 20)][:, idx]                                     # [u][n'] in output row order
+        pad = rows * 64 - blk.shape[1]
+        if pad:
+            blk = np.concatenate([blk, np.zeros((blk.shape[0], pad), np.uint8)], axis=1)
+        by = np.packbits(blk, axis=1, bitorder="big")                            # first genome = most significant bit
+        out[:, a:a + blk.shape[0]] = by.view(">u8").astype(np.uint64).T
+    return out
+
+
+def from_tsv(tsv_path, output_path, phenotype_description, phenotype_metadata_path, gzip):
+    """create.py:119-275: TSV matrix -> Kover HDF5 (pure host code; packs with the MSB-first
+    layout of utils.py:133-156)."""
+    if (phenotype_description is None) != (phenotype_metadata_path is None):
+        raise KoverError("If a phenotype is specified, it must have a description and a metadata file.")
+    parsed = _read_tsv_uniform(tsv_path) or _read_tsv_lines(tsv_path)
+    genome_ids, kmers, cells = parsed
     if len(set(genome_ids)) < len(genome_ids):
         raise KoverError("The genomic data contains genomes with the same identifier.")
-    dense = np.array(cols, dtype=np.uint8).T if cols else np.zeros((len(genome_ids), 0), np.uint8)   # [genome][kmer]
     labels = tags = ctype = None
     ids = genome_ids
     if phenotype_description is not None:
         ids, labels, tags, ctype = parse_metadata(phenotype_metadata_path, genome_ids)
         ids, labels = label_sorted(ids, labels)
     row_of = {g: i for i, g in enumerate(genome_ids)}
-    dense = dense[[row_of[g] for g in ids]] if ids else dense
-    packed = pack_rows(dense)
+    packed = pack_cells(cells, [row_of[g] for g in ids])
     tmp = output_path + ".tmp"
     write_header(tmp, "tsv", tsv_path, phenotype_description, phenotype_metadata_path, gzip, ids, labels, tags, ctype)
     U = len(kmers)
     with h5lite.File(tmp, "r+") as f:
-        klen = len(kmers[0]) if kmers else 1
-        f.create_dataset("kmer_sequences", np.array(kmers, dtype="S%d" % klen), gzip=gzip)
+        f.create_dataset("kmer_sequences", kmers if U else np.zeros(0, dtype="S1"), gzip=gzip)
         f.create_dataset("kmer_matrix", packed, gzip=gzip, chunks=(1, max(1, min(U, BLOCK_SIZE))))
         f.create_dataset("kmer_by_matrix_column", np.arange(U, dtype=minimum_uint(U)), gzip=gzip)
     os.replace(tmp, output_path)

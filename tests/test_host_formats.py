@@ -143,6 +143,40 @@ def test_tsv_writer_and_from_tsv_roundtrip(kd, small_matrix, tmp_path):
     m.free()
 
 
+def test_from_tsv_parsers_agree(kd, tmp_path):
+    """the sliced fast path (uniform rows, what create.py:127-137 assumes) and the line parser give
+    the same arrays; irregular files (CRLF, blank lines, no final newline) fall back to the latter;
+    pack_cells == pack_rows (utils.py:133-156 layout) with a row permutation and > 64 genomes"""
+    rng = np.random.RandomState(4)
+    n, U, k = 70, 500, 9
+    cells = (rng.rand(U, n) < 0.4).astype(np.uint8)
+    kmers = ["".join(rng.choice(list("ACGT"), size=k)) for _ in range(U)]
+    ids = ["g%02d" % i for i in range(n)]
+    lines = ["kmers\t" + "\t".join(ids)] + [kmers[i] + "\t" + "\t".join(map(str, cells[i])) for i in range(U)]
+    uni = tmp_path / "u.tsv"
+    uni.write_text("\n".join(lines) + "\n")
+    fast = kd._read_tsv_uniform(str(uni))
+    slow = kd._read_tsv_lines(str(uni))
+    assert fast is not None
+    for a, b in zip(fast, slow):
+        assert (np.asarray(a) == np.asarray(b)).all()
+    assert fast[0] == ids and fast[1][3] == kmers[3].encode() and (fast[2] == cells).all()
+    for text in ("\r\n".join(lines) + "\r\n", "\n".join(lines[:5] + [""] + lines[5:]) + "\n",
+                 "\n".join(lines[:-1] + [lines[-1][:-2]]) + "\n"):
+        odd = tmp_path / "odd.tsv"
+        odd.write_bytes(text.encode())
+        assert kd._read_tsv_uniform(str(odd)) is None
+    odd.write_bytes(("\r\n".join(lines)).encode())                      # CRLF, no final newline
+    g2, k2, c2 = kd._read_tsv_lines(str(odd))
+    assert g2 == ids and (c2 == cells).all() and k2[-1] == kmers[-1].encode()
+    nofinal = tmp_path / "nf.tsv"
+    nofinal.write_text("\n".join(lines))                                 # uniform but unterminated last row
+    assert (kd._read_tsv_uniform(str(nofinal))[2] == cells).all()
+    perm = rng.permutation(n)[:67]
+    assert (kd.pack_cells(cells, perm) == kd.pack_rows(cells.T[perm])).all()
+    assert kd.pack_cells(cells[:0], perm).shape == (2, 0)
+
+
 def test_genome_list_and_contig_tree(kd, tmp_path):
     """create.py:302 list parsing; src/kover.py:40-49 table of contigs/<genome name>/*.fna"""
     tree = tmp_path / "contigs" / "Escherichia coli"
