@@ -64,6 +64,12 @@ PROTOTYPES = [
     ("grm_batch_export_dict", C.c_int, [_P, _P, _P]),
     ("grm_batch_set_global_dict", C.c_int, [_P, _P, _P, C.c_uint64, C.c_int, _U64P]),
     ("grm_batch_fill", C.c_int, [_P, _PP]),
+    ("grm_dict_accum_create", C.c_int, [_P, _PP]),
+    ("grm_dict_accum_add", C.c_int, [_P, _P]),
+    ("grm_dict_accum_size", C.c_uint64, [_P]),
+    ("grm_dict_accum_free", None, [_P]),
+    ("grm_batch_set_global_dict_accum", C.c_int, [_P, _P, C.c_int, _U64P]),
+    ("grm_matrix_stack_rows", C.c_int, [_PP, C.c_int, _PP]),
     ("grm_batch_n_symbols", C.c_uint64, [_P]),
     ("grm_batch_n_occurrences", C.c_uint64, [_P]),
     ("grm_batch_input_bytes", C.c_uint64, [_P]),

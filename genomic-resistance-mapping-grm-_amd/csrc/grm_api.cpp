@@ -81,6 +81,50 @@ static int fail(grm_ctx *c, int code, const char *fmt, ...)
                         hipGetErrorString(e_), __FILE__, __LINE__);                               \
     } while (0)
 
+// Device allocations are recycled inside the process: hipFree / hipMalloc of the multi-GB working set
+// of a batch cost seconds (measured 4 s per 1000-genome chunk of a chunked run), far more than the
+// kernels that use it.  Released blocks of >= 1 MiB are parked here and handed to the next request
+// they fit (best fit, at most 2x larger); the pool is emptied by grm_destroy and whenever hipMalloc fails.
+struct DevPool {
+    struct Block { void *p; size_t bytes; int device; };
+    std::mutex mu;
+    std::vector<Block> blocks;
+    void *take(size_t n, size_t *got)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); i++)
+            if (blocks[i].device == dev && blocks[i].bytes >= n && blocks[i].bytes <= 2 * n &&
+                (best == blocks.size() || blocks[i].bytes < blocks[best].bytes)) best = i;
+        if (best == blocks.size()) return nullptr;
+        void *p = blocks[best].p;
+        *got = blocks[best].bytes;
+        blocks.erase(blocks.begin() + (long)best);
+        return p;
+    }
+    bool give(void *p, size_t bytes)
+    {
+        if (bytes < ((size_t)1 << 20)) return false;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        std::lock_guard<std::mutex> g(mu);
+        blocks.push_back({p, bytes, dev});
+        return true;
+    }
+    void trim()
+    {
+        std::vector<Block> all;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            all.swap(blocks);
+        }
+        for (auto &b : all) (void)hipFree(b.p);
+    }
+};
+static DevPool g_pool;
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -90,7 +134,7 @@ struct DevBuf {
     ~DevBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && !g_pool.give(p, bytes)) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
     }
@@ -98,7 +142,14 @@ struct DevBuf {
     {
         release();
         if (n == 0) n = 16;
+        size_t got = 0;
+        if (void *q = g_pool.take(n, &got)) { p = q; bytes = got; return hipSuccess; }
         hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {              // make room: give back everything that is parked, try once more
+            (void)hipGetLastError();
+            g_pool.trim();
+            e = hipMalloc(&p, n);
+        }
         if (e == hipSuccess) bytes = n;
         else p = nullptr;
         return e;
@@ -163,6 +214,7 @@ extern "C" void grm_destroy(grm_ctx *c)
     for (auto &r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    g_pool.trim();
     delete c;
 }
 
@@ -1206,6 +1258,117 @@ extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
         if (e3 != hipSuccess) rc = fail(c, GRM_ERR_HIP, "dictionary copy: %s", hipGetErrorString(e3));
     }
     if (rc != GRM_OK) { delete m; return rc; }
+    *out = m;
+    return GRM_OK;
+}
+
+// ---- inputs larger than one device batch: two passes over chunks of genomes -------------------
+// Pass 1 pushes every chunk through partition + local dictionary and keeps only (key, flag) of its
+// distinct k-mers in an accumulator; pass 2 pushes the chunks through again, hands the accumulated
+// entries to grm_batch_set_global_dict (a k-mer seen in several chunks is a run of equal keys: one
+// column carried by several genomes -- the multi-GPU merge, applied over time instead of over ranks)
+// and fills that chunk's word-rows.  grm_matrix_stack_rows puts the row blocks together.
+struct grm_dict_accum {
+    grm_ctx *ctx = nullptr;
+    int words = 0;                 // 0 until the first batch is added
+    uint64_t n = 0, cap = 0;
+    DevBuf keys, flags;
+};
+
+extern "C" int grm_dict_accum_create(grm_ctx *c, grm_dict_accum **out)
+{
+    if (!c) return GRM_ERR_NO_DEVICE;
+    if (!out) return fail(c, GRM_ERR_ARG, "grm_dict_accum_create: NULL out");
+    grm_dict_accum *a = new grm_dict_accum();
+    a->ctx = c;
+    *out = a;
+    return GRM_OK;
+}
+extern "C" void grm_dict_accum_free(grm_dict_accum *a)
+{
+    if (!a) return;
+    (void)hipSetDevice(a->ctx->device);
+    delete a;
+}
+extern "C" uint64_t grm_dict_accum_size(const grm_dict_accum *a) { return a ? a->n : 0; }
+
+// appends the local dictionary of `b` (grm_batch_local_dict must have run)
+extern "C" int grm_dict_accum_add(grm_dict_accum *a, grm_batch *b)
+{
+    if (!a || !b) return GRM_ERR_ARG;
+    grm_ctx *c = a->ctx;
+    if (b->ctx != c) return fail(c, GRM_ERR_ARG, "grm_dict_accum_add: batch of another context");
+    if (!b->have_local) return fail(c, GRM_ERR_STATE, "grm_dict_accum_add before grm_batch_local_dict");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int words = b->k > 32 ? 2 : 1;
+    if (a->words && a->words != words) return fail(c, GRM_ERR_ARG, "grm_dict_accum_add: batches with different k");
+    a->words = words;
+    const uint64_t add = b->n_local, need = a->n + add;
+    if (need > a->cap) {                                   // grow geometrically, keep what is there
+        const uint64_t cap = std::max<uint64_t>(need + need / 2, 1u << 20);
+        DevBuf nk, nf;
+        HIPCHK(c, nk.alloc(cap * 8 * (size_t)words));
+        HIPCHK(c, nf.alloc(cap));
+        if (a->n) {
+            HIPCHK(c, hipMemcpyAsync(nk.p, a->keys.p, a->n * 8 * (size_t)words, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(nf.p, a->flags.p, a->n, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        std::swap(a->keys.p, nk.p); std::swap(a->keys.bytes, nk.bytes);
+        std::swap(a->flags.p, nf.p); std::swap(a->flags.bytes, nf.bytes);
+        a->cap = cap;
+    }
+    if (add) {
+        int rc = grm_batch_export_dict(b, a->keys.as<uint8_t>() + a->n * 8 * (size_t)words, a->flags.as<uint8_t>() + a->n);
+        if (rc) return rc;
+    }
+    a->n = need;
+    return GRM_OK;
+}
+
+extern "C" int grm_batch_set_global_dict_accum(grm_batch *b, const grm_dict_accum *a, int filter_singleton, uint64_t *n_kmers)
+{
+    if (!b || !a) return GRM_ERR_ARG;
+    if (a->words && a->words != (b->k > 32 ? 2 : 1)) return fail(b->ctx, GRM_ERR_ARG, "accumulator holds k-mers of another width");
+    return grm_batch_set_global_dict(b, a->keys.p, a->flags.p, a->n, filter_singleton, n_kmers);
+}
+
+// parts[i]: word-rows of consecutive genome blocks against the SAME dictionary; every part but the last
+// must hold a multiple of 64 genomes.  -> one matrix, rows stacked.
+extern "C" int grm_matrix_stack_rows(grm_matrix *const *parts, int n_parts, grm_matrix **out)
+{
+    if (!parts || n_parts < 1 || !out || !parts[0]) return GRM_ERR_ARG;
+    grm_ctx *c = parts[0]->ctx;
+    if (!c) return GRM_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t U = parts[0]->n_kmers;
+    size_t rows = 0;
+    long genomes = 0;
+    for (int i = 0; i < n_parts; i++) {
+        const grm_matrix *p = parts[i];
+        if (!p || p->ctx != c || p->n_kmers != U || p->k != parts[0]->k || p->words != parts[0]->words)
+            return fail(c, GRM_ERR_ARG, "grm_matrix_stack_rows: part %d does not share the dictionary of part 0", i);
+        if (i + 1 < n_parts && p->n_genomes % 64) return fail(c, GRM_ERR_ARG, "grm_matrix_stack_rows: part %d holds %d genomes (not a multiple of 64)", i, p->n_genomes);
+        rows += p->n_rows;
+        genomes += p->n_genomes;
+    }
+    grm_matrix *m = new grm_matrix();
+    m->ctx = c; m->k = parts[0]->k; m->words = parts[0]->words;
+    m->n_genomes = (int)genomes; m->n_rows = rows; m->n_kmers = U;
+    if (m->d_data.alloc(rows * U * 8) != hipSuccess || m->d_kmers.alloc((U + 2) * 8 * (size_t)m->words) != hipSuccess) {
+        delete m;
+        return fail(c, GRM_ERR_OOM, "grm_matrix_stack_rows: matrix allocation failed (%zu x %zu)", rows, U);
+    }
+    size_t r0 = 0;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n_parts && e == hipSuccess; i++) {
+        if (parts[i]->n_rows && U)
+            e = hipMemcpyAsync(m->d_data.as<uint64_t>() + r0 * U, parts[i]->d_data.p, parts[i]->n_rows * U * 8, hipMemcpyDeviceToDevice, c->stream);
+        r0 += parts[i]->n_rows;
+    }
+    if (e == hipSuccess && U) e = hipMemcpyAsync(m->d_kmers.p, parts[0]->d_kmers.p, U * 8 * (size_t)m->words, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { delete m; return fail(c, GRM_ERR_HIP, "grm_matrix_stack_rows: %s", hipGetErrorString(e)); }
     *out = m;
     return GRM_OK;
 }

@@ -91,6 +91,19 @@ class Context:
         self._chk(self.L.grm_kmer_set_from_host(self.h, kmers.ctypes.data, counts.ctypes.data, len(counts), k, C.byref(h)))
         return KmerSet(self, h)
 
+    # ---- inputs beyond one device batch: dictionary accumulator + row stacking ----
+    def dict_accum(self):
+        h = C.c_void_p()
+        self._chk(self.L.grm_dict_accum_create(self.h, C.byref(h)))
+        return DictAccum(self, h)
+
+    def stack_rows(self, parts):
+        """parts: Matrix objects of consecutive genome blocks against the same dictionary"""
+        arr = (C.c_void_p * max(1, len(parts)))(*[m.h for m in parts])
+        h = C.c_void_p()
+        self._chk(self.L.grm_matrix_stack_rows(arr, len(parts), C.byref(h)))
+        return Matrix(self, h)
+
     # ---- dsk2kover: N sets -> dictionary + presence matrix ----
     def build_matrix(self, sets, filter_singleton=False):
         n = len(sets)
@@ -224,6 +237,25 @@ class Matrix:
             pass
 
 
+class DictAccum:
+    """(k-mer, flag) entries of the local dictionaries of a sequence of batches (pass 1 of the
+    two-pass build for inputs that do not fit HBM at once)"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def add(self, batch):
+        self.ctx._chk(self.ctx.L.grm_dict_accum_add(self.h, batch.h))
+
+    def __len__(self):
+        return int(self.ctx.L.grm_dict_accum_size(self.h))
+
+    def free(self):
+        if self.h:
+            self.ctx.L.grm_dict_accum_free(self.h)
+            self.h = None
+
+
 class Batch:
     """device-resident batch of genomes: parse -> partition -> dictionary -> presence bits"""
 
@@ -277,6 +309,11 @@ class Batch:
     def set_global_dict(self, dev_keys_ptr, dev_flags_ptr, n, filter_singleton):
         u = C.c_uint64()
         self.ctx._chk(self.ctx.L.grm_batch_set_global_dict(self.h, dev_keys_ptr, dev_flags_ptr, n, 1 if filter_singleton else 0, C.byref(u)))
+        return int(u.value)
+
+    def set_global_dict_accum(self, accum, filter_singleton):
+        u = C.c_uint64()
+        self.ctx._chk(self.ctx.L.grm_batch_set_global_dict_accum(self.h, accum.h, 1 if filter_singleton else 0, C.byref(u)))
         return int(u.value)
 
     def fill(self):

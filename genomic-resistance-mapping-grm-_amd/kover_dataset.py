@@ -131,9 +131,11 @@ def _input_bytes(path):
     return n * 4 if path.endswith(".gz") else n        # rough inflate factor for FASTA/FASTQ text
 
 
-def plan_chunks(files_per_genome, budget_bytes):
+def plan_chunks(files_per_genome, budget_bytes, multiple=1):
     """greedy consecutive chunks of genomes whose (estimated, inflated) input stays under the
-    budget; a genome larger than the budget gets a chunk of its own"""
+    budget; a genome larger than the budget gets a chunk of its own.  multiple = 64: every chunk but
+    the last holds a multiple of 64 genomes (whole word-rows, for grm_matrix_stack_rows); None when
+    the budget cannot hold 64 genomes."""
     chunks, cur, cur_bytes = [], [], 0
     for g, files in enumerate(files_per_genome):
         b = sum(_input_bytes(f) for f in files)
@@ -144,6 +146,12 @@ def plan_chunks(files_per_genome, budget_bytes):
         cur_bytes += b
     if cur:
         chunks.append(cur)
+    if multiple > 1 and len(chunks) > 1:
+        flat = [g for c in chunks for g in c]
+        per = (min(len(c) for c in chunks[:-1]) // multiple) * multiple
+        if per == 0:
+            return None
+        chunks = [flat[a:a + per] for a in range(0, len(flat), per)]
     return chunks
 
 
@@ -196,6 +204,65 @@ def counted_sets(ctx, files_per_genome, kmer_size, abundance_min, budget_bytes, 
     return sets
 
 
+def two_pass_matrix(ctx, files_per_genome, chunks, kmer_size, abundance_min, filter_singleton, progress=None):
+    """presence matrix of more genomes than HBM holds at once: pass 1 collects every chunk's local
+    dictionary in a device accumulator, pass 2 fills every chunk's word-rows against the merged
+    dictionary, the row blocks are stacked.  The input is read and uploaded twice (the device pass
+    is a small part of a chunk's time and the next chunk loads beside it)."""
+    progress = progress or (lambda m: None)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def load(chunk):
+        b = ctx.batch(len(chunk))
+        try:
+            for j, g in enumerate(chunk):
+                for f in files_per_genome[g]:
+                    b.add_file(j, f)
+            b.upload()
+        except BaseException:
+            b.free()
+            raise
+        return b
+
+    def chunks_loaded(pool):
+        nxt = pool.submit(load, chunks[0])
+        for i in range(len(chunks)):
+            b = nxt.result()
+            nxt = pool.submit(load, chunks[i + 1]) if i + 1 < len(chunks) else None
+            try:
+                yield i, b
+            except GeneratorExit:
+                if nxt is not None:
+                    nxt.result().free()
+                raise
+            finally:
+                b.free()
+
+    acc = ctx.dict_accum()
+    parts = []
+    try:
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            occ = 0
+            for i, b in chunks_loaded(pool):
+                b.partition(kmer_size, abundance_min)
+                b.local_dict()
+                acc.add(b)
+                occ += b.n_occurrences
+                progress("pass 1: genomes %d..%d, %d dictionary candidates so far" % (chunks[i][0], chunks[i][-1], len(acc)))
+            for i, b in chunks_loaded(pool):
+                b.partition(kmer_size, abundance_min)
+                b.local_dict()
+                n = b.set_global_dict_accum(acc, filter_singleton)
+                parts.append(b.fill())
+                progress("pass 2: genomes %d..%d filled against %d k-mers" % (chunks[i][0], chunks[i][-1], n))
+        m = ctx.stack_rows(parts)
+        return m, occ
+    finally:
+        for p in parts:
+            p.free()
+        acc.free()
+
+
 DEFAULT_BATCH_BYTES = int(os.environ.get("GRM_BATCH_BYTES", str(6 * 10**9)))
 
 
@@ -229,7 +296,7 @@ def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton
             fl = [p]
         files_per_genome.append(fl)
     total = sum(_input_bytes(f) for fl in files_per_genome for f in fl)
-    if total <= DEFAULT_BATCH_BYTES and abundance_min <= 1 and kmer_size <= 32:
+    if total <= DEFAULT_BATCH_BYTES:
         batch = ctx.batch(len(ids))                 # everything resident at once: fused pass
         for g, fl in enumerate(files_per_genome):
             for f in fl:
@@ -240,19 +307,17 @@ def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton
         m = batch.run(kmer_size, abundance_min, bool(filter_singleton))
         progress("device pass done: %d k-mer occurrences" % batch.n_occurrences)
         batch.free()
-    elif kmer_size > 32 and total <= DEFAULT_BATCH_BYTES:
-        batch = ctx.batch(len(ids))
-        for g, fl in enumerate(files_per_genome):
-            for f in fl:
-                batch.add_file(g, f)
-        batch.upload()
-        m = batch.run(kmer_size, abundance_min, bool(filter_singleton))
-        batch.free()
-    else:                                           # the reference's own two steps: multidsk, then dsk2kover
-        sets = counted_sets(ctx, files_per_genome, kmer_size, abundance_min, DEFAULT_BATCH_BYTES, progress)
-        m = ctx.build_matrix(sets, bool(filter_singleton))
-        for s_ in sets:
-            s_.free()
+    else:
+        rows_chunks = plan_chunks(files_per_genome, DEFAULT_BATCH_BYTES, multiple=KMER_MATRIX_PACKING_SIZE)
+        if rows_chunks is not None and (abundance_min <= 1 or kmer_size <= 32):
+            # contig sets beyond one device batch: two passes over chunks of whole word-rows
+            progress("%d genomes in %d chunks, two passes" % (len(ids), len(rows_chunks)))
+            m, _ = two_pass_matrix(ctx, files_per_genome, rows_chunks, kmer_size, abundance_min, bool(filter_singleton), progress)
+        else:                                       # deep read sets: the reference's own two steps, multidsk then dsk2kover
+            sets = counted_sets(ctx, files_per_genome, kmer_size, abundance_min, DEFAULT_BATCH_BYTES, progress)
+            m = ctx.build_matrix(sets, bool(filter_singleton))
+            for s_ in sets:
+                s_.free()
     progress("dictionary: %d k-mers; writing HDF5 (gzip %d)" % (m.n_kmers, gzip))
     m.write_kover_h5(tmp, gzip, BLOCK_SIZE)
     progress("HDF5 written")

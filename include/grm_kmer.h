@@ -142,6 +142,20 @@ int  grm_batch_export_dict(grm_batch *, void *dev_keys_out, void *dev_flags_out)
 int  grm_batch_set_global_dict(grm_batch *, const void *dev_keys, const void *dev_flags, uint64_t n,
                                int filter_singleton, uint64_t *n_kmers);
 int  grm_batch_fill(grm_batch *, grm_matrix **out);
+/* Inputs larger than one device batch (thousands of genomes): two passes over chunks of genomes.
+ * Pass 1, per chunk: upload, grm_batch_partition, grm_batch_local_dict, grm_dict_accum_add, free.
+ * Pass 2, per chunk: upload, partition, local_dict, grm_batch_set_global_dict_accum, grm_batch_fill.
+ * A k-mer seen in several chunks is merged like a k-mer seen on several GPUs; grm_matrix_stack_rows
+ * puts the chunks' word-rows together (every chunk but the last: a multiple of 64 genomes).
+ * Replaces the multidsk -> dsk2kover hand-over through per-genome files for contig inputs
+ * (dataset/create.py:365-390) when they do not fit HBM at once. */
+typedef struct grm_dict_accum grm_dict_accum;
+int      grm_dict_accum_create(grm_ctx *, grm_dict_accum **out);
+int      grm_dict_accum_add(grm_dict_accum *, grm_batch *);
+uint64_t grm_dict_accum_size(const grm_dict_accum *);
+void     grm_dict_accum_free(grm_dict_accum *);
+int      grm_batch_set_global_dict_accum(grm_batch *, const grm_dict_accum *, int filter_singleton, uint64_t *n_kmers);
+int      grm_matrix_stack_rows(grm_matrix *const *parts, int n_parts, grm_matrix **out);
 /* statistics of the last partition */
 uint64_t grm_batch_n_symbols(const grm_batch *);
 uint64_t grm_batch_n_occurrences(const grm_batch *);     /* valid k-mer windows */

@@ -149,6 +149,36 @@ def test_kover_create_from_contig_tree(genomes, tmp_path):
     os.remove(tsv)
 
 
+@pytest.mark.parametrize("k,filt", [(31, True), (47, False)])
+def test_kover_create_two_pass_chunks(tmp_path, k, filt):
+    """contig sets beyond the device budget: two passes over chunks of 64 genomes (dictionary
+    accumulator, row stacking); 150 genomes with a budget of ~70 genome files -> chunks 64, 64, 22"""
+    import grm_amd  # noqa: F401
+    kd = import_module(PKG + ".kover_dataset")
+    synth = import_module(PKG + ".synth")
+    pg = synth.PanGenome(genome_len=20_000, n_snps=300, n_accessory=10, accessory_len=700, seed=11, n_contigs=2)
+    n = 150
+    ids, paths = [], []
+    for g in range(n):
+        p = tmp_path / ("%04d.fna" % g)
+        pg.genome(g).tofile(str(p))
+        ids.append("%04d" % g)
+        paths.append(str(p))
+    size = os.path.getsize(paths[0])
+    data = str(tmp_path / "paths.tsv")
+    open(data, "w").writelines("%s\t%s\n" % (i, p) for i, p in zip(ids, paths))
+    out = str(tmp_path / "BIG.kover")
+    r = _run([os.path.join(CLI, "kover"), "dataset", "create", "from-contigs", "--genomic-data", data, "--output", out,
+              "--kmer-size", str(k), "--compression", "1", "-x"] + ([] if filt else ["--singleton-kmers"]),
+             env={"GRM_BATCH_BYTES": str(size * 70)})
+    assert "two passes" in r.stdout and "3 chunks" in r.stdout, r.stdout
+    rd = kd.KoverDatasetReader(out)
+    assert rd.genome_identifiers == ids
+    want = orc.build_matrix([[open(p, "rb").read()] for p in paths], k, 1, filt)
+    assert rd.kmer_sequences == orc.decode_kmers(want["kmers"], k)
+    assert (rd.kmer_matrix == want["matrix"]).all()
+
+
 def test_kover_create_from_reads_chunked(tmp_path):
     """from-reads (create.py:399-523): a directory of FASTQ files per genome, k=21, abundance-min 2;
     a tiny byte budget forces the multidsk-style chunked counting + dsk2kover-style merge"""

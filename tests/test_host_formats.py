@@ -248,6 +248,12 @@ def test_chunk_plan(kd, tmp_path):
     assert kd.plan_chunks(files, 400) == [[0, 1], [2], [3], [4, 5], [6]]
     assert kd.plan_chunks(files, 10**9) == [list(range(7))]
     assert kd.plan_chunks([], 10) == []
+    # whole word-rows per chunk (two-pass build): every chunk but the last a multiple of 64 genomes
+    many = [[str(tmp_path / "g0.fna")]] * 300                      # 100 bytes each
+    assert kd.plan_chunks(many, 10**9, multiple=64) == [list(range(300))]
+    c = kd.plan_chunks(many, 100 * 150, multiple=64)               # 150 genomes fit -> 128 per chunk
+    assert [len(x) for x in c] == [128, 128, 44] and [g for x in c for g in x] == list(range(300))
+    assert kd.plan_chunks(many, 100 * 63, multiple=64) is None     # the budget cannot hold one word-row
 
 
 def test_split_risk_tables_and_file_layout(kd, small_matrix, tmp_path):
