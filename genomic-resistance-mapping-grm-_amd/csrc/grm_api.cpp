@@ -427,13 +427,14 @@ extern "C" void grm_matrix_free(grm_matrix *m)
 extern "C" int grm_matrix_from_host(const uint64_t *kmers, const uint64_t *data, size_t n_kmers, int n_genomes, int k,
                                     grm_matrix **out)
 {
-    if (!out || n_genomes < 0 || k < 1 || k > 32 || (n_kmers && (!kmers || (n_genomes && !data)))) return GRM_ERR_ARG;
+    if (!out || n_genomes < 0 || k < 1 || k > 64 || (n_kmers && (!kmers || (n_genomes && !data)))) return GRM_ERR_ARG;
     grm_matrix *m = new grm_matrix();
     m->k = k;
+    m->words = k > 32 ? 2 : 1;                      // kmers: n_kmers * words, most significant word first
     m->n_genomes = n_genomes;
     m->n_rows = ((size_t)n_genomes + 63) / 64;
     m->n_kmers = n_kmers;
-    m->h_kmers.assign(kmers, kmers + n_kmers);
+    m->h_kmers.assign(kmers, kmers + n_kmers * (size_t)m->words);
     m->h_kmers.push_back(0);
     m->h_data.assign(data, data + n_kmers * m->n_rows);
     m->h_data.push_back(0);

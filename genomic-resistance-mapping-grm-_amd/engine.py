@@ -362,7 +362,8 @@ class HostMatrix(Matrix):
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1)
         data = np.ascontiguousarray(data, dtype=np.uint64)
         h = C.c_void_p()
-        rc = L.grm_matrix_from_host(kmers.ctypes.data, data.ctypes.data, kmers.size, n_genomes, k, C.byref(h))
+        words = 2 if k > 32 else 1                 # two words per k-mer (most significant first) for 33 <= k <= 64
+        rc = L.grm_matrix_from_host(kmers.ctypes.data, data.ctypes.data, kmers.size // words, n_genomes, k, C.byref(h))
         if rc:
             raise GrmError(rc, "grm_matrix_from_host")
         self.ctx, self.h = HostMatrix._NoCtx(L), h

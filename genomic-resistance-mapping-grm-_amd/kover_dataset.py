@@ -266,6 +266,36 @@ def two_pass_matrix(ctx, files_per_genome, chunks, kmer_size, abundance_min, fil
 DEFAULT_BATCH_BYTES = int(os.environ.get("GRM_BATCH_BYTES", str(6 * 10**9)))
 
 
+def matrix_of_files(ctx, files_per_genome, kmer_size, abundance_min, filter_singleton, progress=None):
+    """genome x k-mer presence matrix of file sets, by the cheapest route that fits the device:
+    one fused pass, two passes over chunks of whole word-rows, or counted sets then merge"""
+    progress = progress or (lambda m: None)
+    total = sum(_input_bytes(f) for fl in files_per_genome for f in fl)
+    if total <= DEFAULT_BATCH_BYTES:
+        batch = ctx.batch(len(files_per_genome))    # everything resident at once: fused pass
+        for g, fl in enumerate(files_per_genome):
+            for f in fl:
+                batch.add_file(g, f)
+        progress("read %d files (%.2f GB)" % (sum(len(fl) for fl in files_per_genome), total / 1e9))
+        batch.upload()
+        progress("uploaded")
+        m = batch.run(kmer_size, abundance_min, filter_singleton)
+        progress("device pass done: %d k-mer occurrences" % batch.n_occurrences)
+        batch.free()
+        return m
+    rows_chunks = plan_chunks(files_per_genome, DEFAULT_BATCH_BYTES, multiple=KMER_MATRIX_PACKING_SIZE)
+    if rows_chunks is not None and (abundance_min <= 1 or kmer_size <= 32):
+        # contig sets beyond one device batch: two passes over chunks of whole word-rows
+        progress("%d genomes in %d chunks, two passes" % (len(files_per_genome), len(rows_chunks)))
+        return two_pass_matrix(ctx, files_per_genome, rows_chunks, kmer_size, abundance_min, filter_singleton, progress)[0]
+    # deep read sets: the reference's own two steps, multidsk then dsk2kover
+    sets = counted_sets(ctx, files_per_genome, kmer_size, abundance_min, DEFAULT_BATCH_BYTES, progress)
+    m = ctx.build_matrix(sets, filter_singleton)
+    for s_ in sets:
+        s_.free()
+    return m
+
+
 def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton, phenotype_description,
                  phenotype_metadata_path, gzip, progress=None, abundance_min=1, source_type="contigs"):
     """create.py:278-396 with the two tool calls replaced by one fused engine pass."""
@@ -295,29 +325,7 @@ def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton
         else:
             fl = [p]
         files_per_genome.append(fl)
-    total = sum(_input_bytes(f) for fl in files_per_genome for f in fl)
-    if total <= DEFAULT_BATCH_BYTES:
-        batch = ctx.batch(len(ids))                 # everything resident at once: fused pass
-        for g, fl in enumerate(files_per_genome):
-            for f in fl:
-                batch.add_file(g, f)
-        progress("read %d files (%.2f GB)" % (sum(len(fl) for fl in files_per_genome), total / 1e9))
-        batch.upload()
-        progress("uploaded")
-        m = batch.run(kmer_size, abundance_min, bool(filter_singleton))
-        progress("device pass done: %d k-mer occurrences" % batch.n_occurrences)
-        batch.free()
-    else:
-        rows_chunks = plan_chunks(files_per_genome, DEFAULT_BATCH_BYTES, multiple=KMER_MATRIX_PACKING_SIZE)
-        if rows_chunks is not None and (abundance_min <= 1 or kmer_size <= 32):
-            # contig sets beyond one device batch: two passes over chunks of whole word-rows
-            progress("%d genomes in %d chunks, two passes" % (len(ids), len(rows_chunks)))
-            m, _ = two_pass_matrix(ctx, files_per_genome, rows_chunks, kmer_size, abundance_min, bool(filter_singleton), progress)
-        else:                                       # deep read sets: the reference's own two steps, multidsk then dsk2kover
-            sets = counted_sets(ctx, files_per_genome, kmer_size, abundance_min, DEFAULT_BATCH_BYTES, progress)
-            m = ctx.build_matrix(sets, bool(filter_singleton))
-            for s_ in sets:
-                s_.free()
+    m = matrix_of_files(ctx, files_per_genome, kmer_size, abundance_min, bool(filter_singleton), progress)
     progress("dictionary: %d k-mers; writing HDF5 (gzip %d)" % (m.n_kmers, gzip))
     m.write_kover_h5(tmp, gzip, BLOCK_SIZE)
     progress("HDF5 written")

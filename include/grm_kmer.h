@@ -108,7 +108,8 @@ int             grm_matrix_column_counts(grm_matrix *, uint32_t *out);
  * row_mask: n_rows host words (bit 63-(i%64) of word i/64 selects genome i); out: n_kmers uint32 */
 int             grm_matrix_sum_rows(grm_matrix *, const uint64_t *row_mask, uint32_t *out);
 /* host-only matrix from caller arrays (copied): rows gathered from several ranks, or tests.
- * Only the accessors and the two writers work on it (no device). */
+ * Only the accessors and the two writers work on it (no device).  kmers: n_kmers words for
+ * k <= 32, 2*n_kmers (most significant word first) for 33 <= k <= 64. */
 int             grm_matrix_from_host(const uint64_t *kmers, const uint64_t *data, size_t n_kmers, int n_genomes, int k,
                                      grm_matrix **out);
 const char     *grm_matrix_last_error(const grm_matrix *);

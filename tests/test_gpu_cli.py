@@ -42,33 +42,40 @@ def genomes(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("k", [31, 47])
-def test_multidsk_then_dsk2kover(genomes, tmp_path, k):
-    """k = 47: the pair carries two-word k-mers (counting and merge on the sort-based two-word path)"""
+@pytest.mark.parametrize("k,per_genome_sets", [(31, False), (47, False), (31, True), (47, True)])
+def test_multidsk_then_dsk2kover(genomes, tmp_path, k, per_genome_sets):
+    """the pair as Kover drives it.  Default: multidsk leaves ONE combined artefact + a reference file
+    under every name Kover expects and dsk2kover only selects / filters / writes; GRM_MULTIDSK_SETS=1:
+    one counted set per genome (k = 47: two-word k-mers on the sort-based path) merged by dsk2kover."""
     import grm_amd  # noqa: F401
     kd = import_module(PKG + ".kover_dataset")
+    env = {"GRM_MULTIDSK_SETS": "1"} if per_genome_sets else {}
     tmp = str(tmp_path)
     lst = os.path.join(tmp, "list_contigs_files")
     open(lst, "w").writelines(p + "\n" for p in genomes)
     # exactly kmer_count.py:28-37
     _run([os.path.join(CLI, "multidsk"), "-file", lst, "-out-dir", tmp, "-kmer-size", str(k), "-abundance-min", "1",
-          "-out-compress", "4", "-nb-cores", "0", "-out-tmp", tmp, "-verbose", "0", "-progress", "True"])
+          "-out-compress", "4", "-nb-cores", "0", "-out-tmp", tmp, "-verbose", "0", "-progress", "True"], env=env)
     h5s = [os.path.join(tmp, os.path.basename(os.path.splitext(p + "\n")[0]) + ".h5") for p in genomes]   # create.py:375
     assert all(os.path.exists(p) for p in h5s)
+    if not per_genome_sets:
+        assert max(os.path.getsize(p) for p in h5s) < 4096           # references, not data
     list_h5 = os.path.join(tmp, "list_h5")
-    open(list_h5, "w").writelines(p + "\n" for p in h5s)
     out = os.path.join(tmp, "DATASET.kover")
     ids = [os.path.basename(p)[:-4] for p in genomes]
+    orders = [list(range(len(genomes))), [4, 0, 7, 2]]               # as listed by Kover; a permuted subset
     for filt in ("singleton", "nothing"):
-        kd.write_header(out, "contigs", lst, None, None, 4, ids, None, None, None, filt)
-        # exactly kmer_pack.py:28-36
-        _run([os.path.join(CLI, "dsk2kover"), "-file", list_h5, "-out", out, "-filter", filt, "-kmer-length", str(k),
-              "-compression", "4", "-chunk-size", "100000", "-nb-genomes", str(len(genomes)), "-verbose", "True"])
-        want = orc.build_matrix([[open(p, "rb").read()] for p in genomes], k, 1, filt == "singleton")
-        r = kd.KoverDatasetReader(out)
-        assert r.kmer_sequences == orc.decode_kmers(want["kmers"], k)
-        assert (r.kmer_matrix == want["matrix"]).all()
-        assert r.genome_identifiers == ids
+        for order in orders:
+            open(list_h5, "w").writelines(h5s[i] + "\n" for i in order)
+            kd.write_header(out, "contigs", lst, None, None, 4, [ids[i] for i in order], None, None, None, filt)
+            # exactly kmer_pack.py:28-36
+            _run([os.path.join(CLI, "dsk2kover"), "-file", list_h5, "-out", out, "-filter", filt, "-kmer-length", str(k),
+                  "-compression", "4", "-chunk-size", "100000", "-nb-genomes", str(len(order)), "-verbose", "True"])
+            want = orc.build_matrix([[open(genomes[i], "rb").read()] for i in order], k, 1, filt == "singleton")
+            r = kd.KoverDatasetReader(out)
+            assert r.kmer_sequences == orc.decode_kmers(want["kmers"], k)
+            assert (r.kmer_matrix == want["matrix"]).all()
+            assert r.genome_identifiers == [ids[i] for i in order]
 
 
 def test_ray_under_fake_mpiexec(genomes, tmp_path):

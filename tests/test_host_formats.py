@@ -220,6 +220,33 @@ def test_kset_container_and_names(tmp_path):
     assert a["file"] == "L" and a["kmer-size"] == "31" and a["progress"] == "True" and a["out-tmp"] == "D"
 
 
+def test_multidsk_artifact_and_row_selection(tmp_path):
+    """the combined artefact multidsk leaves for dsk2kover, its reference files, and the row selection
+    dsk2kover applies when the list order differs (cli/_common.py)"""
+    Cm = _load_cli("_common.py")
+    rng = np.random.RandomState(8)
+    n, U = 70, 300
+    dense = (rng.rand(n, U) < 0.5).astype(np.uint8)
+    kd = import_module(PKG + ".kover_dataset")
+    data = kd.pack_rows(dense)
+    for k in (31, 40):
+        w = 2 if k > 32 else 1
+        kmers = rng.randint(0, 2**62, size=(U, w)).astype(np.uint64)
+        counts = dense.sum(axis=0).astype(np.uint32)
+        art = str(tmp_path / ("m%d.matrix" % k))
+        Cm.write_matrix_artifact(art, k, 1, kmers, data, counts, n)
+        k2, amin, n2, km2, c2, d2 = Cm.read_matrix_artifact(art)
+        assert (k2, amin, n2) == (k, 1, n) and (km2 == kmers).all() and (c2 == counts).all() and (d2 == data).all()
+        ref = str(tmp_path / "g.h5")
+        Cm.write_ref(ref, art, 5, k, 1, 0)
+        assert Cm.read_ref(ref)[:4] == (os.path.abspath(art), 5, k, 1)
+        Cm.write_kset(ref, k, 1, kmers, counts, 9)
+        assert Cm.read_ref(ref) is None                                # a counted set is not a reference
+    assert Cm.select_rows(data, n, list(range(n))) is data
+    order = [69, 3, 64, 0, 63] + list(range(10, 70))
+    assert (Cm.select_rows(data, n, order) == kd.pack_rows(dense[order])).all()
+
+
 def test_ray_conf_grammar(tmp_path):
     ray = _load_cli("Ray")
     conf = tmp_path / "survey.conf"
