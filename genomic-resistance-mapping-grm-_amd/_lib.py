@@ -29,6 +29,7 @@ PROTOTYPES = [
     ("grm_count_genome", C.c_int, [_P, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_uint32, _PP]),
     ("grm_count_genome_buffers", C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_uint32, _PP]),
     ("grm_kmer_set_from_host", C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, _PP]),
+    ("grm_merge_counted_sets", C.c_int, [_P, _PP, C.c_int, C.c_uint32, _PP]),
     ("grm_kmer_set_size", C.c_size_t, [_P]),
     ("grm_kmer_set_k", C.c_int, [_P]),
     ("grm_kmer_set_words", C.c_int, [_P]),

@@ -1263,6 +1263,85 @@ extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
     return GRM_OK;
 }
 
+static int wide_scan(grm_ctx *c, DevBuf &tmp, bool inclusive, const uint32_t *in, uint32_t *out, uint64_t n);
+
+// ---- pooled merge of counted sets (one-word k-mers): the sum of the counts of equal k-mers, filtered ----
+// DSK counts every listed file as ONE pool (src/app.py:1371-1372).  A pool of more than 2^32 - 1 symbols is
+// counted in chunks with abundance-min 1 and the chunk sets are merged here: sort by key, sum runs, filter.
+extern "C" int grm_merge_counted_sets(grm_ctx *c, grm_kmer_set *const *sets, int n_sets, uint32_t abundance_min, grm_kmer_set **out)
+{
+    if (!c) return GRM_ERR_NO_DEVICE;
+    if (!out || n_sets < 0 || (n_sets && !sets)) return fail(c, GRM_ERR_ARG, "grm_merge_counted_sets: bad argument");
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (abundance_min < 1) abundance_min = 1;
+    uint64_t n = 0, occ = 0;
+    int k = n_sets ? sets[0]->k : 1;
+    for (int i = 0; i < n_sets; i++) {
+        if (!sets[i] || sets[i]->k != k) return fail(c, GRM_ERR_ARG, "grm_merge_counted_sets: sets with different k");
+        if (sets[i]->words != 1) return fail(c, GRM_ERR_UNSUPPORTED, "grm_merge_counted_sets: k=%d (two-word k-mers) is not supported", k);
+        n += sets[i]->n;
+        occ += sets[i]->occurrences;
+    }
+    if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "grm_merge_counted_sets: %llu entries exceed 2^32-1", (unsigned long long)n);
+    grm_kmer_set *r = new grm_kmer_set();
+    r->ctx = c; r->k = k; r->words = 1; r->occurrences = occ;
+    auto bail = [&](int code) { delete r; return code; };
+    if (n == 0) { *out = r; return GRM_OK; }
+    DevBuf k0, k1, c0, c1, head, incl, sums, rkeys, keep, pos, tmp;
+    hipError_t e = hipSuccess;
+    auto need = [&](DevBuf &d, size_t bytes) { if (e == hipSuccess) e = d.alloc(bytes); };
+    need(k0, n * 8); need(k1, n * 8); need(c0, n * 4); need(c1, n * 4); need(head, n * 4); need(incl, n * 4);
+    if (e != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "grm_merge_counted_sets: %s", hipGetErrorString(e)));
+    uint64_t at = 0;
+    for (int i = 0; i < n_sets && e == hipSuccess; i++) {
+        const size_t m = sets[i]->n;
+        if (!m) continue;
+        if (sets[i]->on_device) {
+            e = hipMemcpyAsync(k0.as<uint64_t>() + at, sets[i]->d_kmers.p, m * 8, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(c0.as<uint32_t>() + at, sets[i]->d_counts.p, m * 4, hipMemcpyDeviceToDevice, s);
+        } else {
+            e = hipMemcpy(k0.as<uint64_t>() + at, sets[i]->kmers.data(), m * 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(c0.as<uint32_t>() + at, sets[i]->counts.data(), m * 4, hipMemcpyHostToDevice);
+        }
+        at += m;
+    }
+    size_t tb = 0;
+    if (e == hipSuccess) e = sort_pairs_u64_u32(s, k0.as<uint64_t>(), k1.as<uint64_t>(), c0.as<uint32_t>(), c1.as<uint32_t>(), n, nullptr, tb);
+    if (e == hipSuccess) e = tmp.alloc(tb);
+    if (e == hipSuccess) e = sort_pairs_u64_u32(s, k0.as<uint64_t>(), k1.as<uint64_t>(), c0.as<uint32_t>(), c1.as<uint32_t>(), n, tmp.p, tb);
+    if (e != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "grm_merge_counted_sets: %s", hipGetErrorString(e)));
+    launch_runs_mark(s, k1.as<uint64_t>(), n, head.as<uint32_t>());
+    int rc = wide_scan(c, tmp, true, head.as<uint32_t>(), incl.as<uint32_t>(), n);
+    if (rc) return bail(rc);
+    uint32_t n_runs = 0;
+    if (hipMemcpyAsync(&n_runs, incl.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return bail(fail(c, GRM_ERR_HIP, "grm_merge_counted_sets: D2H"));
+    need(sums, (size_t)n_runs * 8); need(rkeys, (size_t)n_runs * 8); need(keep, ((size_t)n_runs + 1) * 4); need(pos, ((size_t)n_runs + 1) * 4);
+    if (e != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "grm_merge_counted_sets: %s", hipGetErrorString(e)));
+    (void)hipMemsetAsync(sums.p, 0, (size_t)n_runs * 8, s);
+    (void)hipMemsetAsync(keep.as<uint32_t>() + n_runs, 0, 4, s);
+    launch_runs_reduce(s, k1.as<uint64_t>(), c1.as<uint32_t>(), head.as<uint32_t>(), incl.as<uint32_t>(), n, rkeys.as<uint64_t>(),
+                       sums.as<unsigned long long>());
+    launch_runs_keep(s, sums.as<unsigned long long>(), n_runs, abundance_min, keep.as<uint32_t>());
+    rc = wide_scan(c, tmp, false, keep.as<uint32_t>(), pos.as<uint32_t>(), (uint64_t)n_runs + 1);
+    if (rc) return bail(rc);
+    uint32_t n_out = 0;
+    if (hipMemcpyAsync(&n_out, pos.as<uint32_t>() + n_runs, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return bail(fail(c, GRM_ERR_HIP, "grm_merge_counted_sets: D2H"));
+    if (r->d_kmers.alloc((size_t)n_out * 8 + 16) != hipSuccess || r->d_counts.alloc((size_t)n_out * 4 + 16) != hipSuccess)
+        return bail(fail(c, GRM_ERR_OOM, "grm_merge_counted_sets: result allocation failed"));
+    launch_runs_emit(s, rkeys.as<uint64_t>(), sums.as<unsigned long long>(), keep.as<uint32_t>(), pos.as<uint32_t>(), n_runs,
+                     r->d_kmers.as<uint64_t>(), r->d_counts.as<uint32_t>());
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "grm_merge_counted_sets failed"));
+    r->n = n_out;
+    r->on_device = true;
+    r->on_host = false;
+    *out = r;
+    return GRM_OK;
+}
+
 // ---- inputs larger than one device batch: two passes over chunks of genomes -------------------
 // Pass 1 pushes every chunk through partition + local dictionary and keeps only (key, flag) of its
 // distinct k-mers in an accumulator; pass 2 pushes the chunks through again, hands the accumulated

@@ -104,6 +104,12 @@ void launch_matrix_fill(hipStream_t s, const uint64_t *keys, const uint64_t *off
 void launch_column_popcount(hipStream_t s, const uint64_t *matrix, uint64_t n_rows, uint64_t n_cols,
                             const uint64_t *row_mask, uint32_t *out);
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint64_t n);
+void launch_runs_mark(hipStream_t s, const uint64_t *keys, uint64_t n, uint32_t *head);
+void launch_runs_reduce(hipStream_t s, const uint64_t *keys, const uint32_t *counts, const uint32_t *head, const uint32_t *incl,
+                        uint64_t n, uint64_t *out_keys, unsigned long long *out_counts);
+void launch_runs_keep(hipStream_t s, const unsigned long long *sums, uint64_t n_runs, uint32_t abundance_min, uint32_t *keep);
+void launch_runs_emit(hipStream_t s, const uint64_t *keys, const unsigned long long *sums, const uint32_t *keep, const uint32_t *pos,
+                      uint64_t n_runs, uint64_t *out_keys, uint32_t *out_counts);
 void launch_split_pairs_u64(hipStream_t s, const uint64_t *pairs, uint64_t n, uint64_t *hi, uint64_t *lo);
 void launch_join_pairs_u64(hipStream_t s, const uint64_t *hi, const uint64_t *lo, uint64_t n, uint64_t *pairs);
 hipError_t set_max_dynamic_lds();

@@ -1467,6 +1467,60 @@ void launch_join_pairs_u64(hipStream_t s, const uint64_t *hi, const uint64_t *lo
     if (!n) return;
     hipLaunchKernelGGL(join_pairs_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, hi, lo, n, pairs);
 }
+// ---- pooled merge of counted sets (dsk over more symbols than one pooled batch holds) ----
+// sorted keys: head[i] = 1 where a run of equal keys starts
+__global__ void runs_mark_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ head)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// run id of entry i = incl[i] - 1 (inclusive scan of head): key to out_keys[run], count summed into out_counts[run]
+// (saturating at 2^32 - 1 is not needed: a count is bounded by the symbols of the inputs, < 2^32 per chunk, and
+// the sum is taken in 64 bits and clamped)
+__global__ void runs_reduce_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ counts,
+                                   const uint32_t *__restrict__ head, const uint32_t *__restrict__ incl, uint64_t n,
+                                   uint64_t *__restrict__ out_keys, unsigned long long *__restrict__ out_counts)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t run = incl[i] - 1;
+        if (head[i]) out_keys[run] = keys[i];
+        atomicAdd(&out_counts[run], (unsigned long long)counts[i]);
+    }
+}
+__global__ void runs_keep_kernel(const unsigned long long *__restrict__ sums, uint64_t n_runs, uint32_t abundance_min,
+                                 uint32_t *__restrict__ keep)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += (uint64_t)gridDim.x * blockDim.x)
+        keep[i] = sums[i] >= abundance_min ? 1u : 0u;
+}
+__global__ void runs_emit_kernel(const uint64_t *__restrict__ keys, const unsigned long long *__restrict__ sums,
+                                 const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, uint64_t n_runs,
+                                 uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_counts)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += (uint64_t)gridDim.x * blockDim.x)
+        if (keep[i]) {
+            out_keys[pos[i]] = keys[i];
+            out_counts[pos[i]] = sums[i] > 0xffffffffull ? 0xffffffffu : (uint32_t)sums[i];
+        }
+}
+void launch_runs_mark(hipStream_t s, const uint64_t *keys, uint64_t n, uint32_t *head)
+{
+    if (n) hipLaunchKernelGGL(runs_mark_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, keys, n, head);
+}
+void launch_runs_reduce(hipStream_t s, const uint64_t *keys, const uint32_t *counts, const uint32_t *head, const uint32_t *incl,
+                        uint64_t n, uint64_t *out_keys, unsigned long long *out_counts)
+{
+    if (n) hipLaunchKernelGGL(runs_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, keys, counts, head, incl, n, out_keys, out_counts);
+}
+void launch_runs_keep(hipStream_t s, const unsigned long long *sums, uint64_t n_runs, uint32_t abundance_min, uint32_t *keep)
+{
+    if (n_runs) hipLaunchKernelGGL(runs_keep_kernel, dim3(grid_for(n_runs, 256)), dim3(256), 0, s, sums, n_runs, abundance_min, keep);
+}
+void launch_runs_emit(hipStream_t s, const uint64_t *keys, const unsigned long long *sums, const uint32_t *keep, const uint32_t *pos,
+                      uint64_t n_runs, uint64_t *out_keys, uint32_t *out_counts)
+{
+    if (n_runs) hipLaunchKernelGGL(runs_emit_kernel, dim3(grid_for(n_runs, 256)), dim3(256), 0, s, keys, sums, keep, pos, n_runs, out_keys, out_counts);
+}
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint64_t n)
 {
     if (!n) return;

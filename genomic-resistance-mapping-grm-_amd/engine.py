@@ -84,6 +84,13 @@ class Context:
         self._chk(self.L.grm_count_genome(self.h, arr, n, k, abundance_min, C.byref(h)))
         return KmerSet(self, h)
 
+    def merge_counted_sets(self, sets, abundance_min=1):
+        """pooled count: sums the counts of equal k-mers over the sets, keeps totals >= abundance_min"""
+        arr = (C.c_void_p * max(1, len(sets)))(*[s.h for s in sets])
+        h = C.c_void_p()
+        self._chk(self.L.grm_merge_counted_sets(self.h, arr, len(sets), abundance_min, C.byref(h)))
+        return KmerSet(self, h)
+
     def kmer_set_from_arrays(self, kmers, counts, k):
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1)
         counts = np.ascontiguousarray(counts, dtype=np.uint32).reshape(-1)

@@ -75,6 +75,9 @@ int  grm_count_genome(grm_ctx *, const char *const *paths, int n_paths, int k, u
                       grm_kmer_set **out);
 int  grm_count_genome_buffers(grm_ctx *, const void *const *bufs, const size_t *lens, int n_bufs, int k,
                               uint32_t abundance_min, grm_kmer_set **out);
+/* pooled merge (DSK counts all listed files as ONE pool, src/app.py:1371-1372): sums the counts of
+ * equal k-mers over the sets and keeps those whose total reaches abundance_min; k <= 32 */
+int  grm_merge_counted_sets(grm_ctx *, grm_kmer_set *const *sets, int n_sets, uint32_t abundance_min, grm_kmer_set **out);
 /* build a set from host arrays (used by dsk2kover when it re-loads multidsk's artefacts); for
  * 33 <= k <= 64 `kmers` holds 2*n words (most significant word of each k-mer first) */
 int  grm_kmer_set_from_host(grm_ctx *, const uint64_t *kmers, const uint32_t *counts, size_t n, int k,
