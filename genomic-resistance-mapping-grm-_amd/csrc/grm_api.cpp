@@ -270,6 +270,25 @@ extern "C" int grm_timing_get(grm_ctx *c, int i, char *name, size_t name_cap, do
 // A counted set lives where it was produced: sets that come out of a device batch stay in HBM
 // (grm_build_matrix consumes them there) and reach the host only when the caller asks for the
 // arrays; sets built from host arrays stay on the host.
+// std::vector whose resize() leaves new elements uninitialised: the host copies of results are
+// filled by a device -> host copy right away, and value-initialising 1 GB first costs ~170 ms of
+// memset + page faults on the calling thread.
+template <typename T> struct default_init_alloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = default_init_alloc<U>; };
+    using std::allocator<T>::allocator;
+    template <typename U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <typename T> using raw_vector = std::vector<T, default_init_alloc<T>>;
+
+// Device -> pageable host copy on the context's own stream (nothing in the library uses the NULL stream)
+static hipError_t d2h(grm_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    return e;
+}
+
 struct grm_kmer_set {
     grm_ctx *ctx = nullptr;
     int k = 0, words = 1;
@@ -277,8 +296,8 @@ struct grm_kmer_set {
     size_t n = 0;
     bool on_device = false, on_host = true;
     DevBuf d_kmers, d_counts;
-    std::vector<uint64_t> kmers;
-    std::vector<uint32_t> counts;
+    raw_vector<uint64_t> kmers;
+    raw_vector<uint32_t> counts;
     bool to_host();
 };
 
@@ -287,7 +306,7 @@ struct grm_matrix {
     int k = 0, words = 1, n_genomes = 0;
     size_t n_rows = 0, n_kmers = 0;
     DevBuf d_kmers, d_data;
-    std::vector<uint64_t> h_kmers, h_data;
+    raw_vector<uint64_t> h_kmers, h_data;
     bool have_kmers = false, have_data = false;
 };
 
@@ -298,8 +317,8 @@ bool grm_kmer_set::to_host()
     counts.resize(n);
     if (n) {
         if (hipSetDevice(ctx->device) != hipSuccess) return false;
-        if (hipMemcpy(kmers.data(), d_kmers.p, n * 8 * (size_t)words, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(counts.data(), d_counts.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        if (d2h(ctx, kmers.data(), d_kmers.p, n * 8 * (size_t)words) != hipSuccess ||
+            d2h(ctx, counts.data(), d_counts.p, n * 4) != hipSuccess) {
             (void)fail(ctx, GRM_ERR_HIP, "k-mer set download failed");
             kmers.clear(); counts.clear();
             return false;
@@ -349,7 +368,7 @@ extern "C" const uint64_t *grm_matrix_kmers(grm_matrix *m)
         m->h_kmers.resize(m->n_kmers * m->words + 1);
         if (m->n_kmers) {
             (void)hipSetDevice(m->ctx->device);
-            if (hipMemcpy(m->h_kmers.data(), m->d_kmers.p, m->n_kmers * m->words * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            if (d2h(m->ctx, m->h_kmers.data(), m->d_kmers.p, m->n_kmers * m->words * 8) != hipSuccess) {
                 fail(m->ctx, GRM_ERR_HIP, "D2H of dictionary failed");
                 return nullptr;
             }
@@ -358,6 +377,26 @@ extern "C" const uint64_t *grm_matrix_kmers(grm_matrix *m)
     }
     return m->h_kmers.data();
 }
+// Row-wise download for the HDF5 writer (grm_h5.cpp), which deflates the rows that have arrived while
+// the next ones are on their way: begin returns the host buffer (nothing copied yet unless the data is
+// already on the host), rows copies word-rows [r0, r1), end marks the host copy complete.
+extern "C" uint64_t *grm_internal_matrix_download_begin(grm_matrix *m, int *already)
+{
+    if (!m) return nullptr;
+    *already = m->have_data ? 1 : 0;
+    if (!m->have_data) m->h_data.resize(m->n_kmers * m->n_rows + 1);
+    return m->h_data.data();
+}
+extern "C" int grm_internal_matrix_download_rows(grm_matrix *m, size_t r0, size_t r1)
+{
+    if (!m || m->have_data || r1 <= r0 || !m->n_kmers) return GRM_OK;
+    if (hipSetDevice(m->ctx->device) != hipSuccess ||
+        d2h(m->ctx, m->h_data.data() + r0 * m->n_kmers, m->d_data.as<uint64_t>() + r0 * m->n_kmers, (r1 - r0) * m->n_kmers * 8) != hipSuccess)
+        return fail(m->ctx, GRM_ERR_HIP, "D2H of matrix rows failed");
+    return GRM_OK;
+}
+extern "C" void grm_internal_matrix_download_end(grm_matrix *m) { if (m) m->have_data = true; }
+
 extern "C" const uint64_t *grm_matrix_data(grm_matrix *m)
 {
     if (!m) return nullptr;
@@ -365,7 +404,7 @@ extern "C" const uint64_t *grm_matrix_data(grm_matrix *m)
         m->h_data.resize(m->n_kmers * m->n_rows + 1);
         if (m->n_kmers && m->n_rows) {
             (void)hipSetDevice(m->ctx->device);
-            if (hipMemcpy(m->h_data.data(), m->d_data.p, m->n_kmers * m->n_rows * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            if (d2h(m->ctx, m->h_data.data(), m->d_data.p, m->n_kmers * m->n_rows * 8) != hipSuccess) {
                 fail(m->ctx, GRM_ERR_HIP, "D2H of matrix failed");
                 return nullptr;
             }

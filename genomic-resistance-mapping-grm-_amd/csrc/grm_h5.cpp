@@ -218,6 +218,9 @@ int write_1d(H5 &H, hid_t file, const char *name, hid_t type, size_t elem_bytes,
 
 // ctx error plumbing lives in grm_api.cpp
 extern "C" int grm_internal_fail(grm_matrix *m, int code, const char *msg);
+extern "C" uint64_t *grm_internal_matrix_download_begin(grm_matrix *m, int *already);
+extern "C" int grm_internal_matrix_download_rows(grm_matrix *m, size_t r0, size_t r1);
+extern "C" void grm_internal_matrix_download_end(grm_matrix *m);
 
 extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, int gzip_level, int chunk_cols)
 {
@@ -236,12 +239,28 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
         fprintf(stderr, "[grm_write_kover_h5] %-28s %8.1f ms\n", what, (t - t_last) * 1e3);
         t_last = t;
     };
-    const uint64_t *kmers = grm_matrix_kmers(m);
-    const uint64_t *data = grm_matrix_data(m);
-    if (!kmers || !data) return GRM_ERR_HIP;
-    lap("device -> host");
     const size_t U = grm_matrix_n_kmers(m), R = grm_matrix_n_rows(m);
     const int k = grm_matrix_k(m);
+    // The dictionary comes down first (small); the matrix then follows row by row on a thread of its own
+    // while this one writes the k-mer strings, and the chunk deflaters below start on a row as soon as
+    // it has arrived.
+    const uint64_t *kmers = grm_matrix_kmers(m);
+    if (!kmers) return GRM_ERR_HIP;
+    int already = 0;
+    const uint64_t *data = grm_internal_matrix_download_begin(m, &already);
+    if (!data) return GRM_ERR_HIP;
+    std::atomic<size_t> rows_ready(already ? R : 0);
+    std::atomic<int> copy_failed(0);
+    std::thread copier([&]() {
+        if (already) return;
+        for (size_t r = 0; r < R; r++) {
+            if (grm_internal_matrix_download_rows(m, r, r + 1) != GRM_OK) { copy_failed = 1; rows_ready = R; return; }
+            rows_ready = r + 1;
+        }
+        grm_internal_matrix_download_end(m);
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{copier};
+    lap("k-mers device -> host");
 
     H.Eset_auto2(0, nullptr, nullptr);
     hid_t file = H.Fopen(existing_h5_path, 1u /* H5F_ACC_RDWR */, 0);
@@ -293,6 +312,7 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
                 std::vector<std::vector<unsigned char>> z;
                 const bool ok = deflate_chunks(n_chunks, (size_t)cw * 8, gzip_level, [&](size_t i, unsigned char *buf) -> const unsigned char * {
                     const size_t r = i / chunks_per_row, c0 = (i % chunks_per_row) * cw;
+                    while (rows_ready.load() <= r) std::this_thread::sleep_for(std::chrono::microseconds(200));     // this row is still on its way
                     const size_t nc = (c0 + cw <= U) ? (size_t)cw : U - c0;
                     const uint64_t *src = data + r * U + c0;
                     if (nc == (size_t)cw) return reinterpret_cast<const unsigned char *>(src);
@@ -301,12 +321,16 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
                     return buf;
                 }, z);
                 if (!ok) { err = "zlib compress2 failed"; rc = -1; }
-                lap("kmer_matrix deflate");
+                if (copy_failed) { err = "device -> host copy of the matrix failed"; rc = -1; }
+                lap("kmer_matrix download + deflate");
                 for (size_t i = 0; i < n_chunks && !rc; i++) {
                     hsize_t off[2] = {i / chunks_per_row, (i % chunks_per_row) * cw};
                     if (H.Dwrite_chunk(ds, 0, 0, off, z[i].size(), z[i].data()) < 0) { err = "H5Dwrite_chunk kmer_matrix"; rc = -1; }
                 }
-            } else if (H.Dwrite(ds, H.U64, 0, 0, 0, data) < 0) { err = "H5Dwrite kmer_matrix"; rc = -1; }
+            } else {
+                copier.join();
+                if (H.Dwrite(ds, H.U64, 0, 0, 0, data) < 0) { err = "H5Dwrite kmer_matrix"; rc = -1; }
+            }
         }
         if (ds >= 0) H.Dclose(ds);
         if (dcpl > 0) H.Pclose(dcpl);
