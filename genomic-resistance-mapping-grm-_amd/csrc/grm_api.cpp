@@ -917,7 +917,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     for (uint32_t g = 0; g < G; g++) max_g = std::max(max_g, b->h_genome_sym_off[g + 1] - b->h_genome_sym_off[g]);
     if (max_g >= 0xffffffffull) return fail(c, GRM_ERR_ARG, "a genome has %llu symbols (limit 2^32-1)", (unsigned long long)max_g);
     if (b->total_syms > max_groups * 64 - 256) return fail(c, GRM_ERR_HIP, "internal: symbol count exceeds the packed buffers");
-    if (k > 32) return GRM_OK;       // two-word k-mers: the caller continues on the sort-based path (grm_wide.hip)
+    if (k > 32) return GRM_OK;       // two-word k-mers: the caller continues on grm_wide_hash.hip / grm_wide.hip
     b->bb = pick_bucket_bits(c, max_g);
     const uint64_t B = 1ull << b->bb;
     const uint64_t n_seg = (uint64_t)G * B;
