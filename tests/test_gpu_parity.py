@@ -304,6 +304,62 @@ def test_two_ranks_real_engine_one_gpu(ctx, k, genome_len):
     assert rows.shape == want["matrix"].shape and (rows == want["matrix"]).all()
 
 
+def _nccl_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    import grm_amd
+    D = import_module("genomic-resistance-mapping-grm-_amd.distributed")
+    S = import_module("genomic-resistance-mapping-grm-_amd.synth")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        pg = S.PanGenome(genome_len=60_000, n_snps=600, n_accessory=6, accessory_len=1500, seed=21, n_contigs=2)
+        with grm_amd.Context(0) as c:
+            batch = c.batch(70)
+            for g in range(70):
+                batch.add_array(g, pg.genome(g))
+            batch.upload()
+            dev = torch.device("cuda", 0)
+            # force the collective code path although there is one rank: counts, padded buffers, all-gather over RCCL
+            n_local = (batch.partition(31, 1), batch.local_dict())[1]
+            keys = torch.empty((max(1, n_local), 1), dtype=torch.int64, device=dev)
+            flags = torch.empty(max(1, n_local), dtype=torch.uint8, device=dev)
+            batch.export_dict(keys.data_ptr(), flags.data_ptr())
+            kall = torch.empty_like(keys)
+            fall = torch.empty_like(flags)
+            D._all_gather(kall, keys, None)
+            D._all_gather(fall, flags, None)
+            torch.cuda.current_stream(dev).synchronize()
+            assert torch.equal(kall, keys) and torch.equal(fall, flags)
+            batch.set_global_dict(kall.data_ptr(), fall.data_ptr(), n_local, True)
+            m = batch.fill()
+            rows = D.gather_rows(m.data(), dev)
+            q.put((m.kmers().copy(), rows))
+            m.free()
+            batch.free()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank(ctx):
+    """the engine and torch's RCCL ("nccl") backend in ONE process on the GPU: same HIP runtime, device
+    tensors through all_gather_into_tensor, raw pointers handed to the engine afterwards"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    p = mpc.Process(target=_nccl_worker, args=(port, q))
+    p.start()
+    kmers, rows = q.get(timeout=240)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    pg = synth.PanGenome(genome_len=60_000, n_snps=600, n_accessory=6, accessory_len=1500, seed=21, n_contigs=2)
+    want = orc.build_matrix([[pg.genome(g).tobytes()] for g in range(70)], 31, 1, True)
+    assert (kmers == want["kmers"]).all() and (rows == want["matrix"]).all()
+
+
 def test_tsv_roundtrip(ctx, tmp_path):
     name, k, genomes = MICRO[2]
     bg = _as_bytes(genomes)
