@@ -883,8 +883,8 @@ __global__ __launch_bounds__(1024) void dict_build_kernel(
         // every key of a pan-genome after the first few genomes -- is done after two LDS reads.  The
         // others go through ONE shared copy of the general insertion code, one key at a time.
         for (uint64_t i0 = lane; i0 < n; i0 += 64 * KIF) {
-            uint64_t kv[KIF], hv[KIF], ck[KIF];
-            uint32_t sl[KIF], cs[KIF];
+            uint64_t kv[KIF], hv[KIF];
+            uint32_t sl[KIF];
 #pragma unroll
             for (int j = 0; j < KIF; j++) {
                 const uint64_t i = i0 + 64u * j;
@@ -895,18 +895,36 @@ __global__ __launch_bounds__(1024) void dict_build_kernel(
                 hv[j] = mix64(kv[j]);
                 sl[j] = hash_slot(hv[j], cap_mask);
             }
-#pragma unroll
-            for (int j = 0; j < KIF; j++) {
-                ck[j] = tkeys[sl[j]];
-                cs[j] = tstate[sl[j]];
-            }
+            // the first PROBES slots of the probe sequence, unconditionally: at the table's load (~0.25) one key
+            // in nine sits past its home slot, and sending all of those through the divergent loop below for
+            // every genome costs more than the extra LDS reads
+            constexpr int PROBES = 2;
             uint32_t todo = 0, act = 0;
+            {
+                uint64_t pk[PROBES][KIF];
+                uint32_t ps[PROBES][KIF];
 #pragma unroll
-            for (int j = 0; j < KIF; j++) {
-                const bool active = kv[j] != EMPTY_KEY && (!sb || hash_sub(hv[j], bb, sb) == sub);
-                const bool done = ck[j] == kv[j] && ((cs[j] >> 31) || cs[j] == g + 1);
-                act |= (uint32_t)active << j;
-                todo |= (uint32_t)(active && !done) << j;
+                for (int p = 0; p < PROBES; p++)
+#pragma unroll
+                    for (int j = 0; j < KIF; j++) {
+                        pk[p][j] = tkeys[(sl[j] + p) & cap_mask];
+                        ps[p][j] = tstate[(sl[j] + p) & cap_mask];
+                    }
+#pragma unroll
+                for (int j = 0; j < KIF; j++) {
+                    const bool active = kv[j] != EMPTY_KEY && (!sb || hash_sub(hv[j], bb, sb) == sub);
+                    bool done = false;
+                    uint32_t at = sl[j];
+#pragma unroll
+                    for (int p = PROBES - 1; p >= 0; p--) {
+                        const bool hit = pk[p][j] == kv[j] && ((ps[p][j] >> 31) || ps[p][j] == g + 1);
+                        if (hit) at = (sl[j] + p) & cap_mask;
+                        done |= hit;
+                    }
+                    sl[j] = at;
+                    act |= (uint32_t)active << j;
+                    todo |= (uint32_t)(active && !done) << j;
+                }
             }
             while (todo) {
                 const int j = __ffs(todo) - 1;
