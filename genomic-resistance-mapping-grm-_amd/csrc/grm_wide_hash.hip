@@ -279,9 +279,20 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
     __syncthreads();
     const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
     const uint32_t max_fill = cap - (cap >> 3);
+    // bounds of the next genome's segment are requested while the current one is processed
+    uint64_t s0 = 0, n = 0;
+    if ((uint32_t)wave < n_genomes) {
+        const uint64_t idx = (uint64_t)wave * B + b;
+        s0 = off[idx];
+        n = off[idx + 1] - s0;
+    }
     for (uint32_t g = wave; g < n_genomes; g += nw) {
-        const uint64_t idx = (uint64_t)g * B + b;
-        const uint64_t s0 = off[idx], n = off[idx + 1] - s0;
+        uint64_t s0_next = 0, n_next = 0;
+        if (g + nw < n_genomes) {
+            const uint64_t idx = (uint64_t)(g + nw) * B + b;
+            s0_next = off[idx];
+            n_next = off[idx + 1] - s0_next;
+        }
         for (uint64_t i0 = lane; i0 < n; i0 += 64 * 2) {
             ulonglong2 kv[2];
             uint64_t hv[2];
@@ -293,17 +304,31 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                 hv[j] = mix128(kv[j].y, kv[j].x);
                 sl[j] = hash_slot(hv[j], cap_mask);
             }
-            uint64_t cl[2], ch[2];
-            uint32_t cs[2];
+            // first and second probe slot in the straight-line part (see dict_build_kernel): a key that sits
+            // one slot past its home must not go through the divergent insertion loop for every genome
+            uint64_t cl[2][2], ch[2][2];
+            uint32_t cs[2][2];
 #pragma unroll
-            for (int j = 0; j < 2; j++) { cl[j] = tlo[sl[j]]; ch[j] = thi[sl[j]]; cs[j] = tstate[sl[j]]; }
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const uint32_t at = (sl[j] + p) & cap_mask;
+                    cl[p][j] = tlo[at]; ch[p][j] = thi[at]; cs[p][j] = tstate[at];
+                }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const bool real = !(kv[j].x == WH_EMPTY && kv[j].y == WH_EMPTY);
                 if (!real) continue;
                 if (sb && hash_sub(hv[j], bb, sb) != sub) continue;
                 uint32_t slot = sl[j];
-                if (!(cl[j] == kv[j].x && ch[j] == kv[j].y && ((cs[j] >> 31) || cs[j] == g + 1))) {
+                bool done = false;
+#pragma unroll
+                for (int p = 1; p >= 0; p--) {
+                    const bool hit = cl[p][j] == kv[j].x && ch[p][j] == kv[j].y && ((cs[p][j] >> 31) || cs[p][j] == g + 1);
+                    if (hit) slot = (sl[j] + p) & cap_mask;
+                    done |= hit;
+                }
+                if (!done) {
                     bool ins;
                     slot = wide_find_or_insert(tlo, thi, cap_mask, kv[j].y, kv[j].x, hv[j], &ins);
                     if (slot == 0xffffffffu) { full = 1; continue; }
@@ -314,6 +339,8 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                 kslot[s0 + i0 + 64u * j] = (uint16_t)((sub << cap_log2) | slot);
             }
         }
+        s0 = s0_next;
+        n = n_next;
         if (full) break;
     }
     __syncthreads();
