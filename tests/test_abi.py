@@ -50,3 +50,23 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 for needle in ("import oracle", "from oracle", "grm_oracle", "oracle_ctypes", "pyoracle", "oracle/"):
                     assert needle not in src, (os.path.join(dirpath, f), needle)
+
+
+def test_header_is_c99_and_a_c_client_links(tmp_path):
+    """the boundary is a C ABI: include/grm_kmer.h must compile as plain C, and a C program must be able
+    to link libgrmkmer.so and use it (here the GPU-free part: host-only matrix -> TSV writer)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "grm_kmer.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    import grm_amd
+    so = grm_amd._lib.LIB_PATH
+    assert os.path.exists(so)
+    exe = str(tmp_path / "c_client")
+    libdir = os.path.dirname(so)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-o", exe, os.path.join(root, "tests", "abi", "c_client.c"),
+                           "-L" + libdir, "-lgrmkmer", "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe, str(tmp_path / "m.tsv")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "c client ok" in r.stdout
+
