@@ -74,6 +74,7 @@ PROTOTYPES = [
     ("grm_batch_n_symbols", C.c_uint64, [_P]),
     ("grm_batch_n_occurrences", C.c_uint64, [_P]),
     ("grm_batch_input_bytes", C.c_uint64, [_P]),
+    ("grm_batch_n_local", C.c_uint64, [_P]),
     ("grm_batch_genome_set", C.c_int, [_P, C.c_int, _PP]),
     ("grm_batch_free", None, [_P]),
 ]

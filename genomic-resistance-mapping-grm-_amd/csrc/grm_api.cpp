@@ -13,6 +13,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -56,6 +57,8 @@ struct grm_ctx {
     int opt_keys_in_flight = -1, opt_table_threads = -1;
     int opt_wide_sort = -1;     // > 0: k > 32 always through the sort-based path (tests)
     int opt_upload_slab_kb = -1; // pinned upload slab size in KiB (tests; default 128 MiB)
+    int opt_direct_permute = -1; // > 0: scattered single-step form of the fill (tests, measurements)
+    int opt_dedup_wg = -1;       // > 0: per-segment dedup in the workgroup form only (tests)
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
 
@@ -231,6 +234,8 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "no_slots") c->opt_no_slots = value;
     else if (n == "wide_sort") c->opt_wide_sort = value;
     else if (n == "upload_slab_kb") c->opt_upload_slab_kb = value;
+    else if (n == "direct_permute") c->opt_direct_permute = value;
+    else if (n == "dedup_wg") c->opt_dedup_wg = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
@@ -581,18 +586,24 @@ struct grm_batch {
     // dictionary
     int sb_dict = 0, sb_fill = 0;
     uint32_t cap_log2 = 12;
-    DevBuf d_local_keys, d_local_flags;
+    // sub-bucket count that the last successful dict_build of this batch needed (for the same k, abundance-min
+    // and bucket geometry): the next run starts there instead of walking up from 0 again
+    int sb_hint = -1, sb_hint_k = 0, sb_hint_bb = -1;
+    uint32_t sb_hint_amin = 0;
+    int dict_launches = 0;         // dict_build launches of the last grm_batch_local_dict (tests)
+    DevBuf d_local_keys, d_local_flags;     // entries of the local dictionary: workgroup wg owns [wg_base, wg_base + wg_cnt)
     uint64_t n_local = 0;
     DevBuf d_dict;                 // sorted, filtered global dictionary (U)
     uint64_t n_dict = 0;
     DevBuf d_dkeys, d_dcol, d_seg_start;   // bucketised view for matrix_fill (probing form)
-    // slot form: dict_build leaves a slot id per key + an image of every table; the fill then
-    // needs neither keys nor probes (used whenever sub id + slot id fit 16 bits)
-    DevBuf d_kslot, d_table_img, d_col_of_slot;
-    bool have_slots = false, fill_by_slots = false;
+    // fused form: dict_build also leaves the presence words of every entry (by workgroup, word-row, entry id);
+    // the fill is then a permutation into column order that needs neither keys nor probes
+    DevBuf d_wg_base, d_wg_cnt, d_matrix_s, d_birth, d_entry_col, d_ctrl, d_prefix, d_entry_major;
+    bool own_dict = false;         // the global dictionary is this batch's own local one: every column has a local entry
+    bool have_bits = false, fill_by_bits = false;
     int filter_singleton = 0;
     // scratch that survives between steps (grow-only)
-    DevBuf t_flag, t_stage_keys, t_stage_flags, t_stage_cnt, t_stage_off;
+    DevBuf t_flag;
     DevBuf t_sk, t_sf, t_keep, t_pos, t_tmp, t_bid, t_col, t_bid_sorted;
     DevBuf t_set_off, t_set_len, t_set_k, t_set_c, t_set_tmp;     // grm_batch_genome_set
 };
@@ -1006,13 +1017,31 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         HIPCHK(c, hipMemsetAsync(d_flag.p, 0, 4, s));
         HIPCHK(c, b->d_len.ensure(n_seg * 4));
         if (want_counts) HIPCHK(c, b->d_kcnt.ensure((b->total_keys + 2) * 4));
-        {
-            TimeScope t(c, "bucket_dedup", b->total_keys);
+        // wave form first (table sized to the expected segment, no barriers); what it marks as too dense goes
+        // through the workgroup form with the full-size table
+        const uint64_t mean_seg = max_g >> b->bb;
+        const uint64_t want = (uint64_t)((double)(mean_seg + 16) + 6.0 * std::sqrt((double)mean_seg + 1.0)) * 5 / 4;
+        int wave_cap = 9;
+        while (wave_cap < 11 && (1ull << wave_cap) < want) wave_cap++;
+        const bool wave_form = c->opt_dedup_wg <= 0;
+        int ov = 0;
+        if (wave_form) {
+            {
+                TimeScope t(c, "bucket_dedup", b->total_keys);
+                launch_bucket_dedup_wave(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), n_seg, wave_cap, abundance_min,
+                                         b->d_len.as<uint32_t>(), want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, d_flag.as<int>());
+            }
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+        }
+        if (!wave_form || ov) {
+            HIPCHK(c, hipMemsetAsync(d_flag.p, 0, 4, s));
+            TimeScope t(c, wave_form ? "bucket_dedup_dense" : "bucket_dedup", b->total_keys);
             launch_bucket_dedup(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), n_seg, b->cap_log2, abundance_min,
-                                b->d_len.as<uint32_t>(), want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, d_flag.as<int>());
+                                b->d_len.as<uint32_t>(), want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, d_flag.as<int>(), wave_form ? 1 : 0);
         }
         HIPCHK(c, hipGetLastError());
-        int ov = 0;
         HIPCHK(c, hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         if (ov) return fail(c, GRM_ERR_OVERFLOW, "bucket_dedup: a (genome,bucket) segment holds more distinct k-mers than the LDS table (cap 2^%u); raise bucket_bits", b->cap_log2);
@@ -1046,8 +1075,30 @@ extern "C" int grm_batch_partition_counts(grm_batch *b, int k, uint32_t abundanc
 extern "C" uint64_t grm_batch_n_symbols(const grm_batch *b) { return b ? b->total_syms : 0; }
 extern "C" uint64_t grm_batch_n_occurrences(const grm_batch *b) { return b ? b->total_keys : 0; }
 extern "C" uint64_t grm_batch_input_bytes(const grm_batch *b) { return b ? b->input_bytes : 0; }
+extern "C" uint64_t grm_batch_n_local(const grm_batch *b) { return b ? b->n_local : 0; }
 
 // ---- dictionary of the local genomes ------------------------------------------------------
+// segment layout of the partitioned keys of a batch (dense, from the histogram)
+static SegLayout batch_segments(const grm_batch *b)
+{
+    SegLayout L;
+    L.off = b->d_off.as<uint64_t>();
+    L.len = b->deduped ? b->d_len.as<uint32_t>() : nullptr;
+    L.stride = 0;
+    return L;
+}
+
+// device control block of dict_build: { n_out u64, overflow i32, need u32 }
+struct DictCtrl {
+    unsigned long long n_out;
+    int overflow;
+    uint32_t need;
+};
+
+// presence words kept by dict_build: 2^(bb+sb) workgroups x word-rows x table slots; beyond this many bytes
+// the probing form of the fill is used instead (it needs no intermediate)
+static const size_t MATRIX_S_LIMIT = (size_t)96 << 30;
+
 extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
 {
     if (!b) return GRM_ERR_ARG;
@@ -1057,7 +1108,8 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     b->have_local = b->have_global = false;
-    b->have_slots = false;
+    b->have_bits = false;
+    b->dict_launches = 0;
     const uint32_t G = (uint32_t)b->n_genomes;
     if (b->total_keys == 0) {
         b->n_local = 0;
@@ -1067,56 +1119,66 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
         if (n_local) *n_local = 0;
         return GRM_OK;
     }
-    const uint32_t cap = 1u << b->cap_log2;
+    const uint32_t cap = 1u << b->cap_log2, max_fill = cap - (cap >> 3);
+    const size_t n_rows = ((size_t)G + 63) / 64;
+    if (n_rows > 0xffffu) return fail(c, GRM_ERR_UNSUPPORTED, "%u genomes in one batch (limit 65535 word-rows); use the chunked flow", G);
+    // sub-buckets: what the caller forces, else what this batch needed last time for the same geometry, else none
     int sb = c->opt_sub_bits >= 0 ? c->opt_sub_bits : 0;
-    DevBuf &d_flag = b->t_flag, &d_stage_keys = b->t_stage_keys, &d_stage_flags = b->t_stage_flags,
-           &d_stage_cnt = b->t_stage_cnt, &d_stage_off = b->t_stage_off;
-    HIPCHK(c, d_flag.ensure(4));
-    for (;; sb++) {
+    if (c->opt_sub_bits < 0 && b->sb_hint >= 0 && b->sb_hint_k == b->k && b->sb_hint_bb == b->bb && b->sb_hint_amin == b->abundance_min)
+        sb = b->sb_hint;
+    HIPCHK(c, b->d_ctrl.ensure(sizeof(DictCtrl)));
+    for (int attempt = 0;; attempt++) {
         if (b->bb + sb > 24) return fail(c, GRM_ERR_OVERFLOW, "dict_build: bucket union does not fit the LDS table even with 2^%d sub-buckets", sb);
         const uint32_t n_wg = 1u << (b->bb + sb);
-        HIPCHK(c, d_stage_keys.ensure((size_t)n_wg * cap * 8));
-        HIPCHK(c, d_stage_flags.ensure((size_t)n_wg * cap));
-        HIPCHK(c, d_stage_cnt.ensure((size_t)n_wg * 4));
-        HIPCHK(c, d_stage_off.ensure(((size_t)n_wg + 1) * 8));
-        HIPCHK(c, hipMemsetAsync(d_flag.p, 0, 4, s));
-        const bool slots = (uint32_t)sb + b->cap_log2 <= 16 && c->opt_no_slots <= 0;
-        if (slots) {
-            HIPCHK(c, b->d_kslot.ensure((b->total_keys + 2) * 2));
-            HIPCHK(c, b->d_table_img.ensure((size_t)n_wg * cap * 8));
+        // every workgroup holds at most max_fill entries, and there are no more entries than keys
+        const uint64_t out_cap = std::min<uint64_t>(b->total_keys, (uint64_t)n_wg * max_fill) + 64;
+        HIPCHK(c, b->d_local_keys.ensure(out_cap * 8));
+        HIPCHK(c, b->d_local_flags.ensure(out_cap));
+        HIPCHK(c, b->d_wg_base.ensure((size_t)n_wg * 8));
+        HIPCHK(c, b->d_wg_cnt.ensure((size_t)n_wg * 4));
+        const size_t ms_bytes = (size_t)n_wg * n_rows * cap * 8;
+        const bool bits = c->opt_no_slots <= 0 && ms_bytes <= MATRIX_S_LIMIT;
+        if (bits) {
+            HIPCHK(c, b->d_matrix_s.ensure(ms_bytes));
+            HIPCHK(c, b->d_birth.ensure((size_t)n_wg * cap * 2));
         }
+        HIPCHK(c, hipMemsetAsync(b->d_ctrl.p, 0, sizeof(DictCtrl), s));
+        DictArgs a;
+        a.keys = b->d_keys.as<uint64_t>();
+        a.seg = batch_segments(b);
+        a.n_genomes = G; a.bb = b->bb; a.sb = sb; a.cap_log2 = b->cap_log2;
+        a.out_keys = b->d_local_keys.as<uint64_t>(); a.out_flags = b->d_local_flags.as<uint8_t>();
+        a.out_cap = out_cap;
+        DictCtrl *ctrl = b->d_ctrl.as<DictCtrl>();
+        a.n_out = &ctrl->n_out; a.overflow = &ctrl->overflow; a.need = &ctrl->need;
+        a.wg_base = b->d_wg_base.as<uint64_t>(); a.wg_cnt = b->d_wg_cnt.as<uint32_t>();
+        a.matrix_s = bits ? b->d_matrix_s.as<uint64_t>() : nullptr;
+        a.birth = bits ? b->d_birth.as<uint16_t>() : nullptr;
         {
             TimeScope t(c, "dict_build", b->total_keys);
-            launch_dict_build(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(),
-                              b->deduped ? b->d_len.as<uint32_t>() : nullptr, G, b->bb, sb, b->cap_log2,
-                              d_stage_keys.as<uint64_t>(), d_stage_flags.as<uint8_t>(), d_stage_cnt.as<uint32_t>(),
-                              slots ? b->d_kslot.as<uint16_t>() : nullptr, slots ? b->d_table_img.as<uint64_t>() : nullptr,
-                              d_flag.as<int>());
+            launch_dict_build(s, a);
         }
-        b->have_slots = slots;
+        b->dict_launches++;
         HIPCHK(c, hipGetLastError());
-        int ov = 0;
-        HIPCHK(c, hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, s));
+        DictCtrl h;
+        HIPCHK(c, hipMemcpyAsync(&h, b->d_ctrl.p, sizeof h, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
-        if (!ov) {
-            launch_scan_u32(s, d_stage_cnt.as<uint32_t>(), n_wg, d_stage_off.as<uint64_t>());
-            HIPCHK(c, hipMemcpyAsync(&b->n_local, d_stage_off.as<uint64_t>() + n_wg, 8, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
-            HIPCHK(c, b->d_local_keys.ensure((b->n_local + 2) * 8));
-            HIPCHK(c, b->d_local_flags.ensure(b->n_local + 16));
-            {
-                TimeScope t(c, "dict_gather", b->n_local);
-                launch_dict_gather(s, d_stage_keys.as<uint64_t>(), d_stage_flags.as<uint8_t>(), d_stage_off.as<uint64_t>(),
-                                   n_wg, cap, b->d_local_keys.as<uint64_t>(), b->d_local_flags.as<uint8_t>());
-            }
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipStreamSynchronize(s));
+        if (!h.overflow) {
+            b->n_local = h.n_out;
+            b->have_bits = bits;
             break;
         }
-        if (c->opt_sub_bits >= 0 && sb >= c->opt_sub_bits + 8)
+        if (h.overflow >= 2 && h.need == 0) return fail(c, GRM_ERR_HIP, "internal: dict_build output capacity exceeded (%llu entries)", (unsigned long long)h.n_out);
+        if (attempt >= 8 || (c->opt_sub_bits >= 0 && sb >= c->opt_sub_bits + 8))
             return fail(c, GRM_ERR_OVERFLOW, "dict_build: overflow persists");
+        // jump to the sub-bucket count the failed launch asks for: its fullest workgroup estimated `need`
+        // distinct k-mers; aim at 70 % of the usable table so that the estimate's error does not cost a third launch
+        int step = 1;
+        while (step < 24 && ((uint64_t)h.need >> step) > (uint64_t)max_fill * 7 / 10) step++;
+        sb += step;
     }
     b->sb_dict = sb;
+    if (c->opt_sub_bits < 0) { b->sb_hint = sb; b->sb_hint_k = b->k; b->sb_hint_bb = b->bb; b->sb_hint_amin = b->abundance_min; }
     b->have_local = true;
     if (n_local) *n_local = b->n_local;
     return GRM_OK;
@@ -1186,6 +1248,7 @@ extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, con
     b->have_global = false;
     b->filter_singleton = filter_singleton;
     b->n_dict = 0;
+    b->own_dict = n && dev_keys == b->d_local_keys.p && n == b->n_local;     // filtered or not: every COLUMN stems from a local entry
     if (n) {
         DevBuf &d_sk = b->t_sk, &d_sf = b->t_sf, &d_keep = b->t_keep, &d_pos = b->t_pos, &d_tmp = b->t_tmp;
         HIPCHK(c, d_sk.ensure(n * 8));
@@ -1216,20 +1279,19 @@ extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, con
     } else {
         HIPCHK(c, b->d_dict.ensure(16));
     }
-    b->fill_by_slots = false;
-    if (b->have_local && b->have_slots && b->total_keys) {
-        // slot form: give every table slot of the local dictionary its global column
-        const size_t n_slots = (size_t)1 << (b->bb + b->sb_dict + b->cap_log2);
-        HIPCHK(c, b->d_col_of_slot.ensure(n_slots * 4));
-        HIPCHK(c, hipMemsetAsync(b->d_col_of_slot.p, 0xff, n_slots * 4, s));
+    b->fill_by_bits = false;
+    if (b->have_local && b->have_bits && b->total_keys) {
+        // fused form: every local entry learns its global column (or that it was filtered out)
+        HIPCHK(c, b->d_entry_col.ensure((b->n_local + 1) * 4));
         {
-            TimeScope t(c, "dict_slot_cols", b->n_dict);
-            launch_dict_slot_cols(s, b->d_dict.as<uint64_t>(), b->n_dict, b->bb, b->sb_dict, b->cap_log2,
-                                  b->d_table_img.as<uint64_t>(), b->d_col_of_slot.as<uint32_t>());
+            TimeScope t(c, "dict_entry_cols", b->n_local);
+            HIPCHK(c, b->d_prefix.ensure(((size_t)1 << 20) * 4 + 16));
+            launch_dict_entry_cols(s, b->d_dict.as<uint64_t>(), b->n_dict, b->d_local_keys.as<uint64_t>(), b->n_local, b->k,
+                                   b->d_prefix.as<uint32_t>(), b->d_entry_col.as<uint32_t>());
         }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(s));
-        b->fill_by_slots = true;
+        b->fill_by_bits = true;
         b->have_global = true;
         if (n_kmers) *n_kmers = b->n_dict;
         return GRM_OK;
@@ -1268,13 +1330,22 @@ extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
     DevBuf &d_flag = b->t_flag;
     if (d_flag.ensure(4) != hipSuccess) { delete m; return fail(c, GRM_ERR_OOM, "alloc"); }
     for (;;) {
-        if (cells) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
+        const bool two_step = b->fill_by_bits && b->total_keys && m->n_rows >= 4 && c->opt_direct_permute <= 0;     // writes every cell
+        if (cells && !two_step) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
         (void)hipMemsetAsync(d_flag.p, 0, 4, s);
-        if (cells && b->total_keys && b->fill_by_slots) {
-            TimeScope t(c, "matrix_fill", b->total_keys);
-            launch_matrix_fill_slots(s, b->d_kslot.as<uint16_t>(), b->d_off.as<uint64_t>(),
-                                     b->deduped ? b->d_len.as<uint32_t>() : nullptr, (uint32_t)b->n_genomes, b->bb, b->sb_dict,
-                                     b->cap_log2, b->d_col_of_slot.as<uint32_t>(), m->d_data.as<uint64_t>(), m->n_kmers);
+        if (cells && b->total_keys && b->fill_by_bits) {
+            // two-step form (entry-major lines, then a transpose) from 4 word-rows up; the intermediate is zeroed
+            // only when some columns may have no entry here (dictionary gathered from several ranks / chunks)
+            uint64_t *em = nullptr;
+            if (m->n_rows >= 4 && c->opt_direct_permute <= 0) {
+                if (b->d_entry_major.ensure(cells * 8) != hipSuccess) { rc = fail(c, GRM_ERR_OOM, "matrix_fill: entry-major scratch"); break; }
+                em = b->d_entry_major.as<uint64_t>();
+                if (!b->own_dict) (void)hipMemsetAsync(em, 0, cells * 8, s);
+            }
+            TimeScope t(c, "matrix_fill", (uint64_t)b->n_local * m->n_rows);
+            launch_matrix_permute(s, b->d_matrix_s.as<uint64_t>(), b->d_birth.as<uint16_t>(), b->d_wg_base.as<uint64_t>(),
+                                  b->d_wg_cnt.as<uint32_t>(), b->d_entry_col.as<uint32_t>(), 1u << (b->bb + b->sb_dict),
+                                  (uint32_t)m->n_rows, b->cap_log2, m->d_data.as<uint64_t>(), m->n_kmers, em);
         } else if (cells && b->total_keys) {
             TimeScope t(c, "matrix_fill", b->total_keys);
             launch_matrix_fill(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), b->deduped ? b->d_len.as<uint32_t>() : nullptr,

@@ -26,6 +26,16 @@ constexpr int L2_TILE = L2_THREADS * L2_PPT;
 constexpr int L2_LDS_BYTES = L2_TILE * 8 + 2048 + 1024 + 1024 + 64;   // keys, gbase[256], hist[256], start[256], scratch[16]
 constexpr int L1_MAX_BITS = 8;                             // coarse fan-out 256: ~32 keys (256 B) per run
 constexpr int L1_LDS_BYTES = L1_TILE * 8 + 2048 + 1024 + 1024 + 64 + L1_TILE;   // keys, gbase[256], hist[256], start[256], scratch[16], bucket bytes
+// Bucket ownership by thread id.  In both partition levels thread t owns bucket t of the tile (its hist / start /
+// gbase entries, and in level 2 the running output position my_next), so a workgroup needs at least as many
+// threads as the level has buckets: 2^L1_MAX_BITS coarse ones, up to 2^(MAX_BUCKET_BITS - L1_MAX_BITS) fine ones
+// in deep mode (bucket_bits 16 -> 256 = every thread of a level-2 workgroup).  A level-2 geometry with fewer
+// threads leaves the upper fine buckets without an owner: their gbase is never written and the copy-out stores
+// through garbage addresses -- only in deep mode, which is how the aborted run of round 1 (bucket_bits 16 failed,
+// 14 passed) presented.  The LDS carve-up below reserves 256 entries for each of the three arrays for the same reason.
+static_assert(L1_THREADS >= (1 << L1_MAX_BITS), "level 1: one thread per coarse bucket");
+static_assert(L2_THREADS >= (1 << (MAX_BUCKET_BITS - L1_MAX_BITS)), "level 2: one thread per fine bucket, deep mode included");
+static_assert((1 << L1_MAX_BITS) <= 256 && (1 << (MAX_BUCKET_BITS - L1_MAX_BITS)) <= 256, "gbase / hist / start hold 256 entries");
 
 // ---- LDS table kernels ----
 constexpr int TABLE_THREADS = 512;                         // 8 waves: one genome per wave at a time
@@ -75,12 +85,51 @@ void launch_keys_partition_scatter(hipStream_t s, const uint64_t *in, uint64_t n
                                    uint32_t n_genomes, int bb, const uint64_t *off, uint32_t *cursor, uint64_t *keys);
 void launch_scan_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *out);
 void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const uint64_t *off, uint64_t n_segments, uint32_t cap_log2,
-                         uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow);
-void launch_dict_build(hipStream_t s, const uint64_t *keys, const uint64_t *off, const uint32_t *len,
-                       uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, uint64_t *stage_keys,
-                       uint8_t *stage_flags, uint32_t *stage_cnt, uint16_t *kslot, uint64_t *table_img, int *overflow);
-void launch_dict_slot_cols(hipStream_t s, const uint64_t *dict, uint64_t n, int bb, int sb, uint32_t cap_log2,
-                           const uint64_t *table_img, uint32_t *col_of_slot);
+                         uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow, int only_marked);
+void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const uint64_t *off, uint64_t n_segments, int wave_cap_log2,
+                              uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow);
+// Segment layout of the partitioned keys: segment idx = genome * 2^bb + bucket.
+//   off != nullptr : keys[off[idx] .. off[idx] + (len ? len[idx] : off[idx+1] - off[idx]))      (histogram-sized, dense)
+//   off == nullptr : keys[idx * stride .. idx * stride + len[idx])                              (fixed-capacity slots)
+struct SegLayout {
+    const uint64_t *off;
+    const uint32_t *len;
+    uint64_t stride;
+};
+// dict_build: per-(bucket, sub-bucket) union over all genomes in an LDS table + the presence bits of
+// every distinct k-mer ("entry"), one word-row (64 genomes) at a time.
+struct DictArgs {
+    const uint64_t *keys;
+    SegLayout seg;
+    uint32_t n_genomes;
+    int bb, sb;
+    uint32_t cap_log2;
+    // entries: workgroup wg reserves [wg_base[wg], wg_base[wg] + wg_cnt[wg]) of out_* with one atomic add on
+    // *n_out; inside the range entries stand in insertion order (entry id).  flag 1 = one genome, 2 = several.
+    uint64_t *out_keys;
+    uint8_t *out_flags;
+    uint64_t out_cap;
+    unsigned long long *n_out;
+    uint64_t *wg_base;
+    uint32_t *wg_cnt;
+    // presence words by (workgroup, word-row, entry id): matrix_s[(wg * n_rows + r) << cap_log2 | id], valid for
+    // r >= birth[wg << cap_log2 | id] (the row in which the entry was inserted); nullptr: no bits wanted
+    uint64_t *matrix_s;
+    uint16_t *birth;
+    int *overflow;          // set to 1 when a table overflowed (retry with more sub-buckets), 2 when out_cap did
+    uint32_t *need;         // max over overflowing workgroups of their estimated distinct k-mers (sizes the retry)
+};
+void launch_dict_build(hipStream_t s, const DictArgs &a);
+// column of every local entry: position of its key in the sorted global dictionary, 0xffffffff if filtered / absent
+// (prefix_first: scratch of 2^20 + 2 uint32)
+void launch_dict_entry_cols(hipStream_t s, const uint64_t *dict, uint64_t n_dict, const uint64_t *entry_keys, uint64_t n_entries, int k,
+                            uint32_t *prefix_first, uint32_t *entry_col);
+// matrix[r][entry_col[e]] = presence word of entry e in row r.  entry_major: scratch of n_cols * n_rows words for
+// the two-step form (zeroed by the caller where a column may have no local entry); nullptr: direct scattered form
+void launch_matrix_permute(hipStream_t s, const uint64_t *matrix_s, const uint16_t *birth, const uint64_t *wg_base,
+                           const uint32_t *wg_cnt, const uint32_t *entry_col, uint32_t n_wg, uint32_t n_rows, uint32_t cap_log2,
+                           uint64_t *matrix, uint64_t n_cols, uint64_t *entry_major);
+// slot form of the fill (two-word pipeline): presence bits from the 2-byte slot ids its dictionary kernel leaves behind
 void launch_matrix_fill_slots(hipStream_t s, const uint16_t *kslot, const uint64_t *off, const uint32_t *len,
                               uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint32_t *col_of_slot,
                               uint64_t *matrix, uint64_t n_cols);

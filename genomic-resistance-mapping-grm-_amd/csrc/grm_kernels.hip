@@ -786,7 +786,7 @@ __device__ __forceinline__ uint32_t lds_find(const uint64_t *tkeys, uint32_t cap
 __global__ __launch_bounds__(TABLE_THREADS) void bucket_dedup_kernel(
     uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, uint64_t n_segments, uint32_t cap_log2,
     uint32_t abundance_min, uint32_t *__restrict__ len_out, uint32_t *__restrict__ counts_out,
-    int *__restrict__ overflow)
+    int *__restrict__ overflow, int only_marked)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
@@ -795,6 +795,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void bucket_dedup_kernel(
     uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 12);   // [16] + flags
     volatile int &full = *reinterpret_cast<volatile int *>(scratch + 16);
     for (uint64_t seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
+        if (only_marked && len_out[seg] != 0xffffffffu) continue;      // second pass: what the wave-level kernel left
         const uint64_t s0 = off[seg];
         const uint64_t n = off[seg + 1] - s0;
         for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tkeys[i] = EMPTY_KEY; tcnt[i] = 0; }
@@ -832,167 +833,447 @@ __global__ __launch_bounds__(TABLE_THREADS) void bucket_dedup_kernel(
     }
 }
 
-// ------------------------------------------------------------------------------------
-// Stage 3a (K5): per-bucket dictionary.  One workgroup per (bucket, sub-bucket) unions the
-// bucket's segment of EVERY genome in an LDS table; a wave takes one genome at a time.
-// state[slot] = first genome seen + 1, bit31 set once a second genome shows up.
-// Output: staged, per workgroup at stride `cap`: distinct keys + flag (1 = one genome,
-// 2 = several) in table-slot order, and the count.
-// ------------------------------------------------------------------------------------
-template <int KIF>
-__global__ __launch_bounds__(1024) void dict_build_kernel(
-    const uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
-    uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, uint64_t *__restrict__ stage_keys,
-    uint8_t *__restrict__ stage_flags, uint32_t *__restrict__ stage_cnt, uint16_t *__restrict__ kslot,
-    uint64_t *__restrict__ table_img, int *__restrict__ overflow)
+// K4, wave form: one WAVE per (genome, bucket) segment, a table of its own in LDS, no workgroup barrier anywhere.
+// The workgroup form above spends a 4096-slot clear, a 4096-slot sweep and ~20 barriers on a segment of ~600
+// keys; here the table is sized to the segment (CAP = 512 / 1024 / 2048 slots) and the three phases -- clear,
+// insert + count, ballot-compaction in place -- run back to back inside the wave (LDS operations of one wave
+// execute in order).  A segment with more distinct k-mers than 7/8 of the table is left untouched and marked
+// (len_out = 0xffffffff, *overflow = 1) for the workgroup form.
+__device__ __forceinline__ void wave_lds_fence()
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
-    uint64_t *tkeys = reinterpret_cast<uint64_t *>(lds_raw);
-    uint32_t *tstate = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 8);
-    uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 12);   // [16] + flags
-    volatile int &full = *reinterpret_cast<volatile int *>(scratch + 16);
-    uint32_t &n_distinct = scratch[17];
-    const uint32_t wg = blockIdx.x;
-    const uint32_t B = 1u << bb;
-    const uint32_t b = wg >> sb, sub = wg & ((1u << sb) - 1);
-    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tkeys[i] = EMPTY_KEY; tstate[i] = 0; }
-    if (threadIdx.x == 0) { full = 0; n_distinct = 0; }
-    __syncthreads();
-    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
-    const uint32_t max_fill = cap - (cap >> 3);     // 87.5 %
-    // segment of the NEXT genome is fetched while the current one is processed (the two dependent
-    // global round trips -- offsets, then keys -- would otherwise serialise per genome)
-    uint64_t s0 = 0, n = 0;
-    if ((uint32_t)wave < n_genomes) {
-        const uint64_t idx = (uint64_t)wave * B + b;
-        s0 = off[idx];
-        n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
-    }
-    for (uint32_t g = wave; g < n_genomes; g += nw) {
-        uint64_t s0_next = 0, n_next = 0;
-        if (g + nw < n_genomes) {
-            const uint64_t idx = (uint64_t)(g + nw) * B + b;
-            s0_next = off[idx];
-            n_next = len ? (uint64_t)len[idx] : off[idx + 1] - s0_next;
-        }
-        // The kernel is instruction-issue bound (SQ counters: more scalar than vector instructions in
-        // the divergent probing loops), so the common case is straight-line: KIF keys per lane, their
-        // hashes, then all first-probe reads (key word + state word) back to back.  A key that is
-        // already present in its first-probe slot and already known to this or several genomes -- almost
-        // every key of a pan-genome after the first few genomes -- is done after two LDS reads.  The
-        // others go through ONE shared copy of the general insertion code, one key at a time.
-        for (uint64_t i0 = lane; i0 < n; i0 += 64 * KIF) {
-            uint64_t kv[KIF], hv[KIF];
-            uint32_t sl[KIF];
+    __asm__ volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): this wave's LDS operations have completed
+    __asm__ volatile("" ::: "memory");
+}
+template <int CAP_LOG2, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void bucket_dedup_wave_kernel(
+    uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, uint64_t n_segments, uint32_t abundance_min,
+    uint32_t *__restrict__ len_out, uint32_t *__restrict__ counts_out, int *__restrict__ overflow)
+{
+    constexpr uint32_t CAP = 1u << CAP_LOG2, MASK = CAP - 1, MAX_FILL = CAP - CAP / 8;
+    __shared__ uint64_t tk_all[WAVES][CAP];
+    __shared__ uint32_t tc_all[WAVES][CAP];
+    const int lane = lane_id(), wave = wave_id();
+    uint64_t *tk = tk_all[wave];
+    uint32_t *tc = tc_all[wave];
+    const uint64_t lane_lt = (1ull << lane) - 1;
+    for (uint64_t seg = (uint64_t)blockIdx.x * WAVES + wave; seg < n_segments; seg += (uint64_t)gridDim.x * WAVES) {
+        const uint64_t s0 = off[seg];
+        const uint64_t n = off[seg + 1] - s0;
+        if (n == 0) { if (lane == 0) len_out[seg] = 0; continue; }
+        for (uint32_t i = lane; i < CAP; i += 64) { tk[i] = EMPTY_KEY; tc[i] = 0; }
+        wave_lds_fence();
+        uint32_t nd = 0;
+        bool over = false;
+        for (uint64_t i0 = 0; i0 < n && !over; i0 += 64 * 4) {
+            uint64_t kv[4];
 #pragma unroll
-            for (int j = 0; j < KIF; j++) {
-                const uint64_t i = i0 + 64u * j;
+            for (int j = 0; j < 4; j++) {
+                const uint64_t i = i0 + 64u * j + lane;
                 kv[j] = i < n ? keys[s0 + i] : EMPTY_KEY;
             }
 #pragma unroll
-            for (int j = 0; j < KIF; j++) {
-                hv[j] = mix64(kv[j]);
-                sl[j] = hash_slot(hv[j], cap_mask);
+            for (int j = 0; j < 4; j++) {
+                bool ins = false;
+                if (kv[j] != EMPTY_KEY) {
+                    const uint32_t slot = lds_find_or_insert(tk, MASK, kv[j], mix64(kv[j]), &ins);
+                    if (slot != 0xffffffffu) atomicAdd(&tc[slot], 1u);
+                    else over = true;
+                }
+                nd += __popcll(__ballot(ins));
             }
-            // the first PROBES slots of the probe sequence, unconditionally: at the table's load (~0.25) one key
-            // in nine sits past its home slot, and sending all of those through the divergent loop below for
-            // every genome costs more than the extra LDS reads
-            constexpr int PROBES = 2;
-            uint32_t todo = 0, act = 0;
-            {
-                uint64_t pk[PROBES][KIF];
-                uint32_t ps[PROBES][KIF];
+            over = __any(over) || nd > MAX_FILL;
+        }
+        if (over) {
+            if (lane == 0) { len_out[seg] = 0xffffffffu; atomicExch(overflow, 1); }
+            wave_lds_fence();
+            continue;
+        }
+        wave_lds_fence();
+        uint32_t base = 0;
+#pragma unroll 4
+        for (uint32_t s = 0; s < CAP; s += 64) {
+            const uint64_t key = tk[s + lane];
+            const uint32_t c = tc[s + lane];
+            const bool keep = key != EMPTY_KEY && c >= abundance_min;
+            const uint64_t m = __ballot(keep);
+            if (keep) {
+                const uint32_t pos = base + __popcll(m & lane_lt);
+                keys[s0 + pos] = key;
+                if (counts_out) counts_out[s0 + pos] = c;
+            }
+            base += __popcll(m);
+        }
+        if (lane == 0) len_out[seg] = base;
+        wave_lds_fence();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Stage 3a (K5): per-bucket dictionary AND presence bits.  One workgroup per (bucket, sub-bucket)
+// unions the bucket's segment of EVERY genome in an LDS table; a wave takes one genome at a time,
+// all waves stay inside one word-row (64 genomes) between two barriers.
+//   tkeys[slot]  the k-mer (linear probing, 64-bit ds_cmpst)
+//   words[slot]  presence bits of the CURRENT word-row: a key that is found ORs its genome's bit in
+//                (ds_or_b64, no return) -- the whole per-occurrence work of a pan-genome
+//   meta[slot]   entry id (insertion order inside the workgroup) | SEEN (had a bit in an earlier row)
+//                | MULTI (carried by several genomes)
+// At the end of a row the words of all occupied slots go to matrix_s[wg][row][entry id] (a dense,
+// contiguous run per workgroup and row) and are cleared.  The per-occurrence 2-byte slot ids of the
+// earlier design (11 GB written here, 11 GB read by the fill, per 1000 genomes) no longer exist:
+// what leaves the kernel is U-sized.  "one genome / several" comes from the bits themselves.
+// ------------------------------------------------------------------------------------
+constexpr uint32_t META_ID = 0x1fffu, META_SEEN = 0x4000u, META_MULTI = 0x8000u;
+
+__device__ __forceinline__ void seg_bounds(const SegLayout &L, uint64_t idx, uint64_t &s0, uint64_t &n)
+{
+    if (L.off) {
+        s0 = L.off[idx];
+        n = L.len ? (uint64_t)L.len[idx] : L.off[idx + 1] - s0;
+    } else {
+        s0 = idx * L.stride;
+        n = L.len[idx];
+    }
+}
+
+// Pair-aligned linear probing: a key's probe sequence starts at the EVEN slot (h & mask & ~1), so that one
+// 16-byte LDS read (ds_read_b128) returns two consecutive slots of it and two reads cover a displacement of
+// up to 3 -- at the table's load that settles all but a few keys per thousand in the straight-line part.
+// returns the slot of key (inserting it if absent), or 0xffffffff when the table is full
+__device__ __forceinline__ uint32_t lds_pair_find_or_insert(uint64_t *tkeys, uint32_t cap_mask, uint64_t key, uint64_t h,
+                                                            bool *inserted)
+{
+    uint32_t slot = hash_slot(h, cap_mask) & ~1u;
+    for (uint32_t probe = 0; probe <= cap_mask; probe++) {
+        uint64_t cur = *reinterpret_cast<volatile uint64_t *>(&tkeys[slot]);
+        if (cur == EMPTY_KEY)
+            cur = atomicCAS((unsigned long long *)&tkeys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        if (cur == EMPTY_KEY) { *inserted = true; return slot; }
+        if (cur == key) { *inserted = false; return slot; }
+        slot = (slot + 1) & cap_mask;
+    }
+    return 0xffffffffu;
+}
+
+struct DictWave {
+    uint64_t *tkeys;
+    unsigned long long *words;
+    uint16_t *meta;
+    volatile int *full;
+    uint32_t *n_distinct;
+    uint32_t cap_mask, max_fill, cap_log2;
+    uint32_t wg, sub, G;
+    int bb, sb;
+    uint16_t *birth;
+    uint32_t *need;
+};
+
+// J x 64 keys of one genome's segment: keys[i0 + 64 j] for j < J (i0 includes the lane), n = segment length
+template <int J>
+__device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__restrict__ keys, uint64_t i0, uint64_t n, uint32_t g,
+                                           uint32_t r, unsigned long long bit)
+{
+    uint64_t kv[J];
+    uint32_t sl[J];
 #pragma unroll
-                for (int p = 0; p < PROBES; p++)
+    for (int j = 0; j < J; j++) {
+        const uint64_t i = i0 + 64u * j;
+        kv[j] = i < n ? keys[i] : EMPTY_KEY;
+    }
+    // all J global loads are in flight; the table is then consulted four keys at a time (the 16-byte reads of
+    // more keys than that at once cost more registers than the LDS latency they would hide)
+    uint32_t todo = 0;
+    constexpr int GRP = J < 4 ? J : 4;
 #pragma unroll
-                    for (int j = 0; j < KIF; j++) {
-                        pk[p][j] = tkeys[(sl[j] + p) & cap_mask];
-                        ps[p][j] = tstate[(sl[j] + p) & cap_mask];
-                    }
+    for (int j0 = 0; j0 < J; j0 += GRP) {
+        ulonglong2 p0[GRP], p1[GRP];
+        uint32_t hs[GRP];
 #pragma unroll
-                for (int j = 0; j < KIF; j++) {
-                    const bool active = kv[j] != EMPTY_KEY && (!sb || hash_sub(hv[j], bb, sb) == sub);
-                    bool done = false;
-                    uint32_t at = sl[j];
+        for (int q = 0; q < GRP; q++) {
+            const uint64_t h = mix64(kv[j0 + q]);
+            sl[j0 + q] = hash_slot(h, w.cap_mask) & ~1u;
+            hs[q] = w.sb ? hash_sub(h, w.bb, w.sb) : 0u;
+        }
 #pragma unroll
-                    for (int p = PROBES - 1; p >= 0; p--) {
-                        const bool hit = pk[p][j] == kv[j] && ((ps[p][j] >> 31) || ps[p][j] == g + 1);
-                        if (hit) at = (sl[j] + p) & cap_mask;
-                        done |= hit;
-                    }
-                    sl[j] = at;
-                    act |= (uint32_t)active << j;
-                    todo |= (uint32_t)(active && !done) << j;
+        for (int q = 0; q < GRP; q++) {
+            p0[q] = *reinterpret_cast<const ulonglong2 *>(&w.tkeys[sl[j0 + q]]);
+            p1[q] = *reinterpret_cast<const ulonglong2 *>(&w.tkeys[(sl[j0 + q] + 2) & w.cap_mask]);
+        }
+#pragma unroll
+        for (int q = 0; q < GRP; q++) {
+            const uint64_t key = kv[j0 + q];
+            const bool active = key != EMPTY_KEY && hs[q] == w.sub;
+            uint32_t at = sl[j0 + q];
+            const bool h0 = p0[q].x == key, h1 = p0[q].y == key, h2 = p1[q].x == key, h3 = p1[q].y == key;
+            if (h1) at = sl[j0 + q] + 1;
+            if (h2) at = (sl[j0 + q] + 2) & w.cap_mask;
+            if (h3) at = (sl[j0 + q] + 3) & w.cap_mask;
+            const bool done = h0 | h1 | h2 | h3;
+            if (active && done) atomicOr(&w.words[at], bit);
+            todo |= (uint32_t)(active && !done) << (j0 + q);
+        }
+    }
+    while (todo) {
+        if (*w.full) break;          // LDS flag: once the table is given up, stop probing it
+        const int j = __ffs(todo) - 1;
+        todo &= todo - 1;
+        uint64_t key = kv[0];
+#pragma unroll
+        for (int q = 1; q < J; q++) { if (j == q) key = kv[q]; }
+        bool ins;
+        const uint32_t slot = lds_pair_find_or_insert(w.tkeys, w.cap_mask, key, mix64(key), &ins);
+        bool over = slot == 0xffffffffu;
+        if (!over) {
+            if (ins) {
+                const uint32_t id = atomicAdd(w.n_distinct, 1u);
+                w.meta[slot] = (uint16_t)(id & META_ID);
+                if (w.birth && id <= w.cap_mask) w.birth[((uint64_t)w.wg << w.cap_log2) + id] = (uint16_t)r;
+                over = id >= w.max_fill;
+            }
+            atomicOr(&w.words[slot], bit);
+        }
+        if (over) {
+            *w.full = 1;
+            // what this workgroup would have needed: the fill it reached, scaled to all genomes
+            const uint64_t est = (uint64_t)w.max_fill * w.G / (g + 1);
+            atomicMax(w.need, (uint32_t)min(est, (uint64_t)0xffffffffu));
+            break;
+        }
+    }
+}
+
+// MAXT: largest workgroup the instance is launched with (the 8-deep form needs more than the 128 VGPRs a
+// 1024-thread workgroup leaves per lane)
+template <int KIF, int MAXT>
+__global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t cap = 1u << a.cap_log2, cap_mask = cap - 1;
+    uint64_t *tkeys = reinterpret_cast<uint64_t *>(lds_raw);
+    unsigned long long *words = reinterpret_cast<unsigned long long *>(lds_raw + (size_t)cap * 8);
+    uint16_t *meta = reinterpret_cast<uint16_t *>(lds_raw + (size_t)cap * 16);
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 18);   // [16] + flags
+    volatile int &full = *reinterpret_cast<volatile int *>(scratch + 16);
+    uint32_t &n_distinct = scratch[17];
+    uint64_t &out_base = *reinterpret_cast<uint64_t *>(scratch + 18);
+    const uint32_t wg = blockIdx.x;
+    const uint32_t B = 1u << a.bb;
+    const int sb = a.sb;
+    const uint32_t b = wg >> sb;
+    const uint32_t G = a.n_genomes, n_rows = (G + 63) >> 6;
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tkeys[i] = EMPTY_KEY; words[i] = 0; meta[i] = 0; }
+    if (threadIdx.x == 0) { full = 0; n_distinct = 0; }
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;     // nw divides 64 (launcher)
+    const uint32_t per_row = 64u / (uint32_t)nw;    // genomes per wave per word-row
+    DictWave w;
+    w.tkeys = tkeys; w.words = words; w.meta = meta; w.full = &full; w.n_distinct = &n_distinct;
+    w.cap_mask = cap_mask; w.max_fill = cap - (cap >> 3); w.cap_log2 = a.cap_log2;
+    w.wg = wg; w.sub = wg & ((1u << sb) - 1); w.G = G; w.bb = a.bb; w.sb = sb; w.birth = a.birth; w.need = a.need;
+    // segment of the NEXT genome is fetched while the current one is processed (the two dependent
+    // global round trips -- bounds, then keys -- would otherwise serialise per genome).  Wave w takes
+    // genomes w, w + nw, ...: since nw divides 64 that sequence walks the word-rows in step with the
+    // other waves.
+    uint32_t g = (uint32_t)wave;
+    uint64_t s0 = 0, n = 0;
+    if (g < G) seg_bounds(a.seg, (uint64_t)g * B + b, s0, n);
+    for (uint32_t r = 0; r < n_rows; r++) {
+        for (uint32_t jr = 0; jr < per_row; jr++, g += nw) {
+            uint64_t s0_next = 0, n_next = 0;
+            if (g + nw < G) seg_bounds(a.seg, (uint64_t)(g + nw) * B + b, s0_next, n_next);
+            if (g < G && !full) {
+                const unsigned long long bit = 1ull << (63 - (g & 63));
+                const uint64_t *seg = a.keys + s0;
+                // The kernel is bound by latency and instruction issue, so the common case is straight-line and
+                // wide: KIF keys per lane in flight, their hashes, two 16-byte table reads each; a key found there
+                // -- almost every key of a pan-genome after the first few genomes -- costs one more LDS OR.  The
+                // tail of the segment goes through a copy of the same code that is exactly as deep as it needs.
+                uint64_t i0 = lane;
+                for (; i0 + 64u * (KIF - 1) < n; i0 += 64 * KIF) dict_chunk<KIF>(w, seg, i0, n, g, r, bit);
+                if (i0 - lane < n && !full) {
+                    const uint32_t nj = (uint32_t)((n - (i0 - lane) + 63) >> 6);        // wave-uniform: 1 .. KIF - 1
+                    if (KIF > 4 && nj > 4) dict_chunk<(KIF > 4 ? KIF : 1)>(w, seg, i0, n, g, r, bit);
+                    else if (KIF > 2 && nj > 2) dict_chunk<(KIF > 2 ? 4 : 1)>(w, seg, i0, n, g, r, bit);
+                    else if (KIF > 1 && nj == 2) dict_chunk<(KIF > 1 ? 2 : 1)>(w, seg, i0, n, g, r, bit);
+                    else dict_chunk<1>(w, seg, i0, n, g, r, bit);
                 }
             }
-            while (todo) {
-                const int j = __ffs(todo) - 1;
-                todo &= todo - 1;
-                uint64_t key = kv[0], h = hv[0];
-#pragma unroll
-                for (int q = 1; q < KIF; q++) { if (j == q) { key = kv[q]; h = hv[q]; } }
-                bool ins;
-                const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, h, &ins);
-                if (slot == 0xffffffffu) { full = 1; act &= ~(1u << j); continue; }
-                if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
-                // state: first genome + 1, bit 31 once a second genome shows up
-                const uint32_t st = atomicCAS(&tstate[slot], 0u, g + 1);
-                if (st != 0 && !(st >> 31) && st != g + 1) atomicOr(&tstate[slot], 0x80000000u);
-#pragma unroll
-                for (int q = 0; q < KIF; q++) { if (j == q) sl[q] = slot; }
-            }
-            // remember where the key lives: the fill pass then needs neither the key nor a probe
-            if (kslot) {
-#pragma unroll
-                for (int j = 0; j < KIF; j++)
-                    if ((act >> j) & 1u) kslot[s0 + i0 + 64u * j] = (uint16_t)((sub << cap_log2) | sl[j]);
+            s0 = s0_next;
+            n = n_next;
+        }
+        __syncthreads();
+        if (full) break;         // read between two barriers: uniform
+        // end of the word-row: publish and clear the words of every occupied slot
+        for (uint32_t slot = threadIdx.x; slot < cap; slot += blockDim.x) {
+            if (tkeys[slot] == EMPTY_KEY) continue;
+            const unsigned long long wd = words[slot];
+            const uint32_t m = meta[slot];
+            if (a.matrix_s) a.matrix_s[(((uint64_t)wg * n_rows + r) << a.cap_log2) + (m & META_ID)] = wd;
+            if (wd) {
+                const bool multi = (m & META_SEEN) || (wd & (wd - 1));
+                meta[slot] = (uint16_t)(m | META_SEEN | (multi ? META_MULTI : 0u));
+                words[slot] = 0;
             }
         }
-        s0 = s0_next;
-        n = n_next;
-        if (full) break;    // LDS flag: a stale read only delays the exit
+        __syncthreads();
     }
     __syncthreads();
     if (full) {
-        if (threadIdx.x == 0) { atomicExch(overflow, 1); stage_cnt[wg] = 0; }
+        if (threadIdx.x == 0) { atomicMax(a.overflow, 1); a.wg_cnt[wg] = 0; a.wg_base[wg] = 0; }
         return;
     }
-    uint32_t base = 0;
-    const uint64_t out0 = (uint64_t)wg * cap;
-    for (uint32_t s = 0; s < cap; s += blockDim.x) {
-        const uint32_t slot = s + threadIdx.x;
-        const uint64_t key = slot < cap ? tkeys[slot] : EMPTY_KEY;
-        const bool keep = key != EMPTY_KEY;
-        uint32_t sweep_total;
-        const uint32_t pos = sweep_compact(keep, scratch, &sweep_total);
-        if (keep) {
-            stage_keys[out0 + base + pos] = key;
-            stage_flags[out0 + base + pos] = (tstate[slot] & 0x80000000u) ? 2 : 1;
-        }
-        base += sweep_total;
+    if (threadIdx.x == 0) {
+        const uint32_t nd = n_distinct;
+        const uint64_t base = atomicAdd(a.n_out, (unsigned long long)nd);
+        const bool fits = base + nd <= a.out_cap;
+        if (!fits) atomicMax(a.overflow, 2);
+        a.wg_base[wg] = base;
+        a.wg_cnt[wg] = fits ? nd : 0u;
+        out_base = fits ? base : ~0ull;
     }
-    if (threadIdx.x == 0) stage_cnt[wg] = base;
-    if (table_img)
-        for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) table_img[out0 + i] = tkeys[i];
+    __syncthreads();
+    const uint64_t base = out_base;
+    if (base == ~0ull) return;
+    for (uint32_t slot = threadIdx.x; slot < cap; slot += blockDim.x) {
+        const uint64_t key = tkeys[slot];
+        if (key == EMPTY_KEY) continue;
+        const uint32_t m = meta[slot];
+        a.out_keys[base + (m & META_ID)] = key;
+        a.out_flags[base + (m & META_ID)] = (m & META_MULTI) ? 2 : 1;
+    }
 }
 
-// column of every table slot: one thread per dictionary entry probes the saved table image of
-// its (bucket, sub-bucket) exactly as dict_build did and records its column there.
-__global__ void dict_slot_cols_kernel(const uint64_t *__restrict__ dict, uint64_t n, int bb, int sb, uint32_t cap_log2,
-                                      const uint64_t *__restrict__ table_img, uint32_t *__restrict__ col_of_slot)
+// column of every local entry = rank of its key in the sorted global dictionary.  A table of the first
+// dictionary position of every PB-bit key prefix (4 MiB, L2-resident) narrows the search to a handful of entries.
+__global__ void dict_prefix_index_kernel(const uint64_t *__restrict__ dict, uint64_t n_dict, int shift, uint32_t n_prefix,
+                                         uint32_t *__restrict__ first)
 {
-    const uint32_t cap_mask = (1u << cap_log2) - 1;
-    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t key = dict[c];
-        const uint64_t h = mix64(key);
-        const uint64_t wg = ((uint64_t)hash_bucket(h, bb) << sb) | hash_sub(h, bb, sb);
-        uint32_t slot = hash_slot(h, cap_mask);
-        for (uint32_t probe = 0; probe <= cap_mask; probe++) {
-            const uint64_t cur = table_img[(wg << cap_log2) + slot];
-            if (cur == key) { col_of_slot[(wg << cap_log2) + slot] = (uint32_t)c; break; }
-            if (cur == EMPTY_KEY) break;            // not carried by any local genome (multi-GPU)
-            slot = (slot + 1) & cap_mask;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p <= n_prefix; p += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t lo = 0, hi = n_dict;
+        if (p == n_prefix) lo = n_dict;
+        else {
+            const uint64_t want = p << shift;
+            while (lo < hi) {
+                const uint64_t m = (lo + hi) >> 1;
+                if (dict[m] < want) lo = m + 1; else hi = m;
+            }
+        }
+        first[p] = (uint32_t)lo;
+    }
+}
+__global__ void dict_entry_cols_kernel(const uint64_t *__restrict__ dict, uint64_t n_dict, const uint64_t *__restrict__ entry_keys,
+                                       uint64_t n_entries, int shift, uint32_t n_prefix, const uint32_t *__restrict__ first,
+                                       uint32_t *__restrict__ entry_col)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_entries; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = entry_keys[i];
+        const uint64_t p = key >> shift;
+        uint32_t c = 0xffffffffu;
+        if (p < n_prefix) {
+            uint64_t lo = first[p], hi = first[p + 1];
+            while (lo < hi) {
+                const uint64_t m = (lo + hi) >> 1;
+                if (dict[m] < key) lo = m + 1; else hi = m;
+            }
+            if (lo < n_dict && dict[lo] == key) c = (uint32_t)lo;
+        }
+        entry_col[i] = c;
+    }
+}
+
+// Stage 3b: presence words from (workgroup, row, entry) order to matrix[row][column].
+// Bit layout: genome i -> row i/64, bit 63-(i%64)  (bin/kover/core/kover/utils.py:133-156).
+// An entry's column is its key's rank by VALUE while entries are grouped by HASH, so consecutive entries go to
+// unrelated columns: written straight into the row-major matrix that is one scattered 8-byte store per
+// (entry, row) -- measured 4x HBM write amplification.  Two steps instead, both with full-line accesses:
+//   matrix_entry_rows   [wg][row][id] -> entry-major lines  me[column][row]  (n_rows x 8 B contiguous per column)
+//   matrix_transpose    me[column][row] -> matrix[row][column] through LDS tiles
+// The direct form stays for matrices of fewer than 4 word-rows, where a line would be a partial one anyway.
+__global__ __launch_bounds__(256) void matrix_permute_kernel(
+    const uint64_t *__restrict__ matrix_s, const uint16_t *__restrict__ birth, const uint64_t *__restrict__ wg_base,
+    const uint32_t *__restrict__ wg_cnt, const uint32_t *__restrict__ entry_col, uint32_t n_wg, uint32_t n_rows, uint32_t cap_log2,
+    uint64_t *__restrict__ matrix, uint64_t n_cols)
+{
+    for (uint32_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
+        const uint32_t n = wg_cnt[wg];
+        const uint64_t base = wg_base[wg];
+        for (uint32_t id = threadIdx.x; id < n; id += blockDim.x) {
+            const uint32_t c = entry_col[base + id];
+            if (c == 0xffffffffu) continue;
+            const uint32_t b0 = birth[((uint64_t)wg << cap_log2) + id];
+            for (uint32_t r = 0; r < n_rows; r++) {
+                const uint64_t v = r >= b0 ? matrix_s[(((uint64_t)wg * n_rows + r) << cap_log2) + id] : 0ull;
+                matrix[(uint64_t)r * n_cols + c] = v;
+            }
+        }
+    }
+}
+
+constexpr int ER_IDS = 256, ER_ROWS = 16;       // tile of matrix_entry_rows: 256 entries x 16 word-rows
+__global__ __launch_bounds__(ER_IDS) void matrix_entry_rows_kernel(
+    const uint64_t *__restrict__ matrix_s, const uint16_t *__restrict__ birth, const uint64_t *__restrict__ wg_base,
+    const uint32_t *__restrict__ wg_cnt, const uint32_t *__restrict__ entry_col, uint32_t n_wg, uint32_t n_rows, uint32_t cap_log2,
+    uint64_t *__restrict__ me)
+{
+    __shared__ uint64_t tile[ER_IDS][ER_ROWS + 1];
+    __shared__ uint32_t cols[ER_IDS];
+    for (uint32_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
+        const uint32_t n = wg_cnt[wg];
+        const uint64_t base = wg_base[wg];
+        for (uint32_t id0 = 0; id0 < n; id0 += ER_IDS) {
+            const uint32_t id = id0 + threadIdx.x;
+            const bool have = id < n;
+            const uint32_t c = have ? entry_col[base + id] : 0xffffffffu;
+            const uint32_t b0 = have ? birth[((uint64_t)wg << cap_log2) + id] : 0u;
+            const uint32_t n_here = min((uint32_t)ER_IDS, n - id0);
+            for (uint32_t r0 = 0; r0 < n_rows; r0 += ER_ROWS) {
+                __syncthreads();            // the previous tile has been written out
+                if (r0 == 0) cols[threadIdx.x] = c;
+#pragma unroll
+                for (int rr = 0; rr < ER_ROWS; rr++) {
+                    const uint32_t r = r0 + rr;
+                    tile[threadIdx.x][rr] = (have && r < n_rows && r >= b0) ? matrix_s[(((uint64_t)wg * n_rows + r) << cap_log2) + id] : 0ull;
+                }
+                __syncthreads();
+                const uint32_t rows_here = min((uint32_t)ER_ROWS, n_rows - r0);
+                for (uint32_t j = threadIdx.x; j < n_here * ER_ROWS; j += ER_IDS) {
+                    const uint32_t il = j / ER_ROWS, rr = j % ER_ROWS;
+                    const uint32_t cc = cols[il];
+                    if (cc != 0xffffffffu && rr < rows_here) me[(uint64_t)cc * n_rows + r0 + rr] = tile[il][rr];
+                }
+            }
+            __syncthreads();                // cols[] is rewritten by the next chunk
+        }
+    }
+}
+
+constexpr int TR_COLS = 64, TR_ROWS = 16;       // tile of matrix_transpose
+__global__ __launch_bounds__(256) void matrix_transpose_kernel(const uint64_t *__restrict__ me, uint64_t n_cols, uint32_t n_rows,
+                                                               uint64_t *__restrict__ matrix)
+{
+    __shared__ uint64_t tile[TR_ROWS][TR_COLS + 1];
+    const uint64_t n_ct = (n_cols + TR_COLS - 1) / TR_COLS;
+    const uint32_t n_rt = (n_rows + TR_ROWS - 1) / TR_ROWS;
+    for (uint64_t t = blockIdx.x; t < n_ct * n_rt; t += gridDim.x) {
+        const uint64_t c0 = (t / n_rt) * TR_COLS;
+        const uint32_t r0 = (uint32_t)(t % n_rt) * TR_ROWS;
+        __syncthreads();
+        // read: 16 consecutive threads take the 16 rows (128 B) of one column
+#pragma unroll
+        for (int pass = 0; pass < TR_COLS * TR_ROWS / 256; pass++) {
+            const uint32_t j = pass * 256 + threadIdx.x;
+            const uint32_t cl = j / TR_ROWS, rr = j % TR_ROWS;
+            const uint64_t c = c0 + cl;
+            tile[rr][cl] = (c < n_cols && r0 + rr < n_rows) ? me[c * n_rows + r0 + rr] : 0ull;
+        }
+        __syncthreads();
+        // write: 64 consecutive threads take 64 consecutive columns (512 B) of one row
+#pragma unroll
+        for (int pass = 0; pass < TR_COLS * TR_ROWS / 256; pass++) {
+            const uint32_t j = pass * 256 + threadIdx.x;
+            const uint32_t rr = j / TR_COLS, cl = j % TR_COLS;
+            const uint64_t c = c0 + cl;
+            if (c < n_cols && r0 + rr < n_rows) matrix[(uint64_t)(r0 + rr) * n_cols + c] = tile[rr][cl];
         }
     }
 }
@@ -1063,20 +1344,6 @@ __global__ __launch_bounds__(1024) void matrix_fill_slots_kernel(
             if (c != 0xffffffffu) matrix[(uint64_t)r * n_cols + c] = words[i];
         }
         __syncthreads();
-    }
-}
-
-// gather the staged per-workgroup dictionaries into one dense list
-__global__ void dict_gather_kernel(const uint64_t *__restrict__ stage_keys, const uint8_t *__restrict__ stage_flags,
-                                   const uint64_t *__restrict__ stage_off /* scan of stage_cnt */, uint32_t cap,
-                                   uint64_t *__restrict__ out_keys, uint8_t *__restrict__ out_flags)
-{
-    const uint32_t wg = blockIdx.x;
-    const uint64_t o = stage_off[wg];
-    const uint32_t n = (uint32_t)(stage_off[wg + 1] - o);
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        out_keys[o + i] = stage_keys[(uint64_t)wg * cap + i];
-        out_flags[o + i] = stage_flags[(uint64_t)wg * cap + i];
     }
 }
 
@@ -1355,43 +1622,80 @@ void launch_scan_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *ou
     hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, s, in, n, out);
 }
 void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const uint64_t *off, uint64_t n_segments, uint32_t cap_log2,
-                         uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow)
+                         uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow, int only_marked)
 {
     if (!n_segments) return;
     const size_t lds = (((size_t)12) << cap_log2) + TABLE_SCRATCH_BYTES;
     const uint32_t grid = (uint32_t)(n_segments < 256u * 16u ? n_segments : 256u * 16u);
     hipLaunchKernelGGL(bucket_dedup_kernel, dim3(grid), dim3(TABLE_THREADS), lds, s, keys, off, n_segments, cap_log2,
-                       abundance_min, len_out, counts_out, overflow);
+                       abundance_min, len_out, counts_out, overflow, only_marked);
 }
-static int g_dict_kif = 4, g_table_threads = TABLE_THREADS;
+// wave form: wave_cap_log2 in {9, 10, 11}
+void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const uint64_t *off, uint64_t n_segments, int wave_cap_log2,
+                              uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow)
+{
+    if (!n_segments) return;
+    // 48 KiB of LDS per workgroup in every form: 3 workgroups per CU
+#define GRM_LAUNCH_DW(C, W)                                                                                               \
+    {                                                                                                                     \
+        const uint64_t wgs = (n_segments + (W) - 1) / (W);                                                                \
+        const uint32_t grid = (uint32_t)(wgs < 256u * 24u ? wgs : 256u * 24u);                                            \
+        hipLaunchKernelGGL((bucket_dedup_wave_kernel<C, W>), dim3(grid), dim3((W) * 64), 0, s, keys, off, n_segments,     \
+                           abundance_min, len_out, counts_out, overflow);                                                 \
+    }
+    if (wave_cap_log2 <= 9) GRM_LAUNCH_DW(9, 8)
+    else if (wave_cap_log2 == 10) GRM_LAUNCH_DW(10, 4)
+    else GRM_LAUNCH_DW(11, 2)
+#undef GRM_LAUNCH_DW
+}
+static int g_dict_kif = 8, g_table_threads = TABLE_THREADS;
 void set_table_tuning(int kif, int threads)
 {
-    g_dict_kif = (kif == 1 || kif == 2 || kif == 8) ? kif : 4;
+    g_dict_kif = (kif == 1 || kif == 2 || kif == 4) ? kif : 8;
     g_table_threads = (threads == 256 || threads == 1024) ? threads : TABLE_THREADS;
 }
-void launch_dict_build(hipStream_t s, const uint64_t *keys, const uint64_t *off, const uint32_t *len,
-                       uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, uint64_t *stage_keys,
-                       uint8_t *stage_flags, uint32_t *stage_cnt, uint16_t *kslot, uint64_t *table_img, int *overflow)
+void launch_dict_build(hipStream_t s, const DictArgs &a)
 {
-    const size_t lds = (((size_t)12) << cap_log2) + TABLE_SCRATCH_BYTES;
-    const dim3 grid(1u << (bb + sb)), block(g_table_threads);
-#define GRM_LAUNCH_DICT(K)                                                                                              \
-    hipLaunchKernelGGL(dict_build_kernel<K>, grid, block, lds, s, keys, off, len, n_genomes, bb, sb, cap_log2, stage_keys, \
-                       stage_flags, stage_cnt, kslot, table_img, overflow)
-    switch (g_dict_kif) {
-    case 1: GRM_LAUNCH_DICT(1); break;
-    case 2: GRM_LAUNCH_DICT(2); break;
-    case 8: GRM_LAUNCH_DICT(8); break;
-    default: GRM_LAUNCH_DICT(4); break;
+    const size_t lds = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES;
+    const dim3 grid(1u << (a.bb + a.sb)), block(g_table_threads);     // 256 / 512 / 1024 threads: the wave count divides 64
+#define GRM_LAUNCH_DICT(K, T) hipLaunchKernelGGL((dict_build_kernel<K, T>), grid, block, lds, s, a)
+    const int kif = (g_table_threads > 512 && g_dict_kif > 4) ? 4 : g_dict_kif;
+    switch (kif) {
+    case 1: GRM_LAUNCH_DICT(1, 1024); break;
+    case 2: GRM_LAUNCH_DICT(2, 1024); break;
+    case 4: GRM_LAUNCH_DICT(4, 1024); break;
+    default: GRM_LAUNCH_DICT(8, 512); break;
     }
 #undef GRM_LAUNCH_DICT
 }
-void launch_dict_slot_cols(hipStream_t s, const uint64_t *dict, uint64_t n, int bb, int sb, uint32_t cap_log2,
-                           const uint64_t *table_img, uint32_t *col_of_slot)
+void launch_dict_entry_cols(hipStream_t s, const uint64_t *dict, uint64_t n_dict, const uint64_t *entry_keys, uint64_t n_entries, int k,
+                            uint32_t *prefix_first /* 2^20 + 2 entries */, uint32_t *entry_col)
 {
-    if (!n) return;
-    hipLaunchKernelGGL(dict_slot_cols_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, dict, n, bb, sb, cap_log2, table_img,
-                       col_of_slot);
+    if (!n_entries) return;
+    const int pb = 2 * k < 20 ? 2 * k : 20;
+    const int shift = 2 * k - pb;
+    const uint32_t n_prefix = 1u << pb;
+    hipLaunchKernelGGL(dict_prefix_index_kernel, dim3(grid_for((uint64_t)n_prefix + 1, 256)), dim3(256), 0, s, dict, n_dict, shift, n_prefix,
+                       prefix_first);
+    hipLaunchKernelGGL(dict_entry_cols_kernel, dim3(grid_for(n_entries, 256, 256u * 32u)), dim3(256), 0, s, dict, n_dict, entry_keys,
+                       n_entries, shift, n_prefix, prefix_first, entry_col);
+}
+void launch_matrix_permute(hipStream_t s, const uint64_t *matrix_s, const uint16_t *birth, const uint64_t *wg_base,
+                           const uint32_t *wg_cnt, const uint32_t *entry_col, uint32_t n_wg, uint32_t n_rows, uint32_t cap_log2,
+                           uint64_t *matrix, uint64_t n_cols, uint64_t *entry_major /* n_cols * n_rows words, zeroed where columns may lack an entry; nullptr: direct form */)
+{
+    if (!n_wg || !n_rows || !n_cols) return;
+    const uint32_t grid = n_wg < 256u * 32u ? n_wg : 256u * 32u;
+    if (!entry_major || n_rows < 4) {
+        hipLaunchKernelGGL(matrix_permute_kernel, dim3(grid), dim3(256), 0, s, matrix_s, birth, wg_base, wg_cnt, entry_col, n_wg, n_rows,
+                           cap_log2, matrix, n_cols);
+        return;
+    }
+    hipLaunchKernelGGL(matrix_entry_rows_kernel, dim3(grid), dim3(ER_IDS), 0, s, matrix_s, birth, wg_base, wg_cnt, entry_col, n_wg, n_rows,
+                       cap_log2, entry_major);
+    const uint64_t n_tiles = ((n_cols + TR_COLS - 1) / TR_COLS) * ((n_rows + TR_ROWS - 1) / TR_ROWS);
+    hipLaunchKernelGGL(matrix_transpose_kernel, dim3((uint32_t)(n_tiles < 256u * 64u ? n_tiles : 256u * 64u)), dim3(256), 0, s, entry_major,
+                       n_cols, n_rows, matrix);
 }
 void launch_matrix_fill_slots(hipStream_t s, const uint16_t *kslot, const uint64_t *off, const uint32_t *len,
                               uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint32_t *col_of_slot,
@@ -1400,12 +1704,6 @@ void launch_matrix_fill_slots(hipStream_t s, const uint16_t *kslot, const uint64
     const size_t lds = ((size_t)12) << cap_log2;
     hipLaunchKernelGGL(matrix_fill_slots_kernel, dim3(1u << (bb + sb)), dim3(g_table_threads), lds, s, kslot, off, len,
                        n_genomes, bb, sb, cap_log2, col_of_slot, matrix, n_cols);
-}
-void launch_dict_gather(hipStream_t s, const uint64_t *stage_keys, const uint8_t *stage_flags, const uint64_t *stage_off,
-                        uint32_t n_wg, uint32_t cap, uint64_t *out_keys, uint8_t *out_flags)
-{
-    hipLaunchKernelGGL(dict_gather_kernel, dim3(n_wg), dim3(256), 0, s, stage_keys, stage_flags, stage_off, cap, out_keys,
-                       out_flags);
 }
 void launch_dict_mark(hipStream_t s, const uint64_t *skeys, const uint8_t *sflags, uint64_t n, int filter_singleton,
                       uint32_t *keep)
@@ -1558,13 +1856,13 @@ hipError_t set_max_dynamic_lds()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_dedup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<8, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(matrix_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;

@@ -24,6 +24,8 @@ namespace grm {
 constexpr int WH_PPT = 16;                       // start positions / keys per thread
 constexpr int WH_THREADS = 256;
 constexpr int WH_TILE = WH_THREADS * WH_PPT;     // 4096 keys staged in LDS
+// thread t owns bucket t of a tile (grm_internal.h, "Bucket ownership by thread id"); this path stays <= 2^13 buckets
+static_assert(WH_THREADS >= (1 << L1_MAX_BITS) && WH_THREADS >= (1 << (MAX_HIST_BITS - L1_MAX_BITS)), "one thread per bucket of a level");
 constexpr int WH_LDS_BYTES = WH_TILE * 16 + 2048 + 1024 + 1024 + 64;
 constexpr uint64_t WH_EMPTY = ~0ull;             // lo == hi == ~0 is never a canonical k-mer
 constexpr uint64_t WH_PENDING = ~0ull;           // hi of a slot that is claimed but not yet published

@@ -83,12 +83,19 @@ def allgather_dict(batch, n_local, device, group=None, words=1):
     return keys_all, flags_all
 
 
-def sharded_step(batch, k, abundance_min, filter_singleton, device, group=None):
+def sharded_step(batch, k, abundance_min, filter_singleton, device, group=None, stats=None):
     """one pass of the hot path on this rank's genomes; returns the rank's Matrix
-    (its word-rows against the GLOBAL dictionary)."""
+    (its word-rows against the GLOBAL dictionary).  stats (optional dict with "bytes", "ms", "calls")
+    accumulates what the exchange step received and how long it took on the host clock."""
+    import time
     batch.partition(k, abundance_min)
     n_local = batch.local_dict()
+    t0 = time.perf_counter()
     keys, flags = allgather_dict(batch, n_local, device, group, words=2 if k > 32 else 1)
+    if stats is not None:
+        stats["bytes"] += int(keys.numel()) * 8 + int(flags.numel())
+        stats["ms"] += (time.perf_counter() - t0) * 1e3
+        stats["calls"] += 1
     batch.set_global_dict(keys.data_ptr(), flags.data_ptr(), int(keys.shape[0]), filter_singleton)
     return batch.fill()
 

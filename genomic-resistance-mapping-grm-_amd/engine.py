@@ -340,6 +340,11 @@ class Batch:
     def input_bytes(self):
         return int(self.ctx.L.grm_batch_input_bytes(self.h))
 
+    @property
+    def n_local(self):
+        """entries of the last local dictionary (distinct k-mers of this batch's genomes)"""
+        return int(self.ctx.L.grm_batch_n_local(self.h))
+
     def free(self):
         if self.h:
             self.ctx.L.grm_batch_free(self.h)

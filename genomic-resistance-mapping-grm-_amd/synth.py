@@ -64,9 +64,16 @@ class PanGenome:
         return np.concatenate(parts)
 
 
+# one random byte -> four letters (two bits each, low bits first)
+_LUT4 = np.array([int(_ACGT[b & 3]) | (int(_ACGT[(b >> 2) & 3]) << 8) | (int(_ACGT[(b >> 4) & 3]) << 16) | (int(_ACGT[(b >> 6) & 3]) << 24)
+                  for b in range(256)], dtype="<u4")
+
+
 def random_genome(idx, genome_len=5_000_000, seed=1234, n_contigs=1):
+    """i.i.d. uniform ACGT: the bytes of PCG64(seed + idx), two bits per base"""
     rng = np.random.default_rng(seed + idx)
-    seq = _ACGT[rng.integers(0, 4, size=genome_len, dtype=np.uint8)]
+    raw = np.frombuffer(rng.bytes((genome_len + 3) // 4), dtype=np.uint8)
+    seq = _LUT4[raw].view(np.uint8)[:genome_len]
     bounds = np.linspace(0, seq.size, max(1, n_contigs) + 1).astype(np.int64)
     return np.concatenate([_fasta_record("r%05d_c%d" % (idx, c), seq[bounds[c]:bounds[c + 1]]) for c in range(max(1, n_contigs))])
 

@@ -164,6 +164,7 @@ int      grm_matrix_stack_rows(grm_matrix *const *parts, int n_parts, grm_matrix
 uint64_t grm_batch_n_symbols(const grm_batch *);
 uint64_t grm_batch_n_occurrences(const grm_batch *);     /* valid k-mer windows */
 uint64_t grm_batch_input_bytes(const grm_batch *);
+uint64_t grm_batch_n_local(const grm_batch *);           /* entries of the last local dictionary */
 /* per-genome distinct k-mers after the last partition (+dedup): sorted set for genome g */
 int  grm_batch_genome_set(grm_batch *, int genome_index, grm_kmer_set **out);
 void grm_batch_free(grm_batch *);

@@ -722,3 +722,140 @@ def test_full_size_properties(ctx):
         kept = np.isin(km[:, 0], kmers)                           # its k-mers that survived the filter ...
         assert int(sel.sum()) == int(kept.sum())                  # ... are exactly the set bits
     m.free(); m2.free(); b.free()
+
+
+# ---- low-sharing inputs (independent random genomes: every k-mer its own column) ----------------
+def _dict_build_launches(ctx):
+    return sum(1 for name, _, _ in ctx.timings() if name == "dict_build")
+
+
+def test_low_sharing_sizes_the_dictionary_in_two_launches(ctx):
+    """mode R: the union of a bucket over the genomes is ~n_genomes times one genome's share, far beyond one
+    LDS table.  The failed first launch reports what it would have needed and the retry jumps there (no walk up
+    one sub-bucket bit at a time); the batch remembers it, so a later pass needs ONE launch.  Bit-exact either way."""
+    n, L, k = 40, 250_000, 31
+    genomes = [[synth.random_genome(i, genome_len=L, seed=4242).tobytes()] for i in range(n)]
+    want = orc.build_matrix(genomes, k, 1, False)
+    b = ctx.batch(n)
+    for g, files in enumerate(genomes):
+        b.add(g, files[0])
+    b.upload()
+    ctx.timing(True)
+    try:
+        for expect_max in (2, 1):
+            ctx.timing_reset()
+            m = b.run(k, 1, False)
+            launches = _dict_build_launches(ctx)
+            assert 1 <= launches <= expect_max, "dict_build launched %d times" % launches
+            assert m.n_kmers == want["kmers"].shape[0]
+            assert (m.kmers() == want["kmers"]).all() and (m.data() == want["matrix"]).all()
+            m.free()
+        # every k-mer of independent genomes is a singleton: the filter leaves nothing (up to chance collisions)
+        m = b.run(k, 1, True)
+        want_f = orc.build_matrix(genomes, k, 1, True)
+        assert m.n_kmers == want_f["kmers"].shape[0] and (m.data() == want_f["matrix"]).all()
+        m.free()
+    finally:
+        ctx.timing(False)
+        b.free()
+
+
+def test_pan_genome_needs_one_dictionary_launch(ctx):
+    """mode P stays on the single-launch path (the sizing ladder must not cost the common case anything)"""
+    genomes = _medium_genomes(n=70, length=200_000, seed=3)
+    b = ctx.batch(len(genomes))
+    for g, files in enumerate(genomes):
+        b.add(g, files[0])
+    b.upload()
+    ctx.timing(True)
+    try:
+        ctx.timing_reset()
+        m = b.run(31, 1, True)
+        assert _dict_build_launches(ctx) == 1
+        want = orc.build_matrix(genomes, 31, 1, True)
+        assert (m.kmers() == want["kmers"]).all() and (m.data() == want["matrix"]).all()
+        m.free()
+    finally:
+        ctx.timing(False)
+        b.free()
+
+
+def test_counting_stage_on_random_genomes(ctx):
+    """the counting stage bench.py times on mode R (parse -> partition -> per-genome dedup + count): every
+    genome's counted set equals the oracle's, k-mer for k-mer and count for count"""
+    n, L, k = 6, 400_000, 31
+    genomes = [synth.random_genome(i, genome_len=L, seed=99, n_contigs=1 + i % 3).tobytes() for i in range(n)]
+    b = ctx.batch(n)
+    for g, f in enumerate(genomes):
+        b.add(g, f)
+    b.upload()
+    b.partition_counts(k, 1)
+    total = 0
+    for g in range(n):
+        km, ct, nocc = orc.count_genome([genomes[g]], k, 1)
+        s = b.genome_set(g)
+        assert s.occurrences == nocc
+        assert s.kmers().shape == km.shape and (s.kmers() == km).all() and (s.counts() == ct).all()
+        total += nocc
+        s.free()
+    assert b.n_occurrences == total
+    b.free()
+
+
+# ---- the reference-held fixture through the HIP path -------------------------------------------
+def test_reference_31mers_through_the_engine(ctx, golden_dir):
+    """the 196 canonical 31-mers the reference ships (page/results/**, output of the real DSK pipeline) as
+    FASTA records, forward in one genome and reverse-complemented in another: the engine must produce exactly
+    those 196 columns, in ascending GATB order, with both strands landing in the same column."""
+    kmers = [l.strip() for l in open(os.path.join(golden_dir, "canonical_31mers.txt")) if l.strip() and not l.startswith("#")]
+    assert len(kmers) == 196
+    fwd = "".join(">f%d\n%s\n" % (i, km) for i, km in enumerate(kmers)).encode()
+    rev = "".join(">r%d\n%s\n" % (i, cases.revcomp(km)) for i, km in enumerate(kmers)).encode()
+    half = "".join(">h%d\n%s\n" % (i, km) for i, km in enumerate(kmers[::2])).encode()
+    b = ctx.batch(3)
+    b.add(0, fwd); b.add(1, rev); b.add(2, half)
+    b.upload()
+    m = b.run(31, 1, False)
+    got = grm.decode_kmers(m.kmers()[:, 0], 31)
+    order = {c: i for i, c in enumerate("ACTG")}
+    assert got == sorted(kmers, key=lambda s: [order[c] for c in s])       # exactly those, ascending under A<C<T<G
+    data = m.data()
+    col = {km: i for i, km in enumerate(got)}
+    for j, km in enumerate(kmers):
+        w = int(data[0, col[km]])
+        assert (w >> 63) & 1 and (w >> 62) & 1                              # forward and reverse strand: same column
+        assert ((w >> 61) & 1) == (1 if j % 2 == 0 else 0)
+    assert b.n_occurrences == 196 * 2 + 98
+    m.free()
+    # and as counted sets (multidsk's output): every k-mer once per genome
+    s = ctx.count_genome([rev], 31, 1)
+    assert grm.decode_kmers(s.kmers()[:, 0], 31) == got and (s.counts() == 1).all()
+    s.free()
+    b.free()
+
+
+@pytest.mark.parametrize("opts", [{}, {"bucket_bits": 7}, {"bucket_bits": 6}, {"bucket_bits": 5, "cap_log2": 13}, {"dedup_wg": 1}])
+def test_counted_sets_through_both_dedup_forms(ctx, opts):
+    """per-segment dedup + count: the wave form (table sized to the segment), segments too dense for it handed to
+    the workgroup form (bucket_bits 6: ~1900 distinct per segment > 7/8 of 2048; bucket_bits 5: ~3700 > 7/8 of 4096
+    needs the 8192-slot table), and the workgroup form alone -- all equal to the oracle's counted sets"""
+    genomes = [g[0] for g in _medium_genomes(n=4, length=120_000, seed=21)]
+    try:
+        for name, v in opts.items():
+            ctx.set_option(name, v)
+        for amin in (1, 2):
+            b = ctx.batch(len(genomes))
+            for g, f in enumerate(genomes):
+                b.add(g, f + b"\n" + f[:30_000])          # a repeated stretch: counts above 1
+            b.upload()
+            b.partition_counts(31, amin)
+            for g in range(len(genomes)):
+                km, ct, nocc = orc.count_genome([genomes[g] + b"\n" + genomes[g][:30_000]], 31, amin)
+                s = b.genome_set(g)
+                assert s.occurrences == nocc
+                assert s.kmers().shape == km.shape and (s.kmers() == km).all() and (s.counts() == ct).all()
+                s.free()
+            b.free()
+    finally:
+        for name in opts:
+            ctx.set_option(name, -1)
