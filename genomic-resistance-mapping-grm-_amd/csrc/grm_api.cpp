@@ -59,6 +59,7 @@ struct grm_ctx {
     int opt_upload_slab_kb = -1; // pinned upload slab size in KiB (tests; default 128 MiB)
     int opt_direct_permute = -1; // > 0: scattered single-step form of the fill (tests, measurements)
     int opt_dedup_wg = -1;       // > 0: per-segment dedup in the workgroup form only (tests)
+    int opt_dense_layout = -1;   // > 0: histogram-sized dense partition layout (tests, measurements)
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
 
@@ -236,6 +237,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "upload_slab_kb") c->opt_upload_slab_kb = value;
     else if (n == "direct_permute") c->opt_direct_permute = value;
     else if (n == "dedup_wg") c->opt_dedup_wg = value;
+    else if (n == "dense_layout") c->opt_dense_layout = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
@@ -583,6 +585,9 @@ struct grm_batch {
     uint64_t total_keys = 0;       // k-mer occurrences
     DevBuf d_counts, d_off, d_cursor, d_cursor1, d_counts1, d_off1, d_keys, d_keys1, d_len, d_kcnt;
     bool deduped = false;
+    uint64_t seg_stride = 0;       // 0: dense layout (d_off); else slack layout: segment i at i * seg_stride, length d_len[i]
+    bool slack_failed = false;     // a slack-layout partition of this batch overflowed: dense layout from then on
+    DevBuf d_marks;                // one bit per segment: left to the workgroup form of the dedup
     // dictionary
     int sb_dict = 0, sb_fill = 0;
     uint32_t cap_log2 = 12;
@@ -605,7 +610,7 @@ struct grm_batch {
     // scratch that survives between steps (grow-only)
     DevBuf t_flag;
     DevBuf t_sk, t_sf, t_keep, t_pos, t_tmp, t_bid, t_col, t_bid_sorted;
-    DevBuf t_set_off, t_set_len, t_set_k, t_set_c, t_set_tmp;     // grm_batch_genome_set
+    DevBuf t_set_off, t_set_src, t_set_len, t_set_k, t_set_c, t_set_tmp;     // grm_batch_genome_set
 };
 
 extern "C" int grm_batch_create(grm_ctx *c, int n_genomes, grm_batch **out)
@@ -863,6 +868,23 @@ static uint32_t pick_cap_log2(grm_ctx *c)
     return (uint32_t)std::min(13, std::max(6, v));
 }
 
+// segment layout of the partitioned keys of a batch: dense (offsets from the histogram; lengths only once a dedup has
+// shortened the segments) or slack (fixed-capacity segments + lengths)
+static SegLayout batch_segments(const grm_batch *b, bool after_dedup = true)
+{
+    SegLayout L;
+    if (b->seg_stride) {
+        L.off = nullptr;
+        L.len = b->d_len.as<uint32_t>();
+        L.stride = b->seg_stride;
+    } else {
+        L.off = b->d_off.as<uint64_t>();
+        L.len = (after_dedup && b->deduped) ? b->d_len.as<uint32_t>() : nullptr;
+        L.stride = 0;
+    }
+    return L;
+}
+
 // parse + histogram + scan + scatter (+ dedup when abundance_min > 1)
 static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, bool want_counts)
 {
@@ -947,9 +969,62 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     const int b1 = scatter_b1_bits(b->bb);
     const bool deep = b->bb > MAX_HIST_BITS;
     const uint64_t n_coarse = (uint64_t)G << b1;
+    HIPCHK(c, b->d_cursor1.ensure(n_coarse * 4));
+    HIPCHK(c, b->t_flag.ensure(16));
+
+    // ---- slack layout: no histogram pass.  The hash spreads a genome's k-mers evenly, so a (genome, fine bucket)
+    // segment holds mean m = symbols / 2^bb keys with a standard deviation of sqrt(m): segments get a fixed capacity
+    // of m + 6 sqrt(m) + 32 keys (m taken from the largest genome) at computed offsets, level 1 reserves space in
+    // fixed-capacity coarse regions, level 2 writes the fine segments and their lengths.  A region or segment that
+    // would overflow (heavily repeated k-mers) raises a flag: the partition is then redone with the histogram-sized
+    // dense layout below, and the batch remembers that for later runs.
+    b->seg_stride = 0;
+    bool slack = !deep && c->opt_dense_layout <= 0 && !b->slack_failed;
+    uint32_t fine_cap = 0;
+    uint64_t region_stride = 0;
+    if (slack) {
+        const uint64_t m = max_g >> b->bb;
+        fine_cap = (uint32_t)((m + (uint64_t)(6.0 * std::sqrt((double)m + 1.0)) + 32 + 15) / 16 * 16);
+        region_stride = (uint64_t)fine_cap << (b->bb - b1);
+        // genomes of very different sizes would waste most of a layout sized for the largest one
+        if ((double)n_seg * fine_cap > 1.75 * (double)b->total_syms + 65536.0) slack = false;
+    }
+    if (slack) {
+        const uint64_t layout_keys = n_seg * (uint64_t)fine_cap;
+        HIPCHK(c, b->d_keys.ensure((layout_keys + 2) * 8));
+        if (b->bb > b1) HIPCHK(c, b->d_keys1.ensure((layout_keys + 2) * 8));
+        HIPCHK(c, b->d_len.ensure((n_seg + 1) * 4));
+        HIPCHK(c, hipMemsetAsync(b->d_cursor1.p, 0, n_coarse * 4, s));
+        HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 16, s));
+        {
+            TimeScope t(c, "kmer_scatter_l1", b->total_syms);
+            launch_kmer_scatter_l1(s, L, nullptr, nullptr, b->d_cursor1.as<uint32_t>(),
+                                   b->bb > b1 ? b->d_keys1.as<uint64_t>() : b->d_keys.as<uint64_t>(), region_stride, b->t_flag.as<int>());
+        }
+        if (b->bb > b1) {
+            TimeScope t(c, "kmer_scatter_l2", b->total_syms);
+            launch_kmer_scatter_l2(s, L, nullptr, b->d_keys1.as<uint64_t>(), b->d_keys.as<uint64_t>(), region_stride, fine_cap,
+                                   b->d_cursor1.as<uint32_t>(), b->d_len.as<uint32_t>(), b->t_flag.as<int>());
+        } else {
+            // one level: the coarse regions ARE the final segments, their fill the segment lengths
+            HIPCHK(c, hipMemcpyAsync(b->d_len.p, b->d_cursor1.p, n_seg * 4, hipMemcpyDeviceToDevice, s));
+        }
+        launch_sum_u32(s, b->d_cursor1.as<uint32_t>(), n_coarse, reinterpret_cast<uint64_t *>(b->t_flag.as<uint8_t>() + 8));
+        HIPCHK(c, hipGetLastError());
+        struct { int over; int pad; uint64_t total; } h;
+        HIPCHK(c, hipMemcpyAsync(&h, b->t_flag.p, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (h.over) {
+            b->slack_failed = true;          // skewed input: dense layout from now on
+            slack = false;
+        } else {
+            b->total_keys = h.total;
+            b->seg_stride = fine_cap;
+        }
+    }
+    if (!slack) {
     HIPCHK(c, b->d_counts.ensure((n_seg + 1) * 4));
     HIPCHK(c, b->d_off.ensure((n_seg + 1) * 8));
-    HIPCHK(c, b->d_cursor1.ensure(n_coarse * 4));
     HIPCHK(c, hipMemsetAsync(b->d_counts.p, 0, (n_seg + 1) * 4, s));
     HIPCHK(c, hipMemsetAsync(b->d_cursor1.p, 0, n_coarse * 4, s));
     auto scan_counts = [&](DevBuf &counts, DevBuf &off, uint64_t n) -> int {
@@ -992,7 +1067,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     {
         TimeScope t(c, "kmer_scatter_l1", b->total_keys);
         launch_kmer_scatter_l1(s, L, b->d_off.as<uint64_t>(), deep ? b->d_off1.as<uint64_t>() : nullptr, b->d_cursor1.as<uint32_t>(),
-                               b->bb > b1 ? b->d_keys1.as<uint64_t>() : b->d_keys.as<uint64_t>());
+                               b->bb > b1 ? b->d_keys1.as<uint64_t>() : b->d_keys.as<uint64_t>(), 0, nullptr);
     }
     if (deep) {
         {
@@ -1005,9 +1080,12 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     if (b->bb > b1) {
         TimeScope t(c, "kmer_scatter_l2", b->total_keys);
         launch_kmer_scatter_l2(s, L, b->d_off.as<uint64_t>(), b->d_keys1.as<uint64_t>(),
-                               b->d_keys.as<uint64_t>());
+                               b->d_keys.as<uint64_t>(), 0, 0, nullptr, nullptr, nullptr);
     }
     HIPCHK(c, hipGetLastError());
+    }
+    // key positions of the layout (dense: the keys themselves; slack: the segment slots): per-key side arrays are this long
+    const uint64_t layout_len = b->seg_stride ? n_seg * b->seg_stride : b->total_keys;
 
     // ---- stage 2 (optional): per-bucket dedup / count / abundance filter ----
     b->cap_log2 = pick_cap_log2(c);
@@ -1015,8 +1093,11 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         DevBuf &d_flag = b->t_flag;
         HIPCHK(c, d_flag.ensure(4));
         HIPCHK(c, hipMemsetAsync(d_flag.p, 0, 4, s));
-        HIPCHK(c, b->d_len.ensure(n_seg * 4));
-        if (want_counts) HIPCHK(c, b->d_kcnt.ensure((b->total_keys + 2) * 4));
+        HIPCHK(c, b->d_len.ensure((n_seg + 1) * 4));
+        if (want_counts) HIPCHK(c, b->d_kcnt.ensure((layout_len + 2) * 4));
+        HIPCHK(c, b->d_marks.ensure((n_seg / 32 + 2) * 4));
+        HIPCHK(c, hipMemsetAsync(b->d_marks.p, 0, (n_seg / 32 + 2) * 4, s));
+        const SegLayout seg = batch_segments(b, false);        // the lengths the partition left (dense: from the offsets)
         // wave form first (table sized to the expected segment, no barriers); what it marks as too dense goes
         // through the workgroup form with the full-size table
         const uint64_t mean_seg = max_g >> b->bb;
@@ -1028,8 +1109,8 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         if (wave_form) {
             {
                 TimeScope t(c, "bucket_dedup", b->total_keys);
-                launch_bucket_dedup_wave(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), n_seg, wave_cap, abundance_min,
-                                         b->d_len.as<uint32_t>(), want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, d_flag.as<int>());
+                launch_bucket_dedup_wave(s, b->d_keys.as<uint64_t>(), seg, n_seg, wave_cap, abundance_min, b->d_len.as<uint32_t>(),
+                                         b->d_marks.as<uint32_t>(), want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, d_flag.as<int>());
             }
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, s));
@@ -1038,8 +1119,8 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         if (!wave_form || ov) {
             HIPCHK(c, hipMemsetAsync(d_flag.p, 0, 4, s));
             TimeScope t(c, wave_form ? "bucket_dedup_dense" : "bucket_dedup", b->total_keys);
-            launch_bucket_dedup(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), n_seg, b->cap_log2, abundance_min,
-                                b->d_len.as<uint32_t>(), want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, d_flag.as<int>(), wave_form ? 1 : 0);
+            launch_bucket_dedup(s, b->d_keys.as<uint64_t>(), seg, n_seg, b->cap_log2, abundance_min, b->d_len.as<uint32_t>(),
+                                wave_form ? b->d_marks.as<uint32_t>() : nullptr, want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, d_flag.as<int>());
         }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&ov, d_flag.p, 4, hipMemcpyDeviceToHost, s));
@@ -1078,16 +1159,6 @@ extern "C" uint64_t grm_batch_input_bytes(const grm_batch *b) { return b ? b->in
 extern "C" uint64_t grm_batch_n_local(const grm_batch *b) { return b ? b->n_local : 0; }
 
 // ---- dictionary of the local genomes ------------------------------------------------------
-// segment layout of the partitioned keys of a batch (dense, from the histogram)
-static SegLayout batch_segments(const grm_batch *b)
-{
-    SegLayout L;
-    L.off = b->d_off.as<uint64_t>();
-    L.len = b->deduped ? b->d_len.as<uint32_t>() : nullptr;
-    L.stride = 0;
-    return L;
-}
-
 // device control block of dict_build: { n_out u64, overflow i32, need u32 }
 struct DictCtrl {
     unsigned long long n_out;
@@ -1348,7 +1419,7 @@ extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
                                   (uint32_t)m->n_rows, b->cap_log2, m->d_data.as<uint64_t>(), m->n_kmers, em);
         } else if (cells && b->total_keys) {
             TimeScope t(c, "matrix_fill", b->total_keys);
-            launch_matrix_fill(s, b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), b->deduped ? b->d_len.as<uint32_t>() : nullptr,
+            launch_matrix_fill(s, b->d_keys.as<uint64_t>(), batch_segments(b),
                                (uint32_t)b->n_genomes, b->bb, b->sb_fill, b->cap_log2, b->d_dkeys.as<uint64_t>(),
                                b->d_dcol.as<uint32_t>(), b->d_seg_start.as<uint64_t>(), m->d_data.as<uint64_t>(), m->n_kmers,
                                d_flag.as<int>());
@@ -2061,24 +2132,41 @@ static int genome_set_impl(grm_batch *b, int g, bool have_counts, grm_kmer_set *
     if (b->total_keys == 0) return GRM_OK;
     std::vector<uint64_t> off(B + 1), dst(B + 1);
     std::vector<uint32_t> len(B);
-    HIPCHK(c, hipMemcpy(off.data(), b->d_off.as<uint64_t>() + (uint64_t)g * B, (B + 1) * 8, hipMemcpyDeviceToHost));
-    set->occurrences = off[B] - off[0];
-    if (b->deduped) HIPCHK(c, hipMemcpy(len.data(), b->d_len.as<uint32_t>() + (uint64_t)g * B, B * 4, hipMemcpyDeviceToHost));
-    else for (uint64_t i = 0; i < B; i++) len[i] = (uint32_t)(off[i + 1] - off[i]);
+    if (b->seg_stride) {
+        // slack layout: computed offsets, lengths from the partition (or the dedup)
+        for (uint64_t i = 0; i <= B; i++) off[i] = ((uint64_t)g * B + i) * b->seg_stride;
+        HIPCHK(c, hipMemcpy(len.data(), b->d_len.as<uint32_t>() + (uint64_t)g * B, B * 4, hipMemcpyDeviceToHost));
+        set->occurrences = 0;        // filled below when the batch kept the pre-dedup counts
+    } else {
+        HIPCHK(c, hipMemcpy(off.data(), b->d_off.as<uint64_t>() + (uint64_t)g * B, (B + 1) * 8, hipMemcpyDeviceToHost));
+        set->occurrences = off[B] - off[0];
+        if (b->deduped) HIPCHK(c, hipMemcpy(len.data(), b->d_len.as<uint32_t>() + (uint64_t)g * B, B * 4, hipMemcpyDeviceToHost));
+        else for (uint64_t i = 0; i < B; i++) len[i] = (uint32_t)(off[i + 1] - off[i]);
+    }
     uint64_t n = 0;
     for (uint64_t i = 0; i < B; i++) { dst[i] = n; n += len[i]; }
+    if (b->seg_stride) {
+        // occurrences of this genome = what level 1 put into its coarse regions
+        const int b1 = scatter_b1_bits(b->bb);
+        std::vector<uint32_t> cur((size_t)1 << b1);
+        HIPCHK(c, hipMemcpy(cur.data(), b->d_cursor1.as<uint32_t>() + ((uint64_t)g << b1), cur.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t v : cur) set->occurrences += v;
+    }
     if (n == 0) return GRM_OK;
     // scratch is the batch's (grow-only); the sorted result goes straight into the set's own buffers
     DevBuf &d_dst_off = b->t_set_off, &d_len = b->t_set_len, &d_k = b->t_set_k, &d_c = b->t_set_c, &d_tmp = b->t_set_tmp;
+    DevBuf &d_src_off = b->t_set_src;
     DevBuf &d_k2 = set->d_kmers, &d_c2 = set->d_counts;
     HIPCHK(c, d_dst_off.ensure(B * 8));
+    HIPCHK(c, d_src_off.ensure(B * 8));
     HIPCHK(c, d_len.ensure(B * 4));
     HIPCHK(c, d_k.ensure(n * 8)); HIPCHK(c, d_c.ensure(n * 4));
     HIPCHK(c, d_k2.alloc(n * 8)); HIPCHK(c, d_c2.alloc(n * 4));
     HIPCHK(c, hipMemcpy(d_dst_off.p, dst.data(), B * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_src_off.p, off.data(), B * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(d_len.p, len.data(), B * 4, hipMemcpyHostToDevice));
     launch_segments_compact(s, b->d_keys.as<uint64_t>(), have_counts ? b->d_kcnt.as<uint32_t>() : nullptr,
-                            b->d_off.as<uint64_t>() + (uint64_t)g * B, d_len.as<uint32_t>(), d_dst_off.as<uint64_t>(),
+                            d_src_off.as<uint64_t>(), d_len.as<uint32_t>(), d_dst_off.as<uint64_t>(),
                             (uint32_t)B, d_k.as<uint64_t>(), d_c.as<uint32_t>());
     size_t tb = 0;
     HIPCHK(c, sort_pairs_u64_u32(s, d_k.as<uint64_t>(), d_k2.as<uint64_t>(), d_c.as<uint32_t>(), d_c2.as<uint32_t>(), n, nullptr, tb));

@@ -74,20 +74,18 @@ void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, cons
 void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
 int scatter_b1_bits(int bb);
 void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *coarse_off,
-                            uint32_t *cursor1, uint64_t *out);
+                            uint32_t *cursor1, uint64_t *out, uint64_t region_stride, int *overflow);
+void launch_sum_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *out);
 void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *coarse_off, uint64_t n_regions, int bb,
                         uint32_t *counts);
 void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *keys1,
-                            uint64_t *keys);
+                            uint64_t *keys, uint64_t region_stride, uint32_t fine_cap, const uint32_t *cursor1, uint32_t *len_out,
+                            int *overflow);
 void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
                                 uint32_t n_genomes, int bb, uint32_t *counts);
 void launch_keys_partition_scatter(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
                                    uint32_t n_genomes, int bb, const uint64_t *off, uint32_t *cursor, uint64_t *keys);
 void launch_scan_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *out);
-void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const uint64_t *off, uint64_t n_segments, uint32_t cap_log2,
-                         uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow, int only_marked);
-void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const uint64_t *off, uint64_t n_segments, int wave_cap_log2,
-                              uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow);
 // Segment layout of the partitioned keys: segment idx = genome * 2^bb + bucket.
 //   off != nullptr : keys[off[idx] .. off[idx] + (len ? len[idx] : off[idx+1] - off[idx]))      (histogram-sized, dense)
 //   off == nullptr : keys[idx * stride .. idx * stride + len[idx])                              (fixed-capacity slots)
@@ -96,6 +94,10 @@ struct SegLayout {
     const uint32_t *len;
     uint64_t stride;
 };
+void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const SegLayout &seg, uint64_t n_segments, uint32_t cap_log2,
+                         uint32_t abundance_min, uint32_t *len_out, const uint32_t *marks, uint32_t *counts_out, int *overflow);
+void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const SegLayout &seg, uint64_t n_segments, int wave_cap_log2,
+                              uint32_t abundance_min, uint32_t *len_out, uint32_t *marks, uint32_t *counts_out, int *overflow);
 // dict_build: per-(bucket, sub-bucket) union over all genomes in an LDS table + the presence bits of
 // every distinct k-mer ("entry"), one word-row (64 genomes) at a time.
 struct DictArgs {
@@ -146,7 +148,7 @@ void launch_segments_compact(hipStream_t s, const uint64_t *src, const uint32_t 
                              uint32_t *dst_cnt);
 void launch_segment_starts(hipStream_t s, const uint32_t *ids, uint64_t n, uint32_t n_ids, uint64_t *start);
 void launch_gather_u64(hipStream_t s, const uint64_t *src, const uint32_t *index, uint64_t n, uint64_t *dst);
-void launch_matrix_fill(hipStream_t s, const uint64_t *keys, const uint64_t *off, const uint32_t *len,
+void launch_matrix_fill(hipStream_t s, const uint64_t *keys, const SegLayout &seg,
                         uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint64_t *dkeys,
                         const uint32_t *dcol, const uint64_t *seg_start, uint64_t *matrix, uint64_t n_cols,
                         int *overflow);

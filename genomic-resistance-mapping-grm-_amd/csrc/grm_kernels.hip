@@ -539,9 +539,14 @@ __global__ __launch_bounds__(KMER_THREADS) void kmer_hist_kernel(KmerArgs a, uin
 // Fine bucket ids are contiguous inside a coarse bucket (bucket = top bits of the hash), so the
 // coarse region of level 1 IS the union of its fine segments and `off` (exclusive scan of the
 // fine histogram) serves both levels.
+// Region of (genome, coarse bucket) in keys1, three ways:
+//   region_stride != 0  fixed-capacity regions, region c at c * region_stride ("slack" layout: no histogram pass at
+//                       all; a region that would overflow raises *overflow and the host falls back to the dense layout)
+//   coarse_off          dense, from the coarse histogram (deep mode)
+//   off                 dense, from the fine histogram (fine ids are nested inside the coarse bucket)
 __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
     KmerArgs a, int b1bits, uint32_t n_tiles, const uint64_t *__restrict__ off, const uint64_t *__restrict__ coarse_off,
-    uint32_t *__restrict__ cursor1, uint64_t *__restrict__ keys1)
+    uint32_t *__restrict__ cursor1, uint64_t *__restrict__ keys1, uint64_t region_stride, int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint64_t *skeys = reinterpret_cast<uint64_t *>(lds_raw);                             // [L1_TILE]
@@ -597,7 +602,9 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
             // start of the coarse region: from the coarse scan (deep mode: fine offsets do not exist
             // yet) or from the fine scan (fine ids are nested inside the coarse bucket)
             const uint64_t cidx = (uint64_t)gen0 * B1 + threadIdx.x;
-            region0 = coarse_off ? coarse_off[cidx] : off[(uint64_t)gen0 * (1ull << a.bb) + ((uint64_t)threadIdx.x << b2bits)];
+            region0 = region_stride ? cidx * region_stride
+                      : coarse_off  ? coarse_off[cidx]
+                                    : off[(uint64_t)gen0 * (1ull << a.bb) + ((uint64_t)threadIdx.x << b2bits)];
             reserved = atomicAdd(&cursor1[cidx], c);
         }
         lds_barrier();      // start[] is visible; the reservation (a global round trip) lands during the placement
@@ -608,11 +615,16 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
                 skeys[at] = kv[i];
                 sbkt[at] = (uint8_t)bk[i];        // the copy-out then needs no hash
             }
-        if (c) gbase[threadIdx.x] = region0 + reserved;
+        if (c) {
+            const bool fits = !region_stride || (uint64_t)reserved + c <= region_stride;
+            if (!fits) atomicExch(overflow, 1);
+            gbase[threadIdx.x] = fits ? region0 + reserved : ~0ull;
+        }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n_tile; i += L1_THREADS) {
             const uint32_t b1 = sbkt[i];
-            keys1[gbase[b1] + (i - start[b1])] = skeys[i];
+            const uint64_t gb = gbase[b1];
+            if (gb != ~0ull) keys1[gb + (i - start[b1])] = skeys[i];
         }
     } else {
         uint32_t gen = genome_of(a.genome_sym_off, a.n_genomes, min(p0, a.total_syms - 1));
@@ -621,8 +633,12 @@ __global__ __launch_bounds__(L1_THREADS) void kmer_scatter_l1_kernel(
             while (p0 + (uint64_t)i >= gend) { gen++; gend = a.genome_sym_off[gen + 1]; }
             const uint32_t b1 = hash_bucket(mix64(canon), b1bits);
             const uint64_t cidx = (uint64_t)gen * B1 + b1;
-            const uint64_t region0 = coarse_off ? coarse_off[cidx] : off[(uint64_t)gen * (1ull << a.bb) + ((uint64_t)b1 << b2bits)];
-            keys1[region0 + atomicAdd(&cursor1[cidx], 1u)] = canon;
+            const uint64_t region0 = region_stride ? cidx * region_stride
+                                     : coarse_off  ? coarse_off[cidx]
+                                                   : off[(uint64_t)gen * (1ull << a.bb) + ((uint64_t)b1 << b2bits)];
+            const uint32_t at = atomicAdd(&cursor1[cidx], 1u);
+            if (region_stride && at >= region_stride) atomicExch(overflow, 1);
+            else keys1[region0 + at] = canon;
         });
     }
 }
@@ -647,9 +663,13 @@ __global__ __launch_bounds__(256) void region_hist_kernel(const uint64_t *__rest
     }
 }
 
+// Level 2.  Dense layout: region and fine segments from `off`.  Slack layout (region_stride != 0): region c of keys1
+// holds cursor1[c] keys at c * region_stride; fine segment f is written at f * fine_cap and its length goes to
+// len_out[f]; a segment that would exceed fine_cap raises *overflow (the host then redoes the partition densely).
 __global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
     const uint64_t *__restrict__ keys1, uint64_t *__restrict__ keys, const uint64_t *__restrict__ off,
-    uint64_t n_regions, int bb, int b1bits)
+    uint64_t n_regions, int bb, int b1bits, uint64_t region_stride, uint32_t fine_cap, const uint32_t *__restrict__ cursor1,
+    uint32_t *__restrict__ len_out, int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint64_t *skeys = reinterpret_cast<uint64_t *>(lds_raw);
@@ -662,10 +682,19 @@ __global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
     for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
         const uint64_t g = region >> b1bits, c1 = region & ((1u << b1bits) - 1);
         const uint64_t fine0 = (g << bb) + (c1 << b2bits);
-        const uint64_t r0 = off[fine0], r1 = off[fine0 + B2];
+        uint64_t r0, r1, my_first = 0;
+        if (region_stride) {
+            r0 = region * region_stride;
+            r1 = r0 + min((uint64_t)cursor1[region], region_stride);
+            if (threadIdx.x < B2) my_first = (fine0 + threadIdx.x) * (uint64_t)fine_cap;
+        } else {
+            r0 = off[fine0];
+            r1 = off[fine0 + B2];
+            if (threadIdx.x < B2) my_first = off[fine0 + threadIdx.x];
+        }
         // a region is written by this workgroup alone, tile after tile: thread t keeps the running
         // output position of fine bucket t in a register (no global cursor, no atomic round trip)
-        uint64_t my_next = threadIdx.x < B2 ? off[fine0 + threadIdx.x] : 0;
+        uint64_t my_next = my_first;
         for (uint64_t base = r0; base < r1; base += L2_TILE) {
             const uint32_t n = (uint32_t)min((uint64_t)L2_TILE, r1 - base);
             if (threadIdx.x < B2) hist[threadIdx.x] = 0;
@@ -690,8 +719,10 @@ __global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
             const uint32_t st = block_scan_sum(c, scratch, &n_tile);
             if (threadIdx.x < B2) {
                 start[threadIdx.x] = st;
-                gbase[threadIdx.x] = my_next;
-                my_next += c;
+                const bool fits = !region_stride || my_next + c <= my_first + fine_cap;
+                if (!fits) atomicExch(overflow, 1);
+                gbase[threadIdx.x] = fits ? my_next : ~0ull;
+                if (fits) my_next += c;
             }
             __syncthreads();
 #pragma unroll
@@ -701,11 +732,24 @@ __global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
             for (uint32_t i = threadIdx.x; i < n; i += L2_THREADS) {
                 const uint64_t key = skeys[i];
                 const uint32_t b2 = hash_bucket(mix64(key), bb) & (B2 - 1);
-                keys[gbase[b2] + (i - start[b2])] = key;
+                const uint64_t gb = gbase[b2];
+                if (gb != ~0ull) keys[gb + (i - start[b2])] = key;
             }
             __syncthreads();
         }
+        if (region_stride && threadIdx.x < B2) len_out[fine0 + threadIdx.x] = (uint32_t)(my_next - my_first);
     }
+}
+
+// sum of n uint32 -> *out (uint64), one workgroup
+__global__ __launch_bounds__(1024) void sum_u32_kernel(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out)
+{
+    __shared__ uint64_t scratch[16];
+    uint64_t s = 0;
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) s += in[i];
+    uint64_t total;
+    (void)block_scan_sum64(s, scratch, &total);
+    if (threadIdx.x == 0) *out = total;
 }
 
 // partition an explicit key list (grm_build_matrix from host-side sets): hist + scatter
@@ -780,13 +824,24 @@ __device__ __forceinline__ uint32_t lds_find(const uint64_t *tkeys, uint32_t cap
     return 0xffffffffu;
 }
 
+__device__ __forceinline__ void seg_bounds(const SegLayout &L, uint64_t idx, uint64_t &s0, uint64_t &n)
+{
+    if (L.off) {
+        s0 = L.off[idx];
+        n = L.len ? (uint64_t)L.len[idx] : L.off[idx + 1] - s0;
+    } else {
+        s0 = idx * L.stride;
+        n = L.len[idx];
+    }
+}
+
 // K4: per-(genome,bucket) dedup + count + abundance filter, in place.
 // After the kernel the segment [off[i], off[i]+len_out[i]) holds the distinct k-mers whose
 // count >= abundance_min (order = table slot order); counts_out (optional) is parallel to keys.
 __global__ __launch_bounds__(TABLE_THREADS) void bucket_dedup_kernel(
-    uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, uint64_t n_segments, uint32_t cap_log2,
-    uint32_t abundance_min, uint32_t *__restrict__ len_out, uint32_t *__restrict__ counts_out,
-    int *__restrict__ overflow, int only_marked)
+    uint64_t *__restrict__ keys, const SegLayout seg_layout, uint64_t n_segments, uint32_t cap_log2,
+    uint32_t abundance_min, uint32_t *__restrict__ len_out, const uint32_t *__restrict__ marks, uint32_t *__restrict__ counts_out,
+    int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
@@ -795,9 +850,9 @@ __global__ __launch_bounds__(TABLE_THREADS) void bucket_dedup_kernel(
     uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 12);   // [16] + flags
     volatile int &full = *reinterpret_cast<volatile int *>(scratch + 16);
     for (uint64_t seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
-        if (only_marked && len_out[seg] != 0xffffffffu) continue;      // second pass: what the wave-level kernel left
-        const uint64_t s0 = off[seg];
-        const uint64_t n = off[seg + 1] - s0;
+        if (marks && !((marks[seg >> 5] >> (seg & 31)) & 1u)) continue;      // second pass: what the wave form left
+        uint64_t s0, n;
+        seg_bounds(seg_layout, seg, s0, n);
         for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tkeys[i] = EMPTY_KEY; tcnt[i] = 0; }
         if (threadIdx.x == 0) full = 0;
         __syncthreads();
@@ -845,67 +900,128 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): this wave's LDS operations have completed
     __asm__ volatile("" ::: "memory");
 }
+// insert four keys per lane: their first-probe reads, then the claims of empty home slots, are in flight together;
+// only a key that finds someone else's key at home walks the probe sequence.  Returns false when the table is full.
+template <uint32_t MASK>
+__device__ __forceinline__ bool dedup_insert4(uint64_t *tk, uint32_t *tc, const uint64_t kv[4], uint32_t &n_ins)
+{
+    uint32_t sl[4];
+    uint64_t cur[4];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        sl[j] = hash_slot(mix64(kv[j]), MASK);
+        cur[j] = *reinterpret_cast<volatile uint64_t *>(&tk[sl[j]]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (kv[j] != EMPTY_KEY && cur[j] == EMPTY_KEY)
+            cur[j] = atomicCAS((unsigned long long *)&tk[sl[j]], (unsigned long long)EMPTY_KEY, (unsigned long long)kv[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        bool ins = false;
+        if (kv[j] != EMPTY_KEY) {
+            uint32_t slot = sl[j];
+            if (cur[j] == EMPTY_KEY) ins = true;                       // the CAS claimed the home slot
+            else if (cur[j] != kv[j]) {                                // someone else's key there: probe on
+                slot = 0xffffffffu;
+                uint32_t at = (sl[j] + 1) & MASK;
+                for (uint32_t probe = 0; probe < MASK; probe++, at = (at + 1) & MASK) {
+                    uint64_t c2 = *reinterpret_cast<volatile uint64_t *>(&tk[at]);
+                    if (c2 == EMPTY_KEY)
+                        c2 = atomicCAS((unsigned long long *)&tk[at], (unsigned long long)EMPTY_KEY, (unsigned long long)kv[j]);
+                    if (c2 == EMPTY_KEY) { ins = true; slot = at; break; }
+                    if (c2 == kv[j]) { slot = at; break; }
+                }
+            }
+            if (slot != 0xffffffffu) atomicAdd(&tc[slot], 1u);
+            else ok = false;
+        }
+        n_ins += __popcll(__ballot(ins));
+    }
+    return ok;
+}
+
 template <int CAP_LOG2, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void bucket_dedup_wave_kernel(
-    uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, uint64_t n_segments, uint32_t abundance_min,
-    uint32_t *__restrict__ len_out, uint32_t *__restrict__ counts_out, int *__restrict__ overflow)
+    uint64_t *__restrict__ keys, const SegLayout seg_layout, uint64_t n_segments, uint32_t abundance_min,
+    uint32_t *__restrict__ len_out, uint32_t *__restrict__ marks, uint32_t *__restrict__ counts_out, int *__restrict__ overflow)
 {
     constexpr uint32_t CAP = 1u << CAP_LOG2, MASK = CAP - 1, MAX_FILL = CAP - CAP / 8;
+    // A wave has few companions on its CU (the tables fill the LDS), so it must keep many bytes in flight by
+    // itself: the first 64 x KD keys of a segment -- the whole segment in the design case -- are loaded in one go, and
+    // the NEXT segment's while the current one is compacted.
+    constexpr int KD = 12;
     __shared__ uint64_t tk_all[WAVES][CAP];
     __shared__ uint32_t tc_all[WAVES][CAP];
     const int lane = lane_id(), wave = wave_id();
     uint64_t *tk = tk_all[wave];
     uint32_t *tc = tc_all[wave];
     const uint64_t lane_lt = (1ull << lane) - 1;
-    for (uint64_t seg = (uint64_t)blockIdx.x * WAVES + wave; seg < n_segments; seg += (uint64_t)gridDim.x * WAVES) {
-        const uint64_t s0 = off[seg];
-        const uint64_t n = off[seg + 1] - s0;
-        if (n == 0) { if (lane == 0) len_out[seg] = 0; continue; }
+    const uint64_t stride = (uint64_t)gridDim.x * WAVES;
+    uint64_t seg = (uint64_t)blockIdx.x * WAVES + wave;
+    if (seg >= n_segments) return;
+    uint64_t s0, n;
+    seg_bounds(seg_layout, seg, s0, n);
+    uint64_t kv[KD];
+#pragma unroll
+    for (int j = 0; j < KD; j++) {
+        const uint64_t i = 64u * j + lane;
+        kv[j] = i < n ? keys[s0 + i] : EMPTY_KEY;
+    }
+    for (;;) {
+        const uint64_t seg_next = seg + stride;
+        uint64_t s0n = 0, nn = 0;
+        if (seg_next < n_segments) seg_bounds(seg_layout, seg_next, s0n, nn);     // needed only after the inserts
         for (uint32_t i = lane; i < CAP; i += 64) { tk[i] = EMPTY_KEY; tc[i] = 0; }
         wave_lds_fence();
         uint32_t nd = 0;
         bool over = false;
-        for (uint64_t i0 = 0; i0 < n && !over; i0 += 64 * 4) {
-            uint64_t kv[4];
+#pragma unroll
+        for (int j0 = 0; j0 < KD; j0 += 4) {
+            if (64u * j0 < n) over |= !dedup_insert4<MASK>(tk, tc, kv + j0, nd);
+        }
+        over = __any(over) || nd > MAX_FILL;
+        // the rest of a segment longer than the register window
+        for (uint64_t i0 = 64u * KD; i0 < n && !over; i0 += 64 * 4) {
+            uint64_t kx[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint64_t i = i0 + 64u * j + lane;
-                kv[j] = i < n ? keys[s0 + i] : EMPTY_KEY;
+                kx[j] = i < n ? keys[s0 + i] : EMPTY_KEY;
             }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                bool ins = false;
-                if (kv[j] != EMPTY_KEY) {
-                    const uint32_t slot = lds_find_or_insert(tk, MASK, kv[j], mix64(kv[j]), &ins);
-                    if (slot != 0xffffffffu) atomicAdd(&tc[slot], 1u);
-                    else over = true;
-                }
-                nd += __popcll(__ballot(ins));
-            }
+            over = !dedup_insert4<MASK>(tk, tc, kx, nd);
             over = __any(over) || nd > MAX_FILL;
         }
+        // next segment's keys: in flight during the compaction below
+#pragma unroll
+        for (int j = 0; j < KD; j++) {
+            const uint64_t i = 64u * j + lane;
+            kv[j] = i < nn ? keys[s0n + i] : EMPTY_KEY;
+        }
         if (over) {
-            if (lane == 0) { len_out[seg] = 0xffffffffu; atomicExch(overflow, 1); }
+            if (lane == 0) { atomicOr(&marks[seg >> 5], 1u << (seg & 31)); atomicExch(overflow, 1); }
+        } else {
             wave_lds_fence();
-            continue;
-        }
-        wave_lds_fence();
-        uint32_t base = 0;
+            uint32_t base = 0;
 #pragma unroll 4
-        for (uint32_t s = 0; s < CAP; s += 64) {
-            const uint64_t key = tk[s + lane];
-            const uint32_t c = tc[s + lane];
-            const bool keep = key != EMPTY_KEY && c >= abundance_min;
-            const uint64_t m = __ballot(keep);
-            if (keep) {
-                const uint32_t pos = base + __popcll(m & lane_lt);
-                keys[s0 + pos] = key;
-                if (counts_out) counts_out[s0 + pos] = c;
+            for (uint32_t s = 0; s < CAP; s += 64) {
+                const uint64_t key = tk[s + lane];
+                const uint32_t c = tc[s + lane];
+                const bool keep = key != EMPTY_KEY && c >= abundance_min;
+                const uint64_t m = __ballot(keep);
+                if (keep) {
+                    const uint32_t pos = base + __popcll(m & lane_lt);
+                    keys[s0 + pos] = key;
+                    if (counts_out) counts_out[s0 + pos] = c;
+                }
+                base += __popcll(m);
             }
-            base += __popcll(m);
+            if (lane == 0) len_out[seg] = base;
         }
-        if (lane == 0) len_out[seg] = base;
         wave_lds_fence();
+        if (seg_next >= n_segments) break;
+        seg = seg_next; s0 = s0n; n = nn;
     }
 }
 
@@ -924,17 +1040,6 @@ __global__ __launch_bounds__(WAVES * 64) void bucket_dedup_wave_kernel(
 // what leaves the kernel is U-sized.  "one genome / several" comes from the bits themselves.
 // ------------------------------------------------------------------------------------
 constexpr uint32_t META_ID = 0x1fffu, META_SEEN = 0x4000u, META_MULTI = 0x8000u;
-
-__device__ __forceinline__ void seg_bounds(const SegLayout &L, uint64_t idx, uint64_t &s0, uint64_t &n)
-{
-    if (L.off) {
-        s0 = L.off[idx];
-        n = L.len ? (uint64_t)L.len[idx] : L.off[idx + 1] - s0;
-    } else {
-        s0 = idx * L.stride;
-        n = L.len[idx];
-    }
-}
 
 // Pair-aligned linear probing: a key's probe sequence starts at the EVEN slot (h & mask & ~1), so that one
 // 16-byte LDS read (ds_read_b128) returns two consecutive slots of it and two reads cover a displacement of
@@ -1423,7 +1528,7 @@ __global__ void gather_u64_kernel(const uint64_t *__restrict__ src, const uint32
 // Bit layout: genome i -> row i/64, bit 63-(i%64)  (bin/kover/core/kover/utils.py:133-156).
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TABLE_THREADS) void matrix_fill_kernel(
-    const uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+    const uint64_t *__restrict__ keys, const SegLayout seg_layout,
     uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint64_t *__restrict__ dkeys,
     const uint32_t *__restrict__ dcol, const uint64_t *__restrict__ seg_start, uint64_t *__restrict__ matrix,
     uint64_t n_cols, int *__restrict__ overflow)
@@ -1458,9 +1563,8 @@ __global__ __launch_bounds__(TABLE_THREADS) void matrix_fill_kernel(
         const uint32_t g_end = min(r * 64 + 64, n_genomes);
         for (uint32_t g = r * 64 + wave; g < g_end; g += nw) {
             const unsigned long long bit = 1ull << (63 - (g & 63));
-            const uint64_t idx = (uint64_t)g * B + b;
-            const uint64_t s0 = off[idx];
-            const uint64_t n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
+            uint64_t s0, n;
+            seg_bounds(seg_layout, (uint64_t)g * B + b, s0, n);
             for (uint64_t i0 = lane; i0 < n; i0 += 64 * KEYS_IN_FLIGHT) {
                 uint64_t kv[KEYS_IN_FLIGHT];
 #pragma unroll
@@ -1578,14 +1682,14 @@ int scatter_b1_bits(int bb) { return bb < L1_MAX_BITS ? bb : L1_MAX_BITS; }
 
 // level 1 writes `out` = keys1 when a second level follows, else the final keys
 void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *coarse_off,
-                            uint32_t *cursor1, uint64_t *out)
+                            uint32_t *cursor1, uint64_t *out, uint64_t region_stride, int *overflow)
 {
     KmerArgs a = make_args(L);
     if (a.total_syms == 0) return;
     const uint32_t n_tiles = (uint32_t)((a.total_syms + L1_TILE - 1) / L1_TILE);
     const uint32_t grid = ((n_tiles + 7) / 8) * 8;
     hipLaunchKernelGGL(kmer_scatter_l1_kernel, dim3(grid), dim3(L1_THREADS), L1_LDS_BYTES, s, a, scatter_b1_bits(L.bb), n_tiles,
-                       off, coarse_off, cursor1, out);
+                       off, coarse_off, cursor1, out, region_stride, overflow);
 }
 void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *coarse_off, uint64_t n_regions, int bb,
                         uint32_t *counts)
@@ -1594,15 +1698,20 @@ void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *co
     const uint32_t grid = (uint32_t)(n_regions < 256u * 32u ? n_regions : 256u * 32u);
     hipLaunchKernelGGL(region_hist_kernel, dim3(grid), dim3(256), 0, s, keys1, coarse_off, n_regions, bb, scatter_b1_bits(bb), counts);
 }
+void launch_sum_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *out)
+{
+    hipLaunchKernelGGL(sum_u32_kernel, dim3(1), dim3(1024), 0, s, in, n, out);
+}
 void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *keys1,
-                            uint64_t *keys)
+                            uint64_t *keys, uint64_t region_stride, uint32_t fine_cap, const uint32_t *cursor1, uint32_t *len_out,
+                            int *overflow)
 {
     const int b1 = scatter_b1_bits(L.bb);
     if (L.total_syms == 0 || L.bb <= b1) return;
     const uint64_t n_regions = (uint64_t)L.n_genomes << b1;
     const uint32_t grid2 = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
     hipLaunchKernelGGL(kmer_scatter_l2_kernel, dim3(grid2), dim3(L2_THREADS), L2_LDS_BYTES, s, keys1, keys, off,
-                       n_regions, L.bb, b1);
+                       n_regions, L.bb, b1, region_stride, fine_cap, cursor1, len_out, overflow);
 }
 void launch_keys_partition_hist(hipStream_t s, const uint64_t *in, uint64_t n, const uint64_t *genome_key_off,
                                 uint32_t n_genomes, int bb, uint32_t *counts)
@@ -1621,18 +1730,18 @@ void launch_scan_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *ou
 {
     hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, s, in, n, out);
 }
-void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const uint64_t *off, uint64_t n_segments, uint32_t cap_log2,
-                         uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow, int only_marked)
+void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const SegLayout &seg, uint64_t n_segments, uint32_t cap_log2,
+                         uint32_t abundance_min, uint32_t *len_out, const uint32_t *marks, uint32_t *counts_out, int *overflow)
 {
     if (!n_segments) return;
     const size_t lds = (((size_t)12) << cap_log2) + TABLE_SCRATCH_BYTES;
     const uint32_t grid = (uint32_t)(n_segments < 256u * 16u ? n_segments : 256u * 16u);
-    hipLaunchKernelGGL(bucket_dedup_kernel, dim3(grid), dim3(TABLE_THREADS), lds, s, keys, off, n_segments, cap_log2,
-                       abundance_min, len_out, counts_out, overflow, only_marked);
+    hipLaunchKernelGGL(bucket_dedup_kernel, dim3(grid), dim3(TABLE_THREADS), lds, s, keys, seg, n_segments, cap_log2,
+                       abundance_min, len_out, marks, counts_out, overflow);
 }
-// wave form: wave_cap_log2 in {9, 10, 11}
-void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const uint64_t *off, uint64_t n_segments, int wave_cap_log2,
-                              uint32_t abundance_min, uint32_t *len_out, uint32_t *counts_out, int *overflow)
+// wave form: wave_cap_log2 in {9, 10, 11}; marks: one bit per segment (zeroed by the caller), set for segments left untouched
+void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const SegLayout &seg, uint64_t n_segments, int wave_cap_log2,
+                              uint32_t abundance_min, uint32_t *len_out, uint32_t *marks, uint32_t *counts_out, int *overflow)
 {
     if (!n_segments) return;
     // 48 KiB of LDS per workgroup in every form: 3 workgroups per CU
@@ -1640,8 +1749,8 @@ void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const uint64_t *off
     {                                                                                                                     \
         const uint64_t wgs = (n_segments + (W) - 1) / (W);                                                                \
         const uint32_t grid = (uint32_t)(wgs < 256u * 24u ? wgs : 256u * 24u);                                            \
-        hipLaunchKernelGGL((bucket_dedup_wave_kernel<C, W>), dim3(grid), dim3((W) * 64), 0, s, keys, off, n_segments,     \
-                           abundance_min, len_out, counts_out, overflow);                                                 \
+        hipLaunchKernelGGL((bucket_dedup_wave_kernel<C, W>), dim3(grid), dim3((W) * 64), 0, s, keys, seg, n_segments,     \
+                           abundance_min, len_out, marks, counts_out, overflow);                                          \
     }
     if (wave_cap_log2 <= 9) GRM_LAUNCH_DW(9, 8)
     else if (wave_cap_log2 == 10) GRM_LAUNCH_DW(10, 4)
@@ -1740,13 +1849,13 @@ void launch_gather_u64(hipStream_t s, const uint64_t *src, const uint32_t *index
     if (!n) return;
     hipLaunchKernelGGL(gather_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, index, n, dst);
 }
-void launch_matrix_fill(hipStream_t s, const uint64_t *keys, const uint64_t *off, const uint32_t *len,
+void launch_matrix_fill(hipStream_t s, const uint64_t *keys, const SegLayout &seg,
                         uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint64_t *dkeys,
                         const uint32_t *dcol, const uint64_t *seg_start, uint64_t *matrix, uint64_t n_cols,
                         int *overflow)
 {
     const size_t lds = (((size_t)16) << cap_log2) + TABLE_SCRATCH_BYTES;
-    hipLaunchKernelGGL(matrix_fill_kernel, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, keys, off, len, n_genomes,
+    hipLaunchKernelGGL(matrix_fill_kernel, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, keys, seg, n_genomes,
                        bb, sb, cap_log2, dkeys, dcol, seg_start, matrix, n_cols, overflow);
 }
 void launch_column_popcount(hipStream_t s, const uint64_t *matrix, uint64_t n_rows, uint64_t n_cols,
