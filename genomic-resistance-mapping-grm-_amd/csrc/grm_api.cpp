@@ -60,6 +60,7 @@ struct grm_ctx {
     int opt_direct_permute = -1; // > 0: scattered single-step form of the fill (tests, measurements)
     int opt_dedup_wg = -1;       // > 0: per-segment dedup in the workgroup form only (tests)
     int opt_dense_layout = -1;   // > 0: histogram-sized dense partition layout (tests, measurements)
+    int opt_no_union = -1;       // > 0: gathered rank dictionaries are sorted as a whole (tests)
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
 
@@ -238,6 +239,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "direct_permute") c->opt_direct_permute = value;
     else if (n == "dedup_wg") c->opt_dedup_wg = value;
     else if (n == "dense_layout") c->opt_dense_layout = value;
+    else if (n == "no_union") c->opt_no_union = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
@@ -557,6 +559,7 @@ static void wide_hash_free(WideHash *w);
 static int wide_stage_local(grm_batch *b, int k);
 static int wide_stage_n_local(grm_batch *b, uint64_t *n_local);
 static int wide_stage_export(grm_batch *b, void *dev_keys_out, void *dev_flags_out);
+static int wide_stage_export_ordered(grm_batch *b, uint8_t *rec, uint64_t flags_off, uint64_t boff_off);
 static int wide_stage_global(grm_batch *b, const void *dev_keys, const void *dev_flags, uint64_t n, int filter_singleton, uint64_t *n_kmers);
 static int wide_stage_fill(grm_batch *b, grm_matrix **out);
 
@@ -608,7 +611,9 @@ struct grm_batch {
     bool have_bits = false, fill_by_bits = false;
     int filter_singleton = 0;
     // scratch that survives between steps (grow-only)
-    DevBuf t_flag;
+    DevBuf t_flag, t_ord_off;
+    DevBuf t_u_off, t_u_len, t_u_foff, t_u_keys, t_u_flags, t_u_wg_base, t_u_wg_cnt;     // union of gathered rank dictionaries
+    int sb_union_hint = 0;
     DevBuf t_sk, t_sf, t_keep, t_pos, t_tmp, t_bid, t_col, t_bid_sorted;
     DevBuf t_set_off, t_set_src, t_set_len, t_set_k, t_set_c, t_set_tmp;     // grm_batch_genome_set
 };
@@ -1170,6 +1175,69 @@ struct DictCtrl {
 // the probing form of the fill is used instead (it needs no intermediate)
 static const size_t MATRIX_S_LIMIT = (size_t)96 << 30;
 
+// One dictionary build with the sizing ladder.  `a` carries the input side (keys, segments, genomes, bb, cap_log2,
+// optional rank flags); the output buffers are sized here for every attempt.  want_bits: also keep the presence words
+// (matrix_s / birth of the batch).  On success *sb_out / *n_out / *bits_out describe what was built.
+struct DictOut {
+    DevBuf *keys, *flags, *wg_base, *wg_cnt;
+};
+static int run_dict_ladder(grm_batch *b, DictArgs a, uint64_t total_keys, int sb, bool want_bits, const DictOut &out, const char *tname,
+                           int *sb_out, uint64_t *n_out, bool *bits_out, int *launches)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    const uint32_t cap = 1u << a.cap_log2, max_fill = cap - (cap >> 3);
+    const size_t n_rows = ((size_t)a.n_genomes + 63) / 64;
+    HIPCHK(c, b->d_ctrl.ensure(sizeof(DictCtrl)));
+    for (int attempt = 0;; attempt++) {
+        if (a.bb + sb > 24) return fail(c, GRM_ERR_OVERFLOW, "%s: bucket union does not fit the LDS table even with 2^%d sub-buckets", tname, sb);
+        const uint32_t n_wg = 1u << (a.bb + sb);
+        // every workgroup holds at most max_fill entries, and there are no more entries than keys
+        const uint64_t out_cap = std::min<uint64_t>(total_keys, (uint64_t)n_wg * max_fill) + 64;
+        HIPCHK(c, out.keys->ensure(out_cap * 8));
+        HIPCHK(c, out.flags->ensure(out_cap));
+        HIPCHK(c, out.wg_base->ensure((size_t)n_wg * 8));
+        HIPCHK(c, out.wg_cnt->ensure(((size_t)n_wg + 1) * 4));
+        const size_t ms_bytes = (size_t)n_wg * n_rows * cap * 8;
+        const bool bits = want_bits && ms_bytes <= MATRIX_S_LIMIT;
+        if (bits) {
+            HIPCHK(c, b->d_matrix_s.ensure(ms_bytes));
+            HIPCHK(c, b->d_birth.ensure((size_t)n_wg * cap * 2));
+        }
+        HIPCHK(c, hipMemsetAsync(b->d_ctrl.p, 0, sizeof(DictCtrl), s));
+        a.sb = sb;
+        a.out_keys = out.keys->as<uint64_t>(); a.out_flags = out.flags->as<uint8_t>();
+        a.out_cap = out_cap;
+        DictCtrl *ctrl = b->d_ctrl.as<DictCtrl>();
+        a.n_out = &ctrl->n_out; a.overflow = &ctrl->overflow; a.need = &ctrl->need;
+        a.wg_base = out.wg_base->as<uint64_t>(); a.wg_cnt = out.wg_cnt->as<uint32_t>();
+        a.matrix_s = bits ? b->d_matrix_s.as<uint64_t>() : nullptr;
+        a.birth = bits ? b->d_birth.as<uint16_t>() : nullptr;
+        {
+            TimeScope t(c, tname, total_keys);
+            launch_dict_build(s, a);
+        }
+        if (launches) (*launches)++;
+        HIPCHK(c, hipGetLastError());
+        DictCtrl h;
+        HIPCHK(c, hipMemcpyAsync(&h, b->d_ctrl.p, sizeof h, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (!h.overflow) {
+            *sb_out = sb;
+            *n_out = h.n_out;
+            *bits_out = bits;
+            return GRM_OK;
+        }
+        if (h.overflow >= 2 && h.need == 0) return fail(c, GRM_ERR_HIP, "internal: %s output capacity exceeded (%llu entries)", tname, (unsigned long long)h.n_out);
+        if (attempt >= 8 || (c->opt_sub_bits >= 0 && sb >= c->opt_sub_bits + 8)) return fail(c, GRM_ERR_OVERFLOW, "%s: overflow persists", tname);
+        // jump to the sub-bucket count the failed launch asks for: its fullest workgroup estimated `need`
+        // distinct k-mers; aim at 70 % of the usable table so that the estimate's error does not cost a third launch
+        int step = 1;
+        while (step < 24 && ((uint64_t)h.need >> step) > (uint64_t)max_fill * 7 / 10) step++;
+        sb += step;
+    }
+}
+
 extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
 {
     if (!b) return GRM_ERR_ARG;
@@ -1177,7 +1245,6 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
     if (!b->partitioned) return fail(c, GRM_ERR_STATE, "grm_batch_local_dict before grm_batch_partition");
     if (b->k > 32) return wide_stage_n_local(b, n_local);
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
     b->have_local = b->have_global = false;
     b->have_bits = false;
     b->dict_launches = 0;
@@ -1190,64 +1257,19 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
         if (n_local) *n_local = 0;
         return GRM_OK;
     }
-    const uint32_t cap = 1u << b->cap_log2, max_fill = cap - (cap >> 3);
-    const size_t n_rows = ((size_t)G + 63) / 64;
-    if (n_rows > 0xffffu) return fail(c, GRM_ERR_UNSUPPORTED, "%u genomes in one batch (limit 65535 word-rows); use the chunked flow", G);
+    if (((size_t)G + 63) / 64 > 0xffffu) return fail(c, GRM_ERR_UNSUPPORTED, "%u genomes in one batch (limit 65535 word-rows); use the chunked flow", G);
     // sub-buckets: what the caller forces, else what this batch needed last time for the same geometry, else none
     int sb = c->opt_sub_bits >= 0 ? c->opt_sub_bits : 0;
     if (c->opt_sub_bits < 0 && b->sb_hint >= 0 && b->sb_hint_k == b->k && b->sb_hint_bb == b->bb && b->sb_hint_amin == b->abundance_min)
         sb = b->sb_hint;
-    HIPCHK(c, b->d_ctrl.ensure(sizeof(DictCtrl)));
-    for (int attempt = 0;; attempt++) {
-        if (b->bb + sb > 24) return fail(c, GRM_ERR_OVERFLOW, "dict_build: bucket union does not fit the LDS table even with 2^%d sub-buckets", sb);
-        const uint32_t n_wg = 1u << (b->bb + sb);
-        // every workgroup holds at most max_fill entries, and there are no more entries than keys
-        const uint64_t out_cap = std::min<uint64_t>(b->total_keys, (uint64_t)n_wg * max_fill) + 64;
-        HIPCHK(c, b->d_local_keys.ensure(out_cap * 8));
-        HIPCHK(c, b->d_local_flags.ensure(out_cap));
-        HIPCHK(c, b->d_wg_base.ensure((size_t)n_wg * 8));
-        HIPCHK(c, b->d_wg_cnt.ensure((size_t)n_wg * 4));
-        const size_t ms_bytes = (size_t)n_wg * n_rows * cap * 8;
-        const bool bits = c->opt_no_slots <= 0 && ms_bytes <= MATRIX_S_LIMIT;
-        if (bits) {
-            HIPCHK(c, b->d_matrix_s.ensure(ms_bytes));
-            HIPCHK(c, b->d_birth.ensure((size_t)n_wg * cap * 2));
-        }
-        HIPCHK(c, hipMemsetAsync(b->d_ctrl.p, 0, sizeof(DictCtrl), s));
-        DictArgs a;
-        a.keys = b->d_keys.as<uint64_t>();
-        a.seg = batch_segments(b);
-        a.n_genomes = G; a.bb = b->bb; a.sb = sb; a.cap_log2 = b->cap_log2;
-        a.out_keys = b->d_local_keys.as<uint64_t>(); a.out_flags = b->d_local_flags.as<uint8_t>();
-        a.out_cap = out_cap;
-        DictCtrl *ctrl = b->d_ctrl.as<DictCtrl>();
-        a.n_out = &ctrl->n_out; a.overflow = &ctrl->overflow; a.need = &ctrl->need;
-        a.wg_base = b->d_wg_base.as<uint64_t>(); a.wg_cnt = b->d_wg_cnt.as<uint32_t>();
-        a.matrix_s = bits ? b->d_matrix_s.as<uint64_t>() : nullptr;
-        a.birth = bits ? b->d_birth.as<uint16_t>() : nullptr;
-        {
-            TimeScope t(c, "dict_build", b->total_keys);
-            launch_dict_build(s, a);
-        }
-        b->dict_launches++;
-        HIPCHK(c, hipGetLastError());
-        DictCtrl h;
-        HIPCHK(c, hipMemcpyAsync(&h, b->d_ctrl.p, sizeof h, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        if (!h.overflow) {
-            b->n_local = h.n_out;
-            b->have_bits = bits;
-            break;
-        }
-        if (h.overflow >= 2 && h.need == 0) return fail(c, GRM_ERR_HIP, "internal: dict_build output capacity exceeded (%llu entries)", (unsigned long long)h.n_out);
-        if (attempt >= 8 || (c->opt_sub_bits >= 0 && sb >= c->opt_sub_bits + 8))
-            return fail(c, GRM_ERR_OVERFLOW, "dict_build: overflow persists");
-        // jump to the sub-bucket count the failed launch asks for: its fullest workgroup estimated `need`
-        // distinct k-mers; aim at 70 % of the usable table so that the estimate's error does not cost a third launch
-        int step = 1;
-        while (step < 24 && ((uint64_t)h.need >> step) > (uint64_t)max_fill * 7 / 10) step++;
-        sb += step;
-    }
+    DictArgs a;
+    memset(&a, 0, sizeof a);
+    a.keys = b->d_keys.as<uint64_t>();
+    a.seg = batch_segments(b);
+    a.n_genomes = G; a.bb = b->bb; a.cap_log2 = b->cap_log2;
+    const DictOut out = {&b->d_local_keys, &b->d_local_flags, &b->d_wg_base, &b->d_wg_cnt};
+    int rc = run_dict_ladder(b, a, b->total_keys, sb, c->opt_no_slots <= 0, out, "dict_build", &sb, &b->n_local, &b->have_bits, &b->dict_launches);
+    if (rc) return rc;
     b->sb_dict = sb;
     if (c->opt_sub_bits < 0) { b->sb_hint = sb; b->sb_hint_k = b->k; b->sb_hint_bb = b->bb; b->sb_hint_amin = b->abundance_min; }
     b->have_local = true;
@@ -1305,51 +1327,47 @@ static int bucketise_dict(grm_batch *b, int sb)
     return GRM_OK;
 }
 
-extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, const void *dev_flags, uint64_t n,
-                                         int filter_singleton, uint64_t *n_kmers)
+// (key, flag) entries -- several per k-mer when it was reported by several ranks or chunks -- -> the sorted,
+// merged, filtered global dictionary b->d_dict / b->n_dict
+static int dict_from_entries(grm_batch *b, const uint64_t *keys, const uint8_t *flags, uint64_t n, int filter_singleton)
 {
-    if (!b) return GRM_ERR_ARG;
     grm_ctx *c = b->ctx;
-    if (!b->partitioned) return fail(c, GRM_ERR_STATE, "grm_batch_set_global_dict before grm_batch_partition");
-    if (n && (!dev_keys || !dev_flags)) return fail(c, GRM_ERR_ARG, "grm_batch_set_global_dict: NULL buffers");
-    if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "dictionary of %llu k-mers exceeds 2^32-1 columns", (unsigned long long)n);
-    HIPCHK(c, hipSetDevice(c->device));
-    if (b->k > 32) return wide_stage_global(b, dev_keys, dev_flags, n, filter_singleton, n_kmers);
     hipStream_t s = c->stream;
-    b->have_global = false;
-    b->filter_singleton = filter_singleton;
     b->n_dict = 0;
-    b->own_dict = n && dev_keys == b->d_local_keys.p && n == b->n_local;     // filtered or not: every COLUMN stems from a local entry
-    if (n) {
-        DevBuf &d_sk = b->t_sk, &d_sf = b->t_sf, &d_keep = b->t_keep, &d_pos = b->t_pos, &d_tmp = b->t_tmp;
-        HIPCHK(c, d_sk.ensure(n * 8));
-        HIPCHK(c, d_sf.ensure(n));
-        HIPCHK(c, d_keep.ensure((n + 1) * 4));
-        HIPCHK(c, d_pos.ensure((n + 1) * 8));
-        {
-            TimeScope t(c, "dict_sort", n);
-            size_t tmp_bytes = 0;
-            HIPCHK(c, sort_pairs_u64_u8(s, (const uint64_t *)dev_keys, d_sk.as<uint64_t>(), (const uint8_t *)dev_flags,
-                                        d_sf.as<uint8_t>(), n, nullptr, tmp_bytes));
-            HIPCHK(c, d_tmp.ensure(tmp_bytes));
-            HIPCHK(c, sort_pairs_u64_u8(s, (const uint64_t *)dev_keys, d_sk.as<uint64_t>(), (const uint8_t *)dev_flags,
-                                        d_sf.as<uint8_t>(), n, d_tmp.p, tmp_bytes));
-            HIPCHK(c, hipMemsetAsync(d_keep.as<uint32_t>() + n, 0, 4, s));
-            launch_dict_mark(s, d_sk.as<uint64_t>(), d_sf.as<uint8_t>(), n, filter_singleton, d_keep.as<uint32_t>());
-            size_t tmp2 = 0;
-            HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, nullptr, tmp2));
-            HIPCHK(c, d_tmp.ensure(tmp2));
-            HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, d_tmp.p, tmp2));
-            HIPCHK(c, hipMemcpyAsync(&b->n_dict, d_pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
-            HIPCHK(c, b->d_dict.ensure((b->n_dict + 2) * 8));
-            launch_dict_select(s, d_sk.as<uint64_t>(), d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n, b->d_dict.as<uint64_t>());
-        }
-        HIPCHK(c, hipGetLastError());
+    if (!n) return b->d_dict.ensure(16) == hipSuccess ? GRM_OK : fail(c, GRM_ERR_OOM, "alloc");
+    if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "dictionary of %llu k-mers exceeds 2^32-1 columns", (unsigned long long)n);
+    DevBuf &d_sk = b->t_sk, &d_sf = b->t_sf, &d_keep = b->t_keep, &d_pos = b->t_pos, &d_tmp = b->t_tmp;
+    HIPCHK(c, d_sk.ensure(n * 8));
+    HIPCHK(c, d_sf.ensure(n));
+    HIPCHK(c, d_keep.ensure((n + 1) * 4));
+    HIPCHK(c, d_pos.ensure((n + 1) * 8));
+    {
+        TimeScope t(c, "dict_sort", n);
+        size_t tmp_bytes = 0;
+        HIPCHK(c, sort_pairs_u64_u8(s, keys, d_sk.as<uint64_t>(), flags, d_sf.as<uint8_t>(), n, nullptr, tmp_bytes));
+        HIPCHK(c, d_tmp.ensure(tmp_bytes));
+        HIPCHK(c, sort_pairs_u64_u8(s, keys, d_sk.as<uint64_t>(), flags, d_sf.as<uint8_t>(), n, d_tmp.p, tmp_bytes));
+        HIPCHK(c, hipMemsetAsync(d_keep.as<uint32_t>() + n, 0, 4, s));
+        launch_dict_mark(s, d_sk.as<uint64_t>(), d_sf.as<uint8_t>(), n, filter_singleton, d_keep.as<uint32_t>());
+        size_t tmp2 = 0;
+        HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, nullptr, tmp2));
+        HIPCHK(c, d_tmp.ensure(tmp2));
+        HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, d_tmp.p, tmp2));
+        HIPCHK(c, hipMemcpyAsync(&b->n_dict, d_pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
-    } else {
-        HIPCHK(c, b->d_dict.ensure(16));
+        HIPCHK(c, b->d_dict.ensure((b->n_dict + 2) * 8));
+        launch_dict_select(s, d_sk.as<uint64_t>(), d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n, b->d_dict.as<uint64_t>());
     }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    return GRM_OK;
+}
+
+// the batch's own structures against b->d_dict: columns of its entries (fused form) or the bucketised dictionary
+static int dict_attach(grm_batch *b, uint64_t *n_kmers)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
     b->fill_by_bits = false;
     if (b->have_local && b->have_bits && b->total_keys) {
         // fused form: every local entry learns its global column (or that it was filtered out)
@@ -1376,6 +1394,142 @@ extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, con
     b->have_global = true;
     if (n_kmers) *n_kmers = b->n_dict;
     return GRM_OK;
+}
+
+extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, const void *dev_flags, uint64_t n,
+                                         int filter_singleton, uint64_t *n_kmers)
+{
+    if (!b) return GRM_ERR_ARG;
+    grm_ctx *c = b->ctx;
+    if (!b->partitioned) return fail(c, GRM_ERR_STATE, "grm_batch_set_global_dict before grm_batch_partition");
+    if (n && (!dev_keys || !dev_flags)) return fail(c, GRM_ERR_ARG, "grm_batch_set_global_dict: NULL buffers");
+    if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "dictionary of %llu k-mers exceeds 2^32-1 columns", (unsigned long long)n);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->k > 32) return wide_stage_global(b, dev_keys, dev_flags, n, filter_singleton, n_kmers);
+    b->have_global = false;
+    b->filter_singleton = filter_singleton;
+    b->own_dict = n && dev_keys == b->d_local_keys.p && n == b->n_local;     // filtered or not: every COLUMN stems from a local entry
+    int rc = dict_from_entries(b, (const uint64_t *)dev_keys, (const uint8_t *)dev_flags, n, filter_singleton);
+    if (rc) return rc;
+    return dict_attach(b, n_kmers);
+}
+
+// ---- multi-GPU exchange: ONE all-gather of fixed-stride records ---------------------------------------------
+// record of a rank (n_max = largest n_local of any rank, B = 2^bucket_bits):
+//   [0, n_max * 8 * words)            keys, grouped by hash bucket (ascending), (hi, lo) pairs for words = 2
+//   [flags_off, flags_off + n_max)    flags
+//   [boff_off, boff_off + 4 (B + 1))  first entry of every hash bucket (uint32), boff[B] = n_local
+extern "C" void grm_exchange_layout(uint64_t n_max, int words, int bucket_bits, uint64_t *flags_off, uint64_t *boff_off, uint64_t *stride)
+{
+    const uint64_t fo = n_max * 8 * (uint64_t)(words < 1 ? 1 : words);
+    const uint64_t bo = (fo + n_max + 15) / 16 * 16;
+    const uint64_t st = (bo + (((uint64_t)1 << bucket_bits) + 1) * 4 + 15) / 16 * 16;
+    if (flags_off) *flags_off = fo;
+    if (boff_off) *boff_off = bo;
+    if (stride) *stride = st;
+}
+extern "C" int grm_batch_bucket_bits(const grm_batch *b) { return b ? b->bb : 0; }
+
+extern "C" int grm_batch_export_dict_ordered(grm_batch *b, void *dev_record, uint64_t flags_off, uint64_t boff_off)
+{
+    if (!b || !dev_record) return GRM_ERR_ARG;
+    grm_ctx *c = b->ctx;
+    if (!b->have_local) return fail(c, GRM_ERR_STATE, "grm_batch_export_dict_ordered before grm_batch_local_dict");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    uint8_t *rec = (uint8_t *)dev_record;
+    if (b->k > 32) return wide_stage_export_ordered(b, rec, flags_off, boff_off);
+    const uint32_t B = 1u << b->bb;
+    if (b->total_keys == 0 || b->n_local == 0) {
+        HIPCHK(c, hipMemsetAsync(rec + boff_off, 0, ((size_t)B + 1) * 4, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        return GRM_OK;
+    }
+    const uint32_t n_wg = 1u << (b->bb + b->sb_dict);
+    HIPCHK(c, b->t_ord_off.ensure(((size_t)n_wg + 2) * 8));
+    HIPCHK(c, hipMemsetAsync(b->d_wg_cnt.as<uint32_t>() + n_wg, 0, 4, s));
+    size_t tb = 0;
+    HIPCHK(c, exclusive_scan_u32_u64(s, b->d_wg_cnt.as<uint32_t>(), b->t_ord_off.as<uint64_t>(), (uint64_t)n_wg + 1, nullptr, tb));
+    HIPCHK(c, b->t_tmp.ensure(tb));
+    HIPCHK(c, exclusive_scan_u32_u64(s, b->d_wg_cnt.as<uint32_t>(), b->t_ord_off.as<uint64_t>(), (uint64_t)n_wg + 1, b->t_tmp.p, tb));
+    launch_dict_export_ordered(s, b->d_local_keys.as<uint64_t>(), b->d_local_flags.as<uint8_t>(), b->d_wg_base.as<uint64_t>(),
+                               b->d_wg_cnt.as<uint32_t>(), b->t_ord_off.as<uint64_t>(), n_wg, b->sb_dict, (uint64_t *)rec, rec + flags_off,
+                               (uint32_t *)(rec + boff_off));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    return GRM_OK;
+}
+
+// dev_payload: the records of all ranks (rank r at r * stride, grm_exchange_layout(n_max, words, max bucket_bits)).
+// counts / bucket_bits: host arrays, one entry per rank.  When every rank used the same bucket geometry the gathered
+// lists are first united bucket by bucket in LDS tables (the ranks of a pan-genome hold nearly the same k-mers, so
+// what has to be sorted shrinks from the sum of the rank dictionaries to their union); otherwise they are sorted as a whole.
+extern "C" int grm_batch_set_global_dict_gathered(grm_batch *b, const void *dev_payload, int n_ranks, uint64_t n_max,
+                                                  const uint64_t *counts, const int *bucket_bits, int filter_singleton, uint64_t *n_kmers)
+{
+    if (!b || n_ranks < 1 || !counts || !bucket_bits) return GRM_ERR_ARG;
+    grm_ctx *c = b->ctx;
+    if (!b->partitioned) return fail(c, GRM_ERR_STATE, "grm_batch_set_global_dict_gathered before grm_batch_partition");
+    if (!dev_payload) return fail(c, GRM_ERR_ARG, "grm_batch_set_global_dict_gathered: NULL payload");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int words = b->k > 32 ? 2 : 1;
+    int bb_max = 0;
+    bool same_bb = true;
+    uint64_t total = 0;
+    for (int r = 0; r < n_ranks; r++) {
+        bb_max = std::max(bb_max, bucket_bits[r]);
+        same_bb = same_bb && bucket_bits[r] == bucket_bits[0];
+        if (counts[r] > n_max) return fail(c, GRM_ERR_ARG, "grm_batch_set_global_dict_gathered: rank %d holds more than n_max entries", r);
+        total += counts[r];
+    }
+    uint64_t flags_off, boff_off, stride;
+    grm_exchange_layout(n_max, words, bb_max, &flags_off, &boff_off, &stride);
+    const uint8_t *payload = (const uint8_t *)dev_payload;
+    if (words == 1 && same_bb && n_ranks <= 63 && total && c->opt_no_union <= 0) {
+        const uint32_t B = 1u << bb_max;
+        const uint64_t n_seg = (uint64_t)n_ranks * B;
+        HIPCHK(c, b->t_u_off.ensure(n_seg * 8));
+        HIPCHK(c, b->t_u_len.ensure(n_seg * 4));
+        HIPCHK(c, b->t_u_foff.ensure(n_seg * 8));
+        launch_union_segments(s, payload, (uint32_t)n_ranks, stride, flags_off, boff_off, B, b->t_u_off.as<uint64_t>(), b->t_u_len.as<uint32_t>(),
+                              b->t_u_foff.as<uint64_t>());
+        HIPCHK(c, hipGetLastError());
+        DictArgs a;
+        memset(&a, 0, sizeof a);
+        a.keys = (const uint64_t *)payload;
+        a.seg.off = b->t_u_off.as<uint64_t>(); a.seg.len = b->t_u_len.as<uint32_t>(); a.seg.stride = 0;
+        a.n_genomes = (uint32_t)n_ranks; a.bb = bb_max; a.cap_log2 = b->cap_log2;
+        a.in_flags = payload; a.in_flag_off = b->t_u_foff.as<uint64_t>();
+        const DictOut out = {&b->t_u_keys, &b->t_u_flags, &b->t_u_wg_base, &b->t_u_wg_cnt};
+        int sb = 0;
+        uint64_t n_union = 0;
+        bool bits = false;
+        int rc = run_dict_ladder(b, a, total, b->sb_union_hint > 0 ? b->sb_union_hint : 0, false, out, "dict_union", &sb, &n_union, &bits, nullptr);
+        if (rc == GRM_OK) {
+            b->sb_union_hint = sb;
+            b->have_global = false;
+            b->filter_singleton = filter_singleton;
+            b->own_dict = false;
+            rc = dict_from_entries(b, b->t_u_keys.as<uint64_t>(), b->t_u_flags.as<uint8_t>(), n_union, filter_singleton);
+            if (rc) return rc;
+            return dict_attach(b, n_kmers);
+        }
+        if (rc != GRM_ERR_OVERFLOW) return rc;         // a union too large for the tables: sort everything instead
+    }
+    // general form: the ranks' entries back to back, then the sort-based merge
+    HIPCHK(c, b->t_u_keys.ensure((total + 2) * 8 * (size_t)words));
+    HIPCHK(c, b->t_u_flags.ensure(total + 16));
+    uint64_t at = 0;
+    for (int r = 0; r < n_ranks; r++) {
+        if (!counts[r]) continue;
+        HIPCHK(c, hipMemcpyAsync(b->t_u_keys.as<uint8_t>() + at * 8 * (size_t)words, payload + (uint64_t)r * stride, counts[r] * 8 * (size_t)words,
+                                 hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(b->t_u_flags.as<uint8_t>() + at, payload + (uint64_t)r * stride + flags_off, counts[r], hipMemcpyDeviceToDevice, s));
+        at += counts[r];
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    return grm_batch_set_global_dict(b, b->t_u_keys.p, b->t_u_flags.p, total, filter_singleton, n_kmers);
 }
 
 extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
@@ -1534,6 +1688,10 @@ struct grm_dict_accum {
     int words = 0;                 // 0 until the first batch is added
     uint64_t n = 0, cap = 0;
     DevBuf keys, flags;
+    // the merged dictionary, computed by the first pass-2 chunk and reused by the others (one-word k-mers)
+    DevBuf dict;
+    uint64_t n_dict = 0;
+    int dict_filter = -1;          // -1: not computed for the current contents
 };
 
 extern "C" int grm_dict_accum_create(grm_ctx *c, grm_dict_accum **out)
@@ -1584,14 +1742,38 @@ extern "C" int grm_dict_accum_add(grm_dict_accum *a, grm_batch *b)
         if (rc) return rc;
     }
     a->n = need;
+    a->dict_filter = -1;
     return GRM_OK;
 }
 
-extern "C" int grm_batch_set_global_dict_accum(grm_batch *b, const grm_dict_accum *a, int filter_singleton, uint64_t *n_kmers)
+extern "C" int grm_batch_set_global_dict_accum(grm_batch *b, const grm_dict_accum *a_, int filter_singleton, uint64_t *n_kmers)
 {
-    if (!b || !a) return GRM_ERR_ARG;
-    if (a->words && a->words != (b->k > 32 ? 2 : 1)) return fail(b->ctx, GRM_ERR_ARG, "accumulator holds k-mers of another width");
-    return grm_batch_set_global_dict(b, a->keys.p, a->flags.p, a->n, filter_singleton, n_kmers);
+    if (!b || !a_) return GRM_ERR_ARG;
+    grm_dict_accum *a = const_cast<grm_dict_accum *>(a_);      // the cached dictionary is not part of its visible state
+    grm_ctx *c = b->ctx;
+    if (a->words && a->words != (b->k > 32 ? 2 : 1)) return fail(c, GRM_ERR_ARG, "accumulator holds k-mers of another width");
+    if (b->k > 32 || !a->n) return grm_batch_set_global_dict(b, a->keys.p, a->flags.p, a->n, filter_singleton, n_kmers);
+    if (!b->partitioned) return fail(c, GRM_ERR_STATE, "grm_batch_set_global_dict_accum before grm_batch_partition");
+    HIPCHK(c, hipSetDevice(c->device));
+    b->have_global = false;
+    b->filter_singleton = filter_singleton;
+    b->own_dict = false;
+    if (a->dict_filter != (filter_singleton ? 1 : 0)) {
+        // sort / merge / filter the accumulated entries ONCE; every chunk of pass 2 then only looks its own entries up
+        int rc = dict_from_entries(b, a->keys.as<uint64_t>(), a->flags.as<uint8_t>(), a->n, filter_singleton);
+        if (rc) return rc;
+        HIPCHK(c, a->dict.ensure((b->n_dict + 2) * 8));
+        if (b->n_dict) HIPCHK(c, hipMemcpyAsync(a->dict.p, b->d_dict.p, b->n_dict * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        a->n_dict = b->n_dict;
+        a->dict_filter = filter_singleton ? 1 : 0;
+    } else {
+        b->n_dict = a->n_dict;
+        HIPCHK(c, b->d_dict.ensure((b->n_dict + 2) * 8));
+        if (b->n_dict) HIPCHK(c, hipMemcpyAsync(b->d_dict.p, a->dict.p, b->n_dict * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return dict_attach(b, n_kmers);
 }
 
 // parts[i]: word-rows of consecutive genome blocks against the SAME dictionary; every part but the last
@@ -1979,6 +2161,23 @@ static int wide_stage_export(grm_batch *b, void *dev_keys_out, void *dev_flags_o
         launch_join_pairs_u64(c->stream, W.loc_hi.as<uint64_t>(), W.loc_lo.as<uint64_t>(), W.n_local, (uint64_t *)dev_keys_out);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(dev_flags_out, W.loc_flags.p, W.n_local, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GRM_OK;
+}
+// the local (hi, lo) lists are already in workgroup (= bucket) order; bucket offsets from the staging scan
+static int wide_stage_export_ordered(grm_batch *b, uint8_t *rec, uint64_t flags_off, uint64_t boff_off)
+{
+    grm_ctx *c = b->ctx;
+    WideHash &W = *b->whash;
+    int rc = wide_stage_export(b, rec, rec + flags_off);
+    if (rc) return rc;
+    const uint32_t B = 1u << b->bb;
+    if (!W.n_local) {
+        HIPCHK(c, hipMemsetAsync(rec + boff_off, 0, ((size_t)B + 1) * 4, c->stream));
+    } else {
+        launch_bucket_offsets(c->stream, W.stage_off.as<uint64_t>(), W.sb, B, (uint32_t *)(rec + boff_off));
+        HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GRM_OK;

@@ -120,8 +120,22 @@ struct DictArgs {
     uint16_t *birth;
     int *overflow;          // set to 1 when a table overflowed (retry with more sub-buckets), 2 when out_cap did
     uint32_t *need;         // max over overflowing workgroups of their estimated distinct k-mers (sizes the retry)
+    // union of the dictionaries of several ranks ("genomes" = ranks, one word-row, at most 63 ranks): every key comes
+    // with its rank-local flag at in_flags[in_flag_off[segment] + i]; a key flagged 2 (several genomes inside its
+    // rank) is marked as carried by several although only one rank holds it.  nullptr otherwise.
+    const uint8_t *in_flags;
+    const uint64_t *in_flag_off;
 };
 void launch_dict_build(hipStream_t s, const DictArgs &a);
+// local dictionary in bucket order: entries of workgroup wg copied to [ord_off[wg], ord_off[wg+1]) (ord_off = exclusive
+// scan of wg_cnt), and the first entry of every hash bucket (2^bb + 1 offsets)
+void launch_dict_export_ordered(hipStream_t s, const uint64_t *keys, const uint8_t *flags, const uint64_t *wg_base, const uint32_t *wg_cnt,
+                                const uint64_t *ord_off, uint32_t n_wg, int sb, uint64_t *out_keys, uint8_t *out_flags, uint32_t *bucket_off);
+void launch_bucket_offsets(hipStream_t s, const uint64_t *ord_off, int sb, uint32_t n_buckets, uint32_t *bucket_off);
+// segment arrays of the rank union over a gathered payload (rank r at r * stride bytes: keys, flags at flags_off, bucket
+// offsets at boff_off): key index (in uint64 units of the payload), length, byte offset of the flags
+void launch_union_segments(hipStream_t s, const uint8_t *payload, uint32_t n_ranks, uint64_t stride, uint64_t flags_off, uint64_t boff_off,
+                           uint32_t n_buckets, uint64_t *off, uint32_t *len, uint64_t *flag_off);
 // column of every local entry: position of its key in the sorted global dictionary, 0xffffffff if filtered / absent
 // (prefix_first: scratch of 2^20 + 2 uint32)
 void launch_dict_entry_cols(hipStream_t s, const uint64_t *dict, uint64_t n_dict, const uint64_t *entry_keys, uint64_t n_entries, int k,

@@ -1074,16 +1074,18 @@ struct DictWave {
 };
 
 // J x 64 keys of one genome's segment: keys[i0 + 64 j] for j < J (i0 includes the lane), n = segment length
-template <int J>
-__device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__restrict__ keys, uint64_t i0, uint64_t n, uint32_t g,
-                                           uint32_t r, unsigned long long bit)
+template <int J, bool FLAGS>
+__device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__restrict__ keys, const uint8_t *__restrict__ flg, uint64_t i0,
+                                           uint64_t n, uint32_t g, uint32_t r, unsigned long long bit)
 {
     uint64_t kv[J];
     uint32_t sl[J];
+    uint32_t several = 0;          // FLAGS: bit j = key j is carried by several genomes inside its rank
 #pragma unroll
     for (int j = 0; j < J; j++) {
         const uint64_t i = i0 + 64u * j;
         kv[j] = i < n ? keys[i] : EMPTY_KEY;
+        if (FLAGS && i < n && flg[i] >= 2) several |= 1u << j;
     }
     // all J global loads are in flight; the table is then consulted four keys at a time (the 16-byte reads of
     // more keys than that at once cost more registers than the LDS latency they would hide)
@@ -1114,7 +1116,7 @@ __device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__
             if (h2) at = (sl[j0 + q] + 2) & w.cap_mask;
             if (h3) at = (sl[j0 + q] + 3) & w.cap_mask;
             const bool done = h0 | h1 | h2 | h3;
-            if (active && done) atomicOr(&w.words[at], bit);
+            if (active && done) atomicOr(&w.words[at], (FLAGS && ((several >> (j0 + q)) & 1u)) ? (bit | 1ull) : bit);
             todo |= (uint32_t)(active && !done) << (j0 + q);
         }
     }
@@ -1135,7 +1137,7 @@ __device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__
                 if (w.birth && id <= w.cap_mask) w.birth[((uint64_t)w.wg << w.cap_log2) + id] = (uint16_t)r;
                 over = id >= w.max_fill;
             }
-            atomicOr(&w.words[slot], bit);
+            atomicOr(&w.words[slot], (FLAGS && ((several >> j) & 1u)) ? (bit | 1ull) : bit);
         }
         if (over) {
             *w.full = 1;
@@ -1149,7 +1151,7 @@ __device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__
 
 // MAXT: largest workgroup the instance is launched with (the 8-deep form needs more than the 128 VGPRs a
 // 1024-thread workgroup leaves per lane)
-template <int KIF, int MAXT>
+template <int KIF, int MAXT, bool FLAGS>
 __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -1180,31 +1182,39 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     // genomes w, w + nw, ...: since nw divides 64 that sequence walks the word-rows in step with the
     // other waves.
     uint32_t g = (uint32_t)wave;
-    uint64_t s0 = 0, n = 0;
-    if (g < G) seg_bounds(a.seg, (uint64_t)g * B + b, s0, n);
+    uint64_t s0 = 0, n = 0, f0 = 0;
+    if (g < G) {
+        seg_bounds(a.seg, (uint64_t)g * B + b, s0, n);
+        if (FLAGS) f0 = a.in_flag_off[(uint64_t)g * B + b];
+    }
     for (uint32_t r = 0; r < n_rows; r++) {
         for (uint32_t jr = 0; jr < per_row; jr++, g += nw) {
-            uint64_t s0_next = 0, n_next = 0;
-            if (g + nw < G) seg_bounds(a.seg, (uint64_t)(g + nw) * B + b, s0_next, n_next);
+            uint64_t s0_next = 0, n_next = 0, f0_next = 0;
+            if (g + nw < G) {
+                seg_bounds(a.seg, (uint64_t)(g + nw) * B + b, s0_next, n_next);
+                if (FLAGS) f0_next = a.in_flag_off[(uint64_t)(g + nw) * B + b];
+            }
             if (g < G && !full) {
                 const unsigned long long bit = 1ull << (63 - (g & 63));
                 const uint64_t *seg = a.keys + s0;
+                const uint8_t *flg = FLAGS ? a.in_flags + f0 : nullptr;
                 // The kernel is bound by latency and instruction issue, so the common case is straight-line and
                 // wide: KIF keys per lane in flight, their hashes, two 16-byte table reads each; a key found there
                 // -- almost every key of a pan-genome after the first few genomes -- costs one more LDS OR.  The
                 // tail of the segment goes through a copy of the same code that is exactly as deep as it needs.
                 uint64_t i0 = lane;
-                for (; i0 + 64u * (KIF - 1) < n; i0 += 64 * KIF) dict_chunk<KIF>(w, seg, i0, n, g, r, bit);
+                for (; i0 + 64u * (KIF - 1) < n; i0 += 64 * KIF) dict_chunk<KIF, FLAGS>(w, seg, flg, i0, n, g, r, bit);
                 if (i0 - lane < n && !full) {
                     const uint32_t nj = (uint32_t)((n - (i0 - lane) + 63) >> 6);        // wave-uniform: 1 .. KIF - 1
-                    if (KIF > 4 && nj > 4) dict_chunk<(KIF > 4 ? KIF : 1)>(w, seg, i0, n, g, r, bit);
-                    else if (KIF > 2 && nj > 2) dict_chunk<(KIF > 2 ? 4 : 1)>(w, seg, i0, n, g, r, bit);
-                    else if (KIF > 1 && nj == 2) dict_chunk<(KIF > 1 ? 2 : 1)>(w, seg, i0, n, g, r, bit);
-                    else dict_chunk<1>(w, seg, i0, n, g, r, bit);
+                    if (KIF > 4 && nj > 4) dict_chunk<(KIF > 4 ? KIF : 1), FLAGS>(w, seg, flg, i0, n, g, r, bit);
+                    else if (KIF > 2 && nj > 2) dict_chunk<(KIF > 2 ? 4 : 1), FLAGS>(w, seg, flg, i0, n, g, r, bit);
+                    else if (KIF > 1 && nj == 2) dict_chunk<(KIF > 1 ? 2 : 1), FLAGS>(w, seg, flg, i0, n, g, r, bit);
+                    else dict_chunk<1, FLAGS>(w, seg, flg, i0, n, g, r, bit);
                 }
             }
             s0 = s0_next;
             n = n_next;
+            f0 = f0_next;
         }
         __syncthreads();
         if (full) break;         // read between two barriers: uniform
@@ -1245,6 +1255,41 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
         const uint32_t m = meta[slot];
         a.out_keys[base + (m & META_ID)] = key;
         a.out_flags[base + (m & META_ID)] = (m & META_MULTI) ? 2 : 1;
+    }
+}
+
+// local dictionary in bucket order (multi-GPU exchange): entries of workgroup wg -> [ord_off[wg], ord_off[wg + 1])
+__global__ void dict_export_ordered_kernel(const uint64_t *__restrict__ keys, const uint8_t *__restrict__ flags,
+                                           const uint64_t *__restrict__ wg_base, const uint32_t *__restrict__ wg_cnt,
+                                           const uint64_t *__restrict__ ord_off, uint32_t n_wg, uint64_t *__restrict__ out_keys,
+                                           uint8_t *__restrict__ out_flags)
+{
+    for (uint32_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
+        const uint32_t n = wg_cnt[wg];
+        const uint64_t src = wg_base[wg], dst = ord_off[wg];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            out_keys[dst + i] = keys[src + i];
+            out_flags[dst + i] = flags[src + i];
+        }
+    }
+}
+__global__ void dict_bucket_offsets_kernel(const uint64_t *__restrict__ ord_off, int sb, uint32_t n_buckets, uint32_t *__restrict__ bucket_off)
+{
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= n_buckets; b += gridDim.x * blockDim.x)
+        bucket_off[b] = (uint32_t)ord_off[(uint64_t)b << sb];
+}
+__global__ void union_segments_kernel(const uint8_t *__restrict__ payload, uint32_t n_ranks, uint64_t stride, uint64_t flags_off,
+                                      uint64_t boff_off, uint32_t n_buckets, uint64_t *__restrict__ off, uint32_t *__restrict__ len,
+                                      uint64_t *__restrict__ flag_off)
+{
+    const uint64_t total = (uint64_t)n_ranks * n_buckets;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = idx / n_buckets, b = idx % n_buckets;
+        const uint32_t *boff = reinterpret_cast<const uint32_t *>(payload + r * stride + boff_off);
+        const uint32_t o0 = boff[b], o1 = boff[b + 1];
+        off[idx] = r * (stride / 8) + o0;
+        len[idx] = o1 - o0;
+        flag_off[idx] = r * stride + flags_off + o0;
     }
 }
 
@@ -1767,15 +1812,37 @@ void launch_dict_build(hipStream_t s, const DictArgs &a)
 {
     const size_t lds = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES;
     const dim3 grid(1u << (a.bb + a.sb)), block(g_table_threads);     // 256 / 512 / 1024 threads: the wave count divides 64
-#define GRM_LAUNCH_DICT(K, T) hipLaunchKernelGGL((dict_build_kernel<K, T>), grid, block, lds, s, a)
+#define GRM_LAUNCH_DICT(K, T, F) hipLaunchKernelGGL((dict_build_kernel<K, T, F>), grid, block, lds, s, a)
+    if (a.in_flags) {                   // union over ranks: not a hot kernel, one instance
+        GRM_LAUNCH_DICT(4, 1024, true);
+        return;
+    }
     const int kif = (g_table_threads > 512 && g_dict_kif > 4) ? 4 : g_dict_kif;
     switch (kif) {
-    case 1: GRM_LAUNCH_DICT(1, 1024); break;
-    case 2: GRM_LAUNCH_DICT(2, 1024); break;
-    case 4: GRM_LAUNCH_DICT(4, 1024); break;
-    default: GRM_LAUNCH_DICT(8, 512); break;
+    case 1: GRM_LAUNCH_DICT(1, 1024, false); break;
+    case 2: GRM_LAUNCH_DICT(2, 1024, false); break;
+    case 4: GRM_LAUNCH_DICT(4, 1024, false); break;
+    default: GRM_LAUNCH_DICT(8, 512, false); break;
     }
 #undef GRM_LAUNCH_DICT
+}
+void launch_bucket_offsets(hipStream_t s, const uint64_t *ord_off, int sb, uint32_t n_buckets, uint32_t *bucket_off)
+{
+    hipLaunchKernelGGL(dict_bucket_offsets_kernel, dim3(grid_for((uint64_t)n_buckets + 1, 256)), dim3(256), 0, s, ord_off, sb, n_buckets,
+                       bucket_off);
+}
+void launch_dict_export_ordered(hipStream_t s, const uint64_t *keys, const uint8_t *flags, const uint64_t *wg_base, const uint32_t *wg_cnt,
+                                const uint64_t *ord_off, uint32_t n_wg, int sb, uint64_t *out_keys, uint8_t *out_flags, uint32_t *bucket_off)
+{
+    hipLaunchKernelGGL(dict_export_ordered_kernel, dim3(n_wg < 256u * 32u ? n_wg : 256u * 32u), dim3(256), 0, s, keys, flags, wg_base, wg_cnt,
+                       ord_off, n_wg, out_keys, out_flags);
+    launch_bucket_offsets(s, ord_off, sb, n_wg >> sb, bucket_off);
+}
+void launch_union_segments(hipStream_t s, const uint8_t *payload, uint32_t n_ranks, uint64_t stride, uint64_t flags_off, uint64_t boff_off,
+                           uint32_t n_buckets, uint64_t *off, uint32_t *len, uint64_t *flag_off)
+{
+    hipLaunchKernelGGL(union_segments_kernel, dim3(grid_for((uint64_t)n_ranks * n_buckets, 256)), dim3(256), 0, s, payload, n_ranks, stride,
+                       flags_off, boff_off, n_buckets, off, len, flag_off);
 }
 void launch_dict_entry_cols(hipStream_t s, const uint64_t *dict, uint64_t n_dict, const uint64_t *entry_keys, uint64_t n_entries, int k,
                             uint32_t *prefix_first /* 2^20 + 2 entries */, uint32_t *entry_col)
@@ -1965,13 +2032,15 @@ hipError_t set_max_dynamic_lds()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_dedup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<1, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<2, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<8, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<8, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(matrix_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;

@@ -4,11 +4,14 @@ torch.distributed over RCCL ("nccl" backend on ROCm) / xGMI.
 Genomes are independent through parse / partition / local dictionary, and again through
 the presence-bit fill; the ONE exchange step is the union of the per-rank dictionaries:
 
-    rank r:  local distinct k-mers (uint64; (hi, lo) pairs for 33 <= k <= 64) + flag
-             (1 = carried by one local genome, 2 = by several)  n_r entries
-    all-gather(n_r)  ->  all-gather of max-padded (keys, flags) buffers
-    every rank: same deterministic sort / merge / singleton filter  ->  identical global
-             dictionary and column order, no second collective
+    rank r:  local distinct k-mers (uint64; (hi, lo) pairs for 33 <= k <= 64), grouped by hash
+             bucket, + flag (1 = carried by one local genome, 2 = by several)  n_r entries
+    sizes (n_r, bucket geometry): host integers over gloo  ->  ONE all-gather over RCCL of one
+             fixed-stride record per rank (keys | flags | bucket offsets)
+    every rank: the gathered lists are united bucket by bucket in LDS tables (ranks of a pan-genome
+             hold nearly the same k-mers: what is left to sort is the union, not the sum), then the
+             same deterministic sort / singleton filter  ->  identical global dictionary and
+             column order, no second collective
     rank r fills only its own word-rows; rank blocks are multiples of 64 genomes so a
     rank owns whole uint64 word-rows and the host (or rank 0) just stacks the rows.
 
@@ -47,56 +50,73 @@ def _all_gather(out, inp, group):
         dist.all_gather_into_tensor(out, inp, group=group)
 
 
-def allgather_dict(batch, n_local, device, group=None, words=1):
-    """the single data-path collective.  batch: object with export_dict(keys_ptr, flags_ptr).
-    -> (keys int64 tensor [n_total, words], flags uint8 tensor [n_total]) on `device`;
-    words = 2 for 33 <= k <= 64: (hi, lo) pairs, 16 bytes per k-mer."""
+_host_groups = {}
+
+
+def _host_group(group):
+    """process group for host-side integers (gloo): the default group when it is gloo already, else a
+    gloo twin of it, created on first use (collectively: every rank reaches this point in the same step)"""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo":
+        return group
+    key = id(group)
+    if key not in _host_groups:
+        _host_groups[key] = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend="gloo")
+    return _host_groups[key]
+
+
+def exchange_dict(batch, n_local, device, group=None, words=1, stats=None):
+    """the exchange step: every rank learns every rank's local dictionary.
+
+    1. sizes: (n_local, bucket_bits) of every rank -- host integers over a gloo group, no device
+       round trip (n_local is on the host already);
+    2. ONE data-path collective: all-gather of one fixed-stride byte record per rank
+       (keys grouped by hash bucket | flags | bucket offsets; layout: grm_exchange_layout).
+    -> (payload uint8 tensor [world * stride], n_max, counts, bucket_bits)"""
+    import time
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    keys = torch.empty((max(1, n_local), words), dtype=torch.int64, device=device)
-    flags = torch.empty(max(1, n_local), dtype=torch.uint8, device=device)
-    batch.export_dict(keys.data_ptr(), flags.data_ptr())
-    if world == 1:
-        return keys[:n_local], flags[:n_local]
-    counts = torch.zeros(world, dtype=torch.int64, device=device)
-    mine = torch.tensor([n_local], dtype=torch.int64, device=device)
-    _all_gather(counts, mine, group)
-    counts_h = counts.cpu().tolist()
-    n_max = max(1, max(counts_h))
-    kpad = torch.zeros((n_max, words), dtype=torch.int64, device=device)
-    fpad = torch.zeros(n_max, dtype=torch.uint8, device=device)
-    kpad[:n_local] = keys[:n_local]
-    fpad[:n_local] = flags[:n_local]
-    kall = torch.empty((world * n_max, words), dtype=torch.int64, device=device)
-    fall = torch.empty(world * n_max, dtype=torch.uint8, device=device)
-    _all_gather(kall, kpad, group)
-    _all_gather(fall, fpad, group)
-    ks = [kall[r * n_max: r * n_max + counts_h[r]] for r in range(world)]
-    fs = [fall[r * n_max: r * n_max + counts_h[r]] for r in range(world)]
-    keys_all, flags_all = torch.cat(ks).contiguous(), torch.cat(fs).contiguous()
-    if keys_all.is_cuda:
-        # the engine launches on ITS OWN stream: the collective and the concatenation above were
-        # only enqueued on torch's stream, so they must have finished before the raw pointers are
-        # handed over (RCCL collectives return to the host before the GPU work is done)
-        torch.cuda.current_stream(keys_all.device).synchronize()
-    return keys_all, flags_all
+    t0 = time.perf_counter()
+    world = dist.get_world_size(group)
+    mine = torch.tensor([n_local, batch.bucket_bits], dtype=torch.int64)
+    sizes = torch.empty(2 * world, dtype=torch.int64)
+    dist.all_gather_into_tensor(sizes, mine, group=_host_group(group))
+    counts = sizes[0::2].tolist()
+    bbs = sizes[1::2].tolist()
+    n_max = max(1, max(counts))
+    flags_off, boff_off, stride = batch.exchange_layout(n_max, words, max(bbs))
+    rec = torch.empty(stride, dtype=torch.uint8, device=device)       # padding is never read
+    batch.export_dict_ordered(rec.data_ptr(), flags_off, boff_off)
+    payload = torch.empty(world * stride, dtype=torch.uint8, device=device)
+    _all_gather(payload, rec, group)
+    if payload.is_cuda:
+        # the engine launches on ITS OWN stream: the collective was only enqueued on torch's stream and
+        # must have finished before the raw pointer is handed over
+        torch.cuda.current_stream(payload.device).synchronize()
+    if stats is not None:
+        stats["bytes"] += world * stride
+        stats["ms"] += (time.perf_counter() - t0) * 1e3
+        stats["calls"] += 1
+    return payload, n_max, counts, bbs
 
 
 def sharded_step(batch, k, abundance_min, filter_singleton, device, group=None, stats=None):
     """one pass of the hot path on this rank's genomes; returns the rank's Matrix
     (its word-rows against the GLOBAL dictionary).  stats (optional dict with "bytes", "ms", "calls")
     accumulates what the exchange step received and how long it took on the host clock."""
-    import time
+    import torch.distributed as dist
     batch.partition(k, abundance_min)
     n_local = batch.local_dict()
-    t0 = time.perf_counter()
-    keys, flags = allgather_dict(batch, n_local, device, group, words=2 if k > 32 else 1)
-    if stats is not None:
-        stats["bytes"] += int(keys.numel()) * 8 + int(flags.numel())
-        stats["ms"] += (time.perf_counter() - t0) * 1e3
-        stats["calls"] += 1
-    batch.set_global_dict(keys.data_ptr(), flags.data_ptr(), int(keys.shape[0]), filter_singleton)
+    words = 2 if k > 32 else 1
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        import torch
+        keys = torch.empty((max(1, n_local), words), dtype=torch.int64, device=device)
+        flags = torch.empty(max(1, n_local), dtype=torch.uint8, device=device)
+        batch.export_dict(keys.data_ptr(), flags.data_ptr())
+        batch.set_global_dict(keys.data_ptr(), flags.data_ptr(), n_local, filter_singleton)
+        return batch.fill()
+    payload, n_max, counts, bbs = exchange_dict(batch, n_local, device, group, words, stats)
+    batch.set_global_dict_gathered(payload.data_ptr(), n_max, counts, bbs, filter_singleton)
     return batch.fill()
 
 

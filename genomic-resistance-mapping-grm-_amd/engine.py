@@ -328,6 +328,29 @@ class Batch:
         self.ctx._chk(self.ctx.L.grm_batch_fill(self.h, C.byref(h)))
         return Matrix(self.ctx, h)
 
+    # the exchange as one all-gather of fixed-stride records (see include/grm_kmer.h)
+    @property
+    def bucket_bits(self):
+        return int(self.ctx.L.grm_batch_bucket_bits(self.h))
+
+    def exchange_layout(self, n_max, words, bucket_bits):
+        """-> (flags_off, boff_off, stride) of a rank's record"""
+        f, o, s = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.ctx.L.grm_exchange_layout(n_max, words, bucket_bits, C.byref(f), C.byref(o), C.byref(s))
+        return int(f.value), int(o.value), int(s.value)
+
+    def export_dict_ordered(self, dev_record_ptr, flags_off, boff_off):
+        self.ctx._chk(self.ctx.L.grm_batch_export_dict_ordered(self.h, dev_record_ptr, flags_off, boff_off))
+
+    def set_global_dict_gathered(self, dev_payload_ptr, n_max, counts, bucket_bits, filter_singleton):
+        n = len(counts)
+        cnt = (C.c_uint64 * n)(*[int(v) for v in counts])
+        bbs = (C.c_int * n)(*[int(v) for v in bucket_bits])
+        u = C.c_uint64()
+        self.ctx._chk(self.ctx.L.grm_batch_set_global_dict_gathered(self.h, dev_payload_ptr, n, n_max, cnt, bbs,
+                                                                    1 if filter_singleton else 0, C.byref(u)))
+        return int(u.value)
+
     @property
     def n_symbols(self):
         return int(self.ctx.L.grm_batch_n_symbols(self.h))

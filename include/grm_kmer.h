@@ -146,6 +146,20 @@ int  grm_batch_export_dict(grm_batch *, void *dev_keys_out, void *dev_flags_out)
 int  grm_batch_set_global_dict(grm_batch *, const void *dev_keys, const void *dev_flags, uint64_t n,
                                int filter_singleton, uint64_t *n_kmers);
 int  grm_batch_fill(grm_batch *, grm_matrix **out);
+/* The exchange as ONE all-gather of fixed-stride records ("one RCCL all-gather over xGMI").  A rank's
+ * record, for n_max = the largest n_local of any rank and the largest bucket_bits of any rank:
+ *     [0, n_max * 8 * words)   keys grouped by hash bucket     [flags_off, +n_max)   flags
+ *     [boff_off, +4 * (2^bucket_bits + 1))   uint32 index of the first entry of every hash bucket
+ * grm_exchange_layout gives the offsets and the record stride (a multiple of 16 bytes); every rank writes its record
+ * with grm_batch_export_dict_ordered, the host all-gathers n_ranks * stride bytes, and
+ * grm_batch_set_global_dict_gathered builds the global dictionary from the gathered payload (counts / bucket_bits:
+ * host arrays with n_local and grm_batch_bucket_bits of every rank).  Replaces the k-mer delivery between Ray's MPI
+ * ranks (src/app.py:1310). */
+void grm_exchange_layout(uint64_t n_max, int words, int bucket_bits, uint64_t *flags_off, uint64_t *boff_off, uint64_t *stride);
+int  grm_batch_bucket_bits(const grm_batch *);
+int  grm_batch_export_dict_ordered(grm_batch *, void *dev_record, uint64_t flags_off, uint64_t boff_off);
+int  grm_batch_set_global_dict_gathered(grm_batch *, const void *dev_payload, int n_ranks, uint64_t n_max, const uint64_t *counts,
+                                        const int *bucket_bits, int filter_singleton, uint64_t *n_kmers);
 /* Inputs larger than one device batch (thousands of genomes): two passes over chunks of genomes.
  * Pass 1, per chunk: upload, grm_batch_partition, grm_batch_local_dict, grm_dict_accum_add, free.
  * Pass 2, per chunk: upload, partition, local_dict, grm_batch_set_global_dict_accum, grm_batch_fill.

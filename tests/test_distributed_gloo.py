@@ -66,6 +66,32 @@ class OracleBatch:
         C.memmove(keys_ptr, self.lk.ctypes.data, self.lk.nbytes)
         C.memmove(flags_ptr, self.lf.ctypes.data, self.lf.nbytes)
 
+    # the exchange record (include/grm_kmer.h: grm_exchange_layout and friends); the layout arithmetic is the
+    # library's own (pure host code), the record is written into host memory
+    bucket_bits = 3
+
+    def exchange_layout(self, n_max, words, bucket_bits):
+        import grm_amd
+        f, o, s = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        grm_amd._lib.load().grm_exchange_layout(n_max, words, bucket_bits, C.byref(f), C.byref(o), C.byref(s))
+        return int(f.value), int(o.value), int(s.value)
+
+    def export_dict_ordered(self, rec_ptr, flags_off, boff_off):
+        C.memmove(rec_ptr, self.lk.ctypes.data, self.lk.nbytes)
+        C.memmove(rec_ptr + flags_off, self.lf.ctypes.data, self.lf.nbytes)
+        boff = np.full((1 << self.bucket_bits) + 1, len(self.lk), dtype=np.uint32)      # everything in bucket 0
+        boff[0] = 0
+        C.memmove(rec_ptr + boff_off, boff.ctypes.data, boff.nbytes)
+
+    def set_global_dict_gathered(self, payload_ptr, n_max, counts, bucket_bits, filter_singleton):
+        flags_off, _, stride = self.exchange_layout(n_max, self.w, max(bucket_bits))
+        raw = np.ctypeslib.as_array(C.cast(payload_ptr, C.POINTER(C.c_uint8)), shape=(stride * len(counts),))
+        keys = [raw[r * stride: r * stride + n * 8 * self.w].view(np.uint64).reshape(n, self.w) for r, n in enumerate(counts)]
+        flags = [raw[r * stride + flags_off: r * stride + flags_off + n] for r, n in enumerate(counts)]
+        k = np.ascontiguousarray(np.concatenate(keys))
+        f = np.ascontiguousarray(np.concatenate(flags))
+        return self.set_global_dict(k.ctypes.data, f.ctypes.data, len(f), filter_singleton)
+
     def set_global_dict(self, keys_ptr, flags_ptr, n, filter_singleton):
         keys = np.ctypeslib.as_array(C.cast(keys_ptr, C.POINTER(C.c_uint64)), shape=(max(n, 1) * self.w,))[:n * self.w].copy().reshape(n, self.w)
         flags = np.ctypeslib.as_array(C.cast(flags_ptr, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()

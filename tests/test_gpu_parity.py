@@ -321,18 +321,12 @@ def _nccl_worker(port, q):
                 batch.add_array(g, pg.genome(g))
             batch.upload()
             dev = torch.device("cuda", 0)
-            # force the collective code path although there is one rank: counts, padded buffers, all-gather over RCCL
+            # force the collective code path although there is one rank: sizes over the gloo twin group, the
+            # record all-gather over RCCL, the rank union on the gathered payload
             n_local = (batch.partition(31, 1), batch.local_dict())[1]
-            keys = torch.empty((max(1, n_local), 1), dtype=torch.int64, device=dev)
-            flags = torch.empty(max(1, n_local), dtype=torch.uint8, device=dev)
-            batch.export_dict(keys.data_ptr(), flags.data_ptr())
-            kall = torch.empty_like(keys)
-            fall = torch.empty_like(flags)
-            D._all_gather(kall, keys, None)
-            D._all_gather(fall, flags, None)
-            torch.cuda.current_stream(dev).synchronize()
-            assert torch.equal(kall, keys) and torch.equal(fall, flags)
-            batch.set_global_dict(kall.data_ptr(), fall.data_ptr(), n_local, True)
+            payload, n_max, counts, bbs = D.exchange_dict(batch, n_local, dev, None, 1)
+            assert counts == [n_local] and n_max == max(1, n_local) and payload.is_cuda
+            batch.set_global_dict_gathered(payload.data_ptr(), n_max, counts, bbs, True)
             m = batch.fill()
             rows = D.gather_rows(m.data(), dev)
             q.put((m.kmers().copy(), rows))
@@ -859,3 +853,64 @@ def test_counted_sets_through_both_dedup_forms(ctx, opts):
     finally:
         for name in opts:
             ctx.set_option(name, -1)
+
+
+@pytest.mark.parametrize("opts", [{}, {"no_union": 1}, {"cap_log2": 8}])
+@pytest.mark.parametrize("k", [31, 47])
+def test_gathered_exchange_in_one_process(ctx, k, opts):
+    """the exchange records of three "ranks" (three batches of one context) laid out as an all-gather would leave
+    them; every batch builds the global dictionary from the payload (rank union in LDS tables, or the sort of
+    everything with no_union / k > 32; cap_log2 8 forces the union through its sizing ladder) and fills its rows:
+    stacked, they are the oracle's matrix.  One rank uses another bucket geometry in a second round (general path)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    pg = synth.PanGenome(genome_len=150_000, n_snps=1500, n_accessory=8, accessory_len=1500, seed=77, n_contigs=2)
+    shards = [(0, 64), (64, 128), (128, 150)]
+    genomes = [pg.genome(g).tobytes() for g in range(150)]
+    words = 2 if k > 32 else 1
+    for filt in (True, False):
+        want = orc.pipeline(genomes, k, 1, filt, min(os.cpu_count() or 1, 16))[0]
+        for odd_geometry in (False, True):
+            if odd_geometry and (k > 32 or opts):
+                continue
+            batches, n_locals, bbs = [], [], []
+            try:
+                for name, v in opts.items():
+                    ctx.set_option(name, v)
+                for r, (a, b_) in enumerate(shards):
+                    if odd_geometry and r == 1:
+                        ctx.set_option("bucket_bits", 6)
+                    b = ctx.batch(b_ - a)
+                    for g in range(a, b_):
+                        b.add(g - a, genomes[g])
+                    b.upload()
+                    b.partition(k, 1)
+                    ctx.set_option("bucket_bits", -1)
+                    n_locals.append(b.local_dict())
+                    bbs.append(b.bucket_bits)
+                    batches.append(b)
+                assert (len(set(bbs)) > 1) == odd_geometry
+                n_max = max(1, max(n_locals))
+                flags_off, boff_off, stride = batches[0].exchange_layout(n_max, words, max(bbs))
+                payload = torch.empty(len(shards) * stride, dtype=torch.uint8, device=dev)
+                for r, b in enumerate(batches):
+                    b.export_dict_ordered(payload.data_ptr() + r * stride, flags_off, boff_off)
+                # the bucket offsets of a record partition its entries
+                boff = payload[boff_off: boff_off + 4 * ((1 << bbs[0]) + 1)].cpu().numpy().view(np.uint32)
+                assert boff[0] == 0 and boff[-1] == n_locals[0] and (np.diff(boff.astype(np.int64)) >= 0).all()
+                rows = []
+                for b in batches:
+                    u = b.set_global_dict_gathered(payload.data_ptr(), n_max, n_locals, bbs, filt)
+                    assert u == want["kmers"].shape[0]
+                    m = b.fill()
+                    assert (m.kmers().reshape(-1) == want["kmers"].reshape(-1)).all()
+                    rows.append(m.data())
+                    m.free()
+                got = np.concatenate(rows)
+                assert got.shape == want["matrix"].shape and (got == want["matrix"]).all()
+            finally:
+                for name in opts:
+                    ctx.set_option(name, -1)
+                ctx.set_option("bucket_bits", -1)
+                for b in batches:
+                    b.free()
