@@ -50,6 +50,9 @@ PROTOTYPES = [
     ("grm_matrix_column_counts", C.c_int, [_P, _P]),
     ("grm_matrix_sum_rows", C.c_int, [_P, _P, _P]),
     ("grm_matrix_from_host", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _PP]),
+    ("grm_matrix_to_device", C.c_int, [_P, _P]),
+    ("grm_matrix_risk_errors", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P]),
+    ("grm_matrix_risk_index", C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
     ("grm_matrix_last_error", C.c_char_p, [_P]),
     ("grm_matrix_free", None, [_P]),
     ("grm_write_tsv", C.c_int, [_P, C.POINTER(C.c_char_p), C.c_char_p]),

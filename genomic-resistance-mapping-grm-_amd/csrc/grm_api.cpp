@@ -314,7 +314,7 @@ struct grm_matrix {
     grm_ctx *ctx = nullptr;
     int k = 0, words = 1, n_genomes = 0;
     size_t n_rows = 0, n_kmers = 0;
-    DevBuf d_kmers, d_data;
+    DevBuf d_kmers, d_data, d_errors;     // d_errors: per-column error counts of the last grm_matrix_risk_errors
     raw_vector<uint64_t> h_kmers, h_data;
     bool have_kmers = false, have_data = false;
 };
@@ -460,6 +460,79 @@ extern "C" int grm_matrix_sum_rows(grm_matrix *m, const uint64_t *row_mask, uint
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, d.p, m->n_kmers * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GRM_OK;
+}
+
+// a host-only matrix (grm_matrix_from_host: rows read back from a .kover file) placed in HBM, so that the
+// learner-side kernels (sum_rows, risk tables) run on it
+extern "C" int grm_matrix_to_device(grm_ctx *c, grm_matrix *m)
+{
+    if (!c) return GRM_ERR_NO_DEVICE;
+    if (!m) return fail(c, GRM_ERR_ARG, "grm_matrix_to_device: NULL matrix");
+    if (m->ctx) return m->ctx == c ? GRM_OK : fail(c, GRM_ERR_ARG, "grm_matrix_to_device: matrix of another context");
+    if (!m->have_data || !m->have_kmers) return fail(c, GRM_ERR_STATE, "grm_matrix_to_device: no host data");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t cells = m->n_rows * m->n_kmers, kw = m->n_kmers * (size_t)m->words;
+    HIPCHK(c, m->d_data.alloc(cells * 8));
+    HIPCHK(c, m->d_kmers.alloc((kw + 2) * 8));
+    if (cells) HIPCHK(c, hipMemcpyAsync(m->d_data.p, m->h_data.data(), cells * 8, hipMemcpyHostToDevice, c->stream));
+    if (kw) HIPCHK(c, hipMemcpyAsync(m->d_kmers.p, m->h_kmers.data(), kw * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    m->ctx = c;
+    return GRM_OK;
+}
+
+// dataset/split.py:171-188, device part (see column_errors_kernel).  hist_out: n_train + 1 host counters.
+extern "C" int grm_matrix_risk_errors(grm_matrix *m, const uint64_t *pos_mask, const uint64_t *neg_mask, uint32_t n_pos, uint32_t n_train,
+                                      uint64_t *hist_out)
+{
+    if (!m || !pos_mask || !neg_mask || !hist_out) return GRM_ERR_ARG;
+    grm_ctx *c = m->ctx;
+    if (!c) return GRM_ERR_NO_DEVICE;
+    if (n_pos > n_train) return fail(c, GRM_ERR_ARG, "grm_matrix_risk_errors: n_pos > n_train");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    DevBuf dm, dh;
+    HIPCHK(c, dm.alloc((2 * m->n_rows + 2) * 8));
+    HIPCHK(c, dh.alloc(((size_t)n_train + 1) * 8));
+    HIPCHK(c, m->d_errors.ensure((m->n_kmers + 1) * 4));
+    HIPCHK(c, hipMemcpyAsync(dm.p, pos_mask, m->n_rows * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dm.as<uint64_t>() + m->n_rows, neg_mask, m->n_rows * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(dh.p, 0, ((size_t)n_train + 1) * 8, s));
+    {
+        TimeScope t(c, "risk_errors", m->n_kmers * m->n_rows);
+        launch_column_errors(s, m->d_data.as<uint64_t>(), m->n_rows, m->n_kmers, dm.as<uint64_t>(), dm.as<uint64_t>() + m->n_rows, n_pos, n_train,
+                             m->d_errors.as<uint32_t>(), dh.as<unsigned long long>());
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hist_out, dh.p, ((size_t)n_train + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return GRM_OK;
+}
+
+// by_kmer[c] = lut_presence[errors[c]], by_anti[c] = lut_absence[errors[c]] (errors of the last grm_matrix_risk_errors);
+// the two look-up tables hold n_lut = n_train + 1 entries; outputs: n_kmers host uint32 each
+extern "C" int grm_matrix_risk_index(grm_matrix *m, const uint32_t *lut_presence, const uint32_t *lut_absence, uint32_t n_lut,
+                                     uint32_t *by_kmer_out, uint32_t *by_anti_out)
+{
+    if (!m || !lut_presence || !lut_absence || !by_kmer_out || !by_anti_out) return GRM_ERR_ARG;
+    grm_ctx *c = m->ctx;
+    if (!c) return GRM_ERR_NO_DEVICE;
+    if (!m->d_errors.p) return fail(c, GRM_ERR_STATE, "grm_matrix_risk_index before grm_matrix_risk_errors");
+    if (!m->n_kmers) return GRM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    DevBuf dl, dout;
+    HIPCHK(c, dl.alloc(((size_t)2 * n_lut + 2) * 4));
+    HIPCHK(c, dout.alloc((size_t)2 * m->n_kmers * 4));
+    HIPCHK(c, hipMemcpyAsync(dl.p, lut_presence, (size_t)n_lut * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dl.as<uint32_t>() + n_lut, lut_absence, (size_t)n_lut * 4, hipMemcpyHostToDevice, s));
+    launch_risk_index(s, m->d_errors.as<uint32_t>(), m->n_kmers, dl.as<uint32_t>(), dl.as<uint32_t>() + n_lut, dout.as<uint32_t>(),
+                      dout.as<uint32_t>() + m->n_kmers);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(by_kmer_out, dout.p, m->n_kmers * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(by_anti_out, dout.as<uint32_t>() + m->n_kmers, m->n_kmers * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
     return GRM_OK;
 }
 

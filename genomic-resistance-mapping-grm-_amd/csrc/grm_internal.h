@@ -168,6 +168,10 @@ void launch_matrix_fill(hipStream_t s, const uint64_t *keys, const SegLayout &se
                         int *overflow);
 void launch_column_popcount(hipStream_t s, const uint64_t *matrix, uint64_t n_rows, uint64_t n_cols,
                             const uint64_t *row_mask, uint32_t *out);
+void launch_column_errors(hipStream_t s, const uint64_t *matrix, uint64_t n_rows, uint64_t n_cols, const uint64_t *pos_mask,
+                          const uint64_t *neg_mask, uint32_t n_pos, uint32_t n_train, uint32_t *errors, unsigned long long *hist);
+void launch_risk_index(hipStream_t s, const uint32_t *errors, uint64_t n_cols, const uint32_t *lut_presence, const uint32_t *lut_absence,
+                       uint32_t *by_kmer, uint32_t *by_anti);
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint64_t n);
 void launch_runs_mark(hipStream_t s, const uint64_t *keys, uint64_t n, uint32_t *head);
 void launch_runs_reduce(hipStream_t s, const uint64_t *keys, const uint32_t *counts, const uint32_t *head, const uint32_t *incl,

@@ -1651,6 +1651,54 @@ __global__ void column_popcount_kernel(const uint64_t *__restrict__ matrix, uint
     }
 }
 
+// `kover dataset split` risk tables (dataset/split.py:171-188), device part: ONE sweep of the matrix with the masks of
+// the positive and the negative training genomes gives every k-mer's error count as a presence rule,
+//     errors[c] = (n_pos - popcount(col & pos)) + popcount(col & neg)        (an integer in 0 .. n_train)
+// and the histogram of those counts (LDS per workgroup when n_train < 8192, flushed with one global add per
+// occupied bin).  The reference's rounding to 5 decimals and unique-indexing then act on at most n_train + 1
+// distinct values; the per-k-mer index tables come from two small look-up tables (risk_index_kernel).
+constexpr uint32_t ERR_LDS_BINS = 8192;
+__global__ __launch_bounds__(256) void column_errors_kernel(const uint64_t *__restrict__ matrix, uint64_t n_rows, uint64_t n_cols,
+                                                            const uint64_t *__restrict__ pos_mask, const uint64_t *__restrict__ neg_mask,
+                                                            uint32_t n_pos, uint32_t n_train, uint32_t *__restrict__ errors,
+                                                            unsigned long long *__restrict__ hist)
+{
+    __shared__ uint32_t lh[ERR_LDS_BINS];
+    const bool lds = n_train < ERR_LDS_BINS;
+    if (lds) {
+        for (uint32_t i = threadIdx.x; i <= n_train; i += blockDim.x) lh[i] = 0;
+        __syncthreads();
+    }
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t p = 0, q = 0;
+        for (uint64_t r = 0; r < n_rows; r++) {
+            const uint64_t w = matrix[r * n_cols + c];
+            p += __popcll(w & pos_mask[r]);
+            q += __popcll(w & neg_mask[r]);
+        }
+        const uint32_t e = n_pos - p + q;
+        errors[c] = e;
+        if (lds) atomicAdd(&lh[e], 1u);
+        else atomicAdd(&hist[e], 1ull);
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i <= n_train; i += blockDim.x) {
+            const uint32_t v = lh[i];
+            if (v) atomicAdd(&hist[i], (unsigned long long)v);
+        }
+    }
+}
+__global__ void risk_index_kernel(const uint32_t *__restrict__ errors, uint64_t n_cols, const uint32_t *__restrict__ lut_presence,
+                                  const uint32_t *__restrict__ lut_absence, uint32_t *__restrict__ by_kmer, uint32_t *__restrict__ by_anti)
+{
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t e = errors[c];
+        by_kmer[c] = lut_presence[e];
+        by_anti[c] = lut_absence[e];
+    }
+}
+
 __global__ void iota_u32_kernel(uint32_t *p, uint64_t n)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)i;
@@ -2012,6 +2060,20 @@ void launch_runs_emit(hipStream_t s, const uint64_t *keys, const unsigned long l
                       uint64_t n_runs, uint64_t *out_keys, uint32_t *out_counts)
 {
     if (n_runs) hipLaunchKernelGGL(runs_emit_kernel, dim3(grid_for(n_runs, 256)), dim3(256), 0, s, keys, sums, keep, pos, n_runs, out_keys, out_counts);
+}
+void launch_column_errors(hipStream_t s, const uint64_t *matrix, uint64_t n_rows, uint64_t n_cols, const uint64_t *pos_mask,
+                          const uint64_t *neg_mask, uint32_t n_pos, uint32_t n_train, uint32_t *errors, unsigned long long *hist)
+{
+    if (!n_cols) return;
+    hipLaunchKernelGGL(column_errors_kernel, dim3(grid_for(n_cols, 256)), dim3(256), 0, s, matrix, n_rows, n_cols, pos_mask, neg_mask, n_pos,
+                       n_train, errors, hist);
+}
+void launch_risk_index(hipStream_t s, const uint32_t *errors, uint64_t n_cols, const uint32_t *lut_presence, const uint32_t *lut_absence,
+                       uint32_t *by_kmer, uint32_t *by_anti)
+{
+    if (!n_cols) return;
+    hipLaunchKernelGGL(risk_index_kernel, dim3(grid_for(n_cols, 256)), dim3(256), 0, s, errors, n_cols, lut_presence, lut_absence, by_kmer,
+                       by_anti);
 }
 void launch_iota_u32(hipStream_t s, uint32_t *p, uint64_t n)
 {

@@ -222,6 +222,44 @@ class Matrix:
         self.ctx._chk(self.ctx.L.grm_matrix_sum_rows(self.h, mask.ctypes.data, out.ctypes.data))
         return out
 
+    def _row_mask(self, genomes):
+        mask = np.zeros(max(1, self.n_rows), dtype=np.uint64)
+        for g in genomes:
+            mask[int(g) // 64] |= np.uint64(1) << np.uint64(63 - (int(g) % 64))       # rules.py:210-222
+        return mask
+
+    def risk_tables(self, labels, train_idx):
+        """dataset/split.py:171-188 on the device-resident matrix: -> (unique_risks float64, unique_risk_by_kmer,
+        unique_risk_by_anti_kmer) exactly as the reference stores them.  The sweep of the matrix and the per-k-mer
+        indexing run on the GPU; the rounding to 5 decimals and the unique() act on the <= n_train + 1 distinct
+        error counts, with numpy, as the reference's own expressions."""
+        from .kover_dataset import minimum_uint
+        labels = np.asarray(labels)
+        train_idx = np.asarray(train_idx, dtype=np.int64)
+        pos, neg = train_idx[labels[train_idx] == 1], train_idx[labels[train_idx] == 0]
+        n_train, U = len(train_idx), self.n_kmers
+        pm, nm = self._row_mask(pos), self._row_mask(neg)
+        hist = np.zeros(n_train + 1, dtype=np.uint64)
+        self.ctx._chk(self.ctx.L.grm_matrix_risk_errors(self.h, pm.ctypes.data, nm.ctypes.data, len(pos), n_train, hist.ctypes.data))
+        present = np.nonzero(hist)[0]
+        risks = present.astype(np.float64)
+        risks /= n_train
+        np.round(risks, 5, out=risks)
+        anti = 1.0 - risks
+        np.round(anti, 5, out=anti)
+        unique = np.unique(np.hstack((risks, anti)))
+        lut_p = np.zeros(n_train + 1, dtype=np.uint32)
+        lut_a = np.zeros(n_train + 1, dtype=np.uint32)
+        lut_p[present] = np.searchsorted(unique, risks)
+        lut_a[present] = np.searchsorted(unique, anti)
+        by_kmer = np.zeros(U, dtype=np.uint32)
+        by_anti = np.zeros(U, dtype=np.uint32)
+        if U:
+            self.ctx._chk(self.ctx.L.grm_matrix_risk_index(self.h, lut_p.ctypes.data, lut_a.ctypes.data, n_train + 1,
+                                                           by_kmer.ctypes.data, by_anti.ctypes.data))
+        dt = minimum_uint(len(unique))
+        return unique, by_kmer.astype(dt), by_anti.astype(dt)
+
     def dev_ptrs(self):
         return self.ctx.L.grm_matrix_dev_kmers(self.h), self.ctx.L.grm_matrix_dev_data(self.h)
 
@@ -405,6 +443,13 @@ class HostMatrix(Matrix):
 
     def _err(self):
         return (self.ctx.L.grm_matrix_last_error(self.h) or b"").decode(errors="replace")
+
+    def to_device(self, ctx):
+        """-> the same matrix, resident in HBM of `ctx` (a full Matrix: sum_rows, risk_tables, ... work)"""
+        ctx._chk(ctx.L.grm_matrix_to_device(ctx.h, self.h))
+        m = Matrix(ctx, self.h)
+        self.h = None
+        return m
 
     def write_tsv(self, genome_ids, path):
         arr = (C.c_char_p * max(1, len(genome_ids)))(*[g.encode() for g in genome_ids])

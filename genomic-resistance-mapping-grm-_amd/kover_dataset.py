@@ -517,6 +517,19 @@ def _popcount64(v):
     return ((v * np.uint64(0x0101010101010101)) >> np.uint64(56)).astype(np.uint32)
 
 
+def device_matrix(ctx, dataset_path):
+    """the packed matrix of a .kover file placed in HBM (engine.Matrix): the learner-side kernels -- sum_rows,
+    the risk tables of `dataset split` -- then run on the device"""
+    from .engine import HostMatrix
+    r = KoverDatasetReader(dataset_path)
+    with r._open() as f:
+        data = f.read("kmer_matrix")
+        n_genomes = f.read("genome_identifiers").shape[0]
+    # the k-mer values play no part in the learner-side kernels: a zero dictionary of the right length
+    hm = HostMatrix(np.zeros(data.shape[1], dtype=np.uint64), data, n_genomes, 1)
+    return hm.to_device(ctx)
+
+
 # ---- kover dataset split (bin/kover/core/kover/dataset/split.py) -----------------------------------
 def kmer_risk_tables(sum_rows, n_kmers, labels, train_idx):
     """split.py:171-188: individual risk of the presence rule of every k-mer on the training set,
@@ -537,7 +550,8 @@ def kmer_risk_tables(sum_rows, n_kmers, labels, train_idx):
     return unique, inverse[:n_kmers].astype(dt), inverse[n_kmers:].astype(dt)
 
 
-def split(dataset_path, split_name, train_idx, test_idx, random_seed, n_folds=0, random_generator=None, sum_rows=None):
+def split(dataset_path, split_name, train_idx, test_idx, random_seed, n_folds=0, random_generator=None, sum_rows=None,
+          risk_tables=None):
     """split.py:110-230 (_split): writes splits/<name>/{train,test}_genome_idx, the risk tables and the
     cross-validation folds into the dataset file."""
     r = KoverDatasetReader(dataset_path)
@@ -568,7 +582,8 @@ def split(dataset_path, split_name, train_idx, test_idx, random_seed, n_folds=0,
     def write_part(f, group, tr, te):
         f.create_dataset(group + "/train_genome_idx", np.sort(tr).astype(idx_dt))
         f.create_dataset(group + "/test_genome_idx", np.sort(te).astype(idx_dt))
-        unique, by_kmer, by_anti = kmer_risk_tables(sum_rows, n_kmers, labels, tr)
+        # risk_tables(labels, train_idx): the device form (engine.Matrix.risk_tables); else the numpy restatement
+        unique, by_kmer, by_anti = risk_tables(labels, tr) if risk_tables else kmer_risk_tables(sum_rows, n_kmers, labels, tr)
         f.create_dataset(group + "/unique_risks", unique)
         f.create_dataset(group + "/unique_risk_by_kmer", by_kmer)
         f.create_dataset(group + "/unique_risk_by_anti_kmer", by_anti)
@@ -593,7 +608,7 @@ def split(dataset_path, split_name, train_idx, test_idx, random_seed, n_folds=0,
                 write_part(f, fg, train_idx[fold_of != fold], train_idx[fold_of == fold])
 
 
-def split_with_proportion(dataset_path, split_name, train_prop, random_seed, n_folds=0, sum_rows=None):
+def split_with_proportion(dataset_path, split_name, train_prop, random_seed, n_folds=0, sum_rows=None, risk_tables=None):
     """split.py:86-107: the same RandomState stream as the reference (shuffle of arange, then the folds)"""
     rng = np.random.RandomState(random_seed)
     with h5lite.File(dataset_path, "r") as f:
@@ -601,10 +616,10 @@ def split_with_proportion(dataset_path, split_name, train_prop, random_seed, n_f
     n_train = int(np.ceil(train_prop * n))
     idx = np.arange(n)
     rng.shuffle(idx)
-    split(dataset_path, split_name, idx[:n_train], idx[n_train:], random_seed, n_folds, rng, sum_rows)
+    split(dataset_path, split_name, idx[:n_train], idx[n_train:], random_seed, n_folds, rng, sum_rows, risk_tables)
 
 
-def split_with_ids(dataset_path, split_name, train_ids_file, test_ids_file, random_seed, n_folds=0, sum_rows=None):
+def split_with_ids(dataset_path, split_name, train_ids_file, test_ids_file, random_seed, n_folds=0, sum_rows=None, risk_tables=None):
     """split.py:31-83"""
     rng = np.random.RandomState(random_seed)
     ids = KoverDatasetReader(dataset_path).genome_identifiers
@@ -617,4 +632,5 @@ def split_with_ids(dataset_path, split_name, train_ids_file, test_ids_file, rand
             raise KoverError("The %s genome identifiers contain IDs that are not in the dataset: %s" % (step, ", ".join(missing)))
         return [index[g] for g in got]
 
-    split(dataset_path, split_name, parse(train_ids_file, "training"), parse(test_ids_file, "testing"), random_seed, n_folds, rng, sum_rows)
+    split(dataset_path, split_name, parse(train_ids_file, "training"), parse(test_ids_file, "testing"), random_seed, n_folds, rng, sum_rows,
+          risk_tables)

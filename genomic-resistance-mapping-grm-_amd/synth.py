@@ -78,6 +78,30 @@ def random_genome(idx, genome_len=5_000_000, seed=1234, n_contigs=1):
     return np.concatenate([_fasta_record("r%05d_c%d" % (idx, c), seq[bounds[c]:bounds[c + 1]]) for c in range(max(1, n_contigs))])
 
 
+class EcoliLike:
+    """BASELINE C1: a handful of contig sets derived from one 4.6 Mbp random ancestor -- per genome 0.5 % private
+    SNPs, 20-100 contigs of uneven length, a few runs of N inside contigs, 80-column FASTA (seeds 1234 + i)"""
+
+    def __init__(self, genome_len=4_600_000, snp_rate=0.005, seed=1234, n_runs=4):
+        self.seed, self.genome_len, self.snp_rate, self.n_runs = seed, genome_len, snp_rate, n_runs
+        self.ancestor = _ACGT[np.random.default_rng(seed).integers(0, 4, size=genome_len, dtype=np.uint8)]
+
+    def genome(self, idx):
+        rng = np.random.default_rng(self.seed + 1 + idx)
+        seq = self.ancestor.copy()
+        n_snps = int(self.genome_len * self.snp_rate)
+        pos = rng.choice(self.genome_len, size=n_snps, replace=False)
+        code = np.searchsorted(_ACGT, seq[pos])
+        seq[pos] = _ACGT[(code + rng.integers(1, 4, size=n_snps)) % 4]
+        for _ in range(self.n_runs):                                   # runs of N (bad bases: k-mers over them are skipped)
+            a = int(rng.integers(0, self.genome_len - 300))
+            seq[a:a + int(rng.integers(1, 200))] = ord("N")
+        n_contigs = int(rng.integers(20, 101))
+        cuts = np.sort(rng.choice(np.arange(1, self.genome_len), size=n_contigs - 1, replace=False))
+        bounds = np.concatenate(([0], cuts, [self.genome_len]))
+        return np.concatenate([_fasta_record("e%03d_contig%d" % (idx, c), seq[bounds[c]:bounds[c + 1]]) for c in range(n_contigs)])
+
+
 def make_genomes(n, mode="P", genome_len=5_000_000, seed=1234, **kw):
     """-> list of uint8 arrays (one FASTA image per genome)"""
     if mode == "P":

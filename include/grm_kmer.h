@@ -115,6 +115,18 @@ int             grm_matrix_sum_rows(grm_matrix *, const uint64_t *row_mask, uint
  * k <= 32, 2*n_kmers (most significant word first) for 33 <= k <= 64. */
 int             grm_matrix_from_host(const uint64_t *kmers, const uint64_t *data, size_t n_kmers, int n_genomes, int k,
                                      grm_matrix **out);
+/* places a host-only matrix (grm_matrix_from_host, e.g. rows read back from a .kover file) in HBM: afterwards the
+ * device entry points (column_counts, sum_rows, risk_errors) work on it */
+int             grm_matrix_to_device(grm_ctx *, grm_matrix *);
+/* `kover dataset split` risk tables (dataset/split.py:171-188), device part: one sweep of the matrix with the row masks
+ * of the positive / negative training genomes: errors[c] = (n_pos - popcount(col & pos)) + popcount(col & neg), kept in
+ * HBM, and hist_out[e] = number of k-mers with e errors (n_train + 1 host counters).  The caller rounds and
+ * unique-indexes the at most n_train + 1 distinct risks as the reference does and hands two look-up tables back:
+ * by_kmer[c] = lut_presence[errors[c]], by_anti[c] = lut_absence[errors[c]] (n_kmers host uint32 each). */
+int             grm_matrix_risk_errors(grm_matrix *, const uint64_t *pos_mask, const uint64_t *neg_mask, uint32_t n_pos, uint32_t n_train,
+                                       uint64_t *hist_out);
+int             grm_matrix_risk_index(grm_matrix *, const uint32_t *lut_presence, const uint32_t *lut_absence, uint32_t n_lut,
+                                      uint32_t *by_kmer_out, uint32_t *by_anti_out);
 const char     *grm_matrix_last_error(const grm_matrix *);
 void            grm_matrix_free(grm_matrix *);
 

@@ -14,6 +14,13 @@ Outputs
                          the canonical form under GATB's A<C<T<G order.
   pack_vectors.json      _pack_binary_bytes_to_ints / _unpack_... / _minimum_uint_size
                          input/output pairs (utils.py:117-187).
+  popcount_vectors.json  masked popcount + row masks of the learner side: the reference's only native file,
+                         learning/common/popcount.pyx, is compiled with this container's Cython into a
+                         temporary directory (nothing of it enters the repo) and inplace_popcount_64 is run
+                         on seeded blocks; build_row_mask (a nested function of
+                         KmerRuleClassifications.sum_rows, learning/common/rules.py:210-222) is AST-extracted
+                         and executed with Python-2 integer division; the column sums are what
+                         rules.py:243-262 accumulates.  Inputs + outputs only.
 """
 import ast, glob, json, os, re, sys
 import numpy as np
@@ -81,6 +88,89 @@ def pack_vectors():
     return len(cases)
 
 
+def load_build_row_mask():
+    """build_row_mask is defined inside sum_rows (rules.py:210-222).  The reference is Python 2: `/` between
+    two ints is floor division there (true division as soon as one side is a float), so every `a / b` of the
+    extracted function is evaluated by a helper with exactly that rule."""
+    src = open(os.path.join(REF, "bin/kover/core/kover/learning/common/rules.py")).read()
+    tree = ast.parse(src)
+    fn = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == "build_row_mask":
+            fn = node
+    assert fn is not None
+
+    class Py2Div(ast.NodeTransformer):
+        def visit_BinOp(self, node):
+            self.generic_visit(node)
+            if isinstance(node.op, ast.Div):
+                return ast.Call(func=ast.Name(id="_py2div", ctx=ast.Load()), args=[node.left, node.right], keywords=[])
+            return node
+
+    def _py2div(a, b):
+        ints = (int, np.integer)
+        return a // b if isinstance(a, ints) and isinstance(b, ints) else a / b
+    fn = Py2Div().visit(fn)
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    from math import ceil
+    ns = {"np": np, "ceil": ceil, "xrange": range, "_py2div": _py2div}
+    exec(compile(mod, "<reference rules.py build_row_mask (in-memory)>", "exec"), ns)
+    return ns["build_row_mask"]
+
+
+def load_reference_popcount():
+    """compile learning/common/popcount.pyx (Cython -> C -> shared object) in a temporary directory and import it"""
+    import importlib.util, shutil, subprocess, sysconfig, tempfile
+    d = tempfile.mkdtemp(prefix="ref_popcount_")
+    pyx = os.path.join(d, "popcount.pyx")
+    shutil.copy(os.path.join(REF, "bin/kover/core/kover/learning/common/popcount.pyx"), pyx)
+    subprocess.check_call([sys.executable, "-m", "cython", "-3", "-o", os.path.join(d, "popcount.c"), pyx])
+    so = os.path.join(d, "popcount" + sysconfig.get_config_var("EXT_SUFFIX"))
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], "-I" + np.get_include(),
+                           "-DNPY_NO_DEPRECATED_API=0", os.path.join(d, "popcount.c"), "-o", so])
+    spec = importlib.util.spec_from_file_location("popcount", so)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, d
+
+
+def popcount_vectors():
+    import shutil
+    build_row_mask = load_build_row_mask()
+    pop, tmp = load_reference_popcount()
+    try:
+        rng = np.random.RandomState(20261004)
+        cases = []
+        for (n_genomes, n_cols, n_sel) in [(1, 4, 1), (64, 5, 20), (65, 5, 33), (130, 9, 57), (200, 6, 200), (1000, 3, 400)]:
+            n_rows = (n_genomes + 63) // 64
+            sel = sorted(rng.choice(n_genomes, size=n_sel, replace=False).tolist())
+            mask = build_row_mask(sel, n_genomes, 64)
+            assert mask.dtype == np.uint64 and mask.shape == (n_rows,)
+            block = rng.randint(0, 2**63, size=(n_rows, n_cols), dtype=np.int64).astype(np.uint64) * np.uint64(2) + \
+                rng.randint(0, 2, size=(n_rows, n_cols)).astype(np.uint64)
+            block[0, 0] = 0                                       # the `!= 0` shortcut of the reference loop
+            # bits beyond the last genome are never set in a real dataset (padding of the last word-row)
+            pad = n_rows * 64 - n_genomes
+            if pad:
+                block[-1] &= ~np.uint64((1 << pad) - 1)
+            work = block.copy()
+            pop.inplace_popcount_64(work, mask)                   # popcount.pyx:76-95
+            sums = work.sum(axis=0)                               # rules.py:262
+            cases.append({"n_genomes": n_genomes, "selected": sel,
+                          "row_mask": [str(int(x)) for x in mask],
+                          "block": [[str(int(x)) for x in row] for row in block],
+                          "popcounts": [[int(x) for x in row] for row in work],
+                          "column_sums": [int(x) for x in sums]})
+        json.dump({"source": "learning/common/popcount.pyx:76-95 compiled with Cython %s and executed; build_row_mask of "
+                             "learning/common/rules.py:210-222 executed with Python-2 division" % __import__("Cython").__version__,
+                   "cases": cases}, open(os.path.join(HERE, "popcount_vectors.json"), "w"), indent=0)
+        return len(cases)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
     print("kmers:", harvest_kmers())
     print("pack cases:", pack_vectors())
+    print("popcount cases:", popcount_vectors())

@@ -231,3 +231,61 @@ def test_kover_create_from_reads_chunked(tmp_path):
     assert r.kmer_sequences == orc.decode_kmers(want["kmers"], 21)
     assert (r.kmer_matrix == want["matrix"]).all()
     assert r.attr("genome_source_type") == "reads" and r.attr("filter") == "nothing"
+
+
+def test_kover_split_on_the_device(tmp_path):
+    """`kover dataset split` with the per-k-mer risk tables from the device sweep (dataset/split.py:171-188): the same
+    groups, indices and tables as the numpy restatement of the reference run on a copy of the file with the same seed;
+    Matrix.risk_tables vs a dense recomputation; sum_rows vs numpy on 130 genomes (3 word-rows, last one ragged)."""
+    import shutil
+    import grm_amd
+    kd = import_module(PKG + ".kover_dataset")
+    h5 = import_module(PKG + ".h5lite")
+    synth = import_module(PKG + ".synth")
+    n, k = 130, 31
+    pg = synth.PanGenome(genome_len=40_000, n_snps=800, n_accessory=10, accessory_len=1500, seed=5, n_contigs=2)
+    d = str(tmp_path)
+    paths = []
+    for g in range(n):
+        p = os.path.join(d, "g%03d.fna" % g)
+        pg.genome(g).tofile(p)
+        paths.append(p)
+    data = os.path.join(d, "paths.tsv")
+    open(data, "w").writelines("g%03d\t%s\n" % (g, p) for g, p in enumerate(paths))
+    md = os.path.join(d, "md.tsv")
+    rng = np.random.RandomState(3)
+    lab = rng.randint(0, 2, size=n)
+    open(md, "w").writelines("g%03d\t%d\n" % (g, lab[g]) for g in range(n))
+    out = os.path.join(d, "D.kover")
+    _run([os.path.join(CLI, "kover"), "dataset", "create", "from-contigs", "--genomic-data", data, "--phenotype-description", "p",
+          "--phenotype-metadata", md, "--output", out, "--kmer-size", str(k), "--compression", "4", "-x"])
+    ref = os.path.join(d, "REF.kover")
+    shutil.copy(out, ref)
+    _run([os.path.join(CLI, "kover"), "dataset", "split", "--dataset", out, "--id", "s", "--train-size", "0.7", "--folds", "3",
+          "--random-seed", "11"])
+    kd.split_with_proportion(ref, "s", 0.7, 11, n_folds=3)            # numpy restatement of rules.py / split.py
+    with h5.File(out) as f, h5.File(ref) as r:
+        groups = ["splits/s"] + ["splits/s/folds/fold_%d" % i for i in (1, 2, 3)]
+        assert sorted(f.list_group("splits/s/folds")) == ["fold_1", "fold_2", "fold_3"]
+        for g in groups:
+            for name in ("train_genome_idx", "test_genome_idx", "unique_risks", "unique_risk_by_kmer", "unique_risk_by_anti_kmer"):
+                a, b = f.read(g + "/" + name), r.read(g + "/" + name)
+                assert a.dtype == b.dtype and a.shape == b.shape and (a == b).all(), (g, name)
+        labels = f.read("phenotype")
+        train = f.read("splits/s/train_genome_idx").astype(np.int64)
+    # the library calls directly, against a dense recomputation
+    with grm_amd.Context(0) as ctx:
+        m = kd.device_matrix(ctx, out)
+        packed = kd.KoverDatasetReader(out).kmer_matrix
+        U = packed.shape[1]
+        dense = np.zeros((n, U), dtype=np.int64)
+        for g in range(n):
+            dense[g] = (packed[g // 64] >> np.uint64(63 - g % 64)) & np.uint64(1)
+        pos, neg = train[labels[train] == 1], train[labels[train] == 0]
+        risk = np.round(((len(pos) - dense[pos].sum(axis=0)) + dense[neg].sum(axis=0)) / len(train), 5)
+        uniq, by_kmer, by_anti = m.risk_tables(labels, train)
+        assert (np.diff(uniq) > 0).all() and (uniq[by_kmer] == risk).all() and (uniq[by_anti] == np.round(1.0 - risk, 5)).all()
+        some = sorted(rng.choice(n, size=57, replace=False).tolist())
+        assert (m.sum_rows(some) == dense[some].sum(axis=0)).all()
+        assert (m.column_counts() == dense.sum(axis=0)).all()
+        m.free()

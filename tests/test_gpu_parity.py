@@ -914,3 +914,18 @@ def test_gathered_exchange_in_one_process(ctx, k, opts):
                 ctx.set_option("bucket_bits", -1)
                 for b in batches:
                     b.free()
+
+
+def test_sum_rows_against_reference_popcount_vectors(ctx, golden_dir):
+    """grm_matrix_sum_rows on the device vs vectors produced by the reference's compiled popcount.pyx and its
+    build_row_mask (tests/golden/make_golden.py): learning/common/rules.py:201-267"""
+    import json
+    d = json.load(open(os.path.join(golden_dir, "popcount_vectors.json")))
+    for c in d["cases"]:
+        block = np.array([[int(x) for x in row] for row in c["block"]], dtype=np.uint64)
+        hm = grm.HostMatrix(np.zeros(block.shape[1], dtype=np.uint64), block, c["n_genomes"], 31)
+        m = hm.to_device(ctx)
+        assert (m.sum_rows(c["selected"]) == np.array(c["column_sums"], dtype=np.uint32)).all()
+        # all-ones mask = carrier counts
+        assert (m.column_counts() == grm.engine.np.array([sum(bin(int(x)).count("1") for x in block[:, j]) for j in range(block.shape[1])])).all()
+        m.free()

@@ -73,3 +73,33 @@ def test_matrix_bits_follow_pack_layout():
             dense[g, index[int(v)]] = 1
     assert (orc.pack_bits(dense, 64) == m["matrix"]).all()
     assert (dense.sum(axis=0) == m["n_genomes_with"]).all()
+
+
+def _popcount_cases(golden_dir):
+    d = json.load(open(os.path.join(golden_dir, "popcount_vectors.json")))
+    for c in d["cases"]:
+        yield (c["n_genomes"], c["selected"], np.array([int(x) for x in c["row_mask"]], dtype=np.uint64),
+               np.array([[int(x) for x in row] for row in c["block"]], dtype=np.uint64),
+               np.array(c["popcounts"], dtype=np.uint64), np.array(c["column_sums"], dtype=np.uint64))
+
+
+def test_row_masks_and_masked_popcount_match_the_reference(golden_dir):
+    """vectors from the reference's own popcount.pyx (compiled) and build_row_mask (rules.py:210-222): the row-mask
+    convention (genome i -> word i//64, bit 63 - i%64) and sum_rows = column sums of popcount(word & mask), as restated
+    by the host-side reader (kover_dataset.KoverDatasetReader.sum_rows) and by the engine's own mask builder"""
+    from importlib import import_module
+    import grm_amd  # noqa: F401
+    kd = import_module("genomic-resistance-mapping-grm-_amd.kover_dataset")
+    eng = import_module("genomic-resistance-mapping-grm-_amd.engine")
+    n_cases = 0
+    for n_genomes, sel, mask, block, pops, sums in _popcount_cases(golden_dir):
+        n_cases += 1
+
+        class R(kd.KoverDatasetReader):
+            kmer_matrix = block
+        assert (R("unused").sum_rows(sel) == sums).all()
+        assert (kd._popcount64(block & mask[:, None]) == pops).all()
+        m = eng.HostMatrix(np.zeros(block.shape[1], dtype=np.uint64), block, n_genomes, 31)
+        assert (eng.Matrix._row_mask(m, sel) == mask).all()
+        m.free()
+    assert n_cases == 6
