@@ -55,7 +55,7 @@ def write_kset(path, k, abundance_min, kmers, counts, n_occ):
     to Kover, so the container is our own: magic, header, uint64 k-mers (two words each, most
     significant first, when k > 32), uint32 counts."""
     tmp = path + ".tmp"
-    words = 2 if k > 32 else 1
+    words = (k + 31) // 32
     kmers = np.ascontiguousarray(kmers, dtype="<u8").reshape(-1)
     if len(kmers) != words * len(counts):
         raise ValueError("k-mer array does not match k=%d (%d words per k-mer)" % (k, words))
@@ -72,7 +72,7 @@ def read_kset(path):
         if f.read(8) != MAGIC:
             raise ValueError("%s is not a k-mer set written by this multidsk" % path)
         k, amin, n, n_occ = struct.unpack("<IIQQ", f.read(24))
-        words = 2 if k > 32 else 1
+        words = (k + 31) // 32
         kmers = np.frombuffer(f.read(8 * n * words), dtype="<u8")
         counts = np.frombuffer(f.read(4 * n), dtype="<u4")
     if len(kmers) != n * words or len(counts) != n:
@@ -95,7 +95,7 @@ def write_matrix_artifact(path, k, abundance_min, kmers, data, counts, n_genomes
     kmers = np.ascontiguousarray(kmers, dtype="<u8")
     data = np.ascontiguousarray(data, dtype="<u8")
     counts = np.ascontiguousarray(counts, dtype="<u4")
-    words = 2 if k > 32 else 1
+    words = (k + 31) // 32
     U = len(counts)
     assert kmers.size == U * words and data.shape == ((n_genomes + 63) // 64, U)
     tmp = path + ".tmp"
@@ -113,7 +113,7 @@ def read_matrix_artifact(path):
         if f.read(8) != MATRIX_MAGIC:
             raise ValueError("%s is not a matrix written by this multidsk" % path)
         k, amin, n_genomes, U = struct.unpack("<IIQQ", f.read(24))
-        words = 2 if k > 32 else 1
+        words = (k + 31) // 32
         rows = (n_genomes + 63) // 64
         kmers = np.fromfile(f, dtype="<u8", count=U * words)
         counts = np.fromfile(f, dtype="<u4", count=U)

@@ -63,6 +63,9 @@ struct grm_ctx {
     int opt_no_union = -1;       // > 0: gathered rank dictionaries are sorted as a whole (tests)
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
+// 64-bit words of a k-mer, most significant first: 1 (k <= 32), 2 (<= 64), 3 (<= 96), 4 (<= 128)
+static inline int words_of(int k) { return (k + 31) / 32; }
+constexpr int GRM_MAX_K = 128;
 
 static int fail(grm_ctx *c, int code, const char *fmt, ...)
 {
@@ -349,12 +352,12 @@ extern "C" int grm_kmer_set_from_host(grm_ctx *c, const uint64_t *kmers, const u
                                       grm_kmer_set **out)
 {
     if (!c || !out || (n && !kmers)) return fail(c, GRM_ERR_ARG, "grm_kmer_set_from_host: bad argument");
-    if (k < 1 || k > 64) return fail(c, GRM_ERR_ARG, "k=%d unsupported (1..64)", k);
+    if (k < 1 || k > GRM_MAX_K) return fail(c, GRM_ERR_ARG, "k=%d unsupported (1..128)", k);
     grm_kmer_set *s = new grm_kmer_set();
     s->k = k;
     s->ctx = c;
     s->n = n;
-    s->words = k > 32 ? 2 : 1;                     // two words per k-mer, most significant first
+    s->words = words_of(k);                        // ceil(k / 32) words per k-mer, most significant first
     s->kmers.assign(kmers, kmers + n * (size_t)s->words);
     if (counts) s->counts.assign(counts, counts + n);
     else s->counts.assign(n, 1u);
@@ -548,10 +551,10 @@ extern "C" void grm_matrix_free(grm_matrix *m)
 extern "C" int grm_matrix_from_host(const uint64_t *kmers, const uint64_t *data, size_t n_kmers, int n_genomes, int k,
                                     grm_matrix **out)
 {
-    if (!out || n_genomes < 0 || k < 1 || k > 64 || (n_kmers && (!kmers || (n_genomes && !data)))) return GRM_ERR_ARG;
+    if (!out || n_genomes < 0 || k < 1 || k > GRM_MAX_K || (n_kmers && (!kmers || (n_genomes && !data)))) return GRM_ERR_ARG;
     grm_matrix *m = new grm_matrix();
     m->k = k;
-    m->words = k > 32 ? 2 : 1;                      // kmers: n_kmers * words, most significant word first
+    m->words = words_of(k);                         // kmers: n_kmers * words, most significant word first
     m->n_genomes = n_genomes;
     m->n_rows = ((size_t)n_genomes + 63) / 64;
     m->n_kmers = n_kmers;
@@ -626,6 +629,8 @@ static bool inflate_gzip(const uint8_t *src, size_t len, std::vector<uint8_t> &o
 
 struct WideSorted;
 static void wide_free(WideSorted *w);
+struct MultiSorted;
+static void multi_free(MultiSorted *w);
 struct WideHash;
 static void wide_hash_free(WideHash *w);
 // staged (multi-GPU) entry points of the two-word hash pipeline, defined next to it
@@ -639,8 +644,9 @@ static int wide_stage_fill(grm_batch *b, grm_matrix **out);
 struct grm_batch {
     grm_ctx *ctx = nullptr;
     WideSorted *wide = nullptr;      // two-word (k > 32) sort path buffers, created on first use
+    MultiSorted *multi = nullptr;    // three- / four-word (k > 64) sort path buffers
     WideHash *whash = nullptr;       // two-word hash-partition path buffers
-    ~grm_batch() { wide_free(wide); wide_hash_free(whash); }
+    ~grm_batch() { wide_free(wide); multi_free(multi); wide_hash_free(whash); }
     int n_genomes = 0;
     std::vector<HostFile> files;
     bool uploaded = false, partitioned = false, have_local = false, have_global = false;
@@ -968,7 +974,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
 {
     grm_ctx *c = b->ctx;
     if (!b->uploaded) return fail(c, GRM_ERR_STATE, "grm_batch_partition before grm_batch_upload");
-    if (k < 1 || k > 64) return fail(c, GRM_ERR_ARG, "k=%d out of range", k);
+    if (k < 1 || k > GRM_MAX_K) return fail(c, GRM_ERR_ARG, "k=%d out of range (1..128)", k);
     if (abundance_min < 1) abundance_min = 1;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -1214,6 +1220,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
 extern "C" int grm_batch_partition(grm_batch *b, int k, uint32_t abundance_min)
 {
     if (!b) return GRM_ERR_ARG;
+    if (k > 64) return fail(b->ctx, GRM_ERR_UNSUPPORTED, "k=%d: the staged (multi-GPU / chunked) API handles k <= 64; use grm_batch_run or counted sets", k);
     if (k > 32 && k <= 64) {
         // two-word k-mers: the hash-partition pipeline, which also leaves the local dictionary behind
         if (abundance_min > 1) return fail(b->ctx, GRM_ERR_UNSUPPORTED, "k=%d: the staged (multi-GPU) API takes abundance-min 1 for k > 32", k);
@@ -1227,7 +1234,7 @@ extern "C" int grm_batch_partition(grm_batch *b, int k, uint32_t abundance_min)
 extern "C" int grm_batch_partition_counts(grm_batch *b, int k, uint32_t abundance_min)
 {
     if (!b) return GRM_ERR_ARG;
-    if (k > 32 && k <= 64) return fail(b->ctx, GRM_ERR_UNSUPPORTED, "k=%d: counted batches handle k <= 32; use grm_count_genome per genome", k);
+    if (k > 32) return fail(b->ctx, GRM_ERR_UNSUPPORTED, "k=%d: counted batches handle k <= 32; use grm_count_genome per genome", k);
     return batch_partition_impl(b, k, abundance_min, true);
 }
 
@@ -1984,6 +1991,233 @@ static int wide_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, WideS
 
 static void wide_free(WideSorted *w) { delete w; }
 
+// ---- three- and four-word k-mers (65..128): sort-based path, grm_multi.hip --------------------------
+// K[w]: the extracted words by symbol position, S[w]: the same in sorted order (W words each, word 0 most
+// significant); pos = position of every sorted entry.  Stable LSD radix sort, one pass per word.
+struct MultiSorted {
+    DevBuf K[4], S[4], I[2], tk;
+    DevBuf key_head, kg_head, sub_id, sub_start, sub_key_head, sub_ok, key_incl, carriers, keep, col, opos, tmp, n_valid;
+    uint32_t n = 0, n_sub = 0;
+    int words = 0;
+    MultiWords sorted() const
+    {
+        MultiWords m;
+        for (int j = 0; j < 4; j++) m.w[j] = S[j].as<uint64_t>();
+        return m;
+    }
+    uint32_t *pos() const { return I[0].as<uint32_t>(); }
+};
+static void multi_free(MultiSorted *w) { delete w; }
+
+// parse must have run (batch_partition_impl with k > 64), or K[] is preloaded with total_syms valid keys
+static int multi_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, MultiSorted &M, bool preloaded = false)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    const int W = words_of(k);
+    const uint64_t N = b->total_syms;
+    if (N >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "k > 64 path is limited to 2^32-1 symbols per batch (got %llu)", (unsigned long long)N);
+    M.n = M.n_sub = 0;
+    M.words = W;
+    b->total_keys = 0;
+    if (N == 0) return GRM_OK;
+    for (int j = 0; j < W; j++) { HIPCHK(c, M.K[j].ensure((N + 2) * 8)); HIPCHK(c, M.S[j].ensure((N + 2) * 8)); }
+    for (int i = 0; i < 2; i++) HIPCHK(c, M.I[i].ensure((N + 2) * 4));
+    HIPCHK(c, M.tk.ensure((N + 2) * 8));
+    HIPCHK(c, M.n_valid.ensure(8));
+    HIPCHK(c, hipMemsetAsync(M.n_valid.p, 0, 8, s));
+    unsigned long long nv = N;
+    if (!preloaded) {
+        MultiWordsOut out;
+        for (int j = 0; j < 4; j++) out.w[j] = M.K[j].as<uint64_t>();
+        {
+            TimeScope t(c, "multi_extract", N);
+            launch_multi_extract(s, W, b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>(), N, k, out, M.n_valid.as<unsigned long long>());
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&nv, M.n_valid.p, 8, hipMemcpyDeviceToHost, s));
+    }
+    {
+        TimeScope t(c, "multi_sort", N);
+        uint32_t *ia = M.I[0].as<uint32_t>(), *ib = M.I[1].as<uint32_t>();
+        launch_iota_u32(s, ia, N);
+        for (int j = W - 1; j >= 0; j--) {                       // least significant word first
+            const uint64_t *src = M.K[j].as<uint64_t>();
+            if (j != W - 1) {                                      // word j in the order reached so far
+                launch_gather_u64(s, M.K[j].as<uint64_t>(), ia, N, M.tk.as<uint64_t>());
+                src = M.tk.as<uint64_t>();
+            }
+            size_t tb = 0;
+            HIPCHK(c, sort_pairs_u64_u32(s, src, M.S[0].as<uint64_t>(), ia, ib, N, nullptr, tb));
+            HIPCHK(c, M.tmp.ensure(tb));
+            HIPCHK(c, sort_pairs_u64_u32(s, src, M.S[0].as<uint64_t>(), ia, ib, N, M.tmp.p, tb));
+            std::swap(ia, ib);
+        }
+        // ia = final order; S[0] already holds word 0 sorted; the other words follow the order
+        if (ia != M.I[0].as<uint32_t>()) HIPCHK(c, hipMemcpyAsync(M.I[0].p, ia, N * 4, hipMemcpyDeviceToDevice, s));
+        for (int j = 1; j < W; j++) launch_gather_u64(s, M.K[j].as<uint64_t>(), M.I[0].as<uint32_t>(), N, M.S[j].as<uint64_t>());
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    b->total_keys = nv;
+    M.n = (uint32_t)nv;
+    const uint32_t n = M.n;
+    if (n == 0) return GRM_OK;
+    TimeScope t(c, "multi_mark", n);
+    HIPCHK(c, M.key_head.ensure((size_t)n * 4)); HIPCHK(c, M.kg_head.ensure((size_t)n * 4)); HIPCHK(c, M.sub_id.ensure((size_t)n * 4));
+    launch_multi_mark(s, W, M.sorted(), M.pos(), b->d_genome_sym_off.as<uint64_t>(), (uint32_t)b->n_genomes, n, M.key_head.as<uint32_t>(),
+                      M.kg_head.as<uint32_t>());
+    int rc = wide_scan(c, M.tmp, false, M.kg_head.as<uint32_t>(), M.sub_id.as<uint32_t>(), n);
+    if (rc) return rc;
+    uint32_t last_id = 0, last_flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&last_id, M.sub_id.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&last_flag, M.kg_head.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    M.n_sub = last_id + last_flag;
+    HIPCHK(c, M.sub_start.ensure(((size_t)M.n_sub + 1) * 4));
+    HIPCHK(c, M.sub_key_head.ensure((size_t)M.n_sub * 4 + 4));
+    HIPCHK(c, M.sub_ok.ensure((size_t)M.n_sub * 4 + 4));
+    launch_wide_sub_start(s, M.kg_head.as<uint32_t>(), M.sub_id.as<uint32_t>(), n, M.n_sub, M.sub_start.as<uint32_t>());
+    launch_wide_sub(s, M.sub_start.as<uint32_t>(), M.key_head.as<uint32_t>(), M.n_sub, abundance_min, M.sub_key_head.as<uint32_t>(),
+                    M.sub_ok.as<uint32_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    return GRM_OK;
+}
+
+static int multi_matrix(grm_batch *b, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out, bool preloaded = false)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    if (!b->multi) b->multi = new MultiSorted();
+    MultiSorted &M = *b->multi;
+    int rc = multi_sort_and_mark(b, k, abundance_min, M, preloaded);
+    if (rc) return rc;
+    const int W = words_of(k);
+    grm_matrix *m = new grm_matrix();
+    m->ctx = c; m->k = k; m->words = W; m->n_genomes = b->n_genomes;
+    m->n_rows = ((size_t)b->n_genomes + 63) / 64;
+    auto bail = [&](int code) { delete m; return code; };
+    uint32_t U = 0;
+    if (M.n_sub) {
+        TimeScope t(c, "multi_reduce", M.n_sub);
+        if (M.key_incl.ensure((size_t)M.n_sub * 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
+        rc = wide_scan(c, M.tmp, true, M.sub_key_head.as<uint32_t>(), M.key_incl.as<uint32_t>(), M.n_sub);
+        if (rc) return bail(rc);
+        uint32_t n_keys = 0;
+        if (hipMemcpyAsync(&n_keys, M.key_incl.as<uint32_t>() + (M.n_sub - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "D2H"));
+        if (M.carriers.ensure((size_t)n_keys * 4 + 4) != hipSuccess || M.keep.ensure((size_t)n_keys * 4 + 4) != hipSuccess ||
+            M.col.ensure((size_t)n_keys * 4 + 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
+        (void)hipMemsetAsync(M.carriers.p, 0, (size_t)n_keys * 4 + 4, s);
+        launch_wide_key_count(s, M.key_incl.as<uint32_t>(), M.sub_ok.as<uint32_t>(), M.n_sub, M.carriers.as<uint32_t>());
+        launch_wide_keep(s, M.carriers.as<uint32_t>(), n_keys, filter_singleton ? 2u : 1u, M.keep.as<uint32_t>());
+        rc = wide_scan(c, M.tmp, false, M.keep.as<uint32_t>(), M.col.as<uint32_t>(), n_keys);
+        if (rc) return bail(rc);
+        uint32_t last_col = 0, last_keep = 0;
+        if (hipMemcpyAsync(&last_col, M.col.as<uint32_t>() + (n_keys - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(&last_keep, M.keep.as<uint32_t>() + (n_keys - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "D2H"));
+        U = last_col + last_keep;
+    }
+    m->n_kmers = U;
+    const size_t cells = m->n_rows * (size_t)U;
+    if (m->d_data.alloc(cells * 8) != hipSuccess || m->d_kmers.alloc(((size_t)U + 1) * 8 * (size_t)W) != hipSuccess)
+        return bail(fail(c, GRM_ERR_OOM, "matrix allocation failed"));
+    if (cells) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
+    if (U) {
+        TimeScope t(c, "multi_emit", M.n_sub);
+        launch_multi_emit(s, W, M.sorted(), M.pos(), b->d_genome_sym_off.as<uint64_t>(), (uint32_t)b->n_genomes, M.sub_start.as<uint32_t>(),
+                          M.sub_key_head.as<uint32_t>(), M.sub_ok.as<uint32_t>(), M.key_incl.as<uint32_t>(), M.keep.as<uint32_t>(),
+                          M.col.as<uint32_t>(), M.n_sub, m->d_kmers.as<uint64_t>(), m->d_data.as<uint64_t>(), U);
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "multi_emit failed"));
+    *out = m;
+    return GRM_OK;
+}
+
+// single-genome batch -> sorted counted set (W words per k-mer)
+static int multi_set(grm_batch *b, int k, uint32_t abundance_min, grm_kmer_set **out)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    if (!b->multi) b->multi = new MultiSorted();
+    MultiSorted &M = *b->multi;
+    int rc = multi_sort_and_mark(b, k, abundance_min, M);
+    if (rc) return rc;
+    const int W = words_of(k);
+    grm_kmer_set *set = new grm_kmer_set();
+    set->ctx = c; set->k = k; set->words = W; set->occurrences = b->total_keys;
+    *out = set;
+    if (!M.n_sub) return GRM_OK;
+    HIPCHK(c, M.opos.ensure((size_t)M.n_sub * 4));
+    rc = wide_scan(c, M.tmp, false, M.sub_ok.as<uint32_t>(), M.opos.as<uint32_t>(), M.n_sub);
+    if (rc) return rc;
+    uint32_t last_pos = 0, last_ok = 0;
+    HIPCHK(c, hipMemcpyAsync(&last_pos, M.opos.as<uint32_t>() + (M.n_sub - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&last_ok, M.sub_ok.as<uint32_t>() + (M.n_sub - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const size_t n_out = (size_t)last_pos + last_ok;
+    if (!n_out) return GRM_OK;
+    HIPCHK(c, set->d_kmers.alloc(n_out * 8 * (size_t)W)); HIPCHK(c, set->d_counts.alloc(n_out * 4));
+    launch_multi_set(s, W, M.sorted(), M.sub_start.as<uint32_t>(), M.sub_ok.as<uint32_t>(), M.opos.as<uint32_t>(), M.n_sub,
+                     set->d_kmers.as<uint64_t>(), set->d_counts.as<uint32_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    set->n = n_out;
+    set->on_device = true;
+    set->on_host = false;
+    return GRM_OK;
+}
+
+// dsk2kover's merge for three- / four-word k-mers: the sets' keys laid out genome after genome, then the same reduction
+static int build_matrix_multi(grm_ctx *c, grm_kmer_set *const *sets, int n_genomes, int filter_singleton, grm_matrix **out)
+{
+    const int k = sets[0]->k, W = sets[0]->words;
+    std::vector<uint64_t> gko(n_genomes + 1, 0);
+    for (int g = 0; g < n_genomes; g++) {
+        if (!sets[g] || sets[g]->k != k || sets[g]->words != W) return fail(c, GRM_ERR_ARG, "grm_build_matrix: sets with different k");
+        gko[g + 1] = gko[g] + sets[g]->n;
+    }
+    const uint64_t n = gko[n_genomes];
+    grm_batch *b = nullptr;
+    int rc = grm_batch_create(c, n_genomes, &b);
+    if (rc) return rc;
+    auto body = [&]() -> int {
+        b->uploaded = true;
+        b->k = k;
+        b->abundance_min = 1;
+        b->total_syms = n;
+        b->multi = new MultiSorted();
+        MultiSorted &M = *b->multi;
+        if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "k > 64 merge is limited to 2^32-1 set entries (got %llu)", (unsigned long long)n);
+        MultiWordsOut dst;
+        for (int j = 0; j < 4; j++) dst.w[j] = nullptr;
+        for (int j = 0; j < W; j++) { HIPCHK(c, M.K[j].ensure((n + 2) * 8)); dst.w[j] = M.K[j].as<uint64_t>(); }
+        HIPCHK(c, b->d_genome_sym_off.ensure(((size_t)n_genomes + 1) * 8));
+        HIPCHK(c, hipMemcpy(b->d_genome_sym_off.p, gko.data(), ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice));
+        DevBuf stage;
+        for (int g = 0; g < n_genomes; g++) {
+            const size_t m = sets[g]->n;
+            if (!m) continue;
+            const uint64_t *src = sets[g]->d_kmers.as<uint64_t>();
+            if (!sets[g]->on_device) {
+                HIPCHK(c, stage.ensure(m * 8 * (size_t)W));
+                HIPCHK(c, hipMemcpy(stage.p, sets[g]->kmers.data(), m * 8 * (size_t)W, hipMemcpyHostToDevice));
+                src = stage.as<uint64_t>();
+            }
+            launch_multi_split(c->stream, W, src, m, dst, gko[g]);
+            if (!sets[g]->on_device) HIPCHK(c, hipStreamSynchronize(c->stream));       // the staging buffer is reused
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return multi_matrix(b, k, 1, filter_singleton, out, true);
+    };
+    rc = body();
+    grm_batch_free(b);
+    return rc;
+}
+
 // ---- two-word k-mers: hash-partition pipeline (grm_wide_hash.hip) ------------------------------
 // Three stages, as for one-word k-mers: local (partition + per-bucket dictionary of this batch's
 // genomes), global (sort / merge / filter of the k-mers of every rank), fill.
@@ -2372,6 +2606,7 @@ extern "C" int grm_batch_run(grm_batch *b, int k, uint32_t abundance_min, int fi
     if (!b || !out) return GRM_ERR_ARG;
     int rc = batch_partition_impl(b, k, abundance_min, false);
     if (rc) return rc;
+    if (k > 64) return multi_matrix(b, k, abundance_min < 1 ? 1 : abundance_min, filter_singleton, out);
     if (k > 32) {
         // hash-partition pipeline when it applies (abundance-min 1, moderate depth); the sort-based path
         // is the general fallback (and can be forced with the "wide_sort" option, for tests)
@@ -2476,7 +2711,8 @@ extern "C" int grm_count_genome_buffers(grm_ctx *c, const void *const *bufs, con
     for (int i = 0; i < n_bufs && !rc; i++) rc = grm_batch_add(b, 0, bufs[i], lens[i]);
     if (!rc) rc = grm_batch_upload(b);
     if (!rc) rc = batch_partition_impl(b, k, abundance_min, true);
-    if (!rc) rc = k > 32 ? wide_set(b, k, abundance_min < 1 ? 1 : abundance_min, out) : genome_set_impl(b, 0, true, out);
+    if (!rc) rc = k > 64 ? multi_set(b, k, abundance_min < 1 ? 1 : abundance_min, out)
+                : k > 32 ? wide_set(b, k, abundance_min < 1 ? 1 : abundance_min, out) : genome_set_impl(b, 0, true, out);
     if (rc && *out) { grm_kmer_set_free(*out); *out = nullptr; }
     grm_batch_free(b);
     return rc;
@@ -2494,7 +2730,8 @@ extern "C" int grm_count_genome(grm_ctx *c, const char *const *paths, int n_path
     for (int i = 0; i < n_paths && !rc; i++) rc = grm_batch_add_file(b, 0, paths[i]);
     if (!rc) rc = grm_batch_upload(b);
     if (!rc) rc = batch_partition_impl(b, k, abundance_min, true);
-    if (!rc) rc = k > 32 ? wide_set(b, k, abundance_min < 1 ? 1 : abundance_min, out) : genome_set_impl(b, 0, true, out);
+    if (!rc) rc = k > 64 ? multi_set(b, k, abundance_min < 1 ? 1 : abundance_min, out)
+                : k > 32 ? wide_set(b, k, abundance_min < 1 ? 1 : abundance_min, out) : genome_set_impl(b, 0, true, out);
     if (rc && *out) { grm_kmer_set_free(*out); *out = nullptr; }
     grm_batch_free(b);
     return rc;
@@ -2558,6 +2795,7 @@ extern "C" int grm_build_matrix(grm_ctx *c, grm_kmer_set *const *sets, int n_gen
     if (!out || n_genomes < 0 || (n_genomes && !sets)) return fail(c, GRM_ERR_ARG, "grm_build_matrix: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    if (n_genomes && sets[0] && sets[0]->words > 2) return build_matrix_multi(c, sets, n_genomes, filter_singleton, out);
     if (n_genomes && sets[0] && sets[0]->words == 2) return build_matrix_wide(c, sets, n_genomes, filter_singleton, out);
     int k = n_genomes ? sets[0]->k : 1;
     std::vector<uint64_t> gko(n_genomes + 1, 0);
@@ -2623,7 +2861,7 @@ static inline void decode_kmer(const uint64_t *w, int words, int k, char *out)
     static const char L[4] = {'A', 'C', 'T', 'G'};
     for (int i = 0; i < k; i++) {
         const int bit = 2 * (k - 1 - i);                  // position from the least significant end
-        const uint64_t word = words == 1 ? w[0] : (bit >= 64 ? w[0] : w[1]);
+        const uint64_t word = w[words - 1 - bit / 64];
         out[i] = L[(word >> (bit & 63)) & 3];
     }
 }

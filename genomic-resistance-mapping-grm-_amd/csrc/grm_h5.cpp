@@ -109,7 +109,7 @@ inline void decode_kmer(const uint64_t *w, int words, int k, char *out)
     static const char L[4] = {'A', 'C', 'T', 'G'};
     for (int i = 0; i < k; i++) {
         const int bit = 2 * (k - 1 - i);
-        const uint64_t word = words == 1 ? w[0] : (bit >= 64 ? w[0] : w[1]);
+        const uint64_t word = w[words - 1 - bit / 64];
         out[i] = L[(word >> (bit & 63)) & 3];
     }
 }

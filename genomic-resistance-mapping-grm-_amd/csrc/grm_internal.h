@@ -215,6 +215,20 @@ void launch_wide_emit(hipStream_t s, const uint64_t *khi, const uint64_t *klo, c
 void launch_wide_set(hipStream_t s, const uint64_t *khi, const uint64_t *klo, const uint32_t *sub_start, const uint32_t *sub_ok,
                      const uint32_t *out_pos, uint32_t n_sub, uint64_t *kmers, uint32_t *counts);
 
+// ---- three- and four-word k-mers, 65 <= k <= 128 (grm_multi.hip) ----
+struct MultiWords { const uint64_t *w[4]; };       // structure of arrays, w[0] most significant
+struct MultiWordsOut { uint64_t *w[4]; };
+void launch_multi_extract(hipStream_t s, int words, const uint64_t *sym2, const uint64_t *inv, uint64_t total_syms, int k,
+                          const MultiWordsOut &out, unsigned long long *n_valid);
+void launch_multi_mark(hipStream_t s, int words, const MultiWords &S, const uint32_t *pos, const uint64_t *gso, uint32_t n_genomes, uint32_t n,
+                       uint32_t *key_head, uint32_t *kg_head);
+void launch_multi_emit(hipStream_t s, int words, const MultiWords &S, const uint32_t *pos, const uint64_t *gso, uint32_t n_genomes,
+                       const uint32_t *sub_start, const uint32_t *sub_key_head, const uint32_t *sub_ok, const uint32_t *key_incl,
+                       const uint32_t *keep, const uint32_t *col, uint32_t n_sub, uint64_t *dict, uint64_t *matrix, uint64_t n_cols);
+void launch_multi_set(hipStream_t s, int words, const MultiWords &S, const uint32_t *sub_start, const uint32_t *sub_ok, const uint32_t *out_pos,
+                      uint32_t n_sub, uint64_t *kmers, uint32_t *counts);
+void launch_multi_split(hipStream_t s, int words, const uint64_t *keys, uint64_t n, const MultiWordsOut &out, uint64_t at);
+
 // ---- two-word k-mers, hash-partition pipeline (grm_wide_hash.hip) ----
 void launch_wh_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
 void launch_wh_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, void *out);

@@ -435,7 +435,7 @@ class HostMatrix(Matrix):
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1)
         data = np.ascontiguousarray(data, dtype=np.uint64)
         h = C.c_void_p()
-        words = 2 if k > 32 else 1                 # two words per k-mer (most significant first) for 33 <= k <= 64
+        words = (k + 31) // 32                     # ceil(k / 32) words per k-mer, most significant first
         rc = L.grm_matrix_from_host(kmers.ctypes.data, data.ctypes.data, kmers.size // words, n_genomes, k, C.byref(h))
         if rc:
             raise GrmError(rc, "grm_matrix_from_host")

@@ -22,57 +22,103 @@
 #include <time.h>
 
 typedef unsigned __int128 u128;
+/* k-mers of up to 128 bases (256 bits); k <= 32 keeps its own one-word fast path below */
+typedef struct { u128 hi, lo; } u256;
+static inline int u256_lt(u256 a, u256 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+static inline int u256_eq(u256 a, u256 b) { return a.hi == b.hi && a.lo == b.lo; }
+static inline u256 u256_push_low(u256 v, unsigned code)           /* (v << 2) | code */
+{
+    v.hi = (v.hi << 2) | (v.lo >> 126);
+    v.lo = (v.lo << 2) | (u128)code;
+    return v;
+}
+static inline u256 u256_push_high(u256 v, unsigned code, int k)   /* (v >> 2) | code << 2(k-1) */
+{
+    v.lo = (v.lo >> 2) | (v.hi << 126);
+    v.hi >>= 2;
+    const int p = 2 * (k - 1);
+    if (p >= 128) v.hi |= (u128)code << (p - 128);
+    else v.lo |= (u128)code << p;
+    return v;
+}
+static inline u256 u256_mask_k(int k)
+{
+    u256 m;
+    const int b = 2 * k;
+    if (b >= 256) { m.hi = ~(u128)0; m.lo = ~(u128)0; }
+    else if (b > 128) { m.hi = ((u128)1 << (b - 128)) - 1; m.lo = ~(u128)0; }
+    else if (b == 128) { m.hi = 0; m.lo = ~(u128)0; }
+    else { m.hi = 0; m.lo = ((u128)1 << b) - 1; }
+    return m;
+}
+static inline u256 u256_and(u256 a, u256 b) { a.hi &= b.hi; a.lo &= b.lo; return a; }
+static inline int words_of_k(int k) { return (k + 31) / 32; }
+/* `words` uint64 of a key, most significant first */
+static inline void u256_store(u256 v, int words, uint64_t *out)
+{
+    const uint64_t w[4] = {(uint64_t)(v.hi >> 64), (uint64_t)v.hi, (uint64_t)(v.lo >> 64), (uint64_t)v.lo};
+    for (int j = 0; j < words; j++) out[j] = w[4 - words + j];
+}
+static inline u256 u256_load(const uint64_t *in, int words)
+{
+    uint64_t w[4] = {0, 0, 0, 0};
+    for (int j = 0; j < words; j++) w[4 - words + j] = in[j];
+    u256 v;
+    v.hi = ((u128)w[0] << 64) | w[1];
+    v.lo = ((u128)w[2] << 64) | w[3];
+    return v;
+}
 
 /* ---------------------------------------------------------------- primitives ------ */
 int orc_base_code(unsigned char c) { return (c >> 1) & 3; }   /* A0 C1 T2 G3  [EXT] */
 int orc_base_bad(unsigned char c)  { return (c >> 3) & 1; }   /* N,n,K,M,... [EXT] */
 
-static inline u128 mask_k(int k) { return k == 64 ? ~(u128)0 : (((u128)1 << (2 * k)) - 1); }
-
 int orc_canonical_ascii(const char *s, int k, uint64_t *out)
 {
-    if (k < 1 || k > 64) return -1;
-    u128 fwd = 0, rc = 0;
+    if (k < 1 || k > 128) return -1;
+    u256 fwd = {0, 0}, rc = {0, 0};
     for (int i = 0; i < k; i++) {
         unsigned char c = (unsigned char)s[i];
         if (orc_base_bad(c)) return -1;
-        u128 code = (u128)orc_base_code(c);
-        fwd = (fwd << 2) | code;
-        rc  = (rc >> 2) | ((code ^ 2) << (2 * (k - 1)));   /* complement = code^2 */
+        unsigned code = (unsigned)orc_base_code(c);
+        fwd = u256_push_low(fwd, code);
+        rc  = u256_push_high(rc, code ^ 2u, k);             /* complement = code^2 */
     }
-    fwd &= mask_k(k);
-    u128 can = fwd < rc ? fwd : rc;
-    if (k <= 32) out[0] = (uint64_t)can;
-    else { out[0] = (uint64_t)(can >> 64); out[1] = (uint64_t)can; }
+    fwd = u256_and(fwd, u256_mask_k(k));
+    u256_store(u256_lt(fwd, rc) ? fwd : rc, words_of_k(k), out);
     return 0;
 }
 
 void orc_decode(const uint64_t *w, int k, char *out)
 {
     static const char L[4] = {'A', 'C', 'T', 'G'};
-    u128 v = k <= 32 ? (u128)w[0] : (((u128)w[0] << 64) | w[1]);
-    for (int i = 0; i < k; i++) out[i] = L[(int)((v >> (2 * (k - 1 - i))) & 3)];
+    const int words = words_of_k(k);
+    for (int i = 0; i < k; i++) {
+        const int bit = 2 * (k - 1 - i);                     /* from the least significant end */
+        const uint64_t word = w[words - 1 - bit / 64];
+        out[i] = L[(int)((word >> (bit & 63)) & 3)];
+    }
 }
 
 /* ------------------------------------------------------------- k-mer scanning ----- */
-typedef struct { u128 *v; size_t n, cap; } kvec128;
+typedef struct { u256 *v; size_t n, cap; } kvec256;
 typedef struct { uint64_t *v; size_t n, cap; } kvec64;
 
 typedef struct {
     int k;
-    u128 mask;
-    u128 fwd, rc;
+    u256 mask;
+    u256 fwd, rc;
     int run;              /* consecutive valid symbols ending here */
     uint64_t nocc;
     int words;
     kvec64 a64;
-    kvec128 a128;
+    kvec256 a256;
     int oom;
 } scanner;
 
-static void sc_reset(scanner *s) { s->run = 0; s->fwd = 0; s->rc = 0; }
+static void sc_reset(scanner *s) { s->run = 0; s->fwd.hi = s->fwd.lo = 0; s->rc.hi = s->rc.lo = 0; }
 
-static void sc_emit(scanner *s, u128 can)
+static void sc_emit(scanner *s, u256 can)
 {
     s->nocc++;
     if (s->words == 1) {
@@ -82,25 +128,25 @@ static void sc_emit(scanner *s, u128 can)
             if (!nv) { s->oom = 1; return; }
             s->a64.v = nv; s->a64.cap = nc;
         }
-        s->a64.v[s->a64.n++] = (uint64_t)can;
+        s->a64.v[s->a64.n++] = (uint64_t)can.lo;
     } else {
-        if (s->a128.n == s->a128.cap) {
-            size_t nc = s->a128.cap ? s->a128.cap * 2 : (1u << 16);
-            u128 *nv = (u128 *)realloc(s->a128.v, nc * sizeof(u128));
+        if (s->a256.n == s->a256.cap) {
+            size_t nc = s->a256.cap ? s->a256.cap * 2 : (1u << 16);
+            u256 *nv = (u256 *)realloc(s->a256.v, nc * sizeof(u256));
             if (!nv) { s->oom = 1; return; }
-            s->a128.v = nv; s->a128.cap = nc;
+            s->a256.v = nv; s->a256.cap = nc;
         }
-        s->a128.v[s->a128.n++] = can;
+        s->a256.v[s->a256.n++] = can;
     }
 }
 
 static inline void sc_feed(scanner *s, unsigned char c)
 {
     if (orc_base_bad(c)) { sc_reset(s); return; }
-    u128 code = (u128)orc_base_code(c);
-    s->fwd = ((s->fwd << 2) | code) & s->mask;
-    s->rc  = (s->rc >> 2) | ((code ^ 2) << (2 * (s->k - 1)));
-    if (++s->run >= s->k) sc_emit(s, s->fwd < s->rc ? s->fwd : s->rc);
+    unsigned code = (unsigned)orc_base_code(c);
+    s->fwd = u256_and(u256_push_low(s->fwd, code), s->mask);
+    s->rc  = u256_push_high(s->rc, code ^ 2u, s->k);
+    if (++s->run >= s->k) sc_emit(s, u256_lt(s->fwd, s->rc) ? s->fwd : s->rc);
 }
 
 /* One file image.  FASTA: a line whose first byte is '>' is a header and starts a new
@@ -158,10 +204,10 @@ static void radix_sort_u64(uint64_t *a, size_t n)
     free(b);
 }
 
-static int cmp_u128(const void *x, const void *y)
+static int cmp_u256(const void *x, const void *y)
 {
-    u128 a = *(const u128 *)x, b = *(const u128 *)y;
-    return a < b ? -1 : (a > b ? 1 : 0);
+    const u256 a = *(const u256 *)x, b = *(const u256 *)y;
+    return u256_lt(a, b) ? -1 : (u256_lt(b, a) ? 1 : 0);
 }
 
 /* sort + run-length + abundance filter -> orc_set */
@@ -170,15 +216,15 @@ static int finish_set(scanner *s, uint32_t abundance_min, orc_set *out)
     memset(out, 0, sizeof(*out));
     out->k = s->k; out->words = s->words; out->n_occurrences = s->nocc;
     if (s->oom) return -2;
-    size_t n = s->words == 1 ? s->a64.n : s->a128.n;
+    size_t n = s->words == 1 ? s->a64.n : s->a256.n;
     if (s->words == 1) radix_sort_u64(s->a64.v, n);
-    else qsort(s->a128.v, n, sizeof(u128), cmp_u128);
+    else qsort(s->a256.v, n, sizeof(u256), cmp_u256);
     /* count distinct */
     size_t nd = 0;
     for (size_t i = 0; i < n;) {
         size_t j = i + 1;
         if (s->words == 1) while (j < n && s->a64.v[j] == s->a64.v[i]) j++;
-        else while (j < n && s->a128.v[j] == s->a128.v[i]) j++;
+        else while (j < n && u256_eq(s->a256.v[j], s->a256.v[i])) j++;
         if ((uint64_t)(j - i) >= abundance_min) nd++;
         i = j;
     }
@@ -189,11 +235,11 @@ static int finish_set(scanner *s, uint32_t abundance_min, orc_set *out)
     for (size_t i = 0; i < n;) {
         size_t j = i + 1;
         if (s->words == 1) while (j < n && s->a64.v[j] == s->a64.v[i]) j++;
-        else while (j < n && s->a128.v[j] == s->a128.v[i]) j++;
+        else while (j < n && u256_eq(s->a256.v[j], s->a256.v[i])) j++;
         uint64_t c = j - i;
         if (c >= abundance_min) {
             if (s->words == 1) out->kmers[o] = s->a64.v[i];
-            else { out->kmers[2 * o] = (uint64_t)(s->a128.v[i] >> 64); out->kmers[2 * o + 1] = (uint64_t)s->a128.v[i]; }
+            else u256_store(s->a256.v[i], s->words, out->kmers + (size_t)s->words * o);
             out->counts[o] = c > 0xffffffffu ? 0xffffffffu : (uint32_t)c;
             o++;
         }
@@ -205,12 +251,12 @@ static int finish_set(scanner *s, uint32_t abundance_min, orc_set *out)
 
 static int sc_init(scanner *s, int k)
 {
-    if (k < 1 || k > 64) return -1;
+    if (k < 1 || k > 128) return -1;
     memset(s, 0, sizeof(*s));
-    s->k = k; s->mask = mask_k(k); s->words = k <= 32 ? 1 : 2;
+    s->k = k; s->mask = u256_mask_k(k); s->words = words_of_k(k);
     return 0;
 }
-static void sc_free(scanner *s) { free(s->a64.v); free(s->a128.v); }
+static void sc_free(scanner *s) { free(s->a64.v); free(s->a256.v); }
 
 int orc_count_buffers(const unsigned char *const *bufs, const size_t *lens, int n_bufs,
                       int k, uint32_t abundance_min, orc_set *out)
@@ -270,19 +316,19 @@ void orc_set_free(orc_set *s)
 }
 
 /* ------------------------------------------------------------- merge / pack ------- */
-static inline u128 set_key(const orc_set *s, size_t i)
+static inline u256 set_key(const orc_set *s, size_t i)
 {
-    return s->words == 1 ? (u128)s->kmers[i] : (((u128)s->kmers[2 * i] << 64) | s->kmers[2 * i + 1]);
+    return u256_load(s->kmers + (size_t)s->words * i, s->words);
 }
 
-typedef struct { u128 key; int g; } hnode;
+typedef struct { u256 key; int g; } hnode;
 
 static void heap_sift_down(hnode *h, size_t n, size_t i)
 {
     for (;;) {
         size_t l = 2 * i + 1, r = l + 1, m = i;
-        if (l < n && (h[l].key < h[m].key || (h[l].key == h[m].key && h[l].g < h[m].g))) m = l;
-        if (r < n && (h[r].key < h[m].key || (h[r].key == h[m].key && h[r].g < h[m].g))) m = r;
+        if (l < n && (u256_lt(h[l].key, h[m].key) || (u256_eq(h[l].key, h[m].key) && h[l].g < h[m].g))) m = l;
+        if (r < n && (u256_lt(h[r].key, h[m].key) || (u256_eq(h[r].key, h[m].key) && h[r].g < h[m].g))) m = r;
         if (m == i) return;
         hnode t = h[i]; h[i] = h[m]; h[m] = t;
         i = m;
@@ -310,10 +356,10 @@ static int merge_range(const orc_set *sets, int n_genomes, const size_t *lo, con
     for (size_t i = hn / 2; i-- > 0;) heap_sift_down(heap, hn, i);
     int rc = 0;
     while (hn) {
-        u128 key = heap[0].key;
+        u256 key = heap[0].key;
         memset(bits, 0, sizeof(uint64_t) * n_rows);
         uint32_t ng = 0;
-        while (hn && heap[0].key == key) {
+        while (hn && u256_eq(heap[0].key, key)) {
             int g = heap[0].g;
             bits[g >> 6] |= (uint64_t)1 << (63 - (g & 63));          /* utils.py:133-156 */
             ng++;
@@ -333,8 +379,7 @@ static int merge_range(const orc_set *sets, int n_genomes, const size_t *lo, con
             if (!a || !b || !c) { rc = -2; break; }
             o->cap = nc;
         }
-        if (words == 1) o->kmers[o->n] = (uint64_t)key;
-        else { o->kmers[2 * o->n] = (uint64_t)(key >> 64); o->kmers[2 * o->n + 1] = (uint64_t)key; }
+        u256_store(key, words, o->kmers + (size_t)words * o->n);
         memcpy(o->cols + o->n * n_rows, bits, n_rows * sizeof(uint64_t));
         o->ng[o->n] = ng;
         o->n++;
@@ -343,16 +388,16 @@ static int merge_range(const orc_set *sets, int n_genomes, const size_t *lo, con
     return rc;
 }
 
-static size_t lower_bound_set(const orc_set *s, u128 key)
+static size_t lower_bound_set(const orc_set *s, u256 key)
 {
     size_t lo = 0, hi = s->n;
-    while (lo < hi) { size_t m = (lo + hi) / 2; if (set_key(s, m) < key) lo = m + 1; else hi = m; }
+    while (lo < hi) { size_t m = (lo + hi) / 2; if (u256_lt(set_key(s, m), key)) lo = m + 1; else hi = m; }
     return lo;
 }
 
 typedef struct {
     const orc_set *sets; int n_genomes; int filter; size_t n_rows; int words;
-    u128 lo_key, hi_key; int has_lo, has_hi;
+    u256 lo_key, hi_key; int has_lo, has_hi;
     mergeout out; int rc;
 } merge_job;
 

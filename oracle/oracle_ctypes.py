@@ -133,13 +133,13 @@ def pipeline(buffers, k, abundance_min, filter_singleton, n_threads):
 def canonical_ascii(s, k=None):
     L = lib()
     k = k or len(s)
-    out = (C.c_uint64 * 2)()
+    out = (C.c_uint64 * 4)()
     rc = L.orc_canonical_ascii(s.encode(), k, out)
     if rc:
         return None
     buf = C.create_string_buffer(k)
     L.orc_decode(out, k, buf)
-    return buf.raw[:k].decode(), [int(out[i]) for i in range(1 if k <= 32 else 2)]
+    return buf.raw[:k].decode(), [int(out[i]) for i in range((k + 31) // 32)]
 
 
 def pack_bits(bits, pack_size):

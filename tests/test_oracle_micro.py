@@ -51,6 +51,27 @@ def test_two_word_k63():
         _check_case(k, genomes, 1, True)
 
 
+def test_three_and_four_word_kmers():
+    """k = 65 .. 128 (the reference's --kmer-size range ends at 128, bin/kover/kover:114): 256-bit keys in the C oracle vs
+    the string mirror, incl. N, lowercase, the reverse strand, a contig shorter than k and duplicates (abundance-min 2)"""
+    rng = np.random.RandomState(8)
+    a = cases.rand_seq(rng, 500)
+    b = cases.rand_seq(rng, 140)
+    genomes = [[cases.fasta([("a", a), ("short", b[:90])])],
+               [cases.fasta([("rc", cases.revcomp(a)[:400]), ("again", a[50:300])])],
+               [cases.fasta([("n", a[:200] + "N" + a[201:]), ("low", b.lower())], width=61)]]
+    for k in (65, 95, 96, 97, 127, 128):
+        _check_case(k, genomes, 1, False)
+        _check_case(k, genomes, 1, True)
+        _check_case(k, genomes, 2, False)
+    # words: most significant first, ceil(k / 32) of them
+    km = "ACGT" * 32
+    can, words = orc.canonical_ascii(km)
+    assert len(words) == 4 and can == pyoracle.canonical(km)
+    v = pyoracle.kmer_value(can)
+    assert [int(w) for w in words] == [(v >> (64 * (3 - j))) & (2**64 - 1) for j in range(4)]
+
+
 def test_hand_computed():
     # k=3 over ACGTT: windows ACG,CGT,GTT ; rc: CGT,ACG,AAC -> canon ACG,ACG,AAC
     km, ct, nocc = orc.count_genome([b">s\nACGTT\n"], 3)
