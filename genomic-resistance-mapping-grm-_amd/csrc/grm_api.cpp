@@ -59,6 +59,7 @@ struct grm_ctx {
     int opt_upload_slab_kb = -1; // pinned upload slab size in KiB (tests; default 128 MiB)
     int opt_direct_permute = -1; // > 0: scattered single-step form of the fill (tests, measurements)
     int opt_dedup_wg = -1;       // > 0: per-segment dedup in the workgroup form only (tests)
+    int opt_dedup_cap_shift = -1; // > 0: wave-form dedup tables 2^shift times larger than the sizing rule asks for (measurements)
     int opt_dense_layout = -1;   // > 0: histogram-sized dense partition layout (tests, measurements)
     int opt_no_union = -1;       // > 0: gathered rank dictionaries are sorted as a whole (tests)
 };
@@ -241,6 +242,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "upload_slab_kb") c->opt_upload_slab_kb = value;
     else if (n == "direct_permute") c->opt_direct_permute = value;
     else if (n == "dedup_wg") c->opt_dedup_wg = value;
+    else if (n == "dedup_cap_shift") c->opt_dedup_cap_shift = value;
     else if (n == "dense_layout") c->opt_dense_layout = value;
     else if (n == "no_union") c->opt_no_union = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
@@ -1188,6 +1190,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         const uint64_t want = (uint64_t)((double)(mean_seg + 16) + 6.0 * std::sqrt((double)mean_seg + 1.0)) * 5 / 4;
         int wave_cap = 9;
         while (wave_cap < 11 && (1ull << wave_cap) < want) wave_cap++;
+        if (c->opt_dedup_cap_shift > 0) wave_cap = std::min(11, wave_cap + c->opt_dedup_cap_shift);
         const bool wave_form = c->opt_dedup_wg <= 0;
         int ov = 0;
         if (wave_form) {

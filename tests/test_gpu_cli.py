@@ -117,7 +117,9 @@ def test_dsk_pooled_count(genomes, tmp_path, k, budget):
         assert f.get_attr("nb_kmers_total") == float(nocc)
 
 
-def test_kover_create_from_contigs(genomes, tmp_path):
+@pytest.mark.parametrize("k", [31, 101])
+def test_kover_create_from_contigs(genomes, tmp_path, k):
+    """k = 101: three-word k-mers through the same command (the reference accepts --kmer-size up to 128, bin/kover/kover:114)"""
     import grm_amd  # noqa: F401
     kd = import_module(PKG + ".kover_dataset")
     ids = [os.path.basename(p)[:-4] for p in genomes]
@@ -128,14 +130,14 @@ def test_kover_create_from_contigs(genomes, tmp_path):
     out = str(tmp_path / "DATASET.kover")
     # the command GRM builds (src/kover.py:52-108)
     _run([os.path.join(CLI, "kover"), "dataset", "create", "from-contigs", "--genomic-data", data,
-          "--phenotype-description", "desc", "--phenotype-metadata", md, "--output", out, "--kmer-size", "31",
+          "--phenotype-description", "desc", "--phenotype-metadata", md, "--output", out, "--kmer-size", str(k),
           "--n-cpu", "4", "--compression", "4", "-x"])
     r = kd.KoverDatasetReader(out)
     order = r.genome_identifiers
     labels = {i: (0 if n % 3 else 1) for n, i in enumerate(ids)}        # tags sorted: R=0, S=1
     assert [labels[i] for i in order] == sorted(labels.values())        # rows label-sorted (create.py:334-336)
-    want = orc.build_matrix([[open(genomes[ids.index(i)], "rb").read()] for i in order], 31, 1, True)
-    assert r.kmer_sequences == orc.decode_kmers(want["kmers"], 31)
+    want = orc.build_matrix([[open(genomes[ids.index(i)], "rb").read()] for i in order], k, 1, True)
+    assert r.kmer_sequences == orc.decode_kmers(want["kmers"], k)
     assert (r.kmer_matrix == want["matrix"]).all()
     assert r.attr("filter") == "singleton" and r.attr("genome_source_type") == "contigs"
     assert r.phenotype[1] == ["R", "S"]
