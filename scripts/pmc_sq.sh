@@ -10,7 +10,7 @@ import csv, glob, collections
 rows = collections.defaultdict(dict)
 for f in glob.glob("gpurun_out/sq?_$TAG/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace(", ", ";")
         if k.startswith("grm::"):
             rows[k][r["Counter_Name"]] = rows[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 names = sorted({c for d in rows.values() for c in d})

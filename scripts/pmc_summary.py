@@ -4,7 +4,7 @@ rows = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob("gpurun_out/pmc_%s_%s/*/*_counter_collection.csv" % (tag, c)):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace(", ", ";")        # template arguments: no commas in a CSV cell
             if not k.startswith("grm::"):
                 continue
             d = rows.setdefault(k, collections.defaultdict(float))
