@@ -114,6 +114,8 @@ def test_medium_pangenome_all_paths(ctx):
     {"bucket_bits": 14}, {"bucket_bits": 16},          # deep mode: fine histogram from the level-1 output
     {"cap_log2": 8, "bucket_bits": 4},          # forces overflow -> sub-bucket retries
     {"no_slots": 1}, {"no_slots": 1, "sub_bits": 2},   # probing form of the fill
+    {"dense_layout": 1}, {"dense_layout": 1, "bucket_bits": 11},      # histogram-sized layout instead of the slack layout
+    {"direct_permute": 1},                             # scattered single-step fill
 ])
 def test_medium_with_forced_geometry(ctx, opts):
     genomes = _medium_genomes(n=5, length=120_000, seed=9)
