@@ -689,6 +689,7 @@ struct grm_batch {
     // the fill is then a permutation into column order that needs neither keys nor probes
     DevBuf d_wg_base, d_wg_cnt, d_matrix_s, d_birth, d_entry_col, d_ctrl, d_prefix, d_entry_major;
     bool own_dict = false;         // the global dictionary is this batch's own local one: every column has a local entry
+    bool entry_cols_ready = false; // d_entry_col was filled by the sort itself (own dictionary)
     bool have_bits = false, fill_by_bits = false;
     int filter_singleton = 0;
     // scratch that survives between steps (grow-only)
@@ -1010,8 +1011,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         HIPCHK(c, b->d_genome_sym_off.ensure(((size_t)G + 1) * 8));
         HIPCHK(c, b->d_scan_scratch.ensure(parse_scan_scratch_bytes(b->n_tiles)));
     }
-    HIPCHK(c, hipMemsetAsync(b->d_sym2.p, 0, max_groups * 16, s));
-    HIPCHK(c, hipMemsetAsync(b->d_inv.p, 0, max_groups * 8, s));
+    // (no memset of the packed stream: parse_pack's companion kernel zeroes the groups that need it)
     {
         TimeScope t(c, "parse_summarize", b->raw_bytes);
         launch_parse_summarize(s, raw, b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_sums.as<TileSummary>());
@@ -1446,6 +1446,46 @@ static int dict_from_entries(grm_batch *b, const uint64_t *keys, const uint8_t *
     return GRM_OK;
 }
 
+// one GPU, the dictionary is the batch's own local one: its entries are distinct already, so they are sorted together
+// with their entry index and every entry's column falls out of the select step (no search afterwards)
+static int dict_from_own_entries(grm_batch *b, int filter_singleton)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    const uint64_t n = b->n_local;
+    b->n_dict = 0;
+    if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "dictionary of %llu k-mers exceeds 2^32-1 columns", (unsigned long long)n);
+    DevBuf &d_sk = b->t_sk, &d_keep = b->t_keep, &d_pos = b->t_pos, &d_tmp = b->t_tmp, &d_i0 = b->t_bid, &d_i1 = b->t_col;
+    HIPCHK(c, d_sk.ensure(n * 8));
+    HIPCHK(c, d_keep.ensure((n + 1) * 4));
+    HIPCHK(c, d_pos.ensure((n + 1) * 8));
+    HIPCHK(c, d_i0.ensure(n * 4));
+    HIPCHK(c, d_i1.ensure(n * 4));
+    HIPCHK(c, b->d_entry_col.ensure((n + 1) * 4));
+    {
+        TimeScope t(c, "dict_sort", n);
+        launch_iota_u32(s, d_i0.as<uint32_t>(), n);
+        size_t tmp_bytes = 0;
+        HIPCHK(c, sort_pairs_u64_u32(s, b->d_local_keys.as<uint64_t>(), d_sk.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, nullptr, tmp_bytes));
+        HIPCHK(c, d_tmp.ensure(tmp_bytes));
+        HIPCHK(c, sort_pairs_u64_u32(s, b->d_local_keys.as<uint64_t>(), d_sk.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, d_tmp.p, tmp_bytes));
+        HIPCHK(c, hipMemsetAsync(d_keep.as<uint32_t>() + n, 0, 4, s));
+        launch_dict_mark_idx(s, b->d_local_flags.as<uint8_t>(), d_i1.as<uint32_t>(), n, filter_singleton, d_keep.as<uint32_t>());
+        size_t tmp2 = 0;
+        HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, nullptr, tmp2));
+        HIPCHK(c, d_tmp.ensure(tmp2));
+        HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, d_tmp.p, tmp2));
+        HIPCHK(c, hipMemcpyAsync(&b->n_dict, d_pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, b->d_dict.ensure((b->n_dict + 2) * 8));
+        launch_dict_select_idx(s, d_sk.as<uint64_t>(), d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), d_i1.as<uint32_t>(), n, b->d_dict.as<uint64_t>(),
+                               b->d_entry_col.as<uint32_t>());
+    }
+    HIPCHK(c, hipGetLastError());
+    b->entry_cols_ready = true;
+    return GRM_OK;
+}
+
 // the batch's own structures against b->d_dict: columns of its entries (fused form) or the bucketised dictionary
 static int dict_attach(grm_batch *b, uint64_t *n_kmers)
 {
@@ -1455,7 +1495,7 @@ static int dict_attach(grm_batch *b, uint64_t *n_kmers)
     if (b->have_local && b->have_bits && b->total_keys) {
         // fused form: every local entry learns its global column (or that it was filtered out)
         HIPCHK(c, b->d_entry_col.ensure((b->n_local + 1) * 4));
-        {
+        if (!b->entry_cols_ready) {
             TimeScope t(c, "dict_entry_cols", b->n_local);
             HIPCHK(c, b->d_prefix.ensure(((size_t)1 << 20) * 4 + 16));
             launch_dict_entry_cols(s, b->d_dict.as<uint64_t>(), b->n_dict, b->d_local_keys.as<uint64_t>(), b->n_local, b->k,
@@ -1492,7 +1532,10 @@ extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, con
     b->have_global = false;
     b->filter_singleton = filter_singleton;
     b->own_dict = n && dev_keys == b->d_local_keys.p && n == b->n_local;     // filtered or not: every COLUMN stems from a local entry
-    int rc = dict_from_entries(b, (const uint64_t *)dev_keys, (const uint8_t *)dev_flags, n, filter_singleton);
+    b->entry_cols_ready = false;
+    int rc;
+    if (b->own_dict && b->have_bits && dev_flags == b->d_local_flags.p) rc = dict_from_own_entries(b, filter_singleton);
+    else rc = dict_from_entries(b, (const uint64_t *)dev_keys, (const uint8_t *)dev_flags, n, filter_singleton);
     if (rc) return rc;
     return dict_attach(b, n_kmers);
 }
@@ -1594,6 +1637,7 @@ extern "C" int grm_batch_set_global_dict_gathered(grm_batch *b, const void *dev_
             b->have_global = false;
             b->filter_singleton = filter_singleton;
             b->own_dict = false;
+            b->entry_cols_ready = false;
             rc = dict_from_entries(b, b->t_u_keys.as<uint64_t>(), b->t_u_flags.as<uint8_t>(), n_union, filter_singleton);
             if (rc) return rc;
             return dict_attach(b, n_kmers);
@@ -1841,6 +1885,7 @@ extern "C" int grm_batch_set_global_dict_accum(grm_batch *b, const grm_dict_accu
     b->have_global = false;
     b->filter_singleton = filter_singleton;
     b->own_dict = false;
+    b->entry_cols_ready = false;
     if (a->dict_filter != (filter_singleton ? 1 : 0)) {
         // sort / merge / filter the accumulated entries ONCE; every chunk of pass 2 then only looks its own entries up
         int rc = dict_from_entries(b, a->keys.as<uint64_t>(), a->flags.as<uint8_t>(), a->n, filter_singleton);

@@ -155,6 +155,9 @@ void launch_dict_mark(hipStream_t s, const uint64_t *skeys, const uint8_t *sflag
                       uint32_t *keep);
 void launch_dict_select(hipStream_t s, const uint64_t *skeys, const uint32_t *keep, const uint64_t *pos, uint64_t n,
                         uint64_t *dict);
+void launch_dict_mark_idx(hipStream_t s, const uint8_t *flags, const uint32_t *sidx, uint64_t n, int filter_singleton, uint32_t *keep);
+void launch_dict_select_idx(hipStream_t s, const uint64_t *skeys, const uint32_t *keep, const uint64_t *pos, const uint32_t *sidx, uint64_t n,
+                            uint64_t *dict, uint32_t *entry_col);
 void launch_dict_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int bb, int sb, uint32_t *bucket_of,
                             uint32_t *col_of);
 void launch_segments_compact(hipStream_t s, const uint64_t *src, const uint32_t *src_cnt, const uint64_t *src_off,

@@ -382,6 +382,23 @@ __global__ void genome_offsets_kernel(const uint64_t *__restrict__ tile_off, con
         genome_sym_off[g] = tile_off[genome_tile_off[g]];
 }
 
+// The packed stream is written group by group (64 symbols) by the tile that holds it: plain stores, except for the
+// groups a tile boundary falls into, which two (or more) tiles OR their parts into.  Only those groups -- one per tile
+// boundary -- and a few groups past the end of the stream (read by the last k-mer windows) must start out as zero.
+__global__ void parse_prezero_kernel(const uint64_t *__restrict__ tile_off, uint32_t n_tiles, uint64_t *__restrict__ sym2,
+                                     uint64_t *__restrict__ inv)
+{
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t <= n_tiles; t += gridDim.x * blockDim.x) {
+        const uint64_t G = tile_off[t] >> 6;
+        const int extra = t == n_tiles ? 4 : 1;
+        for (int e = 0; e < extra; e++) {
+            sym2[2 * (G + e)] = 0;
+            sym2[2 * (G + e) + 1] = 0;
+            inv[G + e] = 0;
+        }
+    }
+}
+
 // P2: same tile scan, now with the tile's incoming line type and first symbol index known.
 // Every chunk packs its symbols into two small bit strings and ORs them into the tile's
 // LDS image of the packed stream (ds_or_b64); the image is then stored with coalesced writes.
@@ -741,15 +758,15 @@ __global__ __launch_bounds__(L2_THREADS) void kmer_scatter_l2_kernel(
     }
 }
 
-// sum of n uint32 -> *out (uint64), one workgroup
-__global__ __launch_bounds__(1024) void sum_u32_kernel(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out)
+// sum of n uint32 added to *out (uint64, zeroed by the caller)
+__global__ __launch_bounds__(256) void sum_u32_kernel(const uint32_t *__restrict__ in, uint64_t n, unsigned long long *__restrict__ out)
 {
     __shared__ uint64_t scratch[16];
     uint64_t s = 0;
-    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) s += in[i];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) s += in[i];
     uint64_t total;
     (void)block_scan_sum64(s, scratch, &total);
-    if (threadIdx.x == 0) *out = total;
+    if (threadIdx.x == 0 && total) atomicAdd(out, (unsigned long long)total);
 }
 
 // partition an explicit key list (grm_build_matrix from host-side sets): hist + scatter
@@ -1520,6 +1537,25 @@ __global__ void dict_select_kernel(const uint64_t *__restrict__ skeys, const uin
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         if (keep[i]) dict[pos[i]] = skeys[i];
 }
+// the same for a list of DISTINCT keys sorted together with their entry index (one GPU: the dictionary is the batch's
+// own): flags are read through the index, and every entry learns its column (0xffffffff: filtered out) right here --
+// no search of the dictionary afterwards
+__global__ void dict_mark_idx_kernel(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ sidx, uint64_t n, int filter_singleton,
+                                     uint32_t *__restrict__ keep)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        keep[i] = (!filter_singleton || flags[sidx[i]] >= 2) ? 1u : 0u;
+}
+__global__ void dict_select_idx_kernel(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ keep,
+                                       const uint64_t *__restrict__ pos, const uint32_t *__restrict__ sidx, uint64_t n,
+                                       uint64_t *__restrict__ dict, uint32_t *__restrict__ entry_col)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const bool k = keep[i] != 0;
+        if (k) dict[pos[i]] = skeys[i];
+        entry_col[sidx[i]] = k ? (uint32_t)pos[i] : 0xffffffffu;
+    }
+}
 // bucket id ((bucket << sb) | sub) and identity column index of every dictionary entry
 __global__ void dict_bucket_ids_kernel(const uint64_t *__restrict__ dict, uint64_t n, int bb, int sb,
                                        uint32_t *__restrict__ bucket_of, uint32_t *__restrict__ col_of)
@@ -1745,6 +1781,7 @@ void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles,
 void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, const uint64_t *tile_off,
                        const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv)
 {
+    hipLaunchKernelGGL(parse_prezero_kernel, dim3(((uint64_t)n_tiles + 256) / 256), dim3(256), 0, s, tile_off, n_tiles, sym2, inv);
     hipLaunchKernelGGL(parse_pack_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, tile_off,
                        tile_state, sym2, inv);
 }
@@ -1793,7 +1830,7 @@ void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *co
 }
 void launch_sum_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *out)
 {
-    hipLaunchKernelGGL(sum_u32_kernel, dim3(1), dim3(1024), 0, s, in, n, out);
+    hipLaunchKernelGGL(sum_u32_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, s, in, n, reinterpret_cast<unsigned long long *>(out));
 }
 void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *keys1,
                             uint64_t *keys, uint64_t region_stride, uint32_t fine_cap, const uint32_t *cursor1, uint32_t *len_out,
@@ -1940,6 +1977,17 @@ void launch_dict_select(hipStream_t s, const uint64_t *skeys, const uint32_t *ke
 {
     if (!n) return;
     hipLaunchKernelGGL(dict_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, skeys, keep, pos, n, dict);
+}
+void launch_dict_mark_idx(hipStream_t s, const uint8_t *flags, const uint32_t *sidx, uint64_t n, int filter_singleton, uint32_t *keep)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(dict_mark_idx_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, flags, sidx, n, filter_singleton, keep);
+}
+void launch_dict_select_idx(hipStream_t s, const uint64_t *skeys, const uint32_t *keep, const uint64_t *pos, const uint32_t *sidx, uint64_t n,
+                            uint64_t *dict, uint32_t *entry_col)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(dict_select_idx_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, skeys, keep, pos, sidx, n, dict, entry_col);
 }
 void launch_dict_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int bb, int sb, uint32_t *bucket_of,
                             uint32_t *col_of)
