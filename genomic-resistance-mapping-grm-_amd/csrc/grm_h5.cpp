@@ -329,7 +329,8 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
                 }
             } else {
                 copier.join();
-                if (H.Dwrite(ds, H.U64, 0, 0, 0, data) < 0) { err = "H5Dwrite kmer_matrix"; rc = -1; }
+                if (copy_failed) { err = "device -> host copy of the matrix failed"; rc = -1; }      // never write rows that did not arrive
+                else if (H.Dwrite(ds, H.U64, 0, 0, 0, data) < 0) { err = "H5Dwrite kmer_matrix"; rc = -1; }
             }
         }
         if (ds >= 0) H.Dclose(ds);
