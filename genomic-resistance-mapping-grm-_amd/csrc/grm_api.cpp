@@ -2270,12 +2270,14 @@ static int build_matrix_multi(grm_ctx *c, grm_kmer_set *const *sets, int n_genom
 // Three stages, as for one-word k-mers: local (partition + per-bucket dictionary of this batch's
 // genomes), global (sort / merge / filter of the k-mers of every rank), fill.
 struct WideHash {
-    DevBuf counts, off, cursor1, keys, keys1, kslot;
-    DevBuf stage_lo, stage_hi, stage_flags, stage_cnt, stage_off, img_lo, img_hi, col_of_slot, flag;
+    DevBuf counts, off, cursor1, keys, keys1, len;
+    DevBuf stage_lo, stage_hi, stage_flags, stage_cnt, stage_off, matrix_s, birth, entry_col, entry_major, flag;
     DevBuf loc_lo, loc_hi, loc_flags, idx0, idx1, idx2, t_a, t_b, keep, pos, tmp, g_hi, g_lo;
-    int sb = 0;
+    int sb = 0, sb_hint = -1, sb_hint_k = 0, sb_hint_bb = -1;
     uint32_t cap_log2 = 0, n_wg = 0, U = 0;
     uint64_t n_local = 0, n_sorted = 0;
+    uint64_t seg_stride = 0;       // 0: dense layout (off); else slack layout (segment i at i * seg_stride, length len[i])
+    bool slack_failed = false, have_bits = false, own_dict = false;
     bool have_local = false, have_global = false;
 };
 static void wide_hash_free(WideHash *w) { delete w; }
@@ -2313,60 +2315,115 @@ static int wide_hash_local(grm_batch *b, int k, bool *fallback)
     L.sym2 = b->d_sym2.as<uint64_t>(); L.inv = b->d_inv.as<uint64_t>(); L.total_syms = b->total_syms;
     L.genome_sym_off = b->d_genome_sym_off.as<uint64_t>(); L.n_genomes = G; L.k = k; L.bb = bb; L.groups_per_thread = 1;
 
-    HIPCHK(c, W.counts.ensure((n_seg + 1) * 4)); HIPCHK(c, W.off.ensure((n_seg + 1) * 8));
-    HIPCHK(c, W.cursor1.ensure(n_coarse * 4)); HIPCHK(c, W.flag.ensure(4));
-    HIPCHK(c, hipMemsetAsync(W.counts.p, 0, (n_seg + 1) * 4, s));
-    HIPCHK(c, hipMemsetAsync(W.cursor1.p, 0, n_coarse * 4, s));
-    {
-        TimeScope t(c, "wh_hist", b->total_syms);
-        launch_wh_hist(s, L, W.counts.as<uint32_t>());
+    HIPCHK(c, W.cursor1.ensure(n_coarse * 4)); HIPCHK(c, W.flag.ensure(16));
+    // ---- partition: slack layout (no histogram pass; see batch_partition_impl), dense layout as the fallback ----
+    W.seg_stride = 0;
+    bool slack = c->opt_dense_layout <= 0 && !W.slack_failed;
+    uint32_t fine_cap = 0;
+    uint64_t region_stride = 0;
+    if (slack) {
+        const uint64_t m = max_g >> bb;
+        fine_cap = (uint32_t)((m + (uint64_t)(6.0 * std::sqrt((double)m + 1.0)) + 32 + 15) / 16 * 16);
+        region_stride = (uint64_t)fine_cap << (bb - b1);
+        if ((double)n_seg * fine_cap > 1.75 * (double)b->total_syms + 65536.0) slack = false;
     }
-    {
-        size_t tb = 0;
-        HIPCHK(c, exclusive_scan_u32_u64(s, W.counts.as<uint32_t>(), W.off.as<uint64_t>(), n_seg + 1, nullptr, tb));
-        HIPCHK(c, W.tmp.ensure(tb));
-        HIPCHK(c, exclusive_scan_u32_u64(s, W.counts.as<uint32_t>(), W.off.as<uint64_t>(), n_seg + 1, W.tmp.p, tb));
+    if (slack) {
+        const uint64_t layout_keys = n_seg * (uint64_t)fine_cap;
+        HIPCHK(c, W.keys.ensure((layout_keys + 4) * 16));
+        if (bb > b1) HIPCHK(c, W.keys1.ensure((layout_keys + 4) * 16));
+        HIPCHK(c, W.len.ensure((n_seg + 1) * 4));
+        HIPCHK(c, hipMemsetAsync(W.cursor1.p, 0, n_coarse * 4, s));
+        HIPCHK(c, hipMemsetAsync(W.flag.p, 0, 16, s));
+        {
+            TimeScope t(c, "wh_scatter_l1", b->total_syms);
+            launch_wh_l1(s, L, nullptr, W.cursor1.as<uint32_t>(), bb > b1 ? W.keys1.p : W.keys.p, region_stride, W.flag.as<int>());
+        }
+        if (bb > b1) {
+            TimeScope t(c, "wh_scatter_l2", b->total_syms);
+            launch_wh_l2(s, L, nullptr, W.keys1.p, W.keys.p, region_stride, fine_cap, W.cursor1.as<uint32_t>(), W.len.as<uint32_t>(), W.flag.as<int>());
+        } else {
+            HIPCHK(c, hipMemcpyAsync(W.len.p, W.cursor1.p, n_seg * 4, hipMemcpyDeviceToDevice, s));
+        }
+        launch_sum_u32(s, W.cursor1.as<uint32_t>(), n_coarse, reinterpret_cast<uint64_t *>(W.flag.as<uint8_t>() + 8));
+        HIPCHK(c, hipGetLastError());
+        struct { int over; int pad; uint64_t total; } h;
+        HIPCHK(c, hipMemcpyAsync(&h, W.flag.p, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (h.over) { W.slack_failed = true; slack = false; }
+        else { b->total_keys = h.total; W.seg_stride = fine_cap; }
     }
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(&b->total_keys, W.off.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    if (!slack) {
+        HIPCHK(c, W.counts.ensure((n_seg + 1) * 4)); HIPCHK(c, W.off.ensure((n_seg + 1) * 8));
+        HIPCHK(c, hipMemsetAsync(W.counts.p, 0, (n_seg + 1) * 4, s));
+        HIPCHK(c, hipMemsetAsync(W.cursor1.p, 0, n_coarse * 4, s));
+        {
+            TimeScope t(c, "wh_hist", b->total_syms);
+            launch_wh_hist(s, L, W.counts.as<uint32_t>());
+        }
+        {
+            size_t tb = 0;
+            HIPCHK(c, exclusive_scan_u32_u64(s, W.counts.as<uint32_t>(), W.off.as<uint64_t>(), n_seg + 1, nullptr, tb));
+            HIPCHK(c, W.tmp.ensure(tb));
+            HIPCHK(c, exclusive_scan_u32_u64(s, W.counts.as<uint32_t>(), W.off.as<uint64_t>(), n_seg + 1, W.tmp.p, tb));
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&b->total_keys, W.off.as<uint64_t>() + n_seg, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        const uint64_t NKd = b->total_keys;
+        HIPCHK(c, W.keys.ensure((NKd + 4) * 16));
+        if (bb > b1) HIPCHK(c, W.keys1.ensure((NKd + 4) * 16));
+        {
+            TimeScope t(c, "wh_scatter_l1", NKd);
+            launch_wh_l1(s, L, W.off.as<uint64_t>(), W.cursor1.as<uint32_t>(), bb > b1 ? W.keys1.p : W.keys.p, 0, nullptr);
+        }
+        if (bb > b1) {
+            TimeScope t(c, "wh_scatter_l2", NKd);
+            launch_wh_l2(s, L, W.off.as<uint64_t>(), W.keys1.p, W.keys.p, 0, 0, nullptr, nullptr, nullptr);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
     const uint64_t NK = b->total_keys;
-    HIPCHK(c, W.keys.ensure((NK + 4) * 16));
-    if (bb > b1) HIPCHK(c, W.keys1.ensure((NK + 4) * 16));
-    {
-        TimeScope t(c, "wh_scatter_l1", NK);
-        launch_wh_l1(s, L, W.off.as<uint64_t>(), W.cursor1.as<uint32_t>(), bb > b1 ? W.keys1.p : W.keys.p);
-    }
-    if (bb > b1) {
-        TimeScope t(c, "wh_scatter_l2", NK);
-        launch_wh_l2(s, L, W.off.as<uint64_t>(), W.keys1.p, W.keys.p);
-    }
-    HIPCHK(c, hipGetLastError());
+    SegLayout seg;
+    if (W.seg_stride) { seg.off = nullptr; seg.len = W.len.as<uint32_t>(); seg.stride = W.seg_stride; }
+    else { seg.off = W.off.as<uint64_t>(); seg.len = nullptr; seg.stride = 0; }
 
-    // ---- per-bucket dictionary, retried with more sub-buckets on LDS overflow ----
-    HIPCHK(c, W.kslot.ensure((NK + 64) * 2));
+    // ---- per-bucket dictionary + presence bits; the sub-bucket count jumps to what a failed launch asked for ----
+    const size_t n_rows = ((size_t)G + 63) / 64;
+    if (n_rows > 0xffffu) { *fallback = true; return GRM_OK; }
+    const uint32_t max_fill = cap - (cap >> 3);
     int sb = c->opt_sub_bits >= 0 ? c->opt_sub_bits : 0;
+    if (c->opt_sub_bits < 0 && W.sb_hint >= 0 && W.sb_hint_k == k && W.sb_hint_bb == bb) sb = W.sb_hint;
     uint32_t n_wg = 0;
-    for (;; sb++) {
-        if ((uint32_t)sb + cap_log2 > 16 || bb + sb > 22) { *fallback = true; return GRM_OK; }
+    bool bits = false;
+    for (int attempt = 0;; attempt++) {
+        if (bb + sb > 22 || attempt > 8) { *fallback = true; return GRM_OK; }
         n_wg = 1u << (bb + sb);
         const size_t slots = (size_t)n_wg * cap;
         HIPCHK(c, W.stage_lo.ensure(slots * 8)); HIPCHK(c, W.stage_hi.ensure(slots * 8)); HIPCHK(c, W.stage_flags.ensure(slots));
-        HIPCHK(c, W.img_lo.ensure(slots * 8)); HIPCHK(c, W.img_hi.ensure(slots * 8));
         HIPCHK(c, W.stage_cnt.ensure((size_t)n_wg * 4 + 4)); HIPCHK(c, W.stage_off.ensure(((size_t)n_wg + 1) * 8));
-        HIPCHK(c, hipMemsetAsync(W.flag.p, 0, 4, s));
+        const size_t ms_bytes = slots * n_rows * 8;
+        bits = ms_bytes <= MATRIX_S_LIMIT;
+        if (!bits) { *fallback = true; return GRM_OK; }            // no probing fill on this path: the sort-based one takes over
+        HIPCHK(c, W.matrix_s.ensure(ms_bytes));
+        HIPCHK(c, W.birth.ensure(slots * 2));
+        HIPCHK(c, hipMemsetAsync(W.flag.p, 0, 16, s));
         {
             TimeScope t(c, "wh_dict_build", NK);
-            launch_wh_dict_build(s, W.keys.p, W.off.as<uint64_t>(), G, bb, sb, cap_log2, W.stage_lo.as<uint64_t>(), W.stage_hi.as<uint64_t>(),
-                                 W.stage_flags.as<uint8_t>(), W.stage_cnt.as<uint32_t>(), W.kslot.as<uint16_t>(), W.img_lo.as<uint64_t>(),
-                                 W.img_hi.as<uint64_t>(), W.flag.as<int>());
+            launch_wh_dict_build(s, W.keys.p, seg, G, bb, sb, cap_log2, W.stage_lo.as<uint64_t>(), W.stage_hi.as<uint64_t>(),
+                                 W.stage_flags.as<uint8_t>(), W.stage_cnt.as<uint32_t>(), W.matrix_s.as<uint64_t>(), W.birth.as<uint16_t>(),
+                                 W.flag.as<int>(), W.flag.as<uint32_t>() + 1);
         }
         HIPCHK(c, hipGetLastError());
-        int ov = 0;
-        HIPCHK(c, hipMemcpyAsync(&ov, W.flag.p, 4, hipMemcpyDeviceToHost, s));
+        struct { int over; uint32_t need; } h;
+        HIPCHK(c, hipMemcpyAsync(&h, W.flag.p, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
-        if (!ov) break;
+        if (!h.over) break;
+        int step = 1;
+        while (step < 22 && ((uint64_t)h.need >> step) > (uint64_t)max_fill * 7 / 10) step++;
+        sb += step;
     }
+    if (c->opt_sub_bits < 0) { W.sb_hint = sb; W.sb_hint_k = k; W.sb_hint_bb = bb; }
+    W.have_bits = bits;
     uint64_t n_local = 0;
     launch_scan_u32(s, W.stage_cnt.as<uint32_t>(), n_wg, W.stage_off.as<uint64_t>());
     HIPCHK(c, hipMemcpyAsync(&n_local, W.stage_off.as<uint64_t>() + n_wg, 8, hipMemcpyDeviceToHost, s));
@@ -2426,6 +2483,16 @@ static int wide_hash_global(grm_batch *b, const uint64_t *hi, const uint64_t *lo
         HIPCHK(c, hipMemcpyAsync(&W.U, W.pos.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
     }
+    // every local entry learns its column (binary search of its (hi, lo) among the sorted entries)
+    HIPCHK(c, W.entry_col.ensure((W.n_local + 1) * 4));
+    if (W.n_local) {
+        TimeScope t(c, "wh_entry_cols", W.n_local);
+        if (n) launch_wh_entry_cols(s, W.t_b.as<uint64_t>(), W.t_a.as<uint64_t>(), W.keep.as<uint32_t>(), W.pos.as<uint32_t>(), n,
+                                    W.loc_hi.as<uint64_t>(), W.loc_lo.as<uint64_t>(), W.n_local, W.entry_col.as<uint32_t>());
+        else HIPCHK(c, hipMemsetAsync(W.entry_col.p, 0xff, W.n_local * 4, s));
+        HIPCHK(c, hipGetLastError());
+    }
+    W.own_dict = n && hi == W.loc_hi.as<uint64_t>() && lo == W.loc_lo.as<uint64_t>() && n == W.n_local;
     W.have_global = true;
     return GRM_OK;
 }
@@ -2435,7 +2502,6 @@ static int wide_hash_fill(grm_batch *b, grm_matrix **out)
     grm_ctx *c = b->ctx;
     hipStream_t s = c->stream;
     WideHash &W = *b->whash;
-    const uint32_t G = (uint32_t)b->n_genomes, cap = 1u << W.cap_log2;
     grm_matrix *m = new grm_matrix();
     m->ctx = c; m->k = b->k; m->words = 2; m->n_genomes = b->n_genomes; m->n_rows = ((size_t)b->n_genomes + 63) / 64;
     auto bail = [&](int code) { delete m; return code; };
@@ -2444,17 +2510,24 @@ static int wide_hash_fill(grm_batch *b, grm_matrix **out)
     const size_t cells = m->n_rows * (size_t)U;
     if (m->d_data.alloc(cells * 8) != hipSuccess || m->d_kmers.alloc(((size_t)U + 1) * 16) != hipSuccess)
         return bail(fail(c, GRM_ERR_OOM, "matrix allocation failed"));
-    if (cells) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
     if (U) {
-        const size_t slots = (size_t)W.n_wg * cap;
-        if (W.col_of_slot.ensure(slots * 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
-        (void)hipMemsetAsync(W.col_of_slot.p, 0xff, slots * 4, s);
-        launch_wh_select_cols(s, W.t_b.as<uint64_t>(), W.t_a.as<uint64_t>(), W.keep.as<uint32_t>(), W.pos.as<uint32_t>(), W.n_sorted, b->bb, W.sb,
-                              W.cap_log2, W.img_lo.as<uint64_t>(), W.img_hi.as<uint64_t>(), m->d_kmers.as<uint64_t>(), W.col_of_slot.as<uint32_t>());
-        if (cells && b->total_keys) {
-            TimeScope t(c, "matrix_fill", b->total_keys);
-            launch_matrix_fill_slots(s, W.kslot.as<uint16_t>(), W.off.as<uint64_t>(), nullptr, G, b->bb, W.sb, W.cap_log2, W.col_of_slot.as<uint32_t>(),
-                                     m->d_data.as<uint64_t>(), U);
+        launch_wh_select(s, W.t_b.as<uint64_t>(), W.t_a.as<uint64_t>(), W.keep.as<uint32_t>(), W.pos.as<uint32_t>(), W.n_sorted, m->d_kmers.as<uint64_t>());
+        if (cells && b->total_keys && W.have_bits) {
+            // the shared fill: entry-major lines + transpose from 4 word-rows up (zeroed when columns may lack a local entry)
+            uint64_t *em = nullptr;
+            const bool two_step = m->n_rows >= 4 && c->opt_direct_permute <= 0;
+            if (two_step) {
+                if (W.entry_major.ensure(cells * 8) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "matrix_fill: entry-major scratch"));
+                em = W.entry_major.as<uint64_t>();
+                if (!W.own_dict) (void)hipMemsetAsync(em, 0, cells * 8, s);
+            } else {
+                (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
+            }
+            TimeScope t(c, "matrix_fill", (uint64_t)W.n_local * m->n_rows);
+            launch_matrix_permute(s, W.matrix_s.as<uint64_t>(), W.birth.as<uint16_t>(), W.stage_off.as<uint64_t>(), W.stage_cnt.as<uint32_t>(),
+                                  W.entry_col.as<uint32_t>(), W.n_wg, (uint32_t)m->n_rows, W.cap_log2, m->d_data.as<uint64_t>(), U, em);
+        } else if (cells) {
+            (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
         }
     }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "wide hash pipeline failed"));
@@ -2482,16 +2555,16 @@ static int wide_stage_local(grm_batch *b, int k)
     if (rc) return rc;
     if (fallback && (b->total_syms == 0 || b->n_genomes == 0)) {       // nothing to count: an empty local dictionary
         WideHash &W = *b->whash;
-        // one all-empty table image, so that the column pass of the fill has something to probe
         W.n_local = 0; W.n_wg = 1; W.sb = 0; W.cap_log2 = 6;
         b->total_keys = 0;
         b->k = k;
         b->bb = 0;
         HIPCHK(c, W.loc_lo.ensure(16)); HIPCHK(c, W.loc_hi.ensure(16)); HIPCHK(c, W.loc_flags.ensure(16));
-        HIPCHK(c, W.img_lo.ensure(64 * 8)); HIPCHK(c, W.img_hi.ensure(64 * 8));
-        HIPCHK(c, hipMemsetAsync(W.img_lo.p, 0xff, 64 * 8, c->stream));
-        HIPCHK(c, hipMemsetAsync(W.img_hi.p, 0xff, 64 * 8, c->stream));
+        HIPCHK(c, W.stage_off.ensure(16)); HIPCHK(c, W.stage_cnt.ensure(16));
+        HIPCHK(c, hipMemsetAsync(W.stage_off.p, 0, 16, c->stream));
+        HIPCHK(c, hipMemsetAsync(W.stage_cnt.p, 0, 16, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        W.have_bits = false;
         W.have_local = true;
     } else if (fallback) {
         return fail(c, GRM_ERR_UNSUPPORTED, "k=%d: this input is too deep for the staged two-word pipeline (use grm_batch_run)", k);

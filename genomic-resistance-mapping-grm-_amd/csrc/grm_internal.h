@@ -145,12 +145,6 @@ void launch_dict_entry_cols(hipStream_t s, const uint64_t *dict, uint64_t n_dict
 void launch_matrix_permute(hipStream_t s, const uint64_t *matrix_s, const uint16_t *birth, const uint64_t *wg_base,
                            const uint32_t *wg_cnt, const uint32_t *entry_col, uint32_t n_wg, uint32_t n_rows, uint32_t cap_log2,
                            uint64_t *matrix, uint64_t n_cols, uint64_t *entry_major);
-// slot form of the fill (two-word pipeline): presence bits from the 2-byte slot ids its dictionary kernel leaves behind
-void launch_matrix_fill_slots(hipStream_t s, const uint16_t *kslot, const uint64_t *off, const uint32_t *len,
-                              uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint32_t *col_of_slot,
-                              uint64_t *matrix, uint64_t n_cols);
-void launch_dict_gather(hipStream_t s, const uint64_t *stage_keys, const uint8_t *stage_flags, const uint64_t *stage_off,
-                        uint32_t n_wg, uint32_t cap, uint64_t *out_keys, uint8_t *out_flags);
 void launch_dict_mark(hipStream_t s, const uint64_t *skeys, const uint8_t *sflags, uint64_t n, int filter_singleton,
                       uint32_t *keep);
 void launch_dict_select(hipStream_t s, const uint64_t *skeys, const uint32_t *keep, const uint64_t *pos, uint64_t n,
@@ -234,18 +228,21 @@ void launch_multi_split(hipStream_t s, int words, const uint64_t *keys, uint64_t
 
 // ---- two-word k-mers, hash-partition pipeline (grm_wide_hash.hip) ----
 void launch_wh_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
-void launch_wh_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, void *out);
-void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const void *keys1, void *keys);
-void launch_wh_dict_build(hipStream_t s, const void *keys, const uint64_t *off, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
-                          uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint16_t *kslot,
-                          uint64_t *img_lo, uint64_t *img_hi, int *overflow);
+void launch_wh_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, void *out, uint64_t region_stride, int *overflow);
+void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const void *keys1, void *keys, uint64_t region_stride,
+                  uint32_t fine_cap, const uint32_t *cursor1, uint32_t *len_out, int *overflow);
+// entries leave staged at wg * cap in entry-id order; presence words at matrix_s[wg][row][entry id] (nullptr: no bits)
+void launch_wh_dict_build(hipStream_t s, const void *keys, const SegLayout &seg, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
+                          uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint64_t *matrix_s,
+                          uint16_t *birth, int *overflow, uint32_t *need);
 void launch_wh_dict_gather(hipStream_t s, const uint64_t *stage_lo, const uint64_t *stage_hi, const uint8_t *stage_flags,
                            const uint64_t *stage_off, uint32_t n_wg, uint32_t cap, uint64_t *out_lo, uint64_t *out_hi, uint8_t *out_flags);
 void launch_wh_mark(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint8_t *flags, const uint32_t *order, uint64_t n,
                     int filter_singleton, uint32_t *keep);
-void launch_wh_select_cols(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
-                           int bb, int sb, uint32_t cap_log2, const uint64_t *img_lo, const uint64_t *img_hi, uint64_t *dict,
-                           uint32_t *col_of_slot);
+void launch_wh_select(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
+                      uint64_t *dict);
+void launch_wh_entry_cols(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
+                          const uint64_t *e_hi, const uint64_t *e_lo, uint64_t n_entries, uint32_t *entry_col);
 hipError_t wh_set_max_dynamic_lds();
 
 }  // namespace grm

@@ -1445,75 +1445,6 @@ __global__ __launch_bounds__(256) void matrix_transpose_kernel(const uint64_t *_
     }
 }
 
-// Stage 3b, slot form: presence bits from the slot ids dict_build left behind.
-// 2 bytes per k-mer occurrence instead of 8, no hashing, no probing.
-__global__ __launch_bounds__(1024) void matrix_fill_slots_kernel(
-    const uint16_t *__restrict__ kslot, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
-    uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint32_t *__restrict__ col_of_slot,
-    uint64_t *__restrict__ matrix, uint64_t n_cols)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
-    uint64_t *words = reinterpret_cast<uint64_t *>(lds_raw);
-    uint32_t *cols = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 8);
-    const uint32_t wg = blockIdx.x;
-    const uint32_t B = 1u << bb;
-    const uint32_t b = wg >> sb, sub = wg & ((1u << sb) - 1);
-    uint32_t any = 0;
-    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) {
-        const uint32_t c = col_of_slot[((uint64_t)wg << cap_log2) + i];
-        cols[i] = c;
-        any |= (c != 0xffffffffu);
-    }
-    if (!__syncthreads_or((int)any)) return;     // no column lives in this (bucket, sub-bucket)
-    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
-    const uint32_t n_rows = (n_genomes + 63) >> 6;
-    for (uint32_t r = 0; r < n_rows; r++) {
-        for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) words[i] = 0;
-        __syncthreads();
-        const uint32_t g_end = min(r * 64 + 64, n_genomes);
-        // the segment bounds of the NEXT genome are requested while the current one is processed
-        // (offsets, then slots: two dependent global round trips per genome otherwise)
-        uint64_t s0 = 0, n = 0;
-        if (r * 64 + wave < g_end) {
-            const uint64_t idx = (uint64_t)(r * 64 + wave) * B + b;
-            s0 = off[idx];
-            n = len ? (uint64_t)len[idx] : off[idx + 1] - s0;
-        }
-        for (uint32_t g = r * 64 + wave; g < g_end; g += nw) {
-            const unsigned long long bit = 1ull << (63 - (g & 63));
-            uint64_t s0_next = 0, n_next = 0;
-            if (g + nw < g_end) {
-                const uint64_t idx = (uint64_t)(g + nw) * B + b;
-                s0_next = off[idx];
-                n_next = len ? (uint64_t)len[idx] : off[idx + 1] - s0_next;
-            }
-            for (uint64_t i0 = lane; i0 < n; i0 += 64 * SLOTS_IN_FLIGHT) {
-                uint32_t sv[SLOTS_IN_FLIGHT];
-#pragma unroll
-                for (int j = 0; j < SLOTS_IN_FLIGHT; j++) {
-                    const uint64_t i = i0 + 64u * j;
-                    sv[j] = i < n ? (uint32_t)kslot[s0 + i] : 0xffffffffu;
-                }
-#pragma unroll
-                for (int j = 0; j < SLOTS_IN_FLIGHT; j++) {
-                    if (sv[j] == 0xffffffffu) continue;
-                    if (sb && (sv[j] >> cap_log2) != sub) continue;
-                    atomicOr((unsigned long long *)&words[sv[j] & cap_mask], bit);
-                }
-            }
-            s0 = s0_next;
-            n = n_next;
-        }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) {
-            const uint32_t c = cols[i];
-            if (c != 0xffffffffu) matrix[(uint64_t)r * n_cols + c] = words[i];
-        }
-        __syncthreads();
-    }
-}
-
 // After sorting the (possibly multi-rank) concatenated dictionaries by key: one thread per
 // element; the head of each run of equal keys decides keep/drop.
 // multi = run longer than 1 (k-mer seen on several ranks) or any member flagged 2.
@@ -1958,14 +1889,6 @@ void launch_matrix_permute(hipStream_t s, const uint64_t *matrix_s, const uint16
     hipLaunchKernelGGL(matrix_transpose_kernel, dim3((uint32_t)(n_tiles < 256u * 64u ? n_tiles : 256u * 64u)), dim3(256), 0, s, entry_major,
                        n_cols, n_rows, matrix);
 }
-void launch_matrix_fill_slots(hipStream_t s, const uint16_t *kslot, const uint64_t *off, const uint32_t *len,
-                              uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint32_t *col_of_slot,
-                              uint64_t *matrix, uint64_t n_cols)
-{
-    const size_t lds = ((size_t)12) << cap_log2;
-    hipLaunchKernelGGL(matrix_fill_slots_kernel, dim3(1u << (bb + sb)), dim3(g_table_threads), lds, s, kslot, off, len,
-                       n_genomes, bb, sb, cap_log2, col_of_slot, matrix, n_cols);
-}
 void launch_dict_mark(hipStream_t s, const uint64_t *skeys, const uint8_t *sflags, uint64_t n, int filter_singleton,
                       uint32_t *keep)
 {
@@ -2154,7 +2077,6 @@ hipError_t set_max_dynamic_lds()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(matrix_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(matrix_fill_slots_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     return e;
 }
 

@@ -1,8 +1,8 @@
 // grm_wide_hash.hip -- the hash-partition pipeline for two-word k-mers (33 <= k <= 64).
 //
-// Same stages as grm_kernels.hip (histogram -> two-level LDS-staged partition -> per-bucket LDS
-// dictionary with slot ids -> slot-form fill), with 16-byte keys (hi, lo).  The fill kernel is
-// shared (it only sees slot ids).  Differences that matter:
+// Same stages as grm_kernels.hip (two-level LDS-staged partition into fixed-capacity segments, or into histogram-sized
+// ones as the fallback -> per-bucket LDS dictionary that also sets the presence bits -> the shared permutation fill),
+// with 16-byte keys (hi, lo).  Differences that matter:
 //   * tiles hold 4096 keys (64 KiB of LDS) instead of 8192;
 //   * LDS tables are {lo[cap], hi[cap], state[cap]} and there is no 128-bit LDS compare-and-swap:
 //     a slot is claimed with a 64-bit CAS on `lo`, then `hi` is published; a prober that meets a
@@ -103,9 +103,11 @@ __global__ __launch_bounds__(WH_THREADS) void wide_hist_kernel(WideArgs a, uint3
 }
 
 // ---- level 1: tile of 4096 positions -> coarse buckets ---------------------------------------
+// region_stride != 0: fixed-capacity regions (slack layout, see kmer_scatter_l1_kernel), else regions from `off`
 __global__ __launch_bounds__(WH_THREADS) void wide_l1_kernel(WideArgs a, int b1bits, uint32_t n_tiles,
                                                              const uint64_t *__restrict__ off, uint32_t *__restrict__ cursor1,
-                                                             ulonglong2 *__restrict__ keys1)
+                                                             ulonglong2 *__restrict__ keys1, uint64_t region_stride,
+                                                             int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     ulonglong2 *skeys = reinterpret_cast<ulonglong2 *>(lds_raw);                          // [WH_TILE]
@@ -140,7 +142,12 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l1_kernel(WideArgs a, int b1b
         start[threadIdx.x] = st;
         if (c) {
             const uint64_t cidx = (uint64_t)gen0 * B1 + threadIdx.x;
-            gbase[threadIdx.x] = off[(uint64_t)gen0 * (1ull << a.bb) + ((uint64_t)threadIdx.x << b2bits)] + atomicAdd(&cursor1[cidx], c);
+            const uint64_t region0 = region_stride ? cidx * region_stride
+                                                   : off[(uint64_t)gen0 * (1ull << a.bb) + ((uint64_t)threadIdx.x << b2bits)];
+            const uint32_t reserved = atomicAdd(&cursor1[cidx], c);
+            const bool fits = !region_stride || (uint64_t)reserved + c <= region_stride;
+            if (!fits) atomicExch(overflow, 1);
+            gbase[threadIdx.x] = fits ? region0 + reserved : ~0ull;
         }
         __syncthreads();
 #pragma unroll
@@ -150,7 +157,8 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l1_kernel(WideArgs a, int b1b
         for (uint32_t i = threadIdx.x; i < n_tile; i += WH_THREADS) {
             const ulonglong2 key = skeys[i];
             const uint32_t b1 = hash_bucket(mix128(key.y, key.x), b1bits);
-            keys1[gbase[b1] + (i - start[b1])] = key;
+            const uint64_t gb = gbase[b1];
+            if (gb != ~0ull) keys1[gb + (i - start[b1])] = key;
         }
     } else {
         if (p0 >= a.total_syms) return;
@@ -160,15 +168,19 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l1_kernel(WideArgs a, int b1b
             while (p0 + (uint64_t)i >= gend) { gen++; gend = a.genome_sym_off[gen + 1]; }
             const uint32_t b1 = hash_bucket(mix128(c.hi, c.lo), b1bits);
             const uint64_t cidx = (uint64_t)gen * B1 + b1;
-            const uint64_t region0 = off[(uint64_t)gen * (1ull << a.bb) + ((uint64_t)b1 << b2bits)];
-            keys1[region0 + atomicAdd(&cursor1[cidx], 1u)] = make_ulonglong2(c.lo, c.hi);
+            const uint64_t region0 = region_stride ? cidx * region_stride : off[(uint64_t)gen * (1ull << a.bb) + ((uint64_t)b1 << b2bits)];
+            const uint32_t at = atomicAdd(&cursor1[cidx], 1u);
+            if (region_stride && at >= region_stride) atomicExch(overflow, 1);
+            else keys1[region0 + at] = make_ulonglong2(c.lo, c.hi);
         });
     }
 }
 
 // ---- level 2: (genome, coarse bucket) region -> fine buckets ------------------------------------
 __global__ __launch_bounds__(WH_THREADS) void wide_l2_kernel(const ulonglong2 *__restrict__ keys1, ulonglong2 *__restrict__ keys,
-                                                             const uint64_t *__restrict__ off, uint64_t n_regions, int bb, int b1bits)
+                                                             const uint64_t *__restrict__ off, uint64_t n_regions, int bb, int b1bits,
+                                                             uint64_t region_stride, uint32_t fine_cap, const uint32_t *__restrict__ cursor1,
+                                                             uint32_t *__restrict__ len_out, int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     ulonglong2 *skeys = reinterpret_cast<ulonglong2 *>(lds_raw);
@@ -181,8 +193,17 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l2_kernel(const ulonglong2 *_
     for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
         const uint64_t g = region >> b1bits, c1 = region & ((1u << b1bits) - 1);
         const uint64_t fine0 = (g << bb) + (c1 << b2bits);
-        const uint64_t r0 = off[fine0], r1 = off[fine0 + B2];
-        uint64_t my_next = threadIdx.x < B2 ? off[fine0 + threadIdx.x] : 0;   // running output position of fine bucket t
+        uint64_t r0, r1, my_first = 0;
+        if (region_stride) {
+            r0 = region * region_stride;
+            r1 = r0 + min((uint64_t)cursor1[region], region_stride);
+            if (threadIdx.x < B2) my_first = (fine0 + threadIdx.x) * (uint64_t)fine_cap;
+        } else {
+            r0 = off[fine0];
+            r1 = off[fine0 + B2];
+            if (threadIdx.x < B2) my_first = off[fine0 + threadIdx.x];
+        }
+        uint64_t my_next = my_first;   // running output position of fine bucket t
         for (uint64_t base = r0; base < r1; base += WH_TILE) {
             const uint32_t n = (uint32_t)min((uint64_t)WH_TILE, r1 - base);
             if (threadIdx.x < B2) hist[threadIdx.x] = 0;
@@ -207,8 +228,10 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l2_kernel(const ulonglong2 *_
             const uint32_t st = block_scan_sum(c, scratch, &n_tile);
             if (threadIdx.x < B2) {
                 start[threadIdx.x] = st;
-                gbase[threadIdx.x] = my_next;
-                my_next += c;
+                const bool fits = !region_stride || my_next + c <= my_first + fine_cap;
+                if (!fits) atomicExch(overflow, 1);
+                gbase[threadIdx.x] = fits ? my_next : ~0ull;
+                if (fits) my_next += c;
             }
             __syncthreads();
 #pragma unroll
@@ -218,10 +241,12 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l2_kernel(const ulonglong2 *_
             for (uint32_t i = threadIdx.x; i < n; i += WH_THREADS) {
                 const ulonglong2 key = skeys[i];
                 const uint32_t b2 = hash_bucket(mix128(key.y, key.x), bb) & (B2 - 1);
-                keys[gbase[b2] + (i - start[b2])] = key;
+                const uint64_t gb = gbase[b2];
+                if (gb != ~0ull) keys[gb + (i - start[b2])] = key;
             }
             __syncthreads();
         }
+        if (region_stride && threadIdx.x < B2) len_out[fine0 + threadIdx.x] = (uint32_t)(my_next - my_first);
     }
 }
 
@@ -236,17 +261,17 @@ __device__ __forceinline__ uint32_t wide_find_or_insert(uint64_t *tlo, uint64_t 
     // every lane goes round this loop until it is done; a lane that meets a claimed-but-unpublished
     // slot re-reads it next time round (the claimer published in the meantime or will soon)
     for (uint32_t guard = 0; guard < 64u * (cap_mask + 1); guard++) {
-        uint64_t cur = *reinterpret_cast<volatile uint64_t *>(&tlo[slot]);
+        uint64_t cur = __hip_atomic_load(&tlo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == WH_EMPTY) {
             cur = atomicCAS((unsigned long long *)&tlo[slot], (unsigned long long)WH_EMPTY, (unsigned long long)lo);
             if (cur == WH_EMPTY) {                                   // claimed: publish hi
-                *reinterpret_cast<volatile uint64_t *>(&thi[slot]) = hi;
+                __hip_atomic_store(&thi[slot], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 *inserted = true;
                 return slot;
             }
         }
         if (cur == lo) {
-            const uint64_t ch = *reinterpret_cast<volatile uint64_t *>(&thi[slot]);
+            const uint64_t ch = __hip_atomic_load(&thi[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ch == hi) return slot;
             if (ch == WH_PENDING) continue;                          // not published yet: look again
         }
@@ -259,114 +284,140 @@ __device__ __forceinline__ uint32_t wide_find_or_insert(uint64_t *tlo, uint64_t 
 // NOTE: hi == WH_PENDING (all ones) together with a real lo is impossible for k <= 63 (hi has
 // at most 62 significant bits); for k == 64 a canonical k-mer cannot start with 32 G's
 // (its reverse complement would start with C's and be smaller), so hi is never all ones either.
+//
+// As dict_build_kernel (grm_kernels.hip): the union of a bucket over all genomes AND the presence bits, one word-row
+// (64 genomes) between two barriers; words[slot] collects the bits of the current row, meta[slot] = entry id | SEEN |
+// MULTI.  Entries leave in entry-id order at wg * cap (staged; the host gathers them densely in workgroup order, which
+// is also the order of the exchange records), the words at matrix_s[wg][row][entry id].
+constexpr uint32_t WMETA_ID = 0x1fffu, WMETA_SEEN = 0x4000u, WMETA_MULTI = 0x8000u;
 __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
-    const ulonglong2 *__restrict__ keys, const uint64_t *__restrict__ off, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
+    const ulonglong2 *__restrict__ keys, const SegLayout seg, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
     uint64_t *__restrict__ stage_lo, uint64_t *__restrict__ stage_hi, uint8_t *__restrict__ stage_flags,
-    uint32_t *__restrict__ stage_cnt, uint16_t *__restrict__ kslot, uint64_t *__restrict__ img_lo, uint64_t *__restrict__ img_hi,
-    int *__restrict__ overflow)
+    uint32_t *__restrict__ stage_cnt, uint64_t *__restrict__ matrix_s, uint16_t *__restrict__ birth, int *__restrict__ overflow,
+    uint32_t *__restrict__ need)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
     uint64_t *tlo = reinterpret_cast<uint64_t *>(lds_raw);
     uint64_t *thi = reinterpret_cast<uint64_t *>(lds_raw + (size_t)cap * 8);
-    uint32_t *tstate = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 16);
-    uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 20);
+    unsigned long long *words = reinterpret_cast<unsigned long long *>(lds_raw + (size_t)cap * 16);
+    uint16_t *meta = reinterpret_cast<uint16_t *>(lds_raw + (size_t)cap * 24);
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 26);
     volatile int &full = *reinterpret_cast<volatile int *>(scratch + 16);
     uint32_t &n_distinct = scratch[17];
     const uint32_t wg = blockIdx.x;
     const uint32_t B = 1u << bb;
     const uint32_t b = wg >> sb, sub = wg & ((1u << sb) - 1);
-    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tlo[i] = WH_EMPTY; thi[i] = WH_PENDING; tstate[i] = 0; }
+    const uint32_t G = n_genomes, n_rows = (G + 63) >> 6;
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tlo[i] = WH_EMPTY; thi[i] = WH_PENDING; words[i] = 0; meta[i] = 0; }
     if (threadIdx.x == 0) { full = 0; n_distinct = 0; }
     __syncthreads();
-    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;
+    const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;        // nw = 8: divides 64
     const uint32_t max_fill = cap - (cap >> 3);
+    const uint32_t per_row = 64u / (uint32_t)nw;
+    auto seg_of = [&](uint32_t gg, uint64_t &s0, uint64_t &n) {
+        const uint64_t idx = (uint64_t)gg * B + b;
+        if (seg.off) { s0 = seg.off[idx]; n = seg.len ? (uint64_t)seg.len[idx] : seg.off[idx + 1] - s0; }
+        else { s0 = idx * seg.stride; n = seg.len[idx]; }
+    };
     // bounds of the next genome's segment are requested while the current one is processed
+    uint32_t g = (uint32_t)wave;
     uint64_t s0 = 0, n = 0;
-    if ((uint32_t)wave < n_genomes) {
-        const uint64_t idx = (uint64_t)wave * B + b;
-        s0 = off[idx];
-        n = off[idx + 1] - s0;
-    }
-    for (uint32_t g = wave; g < n_genomes; g += nw) {
-        uint64_t s0_next = 0, n_next = 0;
-        if (g + nw < n_genomes) {
-            const uint64_t idx = (uint64_t)(g + nw) * B + b;
-            s0_next = off[idx];
-            n_next = off[idx + 1] - s0_next;
-        }
-        for (uint64_t i0 = lane; i0 < n; i0 += 64 * 2) {
-            ulonglong2 kv[2];
-            uint64_t hv[2];
-            uint32_t sl[2];
+    if (g < G) seg_of(g, s0, n);
+    for (uint32_t r = 0; r < n_rows; r++) {
+        for (uint32_t jr = 0; jr < per_row; jr++, g += nw) {
+            uint64_t s0_next = 0, n_next = 0;
+            if (g + nw < G) seg_of(g + nw, s0_next, n_next);
+            if (g < G && !full) {
+                const unsigned long long bit = 1ull << (63 - (g & 63));
+                for (uint64_t i0 = lane; i0 < n && !full; i0 += 64 * 2) {
+                    ulonglong2 kv[2];
+                    uint64_t hv[2];
+                    uint32_t sl[2];
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const uint64_t i = i0 + 64u * j;
-                kv[j] = i < n ? keys[s0 + i] : make_ulonglong2(WH_EMPTY, WH_EMPTY);
-                hv[j] = mix128(kv[j].y, kv[j].x);
-                sl[j] = hash_slot(hv[j], cap_mask);
+                    for (int j = 0; j < 2; j++) {
+                        const uint64_t i = i0 + 64u * j;
+                        kv[j] = i < n ? keys[s0 + i] : make_ulonglong2(WH_EMPTY, WH_EMPTY);
+                        hv[j] = mix128(kv[j].y, kv[j].x);
+                        sl[j] = hash_slot(hv[j], cap_mask);
+                    }
+                    // first and second probe slot in the straight-line part: a key that sits one slot past its home
+                    // must not go through the divergent insertion loop for every genome
+                    uint64_t cl[2][2], ch[2][2];
+#pragma unroll
+                    for (int p = 0; p < 2; p++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const uint32_t at = (sl[j] + p) & cap_mask;
+                            cl[p][j] = tlo[at]; ch[p][j] = thi[at];
+                        }
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const bool real = !(kv[j].x == WH_EMPTY && kv[j].y == WH_EMPTY);
+                        if (!real) continue;
+                        if (sb && hash_sub(hv[j], bb, sb) != sub) continue;
+                        uint32_t slot = sl[j];
+                        bool done = false;
+#pragma unroll
+                        for (int p = 1; p >= 0; p--) {
+                            const bool hit = cl[p][j] == kv[j].x && ch[p][j] == kv[j].y;
+                            if (hit) slot = (sl[j] + p) & cap_mask;
+                            done |= hit;
+                        }
+                        if (!done) {
+                            bool ins;
+                            slot = wide_find_or_insert(tlo, thi, cap_mask, kv[j].y, kv[j].x, hv[j], &ins);
+                            bool over = slot == 0xffffffffu;
+                            if (!over && ins) {
+                                const uint32_t id = atomicAdd(&n_distinct, 1u);
+                                meta[slot] = (uint16_t)(id & WMETA_ID);
+                                if (birth && id < cap) birth[((uint64_t)wg << cap_log2) + id] = (uint16_t)r;
+                                over = id >= max_fill;
+                            }
+                            if (over) {
+                                full = 1;
+                                const uint64_t est = (uint64_t)max_fill * G / (g + 1);
+                                atomicMax(need, (uint32_t)min(est, (uint64_t)0xffffffffu));
+                                if (slot == 0xffffffffu) continue;
+                            }
+                        }
+                        __hip_atomic_fetch_or(&words[slot], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
             }
-            // first and second probe slot in the straight-line part (see dict_build_kernel): a key that sits
-            // one slot past its home must not go through the divergent insertion loop for every genome
-            uint64_t cl[2][2], ch[2][2];
-            uint32_t cs[2][2];
-#pragma unroll
-            for (int p = 0; p < 2; p++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const uint32_t at = (sl[j] + p) & cap_mask;
-                    cl[p][j] = tlo[at]; ch[p][j] = thi[at]; cs[p][j] = tstate[at];
-                }
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const bool real = !(kv[j].x == WH_EMPTY && kv[j].y == WH_EMPTY);
-                if (!real) continue;
-                if (sb && hash_sub(hv[j], bb, sb) != sub) continue;
-                uint32_t slot = sl[j];
-                bool done = false;
-#pragma unroll
-                for (int p = 1; p >= 0; p--) {
-                    const bool hit = cl[p][j] == kv[j].x && ch[p][j] == kv[j].y && ((cs[p][j] >> 31) || cs[p][j] == g + 1);
-                    if (hit) slot = (sl[j] + p) & cap_mask;
-                    done |= hit;
-                }
-                if (!done) {
-                    bool ins;
-                    slot = wide_find_or_insert(tlo, thi, cap_mask, kv[j].y, kv[j].x, hv[j], &ins);
-                    if (slot == 0xffffffffu) { full = 1; continue; }
-                    if (ins && atomicAdd(&n_distinct, 1u) >= max_fill) full = 1;
-                    const uint32_t st = atomicCAS(&tstate[slot], 0u, g + 1);
-                    if (st != 0 && !(st >> 31) && st != g + 1) atomicOr(&tstate[slot], 0x80000000u);
-                }
-                kslot[s0 + i0 + 64u * j] = (uint16_t)((sub << cap_log2) | slot);
+            s0 = s0_next;
+            n = n_next;
+        }
+        __syncthreads();
+        if (full) break;         // read between two barriers: uniform
+        for (uint32_t slot = threadIdx.x; slot < cap; slot += blockDim.x) {
+            if (tlo[slot] == WH_EMPTY) continue;
+            const unsigned long long wd = words[slot];
+            const uint32_t m = meta[slot];
+            if (matrix_s) matrix_s[(((uint64_t)wg * n_rows + r) << cap_log2) + (m & WMETA_ID)] = wd;
+            if (wd) {
+                const bool multi = (m & WMETA_SEEN) || (wd & (wd - 1));
+                meta[slot] = (uint16_t)(m | WMETA_SEEN | (multi ? WMETA_MULTI : 0u));
+                words[slot] = 0;
             }
         }
-        s0 = s0_next;
-        n = n_next;
-        if (full) break;
+        __syncthreads();
     }
     __syncthreads();
     if (full) {
         if (threadIdx.x == 0) { atomicExch(overflow, 1); stage_cnt[wg] = 0; }
         return;
     }
-    uint32_t base = 0;
     const uint64_t out0 = (uint64_t)wg * cap;
-    for (uint32_t s = 0; s < cap; s += blockDim.x) {
-        const uint32_t slot = s + threadIdx.x;
-        const uint64_t lo = slot < cap ? tlo[slot] : WH_EMPTY;
-        const bool keep = lo != WH_EMPTY;
-        uint32_t sweep_total;
-        const uint32_t pos = sweep_compact(keep, scratch, &sweep_total);
-        if (keep) {
-            stage_lo[out0 + base + pos] = lo;
-            stage_hi[out0 + base + pos] = thi[slot];
-            stage_flags[out0 + base + pos] = (tstate[slot] & 0x80000000u) ? 2 : 1;
-        }
-        base += sweep_total;
+    for (uint32_t slot = threadIdx.x; slot < cap; slot += blockDim.x) {
+        const uint64_t lo = tlo[slot];
+        if (lo == WH_EMPTY) continue;
+        const uint32_t m = meta[slot];
+        stage_lo[out0 + (m & WMETA_ID)] = lo;
+        stage_hi[out0 + (m & WMETA_ID)] = thi[slot];
+        stage_flags[out0 + (m & WMETA_ID)] = (m & WMETA_MULTI) ? 2 : 1;
     }
-    if (threadIdx.x == 0) stage_cnt[wg] = base;
-    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { img_lo[out0 + i] = tlo[i]; img_hi[out0 + i] = thi[i]; }
+    if (threadIdx.x == 0) stage_cnt[wg] = n_distinct;
 }
 
 // dense (hi, lo, flag) lists from the staged per-workgroup dictionaries
@@ -397,28 +448,34 @@ __global__ void wide_mark_kernel(const uint64_t *__restrict__ s_hi, const uint64
         keep[i] = (head && (!filter_singleton || several)) ? 1u : 0u;
     }
 }
-// final dictionary (hi, lo interleaved, ascending) + column of every table slot
-__global__ void wide_select_cols_kernel(const uint64_t *__restrict__ s_hi, const uint64_t *__restrict__ s_lo,
-                                        const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, uint64_t n, int bb, int sb,
-                                        uint32_t cap_log2, const uint64_t *__restrict__ img_lo, const uint64_t *__restrict__ img_hi,
-                                        uint64_t *__restrict__ dict, uint32_t *__restrict__ col_of_slot)
+// final dictionary (hi, lo interleaved, ascending)
+__global__ void wide_select_kernel(const uint64_t *__restrict__ s_hi, const uint64_t *__restrict__ s_lo,
+                                   const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, uint64_t n,
+                                   uint64_t *__restrict__ dict)
 {
-    const uint32_t cap_mask = (1u << cap_log2) - 1;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         if (!keep[i]) continue;
-        const uint64_t hi = s_hi[i], lo = s_lo[i];
         const uint32_t c = pos[i];
-        dict[2ull * c] = hi;
-        dict[2ull * c + 1] = lo;
-        const uint64_t h = mix128(hi, lo);
-        const uint64_t wg = ((uint64_t)hash_bucket(h, bb) << sb) | hash_sub(h, bb, sb);
-        uint32_t slot = hash_slot(h, cap_mask);
-        for (uint32_t probe = 0; probe <= cap_mask; probe++) {
-            const uint64_t cl = img_lo[(wg << cap_log2) + slot];
-            if (cl == lo && img_hi[(wg << cap_log2) + slot] == hi) { col_of_slot[(wg << cap_log2) + slot] = c; break; }
-            if (cl == WH_EMPTY) break;
-            slot = (slot + 1) & cap_mask;
+        dict[2ull * c] = s_hi[i];
+        dict[2ull * c + 1] = s_lo[i];
+    }
+}
+// column of every local entry: binary search of its (hi, lo) among the n sorted entries of all ranks; the first entry of
+// its run says whether the k-mer was kept and which column it got (0xffffffff: filtered out)
+__global__ void wide_entry_cols_kernel(const uint64_t *__restrict__ s_hi, const uint64_t *__restrict__ s_lo,
+                                       const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, uint64_t n,
+                                       const uint64_t *__restrict__ e_hi, const uint64_t *__restrict__ e_lo, uint64_t n_entries,
+                                       uint32_t *__restrict__ entry_col)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t hi = e_hi[e], lo = e_lo[e];
+        uint64_t a = 0, b = n;
+        while (a < b) {
+            const uint64_t m = (a + b) >> 1;
+            const uint64_t mh = s_hi[m];
+            if (mh < hi || (mh == hi && s_lo[m] < lo)) a = m + 1; else b = m;
         }
+        entry_col[e] = (a < n && s_hi[a] == hi && s_lo[a] == lo && keep[a]) ? pos[a] : 0xffffffffu;
     }
 }
 
@@ -437,30 +494,31 @@ void launch_wh_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts)
     const uint32_t tpb = 16;       // 64 Ki positions per LDS histogram flush
     hipLaunchKernelGGL(wide_hist_kernel, dim3((n_tiles + tpb - 1) / tpb), dim3(WH_THREADS), (size_t)4 << L.bb, s, wargs(L), n_tiles, tpb, counts);
 }
-void launch_wh_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, void *out)
+void launch_wh_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint32_t *cursor1, void *out, uint64_t region_stride, int *overflow)
 {
     if (!L.total_syms) return;
     const uint32_t n_tiles = (uint32_t)((L.total_syms + WH_TILE - 1) / WH_TILE);
     const uint32_t grid = ((n_tiles + 7) / 8) * 8;
     hipLaunchKernelGGL(wide_l1_kernel, dim3(grid), dim3(WH_THREADS), WH_LDS_BYTES, s, wargs(L), scatter_b1_bits(L.bb), n_tiles, off, cursor1,
-                       reinterpret_cast<ulonglong2 *>(out));
+                       reinterpret_cast<ulonglong2 *>(out), region_stride, overflow);
 }
-void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const void *keys1, void *keys)
+void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const void *keys1, void *keys, uint64_t region_stride,
+                  uint32_t fine_cap, const uint32_t *cursor1, uint32_t *len_out, int *overflow)
 {
     const int b1 = scatter_b1_bits(L.bb);
     if (!L.total_syms || L.bb <= b1) return;
     const uint64_t n_regions = (uint64_t)L.n_genomes << b1;
     const uint32_t grid = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
     hipLaunchKernelGGL(wide_l2_kernel, dim3(grid), dim3(WH_THREADS), WH_LDS_BYTES, s, reinterpret_cast<const ulonglong2 *>(keys1),
-                       reinterpret_cast<ulonglong2 *>(keys), off, n_regions, L.bb, b1);
+                       reinterpret_cast<ulonglong2 *>(keys), off, n_regions, L.bb, b1, region_stride, fine_cap, cursor1, len_out, overflow);
 }
-void launch_wh_dict_build(hipStream_t s, const void *keys, const uint64_t *off, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
-                          uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint16_t *kslot,
-                          uint64_t *img_lo, uint64_t *img_hi, int *overflow)
+void launch_wh_dict_build(hipStream_t s, const void *keys, const SegLayout &seg, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
+                          uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint64_t *matrix_s,
+                          uint16_t *birth, int *overflow, uint32_t *need)
 {
-    const size_t lds = (((size_t)20) << cap_log2) + TABLE_SCRATCH_BYTES;
+    const size_t lds = (((size_t)26) << cap_log2) + TABLE_SCRATCH_BYTES;
     hipLaunchKernelGGL(wide_dict_build_kernel, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, reinterpret_cast<const ulonglong2 *>(keys),
-                       off, n_genomes, bb, sb, cap_log2, stage_lo, stage_hi, stage_flags, stage_cnt, kslot, img_lo, img_hi, overflow);
+                       seg, n_genomes, bb, sb, cap_log2, stage_lo, stage_hi, stage_flags, stage_cnt, matrix_s, birth, overflow, need);
 }
 void launch_wh_dict_gather(hipStream_t s, const uint64_t *stage_lo, const uint64_t *stage_hi, const uint8_t *stage_flags,
                            const uint64_t *stage_off, uint32_t n_wg, uint32_t cap, uint64_t *out_lo, uint64_t *out_hi, uint8_t *out_flags)
@@ -475,14 +533,20 @@ void launch_wh_mark(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, c
     const uint64_t g = (n + 255) / 256;
     hipLaunchKernelGGL(wide_mark_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, s_hi, s_lo, flags, order, n, filter_singleton, keep);
 }
-void launch_wh_select_cols(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
-                           int bb, int sb, uint32_t cap_log2, const uint64_t *img_lo, const uint64_t *img_hi, uint64_t *dict,
-                           uint32_t *col_of_slot)
+void launch_wh_select(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
+                      uint64_t *dict)
 {
     if (!n) return;
     uint64_t g = (n + 255) / 256;
-    hipLaunchKernelGGL(wide_select_cols_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, s_hi, s_lo, keep, pos, n, bb, sb, cap_log2,
-                       img_lo, img_hi, dict, col_of_slot);
+    hipLaunchKernelGGL(wide_select_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, s_hi, s_lo, keep, pos, n, dict);
+}
+void launch_wh_entry_cols(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
+                          const uint64_t *e_hi, const uint64_t *e_lo, uint64_t n_entries, uint32_t *entry_col)
+{
+    if (!n_entries) return;
+    uint64_t g = (n_entries + 255) / 256;
+    hipLaunchKernelGGL(wide_entry_cols_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, s_hi, s_lo, keep, pos, n, e_hi, e_lo,
+                       n_entries, entry_col);
 }
 hipError_t wh_set_max_dynamic_lds()
 {
