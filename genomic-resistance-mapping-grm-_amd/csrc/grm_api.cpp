@@ -62,6 +62,9 @@ struct grm_ctx {
     int opt_dedup_cap_shift = -1; // > 0: wave-form dedup tables 2^shift times larger than the sizing rule asks for (measurements)
     int opt_dense_layout = -1;   // > 0: histogram-sized dense partition layout (tests, measurements)
     int opt_no_union = -1;       // > 0: gathered rank dictionaries are sorted as a whole (tests)
+    int opt_records = -1;        // 0: never use the record (minimizer) form of the partition (tests, measurements)
+    int opt_rec_bucket_shift = -1; // record form: bucket bits on top of the key form's choice (default 1)
+    int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
 // 64-bit words of a k-mer, most significant first: 1 (k <= 32), 2 (<= 64), 3 (<= 96), 4 (<= 128)
@@ -245,6 +248,9 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "dedup_cap_shift") c->opt_dedup_cap_shift = value;
     else if (n == "dense_layout") c->opt_dense_layout = value;
     else if (n == "no_union") c->opt_no_union = value;
+    else if (n == "records") c->opt_records = value;
+    else if (n == "rec_bucket_shift") c->opt_rec_bucket_shift = value;
+    else if (n == "rec_part_bits") c->opt_rec_part_bits = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
@@ -670,6 +676,12 @@ struct grm_batch {
     DevBuf d_counts, d_off, d_cursor, d_cursor1, d_counts1, d_off1, d_keys, d_keys1, d_len, d_kcnt;
     bool deduped = false;
     uint64_t seg_stride = 0;       // 0: dense layout (d_off); else slack layout: segment i at i * seg_stride, length d_len[i]
+    // record form of the partition (grm_superkmer.hip): d_recs holds 16-byte records in the slack layout (seg_stride
+    // records per segment, d_len = records per segment), d_keys is not filled.  rec_failed: a segment overflowed once
+    // (repeat-rich input) or a later stage needed the keys -- the batch stays on the key form from then on.
+    DevBuf d_recs;
+    bool rec_mode = false, rec_failed = false;
+    int rec_part_bits = 0;         // genomes are cut into 2^rec_part_bits parts (segment index: virtual genome * 2^bb + bucket)
     bool slack_failed = false;     // a slack-layout partition of this batch overflowed: dense layout from then on
     DevBuf d_marks;                // one bit per segment: left to the workgroup form of the dedup
     // dictionary
@@ -936,6 +948,10 @@ extern "C" int grm_batch_upload(grm_batch *b)
     return GRM_OK;
 }
 
+// presence words kept by dict_build: 2^(bb+sb) workgroups x word-rows x table slots; beyond this many bytes
+// the probing form of the fill is used instead (it needs no intermediate)
+static const size_t MATRIX_S_LIMIT = (size_t)96 << 30;
+
 static int pick_bucket_bits(grm_ctx *c, uint64_t max_genome_syms)
 {
     if (c->opt_bucket_bits >= 0) return std::min(c->opt_bucket_bits, MAX_BUCKET_BITS);
@@ -1038,6 +1054,64 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     if (b->total_syms > max_groups * 64 - 256) return fail(c, GRM_ERR_HIP, "internal: symbol count exceeds the packed buffers");
     if (k > 32) return GRM_OK;       // two-word k-mers: the caller continues on grm_wide_hash.hip / grm_wide.hip
     b->bb = pick_bucket_bits(c, max_g);
+    b->rec_mode = false;
+    b->cap_log2 = pick_cap_log2(c);
+
+    // ---- record form (grm_superkmer.hip): buckets by minimizer, runs of consecutive k-mers as 16-byte records ----
+    // Applies where nothing downstream needs the keys themselves: abundance-min 1, no counts, and a fill that goes
+    // through the presence bits of dict_build.  Minimizer buckets are less even than hashed k-mers (a bucket holds
+    // ~30 minimizers of very different weight: sigma ~25 % of the mean), hence one more bucket bit than the key form.
+    if (k >= SK_M && abundance_min == 1 && !want_counts && c->opt_records != 0 && c->opt_no_slots <= 0 && !b->rec_failed &&
+        c->opt_dense_layout <= 0) {
+        int bbr = c->opt_bucket_bits >= 0 ? b->bb : b->bb + (c->opt_rec_bucket_shift >= 0 ? c->opt_rec_bucket_shift : 1);
+        bbr = std::min(bbr, superkmer_max_bits());
+        // one workgroup per genome part owns the part's segments: enough parts to fill the device when genomes are few
+        int pbits = 0;
+        while (((uint64_t)G << pbits) < 512 && pbits < 6 && (max_g >> (pbits + 1)) >= 65536) pbits++;
+        if (c->opt_rec_part_bits >= 0) pbits = std::min(c->opt_rec_part_bits, 6);
+        const uint64_t n_seg_r = ((uint64_t)G << pbits) << bbr;
+        const size_t n_rows_b = ((size_t)G + 63) / 64;
+        const size_t ms_bytes = ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << b->cap_log2) * 8;
+        // records per segment: a run ends where the minimizer changes (2 / (w + 1) per position for the w m-mers of a
+        // k-mer) or at the end of a thread's 32 positions; a segment's record count scatters with sigma ~1.85 sqrt(mean)
+        // (simulated: minimizers repeat), the capacity is mean + 10 sigma
+        const int w = k - SK_M + 1;
+        const double per_seg = (double)((max_g >> pbits) >> bbr) * (2.0 / (w + 1) + 1.0 / 32 + 0.005);
+        const uint32_t rcap = (uint32_t)((uint64_t)(per_seg * 1.1 + 18.5 * std::sqrt(per_seg + 1.0) + 16.0 + 15.0) / 16 * 16);
+        // genomes of very different sizes would waste most of a layout sized for the largest one
+        bool rec = n_seg_r < 0xffffffffull && n_rows_b <= 0xffffu && ms_bytes <= MATRIX_S_LIMIT && rcap < 0xfff0u &&
+                   (double)n_seg_r * rcap * 16.0 <= 12.0 * (double)b->total_syms + 65536.0 * 4096.0;
+        if (rec && b->d_recs.ensure((n_seg_r * rcap + 4) * 16) != hipSuccess) { (void)hipGetLastError(); rec = false; }
+        if (rec) {
+            KmerLaunch Lr;
+            Lr.sym2 = b->d_sym2.as<uint64_t>(); Lr.inv = b->d_inv.as<uint64_t>(); Lr.total_syms = b->total_syms;
+            Lr.genome_sym_off = b->d_genome_sym_off.as<uint64_t>(); Lr.n_genomes = G; Lr.k = k; Lr.bb = bbr; Lr.groups_per_thread = 1;
+            const uint64_t n_parts = (uint64_t)G << pbits;
+            HIPCHK(c, b->d_len.ensure((n_seg_r + 1) * 4));
+            HIPCHK(c, b->d_cursor1.ensure(n_parts * 4));
+            HIPCHK(c, b->t_flag.ensure(16));
+            HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 16, s));
+            {
+                TimeScope t(c, "superkmer_scatter", b->total_syms);
+                launch_superkmer_scatter(s, Lr, pbits, b->d_len.as<uint32_t>(), b->d_recs.p, rcap, b->d_cursor1.as<uint32_t>(), b->t_flag.as<int>());
+            }
+            launch_sum_u32(s, b->d_cursor1.as<uint32_t>(), n_parts, reinterpret_cast<uint64_t *>(b->t_flag.as<uint8_t>() + 8));
+            HIPCHK(c, hipGetLastError());
+            struct { int over; int pad; uint64_t total; } h;
+            HIPCHK(c, hipMemcpyAsync(&h, b->t_flag.p, 16, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (!h.over) {
+                b->bb = bbr;
+                b->total_keys = h.total;
+                b->seg_stride = rcap;
+                b->rec_part_bits = pbits;
+                b->rec_mode = true;
+                b->partitioned = true;
+                return GRM_OK;
+            }
+            b->rec_failed = true;            // repeat-rich input: the key form from now on
+        }
+    }
     const uint64_t B = 1ull << b->bb;
     const uint64_t n_seg = (uint64_t)G * B;
 
@@ -1254,9 +1328,6 @@ struct DictCtrl {
     uint32_t need;
 };
 
-// presence words kept by dict_build: 2^(bb+sb) workgroups x word-rows x table slots; beyond this many bytes
-// the probing form of the fill is used instead (it needs no intermediate)
-static const size_t MATRIX_S_LIMIT = (size_t)96 << 30;
 
 // One dictionary build with the sizing ladder.  `a` carries the input side (keys, segments, genomes, bb, cap_log2,
 // optional rank flags); the output buffers are sized here for every attempt.  want_bits: also keep the presence words
@@ -1347,11 +1418,22 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
         sb = b->sb_hint;
     DictArgs a;
     memset(&a, 0, sizeof a);
-    a.keys = b->d_keys.as<uint64_t>();
+    a.keys = b->rec_mode ? nullptr : b->d_keys.as<uint64_t>();
+    a.recs = b->rec_mode ? reinterpret_cast<const ulonglong2 *>(b->d_recs.p) : nullptr;
+    a.k = b->k;
+    a.part_bits = b->rec_mode ? b->rec_part_bits : 0;
     a.seg = batch_segments(b);
     a.n_genomes = G; a.bb = b->bb; a.cap_log2 = b->cap_log2;
     const DictOut out = {&b->d_local_keys, &b->d_local_flags, &b->d_wg_base, &b->d_wg_cnt};
     int rc = run_dict_ladder(b, a, b->total_keys, sb, c->opt_no_slots <= 0, out, "dict_build", &sb, &b->n_local, &b->have_bits, &b->dict_launches);
+    if (b->rec_mode && (rc == GRM_ERR_OVERFLOW || (rc == GRM_OK && !b->have_bits))) {
+        // the probing form of the fill (or a table that no sub-bucket count rescues) needs the keys: partition again in
+        // the key form and stay there
+        b->rec_failed = true;
+        rc = batch_partition_impl(b, b->k, b->abundance_min, false);
+        if (rc) return rc;
+        return grm_batch_local_dict(b, n_local);
+    }
     if (rc) return rc;
     b->sb_dict = sb;
     if (c->opt_sub_bits < 0) { b->sb_hint = sb; b->sb_hint_k = b->k; b->sb_hint_bb = b->bb; b->sb_hint_amin = b->abundance_min; }
@@ -1549,12 +1631,14 @@ extern "C" void grm_exchange_layout(uint64_t n_max, int words, int bucket_bits, 
 {
     const uint64_t fo = n_max * 8 * (uint64_t)(words < 1 ? 1 : words);
     const uint64_t bo = (fo + n_max + 15) / 16 * 16;
-    const uint64_t st = (bo + (((uint64_t)1 << bucket_bits) + 1) * 4 + 15) / 16 * 16;
+    const uint64_t st = (bo + (((uint64_t)1 << (bucket_bits & 0xff)) + 1) * 4 + 15) / 16 * 16;
     if (flags_off) *flags_off = fo;
     if (boff_off) *boff_off = bo;
     if (stride) *stride = st;
 }
-extern "C" int grm_batch_bucket_bits(const grm_batch *b) { return b ? b->bb : 0; }
+// bucket geometry of the batch as ranks compare it: bucket bits, + 0x100 when the buckets are minimizer buckets
+// (record form) -- lists of ranks with different codes cannot be united bucket by bucket
+extern "C" int grm_batch_bucket_bits(const grm_batch *b) { return b ? (b->bb | (b->rec_mode ? 0x100 : 0)) : 0; }
 
 extern "C" int grm_batch_export_dict_ordered(grm_batch *b, void *dev_record, uint64_t flags_off, uint64_t boff_off)
 {
@@ -1604,7 +1688,7 @@ extern "C" int grm_batch_set_global_dict_gathered(grm_batch *b, const void *dev_
     bool same_bb = true;
     uint64_t total = 0;
     for (int r = 0; r < n_ranks; r++) {
-        bb_max = std::max(bb_max, bucket_bits[r]);
+        bb_max = std::max(bb_max, bucket_bits[r] & 0xff);
         same_bb = same_bb && bucket_bits[r] == bucket_bits[0];
         if (counts[r] > n_max) return fail(c, GRM_ERR_ARG, "grm_batch_set_global_dict_gathered: rank %d holds more than n_max entries", r);
         total += counts[r];

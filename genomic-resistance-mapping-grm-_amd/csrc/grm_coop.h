@@ -34,6 +34,20 @@ __device__ __forceinline__ uint32_t wave_scan_excl(uint32_t v)
     return inc - v;
 }
 
+// inclusive prefix sum inside a wave with DPP moves (row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 / :31
+// across them): six dependent VALU instructions instead of six ds_bpermute round trips
+__device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t v)
+{
+    int s = (int)v;
+    s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, false);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, false);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, false);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, false);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, false);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, false);
+    return (uint32_t)s;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

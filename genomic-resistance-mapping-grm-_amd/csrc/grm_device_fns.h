@@ -114,6 +114,21 @@ GRM_HD uint32_t hash_sub(uint64_t h, int bb, int sb)
 }
 GRM_HD uint32_t hash_slot(uint64_t h, uint32_t cap_mask) { return (uint32_t)h & cap_mask; }
 
+// ---- minimizers (record form of the partition, grm_superkmer.hip) ----------------------------
+// order of the canonical m-mers (x < 2^22): the smallest hash inside a k-mer is its minimizer
+GRM_HD uint32_t minimizer_hash(uint32_t x)
+{
+    const uint32_t t = mul24(x, 0x9E3779u);
+    return mul24(t >> 10, 0x85EBCBu) + t;
+}
+// bucket of a k-mer from the hash of its minimizer.  The minimum of k - 10 hashes crowds towards 0, so the bucket is
+// NOT its top bits: the value is hashed once more.
+GRM_HD uint32_t minimizer_bucket(uint32_t hmin, int bb)
+{
+    const uint32_t t = mul24(hmin ^ (hmin >> 24), 0xC2B2AFu);
+    return (t >> 1) >> (31 - bb);
+}
+
 // ---- FASTA byte classification -------------------------------------------------------
 // 4-bit mask of the bytes of x that equal c (SWAR exact zero-byte test, then bit gather)
 GRM_HD uint32_t byte_eq_mask4(uint32_t x, uint32_t c)

@@ -37,6 +37,10 @@ static_assert(L1_THREADS >= (1 << L1_MAX_BITS), "level 1: one thread per coarse 
 static_assert(L2_THREADS >= (1 << (MAX_BUCKET_BITS - L1_MAX_BITS)), "level 2: one thread per fine bucket, deep mode included");
 static_assert((1 << L1_MAX_BITS) <= 256 && (1 << (MAX_BUCKET_BITS - L1_MAX_BITS)) <= 256, "gbase / hist / start hold 256 entries");
 
+// m-mer length of the minimizers (record form of the partition): 4^11 / 2 canonical 11-mers order a 5 Mbp genome's
+// ~250 000 minimizers finely enough for 2^13..2^14 buckets, and the word fits the 24-bit multiplies
+constexpr int SK_M = 11;
+
 // ---- LDS table kernels ----
 constexpr int TABLE_THREADS = 512;                         // 8 waves: one genome per wave at a time
 constexpr int TABLE_SCRATCH_BYTES = 128;
@@ -76,6 +80,14 @@ int scatter_b1_bits(int bb);
 void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *coarse_off,
                             uint32_t *cursor1, uint64_t *out, uint64_t region_stride, int *overflow);
 void launch_sum_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *out);
+// record form of the partition (11 <= k <= 32): runs of consecutive k-mers with the same minimizer bucket -> 16-byte
+// records.  Genome g is cut into 2^part_bits parts ("virtual genomes" vg = (g << part_bits) + part), one workgroup each;
+// segment (vg, bucket) = recs[(vg * 2^bb + bucket) * rcap ..], rcount[vg * 2^bb + bucket] records (every entry written),
+// part_kmers[vg] = k-mer occurrences of the part, *overflow = 1 when a segment would exceed rcap (< 65536).
+void launch_superkmer_scatter(hipStream_t s, const KmerLaunch &L, int part_bits, uint32_t *rcount, void *recs, uint32_t rcap,
+                              uint32_t *part_kmers, int *overflow);
+int superkmer_max_bits();
+int superkmer_lmax(int k);
 void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *coarse_off, uint64_t n_regions, int bb,
                         uint32_t *counts);
 void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *keys1,
@@ -102,6 +114,10 @@ void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const SegLayout &se
 // every distinct k-mer ("entry"), one word-row (64 genomes) at a time.
 struct DictArgs {
     const uint64_t *keys;
+    // record form (grm_superkmer.hip): the segments hold 16-byte records instead of keys (seg counts records); k as given
+    const ulonglong2 *recs;
+    int k;
+    int part_bits;          // record form: segment index = ((genome << part_bits) + part) * 2^bb + bucket
     SegLayout seg;
     uint32_t n_genomes;
     int bb, sb;

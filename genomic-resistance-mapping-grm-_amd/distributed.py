@@ -84,7 +84,7 @@ def exchange_dict(batch, n_local, device, group=None, words=1, stats=None):
     counts = sizes[0::2].tolist()
     bbs = sizes[1::2].tolist()
     n_max = max(1, max(counts))
-    flags_off, boff_off, stride = batch.exchange_layout(n_max, words, max(bbs))
+    flags_off, boff_off, stride = batch.exchange_layout(n_max, words, max(v & 0xff for v in bbs))      # low byte: the bits; 0x100: minimizer buckets
     rec = torch.empty(stride, dtype=torch.uint8, device=device)       # padding is never read
     batch.export_dict_ordered(rec.data_ptr(), flags_off, boff_off)
     payload = torch.empty(world * stride, dtype=torch.uint8, device=device)

@@ -896,12 +896,12 @@ def test_gathered_exchange_in_one_process(ctx, k, opts):
                     batches.append(b)
                 assert (len(set(bbs)) > 1) == odd_geometry
                 n_max = max(1, max(n_locals))
-                flags_off, boff_off, stride = batches[0].exchange_layout(n_max, words, max(bbs))
+                flags_off, boff_off, stride = batches[0].exchange_layout(n_max, words, max(v & 0xff for v in bbs))
                 payload = torch.empty(len(shards) * stride, dtype=torch.uint8, device=dev)
                 for r, b in enumerate(batches):
                     b.export_dict_ordered(payload.data_ptr() + r * stride, flags_off, boff_off)
                 # the bucket offsets of a record partition its entries
-                boff = payload[boff_off: boff_off + 4 * ((1 << bbs[0]) + 1)].cpu().numpy().view(np.uint32)
+                boff = payload[boff_off: boff_off + 4 * ((1 << (bbs[0] & 0xff)) + 1)].cpu().numpy().view(np.uint32)
                 assert boff[0] == 0 and boff[-1] == n_locals[0] and (np.diff(boff.astype(np.int64)) >= 0).all()
                 rows = []
                 for b in batches:
