@@ -676,9 +676,9 @@ struct grm_batch {
     DevBuf d_counts, d_off, d_cursor, d_cursor1, d_counts1, d_off1, d_keys, d_keys1, d_len, d_kcnt;
     bool deduped = false;
     uint64_t seg_stride = 0;       // 0: dense layout (d_off); else slack layout: segment i at i * seg_stride, length d_len[i]
-    // record form of the partition (grm_superkmer.hip): d_recs holds 16-byte records in the slack layout (seg_stride
-    // records per segment, d_len = records per segment), d_keys is not filled.  rec_failed: a segment overflowed once
-    // (repeat-rich input) or a later stage needed the keys -- the batch stays on the key form from then on.
+    // record form of the partition (grm_superkmer.hip): minimizer buckets; d_recs holds the level-1 records, the key
+    // segments are given by d_off AND d_len (regions leave gaps).  rec_failed: a region overflowed once (repeat-rich
+    // input) or a later stage could not use the layout -- the batch stays on the key form from then on.
     DevBuf d_recs;
     bool rec_mode = false, rec_failed = false;
     int rec_part_bits = 0;         // genomes are cut into 2^rec_part_bits parts (segment index: virtual genome * 2^bb + bucket)
@@ -982,7 +982,7 @@ static SegLayout batch_segments(const grm_batch *b, bool after_dedup = true)
         L.stride = b->seg_stride;
     } else {
         L.off = b->d_off.as<uint64_t>();
-        L.len = (after_dedup && b->deduped) ? b->d_len.as<uint32_t>() : nullptr;
+        L.len = (b->rec_mode || (after_dedup && b->deduped)) ? b->d_len.as<uint32_t>() : nullptr;     // record form: regions leave gaps
         L.stride = 0;
     }
     return L;
@@ -1057,43 +1057,55 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     b->rec_mode = false;
     b->cap_log2 = pick_cap_log2(c);
 
-    // ---- record form (grm_superkmer.hip): buckets by minimizer, runs of consecutive k-mers as 16-byte records ----
-    // Applies where nothing downstream needs the keys themselves: abundance-min 1, no counts, and a fill that goes
-    // through the presence bits of dict_build.  Minimizer buckets are less even than hashed k-mers (a bucket holds
-    // ~30 minimizers of very different weight: sigma ~25 % of the mean), hence one more bucket bit than the key form.
-    if (k >= SK_M && abundance_min == 1 && !want_counts && c->opt_records != 0 && c->opt_no_slots <= 0 && !b->rec_failed &&
-        c->opt_dense_layout <= 0) {
-        int bbr = c->opt_bucket_bits >= 0 ? b->bb : b->bb + (c->opt_rec_bucket_shift >= 0 ? c->opt_rec_bucket_shift : 1);
+    // ---- record form (grm_superkmer.hip): buckets by minimizer; level 1 moves runs of consecutive k-mers as 16-byte
+    // records, level 2 expands them into the same bucket-sorted key segments the key form leaves ----
+    // Minimizer buckets are less even than hashed k-mers (a fine bucket holds ~30 minimizers of very different weight:
+    // sigma ~25 % of the mean at 2^13 buckets), hence one more bucket bit than the key form and exact (not slack)
+    // segment sizes inside a region.
+    if (k >= SK_M && abundance_min == 1 && !want_counts && c->opt_records != 0 && !b->rec_failed && c->opt_dense_layout <= 0) {
+        int bbr = c->opt_bucket_bits >= 0 ? b->bb : b->bb + (c->opt_rec_bucket_shift >= 0 ? c->opt_rec_bucket_shift : 0);
         bbr = std::min(bbr, superkmer_max_bits());
-        // one workgroup per genome part owns the part's segments: enough parts to fill the device when genomes are few
+        const int b1r = std::min(bbr, 8);
+        // one workgroup per genome part owns the part's regions: enough parts to fill the device when genomes are few
         int pbits = 0;
         while (((uint64_t)G << pbits) < 512 && pbits < 6 && (max_g >> (pbits + 1)) >= 65536) pbits++;
         if (c->opt_rec_part_bits >= 0) pbits = std::min(c->opt_rec_part_bits, 6);
-        const uint64_t n_seg_r = ((uint64_t)G << pbits) << bbr;
-        const size_t n_rows_b = ((size_t)G + 63) / 64;
-        const size_t ms_bytes = ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << b->cap_log2) * 8;
-        // records per segment: a run ends where the minimizer changes (2 / (w + 1) per position for the w m-mers of a
-        // k-mer) or at the end of a thread's 32 positions; a segment's record count scatters with sigma ~1.85 sqrt(mean)
-        // (simulated: minimizers repeat), the capacity is mean + 10 sigma
+        const uint64_t n_parts = (uint64_t)G << pbits;
+        const uint64_t n_regions = n_parts << b1r, n_seg_r = n_parts << bbr;
+        // records per region: a run ends where the minimizer changes (2 / (w + 1) per position for the w m-mers of a
+        // k-mer), at the end of a thread's 32 positions or after 16 k-mers; k-mers per region: ~0.05 distinct
+        // minimizers per position, sigma of a region = 1.39 x its share / sqrt(its minimizers) (simulated)
         const int w = k - SK_M + 1;
-        const double per_seg = (double)((max_g >> pbits) >> bbr) * (2.0 / (w + 1) + 1.0 / 32 + 0.005);
-        const uint32_t rcap = (uint32_t)((uint64_t)(per_seg * 1.1 + 18.5 * std::sqrt(per_seg + 1.0) + 16.0 + 15.0) / 16 * 16);
+        const double mean_k = (double)((max_g >> pbits) >> b1r) + 1.0;
+        const double mean_r = mean_k * (2.0 / (w + 1) + 1.0 / 32 + 0.02);
+        const uint64_t rstride64 = (uint64_t)(mean_r * 1.05 + 16.0 * std::sqrt(mean_r) + 64.0 + 15.0) / 16 * 16;
+        const uint64_t kstride = (uint64_t)(mean_k + 50.0 * std::sqrt(mean_k) + 256.0 + 15.0) / 16 * 16;
         // genomes of very different sizes would waste most of a layout sized for the largest one
-        bool rec = n_seg_r < 0xffffffffull && n_rows_b <= 0xffffu && ms_bytes <= MATRIX_S_LIMIT && rcap < 0xfff0u &&
-                   (double)n_seg_r * rcap * 16.0 <= 12.0 * (double)b->total_syms + 65536.0 * 4096.0;
-        if (rec && b->d_recs.ensure((n_seg_r * rcap + 4) * 16) != hipSuccess) { (void)hipGetLastError(); rec = false; }
+        bool rec = n_seg_r < 0xffffffffull && rstride64 < 0xffffffffull && kstride < 0xffffffffull &&
+                   (double)n_regions * (double)kstride <= 3.0 * (double)b->total_syms + 65536.0 * 1024.0;
+        if (rec && (b->d_recs.ensure((n_regions * rstride64 + 4) * 16) != hipSuccess || b->d_keys.ensure((n_regions * kstride + 4) * 8) != hipSuccess)) {
+            (void)hipGetLastError();
+            rec = false;
+        }
         if (rec) {
+            const uint32_t rstride = (uint32_t)rstride64;
             KmerLaunch Lr;
             Lr.sym2 = b->d_sym2.as<uint64_t>(); Lr.inv = b->d_inv.as<uint64_t>(); Lr.total_syms = b->total_syms;
             Lr.genome_sym_off = b->d_genome_sym_off.as<uint64_t>(); Lr.n_genomes = G; Lr.k = k; Lr.bb = bbr; Lr.groups_per_thread = 1;
-            const uint64_t n_parts = (uint64_t)G << pbits;
+            HIPCHK(c, b->d_off.ensure((n_seg_r + 1) * 8));
             HIPCHK(c, b->d_len.ensure((n_seg_r + 1) * 4));
+            HIPCHK(c, b->d_counts1.ensure((n_regions + 1) * 4));
             HIPCHK(c, b->d_cursor1.ensure(n_parts * 4));
             HIPCHK(c, b->t_flag.ensure(16));
             HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 16, s));
             {
-                TimeScope t(c, "superkmer_scatter", b->total_syms);
-                launch_superkmer_scatter(s, Lr, pbits, b->d_len.as<uint32_t>(), b->d_recs.p, rcap, b->d_cursor1.as<uint32_t>(), b->t_flag.as<int>());
+                TimeScope t(c, "superkmer_l1", b->total_syms);
+                launch_superkmer_l1(s, Lr, pbits, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), b->d_cursor1.as<uint32_t>(), b->t_flag.as<int>());
+            }
+            {
+                TimeScope t(c, "superkmer_l2", b->total_syms);
+                launch_superkmer_l2(s, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, k, bbr, kstride, b->d_keys.as<uint64_t>(),
+                                    b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->t_flag.as<int>());
             }
             launch_sum_u32(s, b->d_cursor1.as<uint32_t>(), n_parts, reinterpret_cast<uint64_t *>(b->t_flag.as<uint8_t>() + 8));
             HIPCHK(c, hipGetLastError());
@@ -1103,7 +1115,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
             if (!h.over) {
                 b->bb = bbr;
                 b->total_keys = h.total;
-                b->seg_stride = rcap;
+                b->seg_stride = 0;
                 b->rec_part_bits = pbits;
                 b->rec_mode = true;
                 b->partitioned = true;
@@ -1418,17 +1430,14 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
         sb = b->sb_hint;
     DictArgs a;
     memset(&a, 0, sizeof a);
-    a.keys = b->rec_mode ? nullptr : b->d_keys.as<uint64_t>();
-    a.recs = b->rec_mode ? reinterpret_cast<const ulonglong2 *>(b->d_recs.p) : nullptr;
-    a.k = b->k;
+    a.keys = b->d_keys.as<uint64_t>();
     a.part_bits = b->rec_mode ? b->rec_part_bits : 0;
     a.seg = batch_segments(b);
     a.n_genomes = G; a.bb = b->bb; a.cap_log2 = b->cap_log2;
     const DictOut out = {&b->d_local_keys, &b->d_local_flags, &b->d_wg_base, &b->d_wg_cnt};
     int rc = run_dict_ladder(b, a, b->total_keys, sb, c->opt_no_slots <= 0, out, "dict_build", &sb, &b->n_local, &b->have_bits, &b->dict_launches);
-    if (b->rec_mode && (rc == GRM_ERR_OVERFLOW || (rc == GRM_OK && !b->have_bits))) {
-        // the probing form of the fill (or a table that no sub-bucket count rescues) needs the keys: partition again in
-        // the key form and stay there
+    if (b->rec_mode && b->rec_part_bits > 0 && rc == GRM_OK && !b->have_bits) {
+        // the probing form of the fill walks whole genomes: partition again in the key form and stay there
         b->rec_failed = true;
         rc = batch_partition_impl(b, b->k, b->abundance_min, false);
         if (rc) return rc;
@@ -1477,7 +1486,8 @@ static int bucketise_dict(grm_batch *b, int sb)
     HIPCHK(c, d_col.ensure(U * 4));
     HIPCHK(c, d_bid_sorted.ensure(U * 4));
     TimeScope t(c, "dict_bucketise", U);
-    launch_dict_bucket_ids(s, b->d_dict.as<uint64_t>(), U, b->bb, sb, d_bid.as<uint32_t>(), d_col.as<uint32_t>());
+    if (b->rec_mode) launch_minimizer_bucket_ids(s, b->d_dict.as<uint64_t>(), U, b->k, b->bb, sb, d_bid.as<uint32_t>(), d_col.as<uint32_t>());
+    else launch_dict_bucket_ids(s, b->d_dict.as<uint64_t>(), U, b->bb, sb, d_bid.as<uint32_t>(), d_col.as<uint32_t>());
     size_t tmp_bytes = 0;
     HIPCHK(c, sort_pairs_u32_u32(s, d_bid.as<uint32_t>(), d_bid_sorted.as<uint32_t>(), d_col.as<uint32_t>(),
                                  b->d_dcol.as<uint32_t>(), U, b->bb + sb, nullptr, tmp_bytes));

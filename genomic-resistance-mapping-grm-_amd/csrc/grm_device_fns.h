@@ -129,6 +129,23 @@ GRM_HD uint32_t minimizer_bucket(uint32_t hmin, int bb)
     return (t >> 1) >> (31 - bb);
 }
 
+// the same bucket from the k-mer itself (canonical or not: both strands hold the same canonical m-mers), k >= m_len
+GRM_HD uint32_t minimizer_bucket_of_kmer(uint64_t key, int k, int bb, int m_len = 11)
+{
+    const uint32_t mmask = (1u << (2 * m_len)) - 1;
+    uint32_t f = 0, r = 0, hmin = ~0u;
+    for (int j = 0; j < k; j++) {
+        const uint32_t s = (uint32_t)(key >> (2 * (k - 1 - j))) & 3u;
+        f = ((f << 2) | s) & mmask;
+        r = (r >> 2) | ((s ^ 2u) << (2 * (m_len - 1)));
+        if (j >= m_len - 1) {
+            const uint32_t h = minimizer_hash(f < r ? f : r);
+            hmin = h < hmin ? h : hmin;
+        }
+    }
+    return minimizer_bucket(hmin, bb);
+}
+
 // ---- FASTA byte classification -------------------------------------------------------
 // 4-bit mask of the bytes of x that equal c (SWAR exact zero-byte test, then bit gather)
 GRM_HD uint32_t byte_eq_mask4(uint32_t x, uint32_t c)

@@ -80,14 +80,21 @@ int scatter_b1_bits(int bb);
 void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *coarse_off,
                             uint32_t *cursor1, uint64_t *out, uint64_t region_stride, int *overflow);
 void launch_sum_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *out);
-// record form of the partition (11 <= k <= 32): runs of consecutive k-mers with the same minimizer bucket -> 16-byte
-// records.  Genome g is cut into 2^part_bits parts ("virtual genomes" vg = (g << part_bits) + part), one workgroup each;
-// segment (vg, bucket) = recs[(vg * 2^bb + bucket) * rcap ..], rcount[vg * 2^bb + bucket] records (every entry written),
-// part_kmers[vg] = k-mer occurrences of the part, *overflow = 1 when a segment would exceed rcap (< 65536).
-void launch_superkmer_scatter(hipStream_t s, const KmerLaunch &L, int part_bits, uint32_t *rcount, void *recs, uint32_t rcap,
-                              uint32_t *part_kmers, int *overflow);
+// record form of the partition (grm_superkmer.hip; 11 <= k <= 32): buckets by minimizer.  Genome g is cut into
+// 2^part_bits parts ("virtual genomes" vg = (g << part_bits) + part).
+//   level 1: runs of consecutive k-mers with one bucket -> 16-byte records, sorted by the coarse bucket bits:
+//            region (vg, coarse) = recs1[(vg * 2^b1 + coarse) * rstride ..], rcount1[..] records; part_kmers[vg] = k-mer
+//            occurrences of the part; *overflow = 1 when a region would exceed rstride
+//   level 2: records -> canonical k-mers, sorted by the fine bits: segment vg * 2^bb + bucket = keys[off[..] .. + len[..]),
+//            the segments of region r back to back from r * kstride; *overflow = 1 when a region holds more than kstride
+void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int part_bits, void *recs1, uint32_t rstride, uint32_t *rcount1,
+                         uint32_t *part_kmers, int *overflow);
+void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb,
+                         uint64_t kstride, uint64_t *keys, uint64_t *off, uint32_t *len, int *overflow);
+// (bucket << sb) | sub of dictionary keys under minimizer buckets (launch_dict_bucket_ids for the hashed ones)
+void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int k, int bb, int sb, uint32_t *bucket_of, uint32_t *col_of);
 int superkmer_max_bits();
-int superkmer_lmax(int k);
+int superkmer_lmax();
 void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *coarse_off, uint64_t n_regions, int bb,
                         uint32_t *counts);
 void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *keys1,
@@ -114,10 +121,7 @@ void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const SegLayout &se
 // every distinct k-mer ("entry"), one word-row (64 genomes) at a time.
 struct DictArgs {
     const uint64_t *keys;
-    // record form (grm_superkmer.hip): the segments hold 16-byte records instead of keys (seg counts records); k as given
-    const ulonglong2 *recs;
-    int k;
-    int part_bits;          // record form: segment index = ((genome << part_bits) + part) * 2^bb + bucket
+    int part_bits;          // segments of 2^part_bits parts per genome: segment index = ((genome << part_bits) + part) * 2^bb + bucket
     SegLayout seg;
     uint32_t n_genomes;
     int bb, sb;

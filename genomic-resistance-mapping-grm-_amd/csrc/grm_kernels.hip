@@ -1175,59 +1175,9 @@ __device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__
     dict_probe<J, FLAGS>(w, kv, several, g, r, bit);
 }
 
-// ---- record form (grm_superkmer.hip): a segment holds 16-byte records, each a run of len consecutive k-mers with
-// their bases.  A wave takes up to REC_ROUND records at a time: lane i holds record i (also copied to LDS), a scan gives the records'
-// first k-mer indices `off` and their total T, and the heads are marked in a wave-private LDS bitmap, of which lane q
-// then keeps word q (`hword`) and the number of heads in the words before it (`cum`).  K-mer index 64 q + lane belongs to
-// record cum[q] + popc(hword[q] & bits 0..lane) - 1: two readlanes and a popcount, no search.
-constexpr int REC_ROUND = 48;          // records per round: 768 B of records + 192 B of head bitmap per wave in LDS
-constexpr int REC_WAVE_LDS = REC_ROUND * 16 + (REC_ROUND * 32 / 64) * 8;
-struct RecRound {
-    const ulonglong2 *recs;        // the records of the round (wave-private LDS copy)
-    uint32_t off;                  // lane i: first k-mer index of record i
-    uint32_t T;                    // k-mers in the round
-    uint64_t hword;                // lane q: bitmap word q (bit b: a record starts at k-mer index 64 q + b)
-    uint32_t cum;                  // lane q: records starting before k-mer index 64 q
-    uint64_t le_mask;              // bits 0 .. lane
-    int k;
-};
-// J x 64 k-mers of the round, from k-mer index 64 q0 on
-template <int J>
-__device__ __forceinline__ void dict_chunk_rec(const DictWave &w, const RecRound &R, uint32_t q0, uint32_t g, uint32_t r,
-                                               unsigned long long bit)
-{
-    uint64_t kv[J];
-    ulonglong2 rec[J];
-    uint32_t t[J];
-    const uint32_t lane = (uint32_t)lane_id();
-#pragma unroll
-    for (int j = 0; j < J; j++) {
-        const int q = __builtin_amdgcn_readfirstlane((int)(q0 + j));
-        const uint64_t hq = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(R.hword >> 32), q) << 32) |
-                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)R.hword, q);
-        const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)R.cum, q);
-        const uint32_t rr = cq + (uint32_t)__popcll(hq & R.le_mask) - 1u;
-        const uint32_t i = 64u * (uint32_t)q + lane;
-        const uint32_t off_r = (uint32_t)__shfl((int)R.off, (int)(rr & 63u));
-        t[j] = i - off_r;
-        rec[j] = R.recs[i < R.T ? rr : 0u];
-    }
-    const int up = 64 - 2 * R.k;
-#pragma unroll
-    for (int j = 0; j < J; j++) {
-        const uint32_t i = 64u * (q0 + j) + lane;
-        const int sh = 2 * (int)(t[j] & 31u);
-        const uint64_t a = sh ? ((rec[j].x << sh) | (rec[j].y >> (64 - sh))) : rec[j].x;
-        const uint64_t fwd = a >> up;
-        const uint64_t rc = revcomp_m(fwd, R.k);
-        kv[j] = i < R.T ? (fwd < rc ? fwd : rc) : EMPTY_KEY;
-    }
-    dict_probe<J, false>(w, kv, 0u, g, r, bit);
-}
-
 // MAXT: largest workgroup the instance is launched with (the 8-deep form needs more than the 128 VGPRs a
 // 1024-thread workgroup leaves per lane)
-template <int KIF, int MAXT, bool FLAGS, bool REC>
+template <int KIF, int MAXT, bool FLAGS>
 __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -1248,8 +1198,8 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     if (threadIdx.x == 0) { full = 0; n_distinct = 0; }
     __syncthreads();
     const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;     // nw divides 64 (launcher)
-    // record form: a genome may come in 2^part_bits parts ("virtual genomes" g, real genome g >> pb)
-    const int pb = REC ? a.part_bits : 0;
+    // a genome may come in 2^part_bits parts ("virtual genomes" g, real genome g >> pb; record form of the partition)
+    const int pb = a.part_bits;
     const uint32_t GV = G << pb;
     const uint32_t per_row = (64u << pb) / (uint32_t)nw;    // (virtual) genomes per wave per word-row
     DictWave w;
@@ -1260,31 +1210,18 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     // global round trips -- bounds, then keys -- would otherwise serialise per genome).  Wave w takes
     // genomes w, w + nw, ...: since nw divides 64 that sequence walks the word-rows in step with the
     // other waves.
-    // Record form: the bounds run two genomes ahead and the first REC_ROUND records one genome ahead (rec_pre), so that
-    // neither round trip is waited for.
     uint32_t g = (uint32_t)wave;
     uint64_t s0 = 0, n = 0, f0 = 0;
-    uint64_t s0_next = 0, n_next = 0, f0_next = 0;
-    ulonglong2 rec_pre = make_ulonglong2(0, 0);
     if (g < GV) {
         seg_bounds(a.seg, (uint64_t)g * B + b, s0, n);
         if (FLAGS) f0 = a.in_flag_off[(uint64_t)g * B + b];
-        if (REC && (uint64_t)lane < n && lane < REC_ROUND) rec_pre = a.recs[s0 + lane];
     }
-    if (REC && g + nw < GV) seg_bounds(a.seg, (uint64_t)(g + nw) * B + b, s0_next, n_next);
     for (uint32_t r = 0; r < n_rows; r++) {
         for (uint32_t jr = 0; jr < per_row; jr++, g += nw) {
-            uint64_t s0_nn = 0, n_nn = 0;
-            ulonglong2 rec_next = make_ulonglong2(0, 0);
-            if (!REC) {
-                s0_next = n_next = f0_next = 0;
-                if (g + nw < GV) {
-                    seg_bounds(a.seg, (uint64_t)(g + nw) * B + b, s0_next, n_next);
-                    if (FLAGS) f0_next = a.in_flag_off[(uint64_t)(g + nw) * B + b];
-                }
-            } else {
-                if (g + 2 * nw < GV) seg_bounds(a.seg, (uint64_t)(g + 2 * nw) * B + b, s0_nn, n_nn);
-                if ((uint64_t)lane < n_next && lane < REC_ROUND) rec_next = a.recs[s0_next + lane];
+            uint64_t s0_next = 0, n_next = 0, f0_next = 0;
+            if (g + nw < GV) {
+                seg_bounds(a.seg, (uint64_t)(g + nw) * B + b, s0_next, n_next);
+                if (FLAGS) f0_next = a.in_flag_off[(uint64_t)(g + nw) * B + b];
             }
             if (g < GV && !full) {
                 const uint32_t gr = g >> pb;
@@ -1295,58 +1232,19 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                 // wide: KIF keys per lane in flight, their hashes, two 16-byte table reads each; a key found there
                 // -- almost every key of a pan-genome after the first few genomes -- costs one more LDS OR.  The
                 // tail of the segment goes through a copy of the same code that is exactly as deep as it needs.
-                if (!REC) {
                 uint64_t i0 = lane;
-                for (; i0 + 64u * (KIF - 1) < n; i0 += 64 * KIF) dict_chunk<KIF, FLAGS>(w, seg, flg, i0, n, g, r, bit);
+                for (; i0 + 64u * (KIF - 1) < n; i0 += 64 * KIF) dict_chunk<KIF, FLAGS>(w, seg, flg, i0, n, gr, r, bit);
                 if (i0 - lane < n && !full) {
                     const uint32_t nj = (uint32_t)((n - (i0 - lane) + 63) >> 6);        // wave-uniform: 1 .. KIF - 1
-                    if (KIF > 4 && nj > 4) dict_chunk<(KIF > 4 ? KIF : 1), FLAGS>(w, seg, flg, i0, n, g, r, bit);
-                    else if (KIF > 2 && nj > 2) dict_chunk<(KIF > 2 ? 4 : 1), FLAGS>(w, seg, flg, i0, n, g, r, bit);
-                    else if (KIF > 1 && nj == 2) dict_chunk<(KIF > 1 ? 2 : 1), FLAGS>(w, seg, flg, i0, n, g, r, bit);
-                    else dict_chunk<1, FLAGS>(w, seg, flg, i0, n, g, r, bit);
-                }
-                } else {
-                // record form: n records of this genome at a.recs + s0, REC_ROUND at a time; the first round's records
-                // were requested one genome ahead (rec_pre)
-                const ulonglong2 *rseg = a.recs + s0;
-                uint8_t *wl = lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)wave * REC_WAVE_LDS;
-                ulonglong2 *wrec = reinterpret_cast<ulonglong2 *>(wl);
-                unsigned long long *bm = reinterpret_cast<unsigned long long *>(wl + REC_ROUND * 16);
-                RecRound R;
-                R.k = a.k;
-                R.le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-                R.recs = wrec;
-                for (uint64_t r0 = 0; r0 < n && !full; r0 += REC_ROUND) {
-                    const uint32_t nr = (uint32_t)min((uint64_t)REC_ROUND, n - r0);
-                    ulonglong2 rec = rec_pre;
-                    if (r0) rec = (uint32_t)lane < nr ? rseg[r0 + lane] : make_ulonglong2(0, 0);
-                    const uint32_t len = (uint32_t)lane < nr ? (uint32_t)(rec.y & 0xffull) : 0u;
-                    const uint32_t inc = wave_scan_incl_dpp(len);
-                    R.off = inc - len;
-                    R.T = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                    if ((uint32_t)lane < nr) wrec[lane] = rec;
-                    if (lane < REC_ROUND * 32 / 64) bm[lane] = 0;
-                    if (len) atomicOr(&bm[R.off >> 6], 1ull << (R.off & 63u));
-                    R.hword = lane < REC_ROUND * 32 / 64 ? bm[lane] : 0ull;
-                    const uint32_t hc = (uint32_t)__popcll(R.hword);
-                    R.cum = wave_scan_incl_dpp(hc) - hc;
-                    const uint32_t nq = (R.T + 63u) >> 6;
-                    uint32_t q = 0;
-                    for (; q + KIF <= nq && !full; q += KIF) dict_chunk_rec<KIF>(w, R, q, gr, r, bit);
-                    if (q < nq && !full) {
-                        const uint32_t nj = nq - q;                                           // wave-uniform: 1 .. KIF - 1
-                        if (KIF > 4 && nj > 4) dict_chunk_rec<(KIF > 4 ? KIF : 1)>(w, R, q, gr, r, bit);
-                        else if (KIF > 2 && nj > 2) dict_chunk_rec<(KIF > 2 ? 4 : 1)>(w, R, q, gr, r, bit);
-                        else if (KIF > 1 && nj == 2) dict_chunk_rec<(KIF > 1 ? 2 : 1)>(w, R, q, gr, r, bit);
-                        else dict_chunk_rec<1>(w, R, q, gr, r, bit);
-                    }
-                }
+                    if (KIF > 4 && nj > 4) dict_chunk<(KIF > 4 ? KIF : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
+                    else if (KIF > 2 && nj > 2) dict_chunk<(KIF > 2 ? 4 : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
+                    else if (KIF > 1 && nj == 2) dict_chunk<(KIF > 1 ? 2 : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
+                    else dict_chunk<1, FLAGS>(w, seg, flg, i0, n, gr, r, bit);
                 }
             }
             s0 = s0_next;
             n = n_next;
             f0 = f0_next;
-            if (REC) { rec_pre = rec_next; s0_next = s0_nn; n_next = n_nn; }
         }
         __syncthreads();
         if (full) break;         // read between two barriers: uniform
@@ -1941,25 +1839,19 @@ void set_table_tuning(int kif, int threads)
 }
 void launch_dict_build(hipStream_t s, const DictArgs &a)
 {
-    // record form: + the records and the head bitmap of a round per wave
-    const size_t lds = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (a.recs ? (size_t)(g_table_threads / 64) * REC_WAVE_LDS : 0);
+    const size_t lds = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES;
     const dim3 grid(1u << (a.bb + a.sb)), block(g_table_threads);     // 256 / 512 / 1024 threads: the wave count divides 64
-#define GRM_LAUNCH_DICT(K, T, F, R) hipLaunchKernelGGL((dict_build_kernel<K, T, F, R>), grid, block, lds, s, a)
+#define GRM_LAUNCH_DICT(K, T, F) hipLaunchKernelGGL((dict_build_kernel<K, T, F>), grid, block, lds, s, a)
     if (a.in_flags) {                   // union over ranks: not a hot kernel, one instance
-        GRM_LAUNCH_DICT(4, 1024, true, false);
+        GRM_LAUNCH_DICT(4, 1024, true);
         return;
     }
     const int kif = (g_table_threads > 512 && g_dict_kif > 4) ? 4 : g_dict_kif;
-    if (a.recs) {
-        if (kif >= 8) GRM_LAUNCH_DICT(8, 512, false, true);
-        else GRM_LAUNCH_DICT(4, 1024, false, true);
-        return;
-    }
     switch (kif) {
-    case 1: GRM_LAUNCH_DICT(1, 1024, false, false); break;
-    case 2: GRM_LAUNCH_DICT(2, 1024, false, false); break;
-    case 4: GRM_LAUNCH_DICT(4, 1024, false, false); break;
-    default: GRM_LAUNCH_DICT(8, 512, false, false); break;
+    case 1: GRM_LAUNCH_DICT(1, 1024, false); break;
+    case 2: GRM_LAUNCH_DICT(2, 1024, false); break;
+    case 4: GRM_LAUNCH_DICT(4, 1024, false); break;
+    default: GRM_LAUNCH_DICT(8, 512, false); break;
     }
 #undef GRM_LAUNCH_DICT
 }
@@ -2186,19 +2078,15 @@ hipError_t set_max_dynamic_lds()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_dedup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<1, 1024, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<1, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<2, 1024, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<2, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<8, 512, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<8, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<8, 512, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(matrix_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;

@@ -1,25 +1,34 @@
 // grm_superkmer.hip -- record form of the partition (11 <= k <= 32, abundance-min 1, matrix path).
 //
-// The key form (grm_kernels.hip, levels 1 and 2) moves every canonical k-mer through HBM three times as an 8-byte key
-// (write, read + write, read: 160 GB per 1000 x 5 Mbp).  Here the bucket of a k-mer is a function of its MINIMIZER --
-// the canonical 11-mer with the smallest hash among the k - 10 it contains -- so consecutive k-mers of a sequence fall
-// into the same bucket for (k - 9) / 2 positions on average (what DSK itself does with its minimizer partitions [EXT]).
-// A run of consecutive valid k-mer starts with the same bucket travels as ONE 16-byte record that carries its own
-// bases: 2 bits x (len + k - 1 <= 60 bases) MSB-first in x and the upper 56 bits of y, len in the low byte of y.
-// One kernel, one level: 8 B per k-mer become about 2 B, and dict_build (record form) rebuilds the canonical k-mers
-// from the records while it unions the bucket.  A k-mer and its reverse complement contain the same canonical
-// 11-mers, so the bucket is a function of the canonical k-mer, on every rank alike.
+// The key form (grm_kernels.hip, levels 1 and 2) moves every canonical k-mer through HBM as an 8-byte key: written by
+// level 1, read and written by level 2, read by the consumer -- 160 GB per 1000 x 5 Mbp.  Here the bucket of a k-mer
+// is a function of its MINIMIZER -- the canonical 11-mer with the smallest hash among the k - 10 it contains -- so
+// consecutive k-mers of a sequence share their bucket for (k - 9) / 2 positions on average (what DSK itself does with its
+// minimizer partitions [EXT]).  A run of up to 16 consecutive valid k-mer starts with the same bucket travels through
+// level 1 as ONE 16-byte record that carries its own bases:
+//     x            bases 0..31 of the run, MSB-first
+//     y[63..34]    bases 32..46                        (len + k - 1 <= 47 bases)
+//     y[15..8]     fine bucket (the bucket bits below the 8 coarse ones)
+//     y[7..0]      len = k-mers in the run (1..16)
+// so 8 B per k-mer become ~2 B between the levels.  Level 2 owns a (genome part, coarse bucket) region: it sorts the
+// region's records by fine bucket and EXPANDS them to canonical k-mers on the way out, leaving the same bucket-sorted
+// key segments as the key form for every consumer (dict_build, dedup, the probing fill).  A k-mer and its reverse
+// complement contain the same canonical 11-mers, so the bucket is a function of the canonical k-mer, on every rank alike
+// (minimizer_bucket_of_kmer re-derives it from a key where a consumer has only the key).
 #include "grm_internal.h"
 #include "grm_device_fns.h"
 #include "grm_coop.h"
 #include <algorithm>
-#include <cstdlib>
 
 namespace grm {
 
 constexpr int SK_THREADS = 512;
 constexpr int SK_PPT = 32;                            // k-mer start positions per thread and step: one packed word
-constexpr int SK_MAX_BITS = 14;                       // 2^14 packed 16-bit cursors = 32 KB of LDS
+constexpr int SK_LMAX = 16;                           // k-mers per record
+constexpr int SK_STAGE = 2560;                        // records staged per sub-step of level 1 (a step of 31-mers yields ~2300)
+constexpr int SK_MAX_BITS = 14;                       // 8 coarse + at most 6 fine bits
+constexpr int SK2_THREADS = 256;
+constexpr int SK2_TILE_KEYS = SK2_THREADS * SK_LMAX;                // one record per thread: at most 4096 keys = 32 KB of LDS per tile
 
 struct SkArgs {
     const uint64_t *sym2;
@@ -27,36 +36,40 @@ struct SkArgs {
     uint64_t total_syms;
     const uint64_t *genome_sym_off;
     uint32_t n_genomes;
-    int k, bb, lmax;
+    int k, bb;
     int part_bits;                                    // a genome is cut into 2^part_bits parts, one workgroup each
 };
 
-// One workgroup per (genome, part): it owns the part's 2^bb record segments, so the slot of a record comes from an LDS
-// cursor -- a returning GLOBAL atomic per record (6e8 of them, each to its own address) measured 20 ms of the first
-// form's 35, and an add per wave to one global counter another 28 (same-address atomics serialise in L2).
-// Per step a thread takes one packed word (32 start positions): minimizer bucket of every valid k-mer start, then run by
-// run one LDS atomic and one 16-byte store.  W = k - SK_M + 1 m-mers per k-mer (template: the window minimum is a fixed
-// pattern of register moves).
+// ---- level 1 -----------------------------------------------------------------------------------------------------
+// One workgroup per (genome, part) = "virtual genome" vg: it owns the part's 2^b1 coarse regions of records1, so the
+// place of a record needs no global atomic (a returning global atomic per record measured 20 ms for 6e8 records, and an
+// add per wave to ONE global counter 28 ms: same-address atomics serialise in L2).  Per step a thread takes one packed
+// word (32 start positions): minimizer bucket of every valid k-mer start (W = k - SK_M + 1 m-mers per k-mer; template:
+// the window minimum is a fixed pattern of register moves), runs -> records; the step's records are counting-sorted by
+// coarse bucket in LDS and leave as one contiguous run per coarse bucket.
 template <int W>
-__global__ __launch_bounds__(SK_THREADS) void superkmer_kernel(SkArgs a, uint32_t *__restrict__ rcount, ulonglong2 *__restrict__ recs,
-                                                                uint32_t rcap, uint32_t *__restrict__ part_kmers, int *__restrict__ overflow)
+__global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulonglong2 *__restrict__ recs1, uint32_t rstride,
+                                                                   uint32_t *__restrict__ rcount1, uint32_t *__restrict__ part_kmers,
+                                                                   int *__restrict__ overflow)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    uint32_t *s_bk = reinterpret_cast<uint32_t *>(lds_raw);                               // [SK_THREADS * 16]: 16-bit bucket per position
-    uint32_t *cur = s_bk + SK_THREADS * (SK_PPT / 2);                                     // [2^bb / 2]: two 16-bit cursors per word
-    uint32_t *scratch = cur + ((1u << a.bb) + 1) / 2;                                     // [16]
+    __shared__ uint32_t s_bk[SK_THREADS * (SK_PPT / 2)];     // 16-bit bucket of every position of the step
+    __shared__ ulonglong2 s_rec[SK_STAGE];
+    __shared__ uint8_t s_c[SK_STAGE];                        // coarse bucket of s_rec[i]
+    __shared__ uint32_t hist[256], start[256];
+    __shared__ uint64_t gbase[256];
+    __shared__ uint32_t scratch[32];
     constexpr int NM = SK_PPT + W - 1;                 // m-mer positions a thread looks at
-    const uint32_t B = 1u << a.bb;
-    const uint32_t vg = blockIdx.x;                    // virtual genome = genome * parts + part
+    const int b1 = a.bb < 8 ? a.bb : 8, b2 = a.bb - b1;
+    const uint32_t B1 = 1u << b1;
+    const uint32_t vg = blockIdx.x;
     const uint32_t gen = vg >> a.part_bits, part = vg & ((1u << a.part_bits) - 1u);
     const uint64_t lo = a.genome_sym_off[gen], hi = a.genome_sym_off[gen + 1];
     const uint64_t w_lo = lo >> 5, w_hi = (hi + 31) >> 5;
     const uint64_t per_part = (w_hi - w_lo + (1u << a.part_bits) - 1) >> a.part_bits;
     const uint64_t w_a = min(w_lo + (uint64_t)part * per_part, w_hi), w_b = min(w_a + per_part, w_hi);
-    for (uint32_t i = threadIdx.x; i < (B + 1) / 2; i += SK_THREADS) cur[i] = 0;
-    __syncthreads();
     const uint16_t *my_bk = reinterpret_cast<const uint16_t *>(s_bk) + threadIdx.x * SK_PPT;
-    ulonglong2 *seg0 = recs + (uint64_t)vg * B * rcap;
+    uint32_t my_fill = 0;                              // thread t: records written so far to coarse region t
+    const uint64_t my_region = ((uint64_t)vg * B1 + threadIdx.x) * rstride;
     uint32_t n_valid = 0;
     bool over = false;
     for (uint64_t wbase = w_a; wbase < w_b; wbase += SK_THREADS) {
@@ -109,12 +122,10 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_kernel(SkArgs a, uint32_
                 const bool hd = vi && (i == 0 || !((valid >> (i > 0 ? i - 1 : 0)) & 1u) || bk[i] != bk[i > 0 ? i - 1 : 0]);
                 heads |= (uint32_t)hd << i;
             }
-            // a record holds at most lmax k-mers (its bases must fit 120 bits): split a longer run
-            if (a.lmax < SK_PPT) {
+            // a record holds at most SK_LMAX k-mers: a start with no head among the SK_LMAX positions up to it opens one
 #pragma unroll
-                for (int i = 29; i < SK_PPT; i++) {
-                    if (i >= a.lmax && ((valid >> i) & 1u) && ((heads >> (i + 1 - a.lmax)) & ((1u << a.lmax) - 1u)) == 0) heads |= 1u << i;
-                }
+            for (int i = SK_LMAX; i < SK_PPT; i++) {
+                if (((valid >> i) & 1u) && ((heads >> (i + 1 - SK_LMAX)) & ((1u << SK_LMAX) - 1u)) == 0) heads |= 1u << i;
             }
             // the bucket of a run's first position is the only per-position value the emission needs, and it is
             // indexed by a run-time position: through LDS (each thread reads back its own 64 bytes)
@@ -123,66 +134,238 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_kernel(SkArgs a, uint32_
         }
         // ends of runs: the next head, the next invalid start, or the end of the word
         const uint64_t bnd = (uint64_t)(heads | ~valid) | (1ull << SK_PPT);
-        // the runs of a lane leave one per round (a lane has ~4, at most 32)
-        uint32_t hd = heads;
-        while (hd) {
-            const int i = __ffs(hd) - 1;
-            hd &= hd - 1;
-            const uint32_t len = (uint32_t)__ffsll((unsigned long long)(bnd >> (i + 1)));
-            ulonglong2 rec;
-            rec.x = i ? ((w0 << (2 * i)) | (w1 >> (64 - 2 * i))) : w0;
-            rec.y = ((w1 << (2 * i)) & ~0xffull) | len;
-            const uint32_t bkt = my_bk[i];
-            const uint32_t sh = (bkt & 1u) * 16u;
-            const uint32_t slot = (atomicAdd(&cur[bkt >> 1], 1u << sh) >> sh) & 0xffffu;
-            if (slot < rcap) seg0[(uint64_t)bkt * rcap + slot] = rec;
-            else over = true;
+        uint32_t n_rec;
+        const uint32_t base = block_scan_sum((uint32_t)__popc(heads), scratch, &n_rec);
+        // sub-steps of at most SK_STAGE records (one, unless k is close to 11 and nearly every start opens a run)
+        for (uint32_t sub0 = 0; sub0 < n_rec; sub0 += SK_STAGE) {
+            if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+            __syncthreads();
+            {   // count per coarse bucket
+                uint32_t hd = heads, idx = base - sub0;
+                while (hd) {
+                    const int i = __ffs(hd) - 1;
+                    hd &= hd - 1;
+                    if (idx < (uint32_t)SK_STAGE) atomicAdd(&hist[my_bk[i] >> b2], 1u);
+                    idx++;
+                }
+            }
+            __syncthreads();
+            const uint32_t c_cnt = threadIdx.x < 256 ? hist[threadIdx.x] : 0u;
+            uint32_t n_here;
+            const uint32_t st = block_scan_sum(c_cnt, scratch, &n_here);
+            if (threadIdx.x < 256) {
+                start[threadIdx.x] = st;
+                hist[threadIdx.x] = 0;                 // now the running rank inside the coarse bucket
+                const bool fits = (uint64_t)my_fill + c_cnt <= rstride;
+                if (!fits) over = true;
+                gbase[threadIdx.x] = (fits && threadIdx.x < B1) ? my_region + my_fill : ~0ull;
+                if (fits) my_fill += c_cnt;
+            }
+            __syncthreads();
+            {   // place
+                uint32_t hd = heads, idx = base - sub0;
+                while (hd) {
+                    const int i = __ffs(hd) - 1;
+                    hd &= hd - 1;
+                    if (idx < (uint32_t)SK_STAGE) {
+                        const uint32_t len = (uint32_t)__ffsll((unsigned long long)(bnd >> (i + 1)));
+                        const uint32_t bkt = my_bk[i];
+                        const uint32_t c = bkt >> b2;
+                        ulonglong2 rec;
+                        rec.x = i ? ((w0 << (2 * i)) | (w1 >> (64 - 2 * i))) : w0;
+                        rec.y = ((w1 << (2 * i)) & ~0xffffull) | ((uint64_t)(bkt & ((1u << b2) - 1u)) << 8) | len;
+                        const uint32_t pos = start[c] + atomicAdd(&hist[c], 1u);
+                        s_rec[pos] = rec;
+                        s_c[pos] = (uint8_t)c;
+                    }
+                    idx++;
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n_here; i += SK_THREADS) {
+                const uint32_t c = s_c[i];
+                const uint64_t gb = gbase[c];
+                if (gb != ~0ull) recs1[gb + (i - start[c])] = s_rec[i];
+            }
+            __syncthreads();
         }
     }
     if (over) atomicExch(overflow, 1);
-    __syncthreads();
-    // records per segment; k-mer occurrences (= valid starts) of the part
-    for (uint32_t b2 = threadIdx.x; b2 < B; b2 += SK_THREADS) {
-        const uint32_t c = (cur[b2 >> 1] >> ((b2 & 1u) * 16u)) & 0xffffu;
-        rcount[(uint64_t)vg * B + b2] = min(c, rcap);
-    }
+    if (threadIdx.x < B1) rcount1[(uint64_t)vg * B1 + threadIdx.x] = my_fill;
     uint32_t total;
     (void)block_scan_sum(n_valid, scratch, &total);
     if (threadIdx.x == 0) part_kmers[vg] = total;
 }
 
-template <int W>
-static void launch_sk(hipStream_t s, const SkArgs &a, uint32_t *rcount, ulonglong2 *recs, uint32_t rcap, uint32_t *part_kmers, int *overflow)
+// ---- level 2 -----------------------------------------------------------------------------------------------------
+// One workgroup per (virtual genome, coarse bucket) region at a time.  Pass A adds up the k-mers per fine bucket (the
+// region is a few ten KB: its second reading comes from L2) and lays the region's fine key segments out back to back
+// at region * kstride: off / len of segment vg * 2^bb + bucket.  Pass B takes tiles of 256 records (the next tile's
+// records are requested before the current one is worked on).  A record's k-mers go to ONE fine bucket, so the rank of
+// the record inside its bucket (one returning LDS atomic per record) places all of them.  A lane rolls through its record
+// (forward and reverse-complement words, as the key form's extraction does) and stores the canonical k-mers into the
+// tile's LDS image, which leaves as one contiguous run per fine bucket.  Records hold 1..16 k-mers: the tile's records are
+// first sorted by length (a counting sort through LDS), so that the lanes of a wave roll for about the same number of
+// steps -- unsorted, half of the lanes idle.
+__global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglong2 *__restrict__ recs1, uint32_t rstride,
+                                                                    const uint32_t *__restrict__ rcount1, uint64_t n_regions, int k, int bb,
+                                                                    uint64_t kstride, uint64_t *__restrict__ keys, uint64_t *__restrict__ off,
+                                                                    uint32_t *__restrict__ len_out, int *__restrict__ overflow)
 {
-    const size_t lds = (size_t)SK_THREADS * (SK_PPT / 2) * 4 + (((size_t)1 << a.bb) + 1) / 2 * 4 + 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(superkmer_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
+    __shared__ uint64_t skeys[SK2_TILE_KEYS];
+    __shared__ ulonglong2 srec[SK2_THREADS];
+    constexpr int NF = 1 << (SK_MAX_BITS - 8);          // fine buckets of a region
+    __shared__ uint32_t gbase[NF];                      // relative to the region's first key
+    __shared__ uint32_t hist[NF], start[NF], lhist[64], lstart[64];
+    __shared__ uint32_t scratch[32];
+    const int b1 = bb < 8 ? bb : 8, b2 = bb - b1;
+    const uint32_t B2 = 1u << b2;
+    const int up = 64 - 2 * k;
+    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const int rcshift = 2 * (k - 1);
+    const int lane = lane_id(), wave = wave_id();
+    for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
+        const uint32_t n = min(rcount1[region], rstride);
+        const ulonglong2 *rr = recs1 + region * rstride;
+        const uint64_t seg0 = region << b2;            // segment index of the region's fine bucket 0: (vg * B1 + c) * B2
+        ulonglong2 rec_next = threadIdx.x < n ? rr[threadIdx.x] : make_ulonglong2(0, 0);
+        // ---- pass A: k-mers per fine bucket -> segment offsets ----
+        if (threadIdx.x < NF) hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += SK2_THREADS) {
+            const uint64_t y = rr[i].y;
+            atomicAdd(&hist[(uint32_t)(y >> 8) & 0xffu], (uint32_t)(y & 0xffu));
+        }
+        __syncthreads();
+        const uint32_t cnt = threadIdx.x < B2 ? hist[threadIdx.x] : 0u;
+        uint32_t region_keys;
+        const uint32_t pre = block_scan_sum(cnt, scratch, &region_keys);
+        const bool region_fits = region_keys <= kstride;           // uniform
+        if (!region_fits && threadIdx.x == 0) atomicExch(overflow, 1);
+        const uint64_t key0 = region * kstride;
+        uint32_t my_next = pre;                                     // thread f: running output position of fine bucket f
+        if (threadIdx.x < B2) {
+            off[seg0 + threadIdx.x] = key0 + my_next;
+            len_out[seg0 + threadIdx.x] = region_fits ? cnt : 0u;
+        }
+        if (!region_fits) continue;
+        // ---- pass B: tiles of SK2_THREADS records ----
+        for (uint32_t t0 = 0; t0 < n; t0 += SK2_THREADS) {
+            ulonglong2 rec = rec_next;
+            {
+                const uint32_t i = t0 + SK2_THREADS + threadIdx.x;
+                rec_next = i < n ? rr[i] : make_ulonglong2(0, 0);
+            }
+            if (threadIdx.x < NF) hist[threadIdx.x] = 0;
+            if (threadIdx.x < 64) lhist[threadIdx.x] = 0;
+            __syncthreads();
+            const uint32_t ln = (uint32_t)(rec.y & 0xffu);               // 0 for the padding of the last tile
+            const uint32_t fine = (uint32_t)(rec.y >> 8) & 0xffu;
+            const uint32_t frank = ln ? atomicAdd(&hist[fine], ln) : 0u;  // first k-mer of the record inside its fine bucket
+            const uint32_t lrank = atomicAdd(&lhist[ln & 63u], 1u);
+            __syncthreads();
+            if (wave == 0) {
+                const uint32_t c = lhist[lane];
+                lstart[lane] = wave_scan_incl_dpp(c) - c;
+            }
+            const uint32_t c2 = threadIdx.x < B2 ? hist[threadIdx.x] : 0u;
+            uint32_t n_tile;
+            const uint32_t st = block_scan_sum(c2, scratch, &n_tile);      // its barriers also publish lstart
+            if (threadIdx.x < B2) {
+                start[threadIdx.x] = st;
+                gbase[threadIdx.x] = my_next;
+                my_next += c2;
+            }
+            // by length: thread j continues with the j-th shortest record (the rank inside the fine bucket travels in
+            // bits of y that hold bases no k-mer of the record reaches)
+            srec[lstart[ln & 63u] + lrank] = make_ulonglong2(rec.x, (rec.y & ~(0x3ffffull << 16)) | ((uint64_t)frank << 16));
+            __syncthreads();
+            {
+                const ulonglong2 r2 = srec[threadIdx.x];
+                const uint32_t l2 = (uint32_t)(r2.y & 0xffu);
+                if (l2) {
+                    uint32_t at = start[(uint32_t)(r2.y >> 8) & 0xffu] + ((uint32_t)(r2.y >> 16) & 0x3ffffu);
+                    uint64_t fwd = r2.x >> up;
+                    uint64_t rc = revcomp_m(fwd, k);
+                    // the bases after the first k-mer, MSB-aligned (at most 15 are used)
+                    uint64_t rest = k < 32 ? ((r2.x << (2 * k)) | (r2.y >> up)) : r2.y;
+                    for (uint32_t t = 0;; t++) {
+                        skeys[at++] = fwd < rc ? fwd : rc;
+                        if (t + 1 >= l2) break;
+                        const uint64_t s = rest >> 62;
+                        rest <<= 2;
+                        fwd = ((fwd << 2) | s) & mask;
+                        rc = (rc >> 2) | ((s ^ 2ull) << rcshift);
+                    }
+                }
+            }
+            __syncthreads();
+            // one contiguous run per fine bucket: the waves take the buckets in turn
+            for (uint32_t f = (uint32_t)wave; f < B2; f += SK2_THREADS / 64) {
+                const uint32_t nf = hist[f], src = start[f];
+                const uint64_t dst = key0 + gbase[f];
+                for (uint32_t i = (uint32_t)lane; i < nf; i += 64) keys[dst + i] = skeys[src + i];
+            }
+            __syncthreads();
+        }
     }
-    hipLaunchKernelGGL(superkmer_kernel<W>, dim3(a.n_genomes << a.part_bits), dim3(SK_THREADS), lds, s, a, rcount, recs, rcap, part_kmers, overflow);
 }
 
-int superkmer_lmax(int k) { return std::min(SK_PPT, 61 - k); }
-int superkmer_max_bits() { return SK_MAX_BITS; }
+// bucket ((bucket << sb) | sub) of dictionary keys under minimizer buckets (the probing form of the fill builds its
+// per-bucket tables from the dictionary): the minimizer is re-derived from the k-mer itself
+__global__ void minimizer_bucket_ids_kernel(const uint64_t *__restrict__ dict, uint64_t n, int k, int bb, int sb,
+                                            uint32_t *__restrict__ bucket_of, uint32_t *__restrict__ col_of)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = dict[i];
+        bucket_of[i] = (minimizer_bucket_of_kmer(key, k, bb, SK_M) << sb) | hash_sub(mix64(key), bb, sb);
+        col_of[i] = (uint32_t)i;
+    }
+}
 
-void launch_superkmer_scatter(hipStream_t s, const KmerLaunch &L, int part_bits, uint32_t *rcount, void *recs, uint32_t rcap, uint32_t *part_kmers,
-                              int *overflow)
+template <int W>
+static void launch_sk1(hipStream_t s, const SkArgs &a, ulonglong2 *recs1, uint32_t rstride, uint32_t *rcount1, uint32_t *part_kmers, int *overflow)
+{
+    hipLaunchKernelGGL(superkmer_l1_kernel<W>, dim3(a.n_genomes << a.part_bits), dim3(SK_THREADS), 0, s, a, recs1, rstride, rcount1, part_kmers,
+                       overflow);
+}
+
+int superkmer_max_bits() { return SK_MAX_BITS; }
+int superkmer_lmax() { return SK_LMAX; }
+
+void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int part_bits, void *recs1, uint32_t rstride, uint32_t *rcount1,
+                         uint32_t *part_kmers, int *overflow)
 {
     if (!L.total_syms || !L.n_genomes) return;
     SkArgs a;
     a.sym2 = L.sym2; a.inv = L.inv; a.total_syms = L.total_syms; a.genome_sym_off = L.genome_sym_off;
-    a.n_genomes = L.n_genomes; a.k = L.k; a.bb = L.bb; a.lmax = superkmer_lmax(L.k);
+    a.n_genomes = L.n_genomes; a.k = L.k; a.bb = L.bb;
     a.part_bits = part_bits;
-    ulonglong2 *r = reinterpret_cast<ulonglong2 *>(recs);
+    ulonglong2 *r = reinterpret_cast<ulonglong2 *>(recs1);
     switch (L.k - SK_M + 1) {
-#define GRM_SK_CASE(W) case W: launch_sk<W>(s, a, rcount, r, rcap, part_kmers, overflow); break;
+#define GRM_SK_CASE(W) case W: launch_sk1<W>(s, a, r, rstride, rcount1, part_kmers, overflow); break;
         GRM_SK_CASE(1) GRM_SK_CASE(2) GRM_SK_CASE(3) GRM_SK_CASE(4) GRM_SK_CASE(5) GRM_SK_CASE(6) GRM_SK_CASE(7) GRM_SK_CASE(8)
         GRM_SK_CASE(9) GRM_SK_CASE(10) GRM_SK_CASE(11) GRM_SK_CASE(12) GRM_SK_CASE(13) GRM_SK_CASE(14) GRM_SK_CASE(15)
         GRM_SK_CASE(16) GRM_SK_CASE(17) GRM_SK_CASE(18) GRM_SK_CASE(19) GRM_SK_CASE(20) GRM_SK_CASE(21) GRM_SK_CASE(22)
 #undef GRM_SK_CASE
         default: break;     // the host only asks for 11 <= k <= 32
     }
+}
+
+void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb,
+                         uint64_t kstride, uint64_t *keys, uint64_t *off, uint32_t *len, int *overflow)
+{
+    if (!n_regions) return;
+    const uint32_t grid = (uint32_t)(n_regions < 256u * 32u ? n_regions : 256u * 32u);
+    hipLaunchKernelGGL(superkmer_l2_kernel, dim3(grid), dim3(SK2_THREADS), 0, s, reinterpret_cast<const ulonglong2 *>(recs1), rstride, rcount1,
+                       n_regions, k, bb, kstride, keys, off, len, overflow);
+}
+
+void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int k, int bb, int sb, uint32_t *bucket_of, uint32_t *col_of)
+{
+    if (!n) return;
+    const uint64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(minimizer_bucket_ids_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, dict, n, k, bb, sb, bucket_of, col_of);
 }
 
 }  // namespace grm
