@@ -41,12 +41,16 @@ ALGO_BYTES = {
     "parse_summarize": 1.0,          # per input byte: read 1
     "parse_pack": 1.0 + 0.375,       # per input byte: read 1, write 2+1 bits per symbol (<= byte count)
     "kmer_hist": 0.375,              # per symbol: read packed stream
-    "kmer_scatter_l1": 0.375 + 8.0,  # per k-mer occurrence: read packed stream, write one u64 key
-    "kmer_scatter_l2": 16.0,         # per key: read 8, write 8 (second radix level)
+    "kmer_scatter_l1": 0.375 + 8.0,  # key form, per k-mer occurrence: read packed stream, write one u64 key
+    "kmer_scatter_l2": 16.0,         # key form, per key: read 8, write 8 (second radix level)
+    "superkmer_l2": 32.0,            # record form, per 16-byte run record: read 16, write 16
+    "superkmer_l2_keys": None,       # record form with key segments: 16 per record read + 8 per k-mer written (below)
     "bucket_dedup": 16.0 + 4.0,      # per key: read 8, write <= 8 + a 4-byte count
     "dict_build": 8.0,               # per key: read 8 (what it writes is dictionary-sized, added per launch below)
     "matrix_fill": 16.0,             # per (entry, word-row): read one presence word, write it to its column
 }
+# algorithmic bytes per k-mer occurrence of the straightforward extract / sort / fill pipeline
+SURVEY_BYTES_PER_KMER = {1: 57.0, 2: 113.0}
 
 
 def parse_args():
@@ -154,13 +158,21 @@ def kernel_table(ctx, n_cols, n_rows, n_local):
         d["launches"] += 1
         d["units"] += units
     kernels = {}
+    # record form of the partition: the run records (16 B) level 1 wrote = the units of "superkmer_l2"
+    n_records = per["superkmer_l2"]["units"] / per["superkmer_l2"]["launches"] if "superkmer_l2" in per else None
     for name, d in per.items():
         avg_ms = d["ms"] / d["launches"]
         e = {"avg_ms": round(avg_ms, 4), "launches": d["launches"]}
-        if name in ALGO_BYTES and avg_ms > 0:
+        byts = None
+        if name == "superkmer_l1" and n_records is not None:
+            byts = 0.375 * d["units"] / d["launches"] + 16.0 * n_records           # read the packed stream, write the records
+        elif name == "dict_build" and n_records is not None:
+            byts = 16.0 * n_records + 8.0 * n_local * n_rows + 9.0 * n_local        # read the records; presence words + (key, flag) per entry
+        elif ALGO_BYTES.get(name) is not None:
             byts = ALGO_BYTES[name] * d["units"] / d["launches"]
             if name == "dict_build":
                 byts += 8.0 * n_local * n_rows + 9.0 * n_local      # presence words + (key, flag) of every entry
+        if byts is not None and avg_ms > 0:
             e["algo_GBps"] = round(byts / (avg_ms * 1e-3) / 1e9, 1)
             e["algo_bytes"] = byts
         kernels[name] = e
@@ -394,6 +406,13 @@ def main():
             "bases_per_s": round(syms_total * args.steps / elapsed, 1),
             "roofline": roofline, "kernels": kernels, "setup_s": round(setup_s, 1),
         }
+        if args.stage == "matrix" and args.k <= 64:
+            # the whole pass against SURVEY.md 8(d)'s byte model of the straightforward extract / sort / fill pipeline
+            # (1 + 7W bytes per occurrence): the record form moves fewer bytes than that model, so this can pass 1
+            bpk = SURVEY_BYTES_PER_KMER[1 if args.k <= 32 else 2]
+            gbps = occ_total * bpk * args.steps / elapsed / 1e9 / world
+            out["survey_model"] = {"bytes_per_kmer": bpk, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                                   "frac": round(gbps / HBM_PEAK_GBS, 4)}
         if world > 1:
             out["collective"] = {"backend": D.backend, "world_size_seen": D.dist.get_world_size(),
                                  "allgather_calls": xfer["calls"] if xfer else 0,

@@ -65,6 +65,7 @@ struct grm_ctx {
     int opt_records = -1;        // 0: never use the record (minimizer) form of the partition (tests, measurements)
     int opt_rec_bucket_shift = -1; // record form: bucket bits on top of the key form's choice (default 1)
     int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
+    int opt_rec_keys = -1;       // > 0: record form always expands to key segments in level 2 (tests, measurements)
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
 // 64-bit words of a k-mer, most significant first: 1 (k <= 32), 2 (<= 64), 3 (<= 96), 4 (<= 128)
@@ -251,6 +252,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "records") c->opt_records = value;
     else if (n == "rec_bucket_shift") c->opt_rec_bucket_shift = value;
     else if (n == "rec_part_bits") c->opt_rec_part_bits = value;
+    else if (n == "rec_keys") c->opt_rec_keys = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
@@ -679,8 +681,12 @@ struct grm_batch {
     // record form of the partition (grm_superkmer.hip): minimizer buckets; d_recs holds the level-1 records, the key
     // segments are given by d_off AND d_len (regions leave gaps).  rec_failed: a region overflowed once (repeat-rich
     // input) or a later stage could not use the layout -- the batch stays on the key form from then on.
-    DevBuf d_recs;
-    bool rec_mode = false, rec_failed = false;
+    // rec_dict: the segments (d_off / d_len) are still segments of RECORDS in d_recs2 -- dict_build decodes them; the keys
+    // are expanded from d_recs only if a later stage asks for them (batch_expand_keys).
+    DevBuf d_recs, d_recs2;
+    bool rec_mode = false, rec_failed = false, rec_dict = false;
+    uint32_t rec_rstride = 0;
+    uint64_t rec_kstride = 0, rec_regions = 0;
     int rec_part_bits = 0;         // genomes are cut into 2^rec_part_bits parts (segment index: virtual genome * 2^bb + bucket)
     bool slack_failed = false;     // a slack-layout partition of this batch overflowed: dense layout from then on
     DevBuf d_marks;                // one bit per segment: left to the workgroup form of the dedup
@@ -1073,17 +1079,19 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         const uint64_t n_parts = (uint64_t)G << pbits;
         const uint64_t n_regions = n_parts << b1r, n_seg_r = n_parts << bbr;
         // records per region: a run ends where the minimizer changes (2 / (w + 1) per position for the w m-mers of a
-        // k-mer), at the end of a thread's 32 positions or after 16 k-mers; k-mers per region: ~0.05 distinct
-        // minimizers per position, sigma of a region = 1.39 x its share / sqrt(its minimizers) (simulated)
+        // k-mer) or at the end of a thread's 32 positions, and runs of roughly geometric length are cut every
+        // superkmer_lmax() k-mers; k-mers per region: ~0.05 distinct minimizers per position, sigma of a region =
+        // 1.39 x its share / sqrt(its minimizers) (both simulated)
         const int w = k - SK_M + 1;
         const double mean_k = (double)((max_g >> pbits) >> b1r) + 1.0;
-        const double mean_r = mean_k * (2.0 / (w + 1) + 1.0 / 32 + 0.02);
-        const uint64_t rstride64 = (uint64_t)(mean_r * 1.05 + 16.0 * std::sqrt(mean_r) + 64.0 + 15.0) / 16 * 16;
+        const double d0 = 2.0 / (w + 1) + 1.0 / 32;                       // runs per position before the cap on their length
+        const double mean_r = mean_k * (d0 * (1.0 + 1.0 / (std::exp(superkmer_lmax() * d0) - 1.0)) + 0.005);
+        const uint64_t rstride64 = (uint64_t)(mean_r * 1.02 + 14.0 * std::sqrt(mean_r) + 32.0 + 15.0) / 16 * 16;     // mean + 7.5 sigma
         const uint64_t kstride = (uint64_t)(mean_k + 50.0 * std::sqrt(mean_k) + 256.0 + 15.0) / 16 * 16;
         // genomes of very different sizes would waste most of a layout sized for the largest one
         bool rec = n_seg_r < 0xffffffffull && rstride64 < 0xffffffffull && kstride < 0xffffffffull &&
                    (double)n_regions * (double)kstride <= 3.0 * (double)b->total_syms + 65536.0 * 1024.0;
-        if (rec && (b->d_recs.ensure((n_regions * rstride64 + 4) * 16) != hipSuccess || b->d_keys.ensure((n_regions * kstride + 4) * 8) != hipSuccess)) {
+        if (rec && b->d_recs.ensure((n_regions * rstride64 + 4) * 16) != hipSuccess) {
             (void)hipGetLastError();
             rec = false;
         }
@@ -1096,28 +1104,46 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
             HIPCHK(c, b->d_len.ensure((n_seg_r + 1) * 4));
             HIPCHK(c, b->d_counts1.ensure((n_regions + 1) * 4));
             HIPCHK(c, b->d_cursor1.ensure(n_parts * 4));
-            HIPCHK(c, b->t_flag.ensure(16));
-            HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 16, s));
+            HIPCHK(c, b->t_flag.ensure(32));
+            HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 32, s));
             {
                 TimeScope t(c, "superkmer_l1", b->total_syms);
                 launch_superkmer_l1(s, Lr, pbits, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), b->d_cursor1.as<uint32_t>(), b->t_flag.as<int>());
             }
-            {
-                TimeScope t(c, "superkmer_l2", b->total_syms);
+            // the fill through the presence bits needs no keys at all: dict_build then decodes the records itself and
+            // level 2 only sorts them by fine bucket; else (probing fill) level 2 expands them to key segments
+            const size_t n_rows_b = ((size_t)G + 63) / 64;
+            const bool by_records = c->opt_no_slots <= 0 && c->opt_rec_keys <= 0 && n_rows_b <= 0xffffu &&
+                                    ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << b->cap_log2) * 8 <= MATRIX_S_LIMIT &&
+                                    b->d_recs2.ensure((n_regions * rstride64 + 4) * 16) == hipSuccess;
+            if (!by_records) (void)hipGetLastError();
+            b->rec_rstride = rstride; b->rec_kstride = kstride; b->rec_regions = n_regions;
+            int l2_idx = -1;
+            if (by_records) {
+                TimeScope t(c, "superkmer_l2", b->total_syms);        // (units: the record count, once it is known)
+                l2_idx = t.idx;
+                launch_superkmer_l2_records(s, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, bbr, b->d_recs2.p,
+                                            b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>());
+            } else {
+                HIPCHK(c, b->d_keys.ensure((n_regions * kstride + 4) * 8));
+                TimeScope t(c, "superkmer_l2_keys", b->total_syms);
                 launch_superkmer_l2(s, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, k, bbr, kstride, b->d_keys.as<uint64_t>(),
                                     b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->t_flag.as<int>());
             }
             launch_sum_u32(s, b->d_cursor1.as<uint32_t>(), n_parts, reinterpret_cast<uint64_t *>(b->t_flag.as<uint8_t>() + 8));
+            launch_sum_u32(s, b->d_counts1.as<uint32_t>(), n_regions, reinterpret_cast<uint64_t *>(b->t_flag.as<uint8_t>() + 16));
             HIPCHK(c, hipGetLastError());
-            struct { int over; int pad; uint64_t total; } h;
-            HIPCHK(c, hipMemcpyAsync(&h, b->t_flag.p, 16, hipMemcpyDeviceToHost, s));
+            struct { int over; int pad; uint64_t total; uint64_t records; uint64_t pad2; } h;
+            HIPCHK(c, hipMemcpyAsync(&h, b->t_flag.p, 32, hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
+            if (l2_idx >= 0 && l2_idx < (int)c->recs.size()) c->recs[l2_idx].units = h.records;
             if (!h.over) {
                 b->bb = bbr;
                 b->total_keys = h.total;
                 b->seg_stride = 0;
                 b->rec_part_bits = pbits;
                 b->rec_mode = true;
+                b->rec_dict = by_records;
                 b->partitioned = true;
                 return GRM_OK;
             }
@@ -1404,6 +1430,28 @@ static int run_dict_ladder(grm_batch *b, DictArgs a, uint64_t total_keys, int sb
     }
 }
 
+// record form: key segments from the level-1 records, for a consumer that cannot decode records
+static int batch_expand_keys(grm_batch *b)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    HIPCHK(c, b->d_keys.ensure((b->rec_regions * b->rec_kstride + 4) * 8));
+    HIPCHK(c, b->t_flag.ensure(16));
+    HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 16, s));
+    {
+        TimeScope t(c, "superkmer_l2_keys", b->total_syms);
+        launch_superkmer_l2(s, b->d_recs.p, b->rec_rstride, b->d_counts1.as<uint32_t>(), b->rec_regions, b->k, b->bb, b->rec_kstride,
+                            b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->t_flag.as<int>());
+    }
+    HIPCHK(c, hipGetLastError());
+    int over = 0;
+    HIPCHK(c, hipMemcpyAsync(&over, b->t_flag.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (over) return fail(c, GRM_ERR_OVERFLOW, "record form: a region holds more k-mers than its key capacity");
+    b->rec_dict = false;
+    return GRM_OK;
+}
+
 extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
 {
     if (!b) return GRM_ERR_ARG;
@@ -1430,20 +1478,28 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
         sb = b->sb_hint;
     DictArgs a;
     memset(&a, 0, sizeof a);
-    a.keys = b->d_keys.as<uint64_t>();
+    a.keys = b->rec_dict ? nullptr : b->d_keys.as<uint64_t>();
+    a.recs = b->rec_dict ? reinterpret_cast<const ulonglong2 *>(b->d_recs2.p) : nullptr;
+    a.k = b->k;
     a.part_bits = b->rec_mode ? b->rec_part_bits : 0;
     a.seg = batch_segments(b);
     a.n_genomes = G; a.bb = b->bb; a.cap_log2 = b->cap_log2;
     const DictOut out = {&b->d_local_keys, &b->d_local_flags, &b->d_wg_base, &b->d_wg_cnt};
     int rc = run_dict_ladder(b, a, b->total_keys, sb, c->opt_no_slots <= 0, out, "dict_build", &sb, &b->n_local, &b->have_bits, &b->dict_launches);
-    if (b->rec_mode && b->rec_part_bits > 0 && rc == GRM_OK && !b->have_bits) {
-        // the probing form of the fill walks whole genomes: partition again in the key form and stay there
-        b->rec_failed = true;
-        rc = batch_partition_impl(b, b->k, b->abundance_min, false);
-        if (rc) return rc;
-        return grm_batch_local_dict(b, n_local);
-    }
     if (rc) return rc;
+    if (b->rec_mode && !b->have_bits) {
+        // the probing form of the fill reads key segments, genome by genome
+        if (b->rec_part_bits > 0) {
+            b->rec_failed = true;            // ... of whole genomes: partition again in the key form and stay there
+            rc = batch_partition_impl(b, b->k, b->abundance_min, false);
+            if (rc) return rc;
+            return grm_batch_local_dict(b, n_local);
+        }
+        if (b->rec_dict) {
+            rc = batch_expand_keys(b);
+            if (rc) return rc;
+        }
+    }
     b->sb_dict = sb;
     if (c->opt_sub_bits < 0) { b->sb_hint = sb; b->sb_hint_k = b->k; b->sb_hint_bb = b->bb; b->sb_hint_amin = b->abundance_min; }
     b->have_local = true;

@@ -91,6 +91,10 @@ void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int part_bits, void
                          uint32_t *part_kmers, int *overflow);
 void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb,
                          uint64_t kstride, uint64_t *keys, uint64_t *off, uint32_t *len, int *overflow);
+//   level 2, records only: the region's records sorted by the fine bits, region r again at r * rstride of recs2: segment
+//            vg * 2^bb + bucket = recs2[off[..] .. + len[..]) (in records; dict_build decodes them, DictArgs::recs)
+void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb,
+                                 void *recs2, uint64_t *off, uint32_t *len);
 // (bucket << sb) | sub of dictionary keys under minimizer buckets (launch_dict_bucket_ids for the hashed ones)
 void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int k, int bb, int sb, uint32_t *bucket_of, uint32_t *col_of);
 int superkmer_max_bits();
@@ -122,6 +126,10 @@ void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const SegLayout &se
 struct DictArgs {
     const uint64_t *keys;
     int part_bits;          // segments of 2^part_bits parts per genome: segment index = ((genome << part_bits) + part) * 2^bb + bucket
+    // record form: the segments hold the 16-byte run records of grm_superkmer.hip (1..8 k-mers each) instead of keys,
+    // seg counts records; k as given (keys == nullptr then)
+    const ulonglong2 *recs;
+    int k;
     SegLayout seg;
     uint32_t n_genomes;
     int bb, sb;

@@ -1177,7 +1177,7 @@ __device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__
 
 // MAXT: largest workgroup the instance is launched with (the 8-deep form needs more than the 128 VGPRs a
 // 1024-thread workgroup leaves per lane)
-template <int KIF, int MAXT, bool FLAGS>
+template <int KIF, int MAXT, bool FLAGS, bool REC>
 __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -1216,35 +1216,98 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
         seg_bounds(a.seg, (uint64_t)g * B + b, s0, n);
         if (FLAGS) f0 = a.in_flag_off[(uint64_t)g * B + b];
     }
+    // record form: decoding constants, and a wave-private table of the (up to 8) genomes a wave pools
+    const int kk = REC ? a.k : 1;
+    const int up = 64 - 2 * kk, rcshift = 2 * (kk - 1);
+    const uint64_t kmask = kk == 32 ? ~0ull : ((1ull << (2 * kk)) - 1);
+    uint64_t *tabD = reinterpret_cast<uint64_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES) + 8 * wave;
+    uint32_t *tabS = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)nw * 64) + 8 * wave;
     for (uint32_t r = 0; r < n_rows; r++) {
-        for (uint32_t jr = 0; jr < per_row; jr++, g += nw) {
-            uint64_t s0_next = 0, n_next = 0, f0_next = 0;
-            if (g + nw < GV) {
-                seg_bounds(a.seg, (uint64_t)(g + nw) * B + b, s0_next, n_next);
-                if (FLAGS) f0_next = a.in_flag_off[(uint64_t)(g + nw) * B + b];
-            }
-            if (g < GV && !full) {
-                const uint32_t gr = g >> pb;
-                const unsigned long long bit = 1ull << (63 - (gr & 63));
-                const uint64_t *seg = a.keys + s0;
-                const uint8_t *flg = FLAGS ? a.in_flags + f0 : nullptr;
-                // The kernel is bound by latency and instruction issue, so the common case is straight-line and
-                // wide: KIF keys per lane in flight, their hashes, two 16-byte table reads each; a key found there
-                // -- almost every key of a pan-genome after the first few genomes -- costs one more LDS OR.  The
-                // tail of the segment goes through a copy of the same code that is exactly as deep as it needs.
-                uint64_t i0 = lane;
-                for (; i0 + 64u * (KIF - 1) < n; i0 += 64 * KIF) dict_chunk<KIF, FLAGS>(w, seg, flg, i0, n, gr, r, bit);
-                if (i0 - lane < n && !full) {
-                    const uint32_t nj = (uint32_t)((n - (i0 - lane) + 63) >> 6);        // wave-uniform: 1 .. KIF - 1
-                    if (KIF > 4 && nj > 4) dict_chunk<(KIF > 4 ? KIF : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
-                    else if (KIF > 2 && nj > 2) dict_chunk<(KIF > 2 ? 4 : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
-                    else if (KIF > 1 && nj == 2) dict_chunk<(KIF > 1 ? 2 : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
-                    else dict_chunk<1, FLAGS>(w, seg, flg, i0, n, gr, r, bit);
+        if (REC) {
+            // Record form.  A record holds a run of 1..8 consecutive k-mers with their bases; ONE LANE decodes one record
+            // (first k-mer by a shift and a reverse complement, the others by rolling both words) and takes its up to 8
+            // keys to the table.  The records of the wave's genomes of this word-row are pooled, 8 genomes at a time, so
+            // that the lanes of the last instruction of a genome are not left idle: lane -> (genome, record) through the
+            // running totals of the pooled segments.
+            const uint32_t row_first = (r * 64u) << pb;
+            for (uint32_t j0 = 0; j0 < per_row && !full; j0 += 8) {
+                const uint32_t vgj = row_first + (uint32_t)wave + (j0 + (uint32_t)lane) * (uint32_t)nw;
+                uint64_t sj = 0, nj = 0;
+                if (lane < 8 && j0 + (uint32_t)lane < per_row && vgj < GV) seg_bounds(a.seg, (uint64_t)vgj * B + b, sj, nj);
+                const uint32_t n32 = (uint32_t)nj;
+                const uint32_t inc = wave_scan_incl_dpp(n32);
+                const uint32_t cumj = inc - n32;
+                const uint32_t N = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                if (lane < 8) {
+                    tabD[lane] = sj - cumj;
+                    tabS[lane] = 63u - ((vgj >> pb) & 63u);
+                }
+                const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 1), t2 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 2),
+                               t3 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 3), t4 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 4),
+                               t5 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 5), t6 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 6),
+                               t7 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 7);
+                // (the records of the next 64 lanes are requested before the current ones go to the table)
+                auto fetch = [&](uint32_t q, ulonglong2 &rec, uint32_t &sh) {
+                    const uint32_t j = (uint32_t)(q >= t1) + (uint32_t)(q >= t2) + (uint32_t)(q >= t3) + (uint32_t)(q >= t4) +
+                                       (uint32_t)(q >= t5) + (uint32_t)(q >= t6) + (uint32_t)(q >= t7);
+                    rec = q < N ? a.recs[tabD[j] + q] : make_ulonglong2(0, 0);
+                    sh = tabS[j];
+                };
+                ulonglong2 rec_n;
+                uint32_t sh_n;
+                fetch((uint32_t)lane, rec_n, sh_n);
+                for (uint32_t q0 = 0; q0 < N && !full; q0 += 64) {
+                    const ulonglong2 rec = rec_n;
+                    const uint32_t sh = sh_n;
+                    fetch(q0 + 64u + (uint32_t)lane, rec_n, sh_n);
+                    const unsigned long long bit = 1ull << sh;
+                    const uint32_t len = (uint32_t)(rec.y & 0xffu);
+                    uint64_t fwd = rec.x >> up;
+                    uint64_t rc = revcomp_m(fwd, kk);
+                    uint64_t rest = kk < 32 ? ((rec.x << (2 * kk)) | (rec.y >> up)) : rec.y;
+                    uint64_t kv[8];
+                    kv[0] = len ? (fwd < rc ? fwd : rc) : EMPTY_KEY;
+#pragma unroll
+                    for (int t = 1; t < 8; t++) {
+                        const uint64_t sy = rest >> 62;
+                        rest <<= 2;
+                        fwd = ((fwd << 2) | sy) & kmask;
+                        rc = (rc >> 2) | ((sy ^ 2ull) << rcshift);
+                        kv[t] = (uint32_t)t < len ? (fwd < rc ? fwd : rc) : EMPTY_KEY;
+                    }
+                    dict_probe<8, false>(w, kv, 0u, r * 64u + 63u - sh, r, bit);      // (the lane's genome: sizes the retry on overflow)
                 }
             }
-            s0 = s0_next;
-            n = n_next;
-            f0 = f0_next;
+        } else {
+        for (uint32_t jr = 0; jr < per_row; jr++, g += nw) {
+                uint64_t s0_next = 0, n_next = 0, f0_next = 0;
+                if (g + nw < GV) {
+                    seg_bounds(a.seg, (uint64_t)(g + nw) * B + b, s0_next, n_next);
+                    if (FLAGS) f0_next = a.in_flag_off[(uint64_t)(g + nw) * B + b];
+                }
+                if (g < GV && !full) {
+                    const uint32_t gr = g >> pb;
+                    const unsigned long long bit = 1ull << (63 - (gr & 63));
+                    const uint64_t *seg = a.keys + s0;
+                    const uint8_t *flg = FLAGS ? a.in_flags + f0 : nullptr;
+                    // The kernel is bound by latency and instruction issue, so the common case is straight-line and
+                    // wide: KIF keys per lane in flight, their hashes, two 16-byte table reads each; a key found there
+                    // -- almost every key of a pan-genome after the first few genomes -- costs one more LDS OR.  The
+                    // tail of the segment goes through a copy of the same code that is exactly as deep as it needs.
+                    uint64_t i0 = lane;
+                    for (; i0 + 64u * (KIF - 1) < n; i0 += 64 * KIF) dict_chunk<KIF, FLAGS>(w, seg, flg, i0, n, gr, r, bit);
+                    if (i0 - lane < n && !full) {
+                        const uint32_t nj = (uint32_t)((n - (i0 - lane) + 63) >> 6);        // wave-uniform: 1 .. KIF - 1
+                        if (KIF > 4 && nj > 4) dict_chunk<(KIF > 4 ? KIF : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
+                        else if (KIF > 2 && nj > 2) dict_chunk<(KIF > 2 ? 4 : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
+                        else if (KIF > 1 && nj == 2) dict_chunk<(KIF > 1 ? 2 : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
+                        else dict_chunk<1, FLAGS>(w, seg, flg, i0, n, gr, r, bit);
+                    }
+                }
+                s0 = s0_next;
+                n = n_next;
+                f0 = f0_next;
+            }
         }
         __syncthreads();
         if (full) break;         // read between two barriers: uniform
@@ -1839,19 +1902,25 @@ void set_table_tuning(int kif, int threads)
 }
 void launch_dict_build(hipStream_t s, const DictArgs &a)
 {
-    const size_t lds = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES;
+    // record form: + a 96-byte table of the pooled genomes per wave
+    const size_t lds = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (a.recs ? (size_t)(g_table_threads / 64) * 96 : 0);
     const dim3 grid(1u << (a.bb + a.sb)), block(g_table_threads);     // 256 / 512 / 1024 threads: the wave count divides 64
-#define GRM_LAUNCH_DICT(K, T, F) hipLaunchKernelGGL((dict_build_kernel<K, T, F>), grid, block, lds, s, a)
+#define GRM_LAUNCH_DICT(K, T, F, R) hipLaunchKernelGGL((dict_build_kernel<K, T, F, R>), grid, block, lds, s, a)
     if (a.in_flags) {                   // union over ranks: not a hot kernel, one instance
-        GRM_LAUNCH_DICT(4, 1024, true);
+        GRM_LAUNCH_DICT(4, 1024, true, false);
+        return;
+    }
+    if (a.recs) {                       // one record (up to 8 keys) per lane; 8 waves (the instance's launch bound)
+        const size_t lds_r = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (size_t)(TABLE_THREADS / 64) * 96;
+        hipLaunchKernelGGL((dict_build_kernel<8, 512, false, true>), grid, dim3(TABLE_THREADS), lds_r, s, a);
         return;
     }
     const int kif = (g_table_threads > 512 && g_dict_kif > 4) ? 4 : g_dict_kif;
     switch (kif) {
-    case 1: GRM_LAUNCH_DICT(1, 1024, false); break;
-    case 2: GRM_LAUNCH_DICT(2, 1024, false); break;
-    case 4: GRM_LAUNCH_DICT(4, 1024, false); break;
-    default: GRM_LAUNCH_DICT(8, 512, false); break;
+    case 1: GRM_LAUNCH_DICT(1, 1024, false, false); break;
+    case 2: GRM_LAUNCH_DICT(2, 1024, false, false); break;
+    case 4: GRM_LAUNCH_DICT(4, 1024, false, false); break;
+    default: GRM_LAUNCH_DICT(8, 512, false, false); break;
     }
 #undef GRM_LAUNCH_DICT
 }
@@ -2078,15 +2147,17 @@ hipError_t set_max_dynamic_lds()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_dedup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<1, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<1, 1024, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<2, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<2, 1024, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<8, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<8, 512, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<4, 1024, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dict_build_kernel<8, 512, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(matrix_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return e;

@@ -24,10 +24,12 @@ namespace grm {
 
 constexpr int SK_THREADS = 512;
 constexpr int SK_PPT = 32;                            // k-mer start positions per thread and step: one packed word
-constexpr int SK_LMAX = 16;                           // k-mers per record
+constexpr int SK_LMAX = 8;                            // k-mers per record: what one lane of dict_build (record form) decodes at a time
 constexpr int SK_STAGE = 2560;                        // records staged per sub-step of level 1 (a step of 31-mers yields ~2300)
 constexpr int SK_MAX_BITS = 14;                       // 8 coarse + at most 6 fine bits
 constexpr int SK2_THREADS = 256;
+constexpr int SK2R_THREADS = 512;                     // level 2, records only
+constexpr int SK2_MAXR = 10;                          // records per thread a staged region of it may hold (80 KB of LDS)
 constexpr int SK2_TILE_KEYS = SK2_THREADS * SK_LMAX;                // one record per thread: at most 4096 keys = 32 KB of LDS per tile
 
 struct SkArgs {
@@ -311,6 +313,92 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
     }
 }
 
+// Level 2 without the expansion (dict_build decodes the records itself, record form): the region's records sorted by fine
+// bucket, in place of the region in a second buffer.  STAGED: the region is read once into LDS (a returning LDS atomic
+// gives every record its rank inside its fine bucket, kept in bits of y that hold bases no k-mer reaches) and written
+// from there; regions too large for that are swept twice (count, then place; the second sweep comes from L2).
+// Segment vg * 2^bb + bucket = recs2[off[..] .. + len[..]) in RECORDS.
+template <bool STAGED>
+__global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(const ulonglong2 *__restrict__ recs1, uint32_t rstride,
+                                                                            const uint32_t *__restrict__ rcount1, uint64_t n_regions, int bb,
+                                                                            ulonglong2 *__restrict__ recs2, uint64_t *__restrict__ off,
+                                                                            uint32_t *__restrict__ len_out)
+{
+    constexpr int NF = 1 << (SK_MAX_BITS - 8);
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    ulonglong2 *srec = reinterpret_cast<ulonglong2 *>(lds_raw);          // [rstride] when STAGED
+    __shared__ uint32_t hist[NF], start[NF];
+    __shared__ uint32_t scratch[32];
+    const int b1 = bb < 8 ? bb : 8, b2 = bb - b1;
+    const uint32_t B2 = 1u << b2;
+    constexpr uint64_t RANK_MASK = 0x3ffffull << 16;
+    for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
+        const uint32_t n = min(rcount1[region], rstride);
+        const ulonglong2 *rr = recs1 + region * rstride;
+        ulonglong2 *out = recs2 + region * rstride;
+        const uint64_t seg0 = region << b2;
+        if (threadIdx.x < NF) hist[threadIdx.x] = 0;
+        __syncthreads();
+        if (STAGED) {
+            // all of a thread's loads are in flight before the first one is used
+            ulonglong2 in[SK2_MAXR];
+#pragma unroll
+            for (int j = 0; j < SK2_MAXR; j++) {
+                const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
+                in[j] = i < n ? rr[i] : make_ulonglong2(0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < SK2_MAXR; j++) {
+                const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
+                if (i < n) {
+                    const uint32_t rank = atomicAdd(&hist[(uint32_t)(in[j].y >> 8) & 0xffu], 1u);
+                    srec[i] = make_ulonglong2(in[j].x, (in[j].y & ~RANK_MASK) | ((uint64_t)rank << 16));
+                }
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) atomicAdd(&hist[(uint32_t)(rr[i].y >> 8) & 0xffu], 1u);
+        }
+        __syncthreads();
+        const uint32_t cnt = threadIdx.x < B2 ? hist[threadIdx.x] : 0u;
+        uint32_t total;
+        const uint32_t pre = block_scan_sum(cnt, scratch, &total);
+        if (threadIdx.x < B2) {
+            start[threadIdx.x] = pre;
+            hist[threadIdx.x] = 0;                     // (two-sweep form: now the running rank)
+            off[seg0 + threadIdx.x] = region * rstride + pre;
+            len_out[seg0 + threadIdx.x] = cnt;
+        }
+        __syncthreads();
+        if (STAGED) {
+            // in-place permutation of the LDS image through registers (a thread holds its <= SK2_MAXR records), then the
+            // sorted region leaves with full-line stores: scattered 16-byte stores ran into the L2 request rate
+            ulonglong2 mine[SK2_MAXR];
+#pragma unroll
+            for (int j = 0; j < SK2_MAXR; j++) {
+                const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
+                mine[j] = i < n ? srec[i] : make_ulonglong2(0, 0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < SK2_MAXR; j++) {
+                const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
+                if (i < n)
+                    srec[start[(uint32_t)(mine[j].y >> 8) & 0xffu] + ((uint32_t)(mine[j].y >> 16) & 0x3ffffu)] =
+                        make_ulonglong2(mine[j].x, mine[j].y & ~RANK_MASK);
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) out[i] = srec[i];
+        } else {
+            for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) {
+                const ulonglong2 rec = rr[i];
+                const uint32_t f = (uint32_t)(rec.y >> 8) & 0xffu;
+                out[start[f] + atomicAdd(&hist[f], 1u)] = rec;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // bucket ((bucket << sb) | sub) of dictionary keys under minimizer buckets (the probing form of the fill builds its
 // per-bucket tables from the dictionary): the minimizer is re-derived from the k-mer itself
 __global__ void minimizer_bucket_ids_kernel(const uint64_t *__restrict__ dict, uint64_t n, int k, int bb, int sb,
@@ -359,6 +447,27 @@ void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, con
     const uint32_t grid = (uint32_t)(n_regions < 256u * 32u ? n_regions : 256u * 32u);
     hipLaunchKernelGGL(superkmer_l2_kernel, dim3(grid), dim3(SK2_THREADS), 0, s, reinterpret_cast<const ulonglong2 *>(recs1), rstride, rcount1,
                        n_regions, k, bb, kstride, keys, off, len, overflow);
+}
+
+void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb,
+                                 void *recs2, uint64_t *off, uint32_t *len)
+{
+    if (!n_regions) return;
+    const uint32_t grid = (uint32_t)(n_regions < 256u * 32u ? n_regions : 256u * 32u);
+    const size_t lds = (size_t)rstride * 16;
+    const ulonglong2 *r1 = reinterpret_cast<const ulonglong2 *>(recs1);
+    ulonglong2 *r2 = reinterpret_cast<ulonglong2 *>(recs2);
+    if (rstride <= (uint32_t)SK2_MAXR * SK2R_THREADS) {             // <= 80 KB: two workgroups per CU
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(superkmer_l2_records_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      96 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(superkmer_l2_records_kernel<true>, dim3(grid), dim3(SK2R_THREADS), lds, s, r1, rstride, rcount1, n_regions, bb, r2, off, len);
+    } else {
+        hipLaunchKernelGGL(superkmer_l2_records_kernel<false>, dim3(grid), dim3(SK2R_THREADS), 0, s, r1, rstride, rcount1, n_regions, bb, r2, off, len);
+    }
 }
 
 void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int k, int bb, int sb, uint32_t *bucket_of, uint32_t *col_of)

@@ -116,6 +116,11 @@ def test_medium_pangenome_all_paths(ctx):
     {"no_slots": 1}, {"no_slots": 1, "sub_bits": 2},   # probing form of the fill
     {"dense_layout": 1}, {"dense_layout": 1, "bucket_bits": 11},      # histogram-sized layout instead of the slack layout
     {"direct_permute": 1},                             # scattered single-step fill
+    {"records": 0},                                    # key form of the partition (hashed buckets, levels 1 and 2 on keys)
+    {"rec_keys": 1}, {"rec_keys": 1, "bucket_bits": 10},       # record form, level 2 expanding to key segments
+    {"rec_part_bits": 2}, {"rec_part_bits": 3, "rec_keys": 1},  # genomes cut into parts (one workgroup each)
+    {"rec_bucket_shift": 1}, {"bucket_bits": 6}, {"bucket_bits": 9, "sub_bits": 1},
+    {"rec_part_bits": 1, "no_slots": 1},               # probing fill asked of a partition in parts: falls back to the key form
 ])
 def test_medium_with_forced_geometry(ctx, opts):
     genomes = _medium_genomes(n=5, length=120_000, seed=9)
@@ -127,6 +132,23 @@ def test_medium_with_forced_geometry(ctx, opts):
     finally:
         for name in opts:
             ctx.set_option(name, -1)
+
+
+@pytest.mark.parametrize("k", [11, 12, 13, 16, 21, 27, 28, 29, 30, 32])
+def test_record_form_over_k(ctx, k):
+    """the record form of the partition (minimizer buckets, runs of k-mers as records) at both ends of its range of k: one
+    m-mer per k-mer (k = 11, every start opens a run), the longest windows, and the widest keys (k = 32)"""
+    genomes = _medium_genomes(n=4, length=90_000, seed=21 + k)
+    rng = np.random.RandomState(k)
+    genomes.append([cases.fasta([("low", "ACGT" * 500 + "A" * 300 + cases.rand_seq(rng, 4000) + "N" * 40 + "CAG" * 400)], width=70)])
+    for opts in ({}, {"rec_keys": 1}):
+        try:
+            for name, v in opts.items():
+                ctx.set_option(name, v)
+            _check(ctx, genomes, k, 1, False)
+        finally:
+            for name in opts:
+                ctx.set_option(name, -1)
 
 
 def test_parser_stress_layouts(ctx):
