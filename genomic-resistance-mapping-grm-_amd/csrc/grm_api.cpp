@@ -1069,9 +1069,9 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     // sigma ~25 % of the mean at 2^13 buckets), hence one more bucket bit than the key form and exact (not slack)
     // segment sizes inside a region.
     if (k >= SK_M && abundance_min == 1 && !want_counts && c->opt_records != 0 && !b->rec_failed && c->opt_dense_layout <= 0) {
-        int bbr = c->opt_bucket_bits >= 0 ? b->bb : b->bb + (c->opt_rec_bucket_shift >= 0 ? c->opt_rec_bucket_shift : 0);
+        int bbr = c->opt_bucket_bits >= 0 ? b->bb : b->bb + (c->opt_rec_bucket_shift >= 0 ? c->opt_rec_bucket_shift : 1);
         bbr = std::min(bbr, superkmer_max_bits());
-        const int b1r = std::min(bbr, 8);
+        const int b1r = superkmer_coarse_bits(bbr);
         // one workgroup per genome part owns the part's regions: enough parts to fill the device when genomes are few
         int pbits = 0;
         while (((uint64_t)G << pbits) < 512 && pbits < 6 && (max_g >> (pbits + 1)) >= 65536) pbits++;
@@ -1108,7 +1108,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
             HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 32, s));
             {
                 TimeScope t(c, "superkmer_l1", b->total_syms);
-                launch_superkmer_l1(s, Lr, pbits, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), b->d_cursor1.as<uint32_t>(), b->t_flag.as<int>());
+                launch_superkmer_l1(s, Lr, b1r, pbits, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), b->d_cursor1.as<uint32_t>(), b->t_flag.as<int>());
             }
             // the fill through the presence bits needs no keys at all: dict_build then decodes the records itself and
             // level 2 only sorts them by fine bucket; else (probing fill) level 2 expands them to key segments
@@ -1122,12 +1122,12 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
             if (by_records) {
                 TimeScope t(c, "superkmer_l2", b->total_syms);        // (units: the record count, once it is known)
                 l2_idx = t.idx;
-                launch_superkmer_l2_records(s, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, bbr, b->d_recs2.p,
+                launch_superkmer_l2_records(s, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, bbr, b1r, b->d_recs2.p,
                                             b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>());
             } else {
                 HIPCHK(c, b->d_keys.ensure((n_regions * kstride + 4) * 8));
                 TimeScope t(c, "superkmer_l2_keys", b->total_syms);
-                launch_superkmer_l2(s, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, k, bbr, kstride, b->d_keys.as<uint64_t>(),
+                launch_superkmer_l2(s, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, k, bbr, b1r, kstride, b->d_keys.as<uint64_t>(),
                                     b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->t_flag.as<int>());
             }
             launch_sum_u32(s, b->d_cursor1.as<uint32_t>(), n_parts, reinterpret_cast<uint64_t *>(b->t_flag.as<uint8_t>() + 8));
@@ -1440,7 +1440,7 @@ static int batch_expand_keys(grm_batch *b)
     HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 16, s));
     {
         TimeScope t(c, "superkmer_l2_keys", b->total_syms);
-        launch_superkmer_l2(s, b->d_recs.p, b->rec_rstride, b->d_counts1.as<uint32_t>(), b->rec_regions, b->k, b->bb, b->rec_kstride,
+        launch_superkmer_l2(s, b->d_recs.p, b->rec_rstride, b->d_counts1.as<uint32_t>(), b->rec_regions, b->k, b->bb, superkmer_coarse_bits(b->bb), b->rec_kstride,
                             b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->t_flag.as<int>());
     }
     HIPCHK(c, hipGetLastError());

@@ -87,17 +87,18 @@ void launch_sum_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *out
 //            occurrences of the part; *overflow = 1 when a region would exceed rstride
 //   level 2: records -> canonical k-mers, sorted by the fine bits: segment vg * 2^bb + bucket = keys[off[..] .. + len[..]),
 //            the segments of region r back to back from r * kstride; *overflow = 1 when a region holds more than kstride
-void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int part_bits, void *recs1, uint32_t rstride, uint32_t *rcount1,
+void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int b1, int part_bits, void *recs1, uint32_t rstride, uint32_t *rcount1,
                          uint32_t *part_kmers, int *overflow);
-void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb,
+void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb, int b1,
                          uint64_t kstride, uint64_t *keys, uint64_t *off, uint32_t *len, int *overflow);
 //   level 2, records only: the region's records sorted by the fine bits, region r again at r * rstride of recs2: segment
 //            vg * 2^bb + bucket = recs2[off[..] .. + len[..]) (in records; dict_build decodes them, DictArgs::recs)
-void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb,
+void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb, int b1,
                                  void *recs2, uint64_t *off, uint32_t *len);
 // (bucket << sb) | sub of dictionary keys under minimizer buckets (launch_dict_bucket_ids for the hashed ones)
 void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int k, int bb, int sb, uint32_t *bucket_of, uint32_t *col_of);
 int superkmer_max_bits();
+int superkmer_coarse_bits(int bb);      // b1 of a partition with 2^bb buckets
 int superkmer_lmax();
 void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *coarse_off, uint64_t n_regions, int bb,
                         uint32_t *counts);

@@ -22,14 +22,12 @@
 
 namespace grm {
 
-constexpr int SK_THREADS = 512;
+constexpr int SK_THREADS = 1024;
 constexpr int SK_PPT = 32;                            // k-mer start positions per thread and step: one packed word
 constexpr int SK_LMAX = 8;                            // k-mers per record: what one lane of dict_build (record form) decodes at a time
-constexpr int SK_STAGE = 2560;                        // records staged per sub-step of level 1 (a step of 31-mers yields ~2300)
-constexpr int SK_MAX_BITS = 14;                       // 8 coarse + at most 6 fine bits
+constexpr int SK_MAX_BITS = 14;                       // at most 9 coarse bits (SK_THREADS cursors), the fine field of a record has 8 bits; NF fine buckets in level 2
 constexpr int SK2_THREADS = 256;
 constexpr int SK2R_THREADS = 512;                     // level 2, records only
-constexpr int SK2_MAXR = 10;                          // records per thread a staged region of it may hold (80 KB of LDS)
 constexpr int SK2_TILE_KEYS = SK2_THREADS * SK_LMAX;                // one record per thread: at most 4096 keys = 32 KB of LDS per tile
 
 struct SkArgs {
@@ -39,6 +37,7 @@ struct SkArgs {
     const uint64_t *genome_sym_off;
     uint32_t n_genomes;
     int k, bb;
+    int b1;                                           // coarse bits of the bucket (level 1); the other bb - b1 are the fine ones
     int part_bits;                                    // a genome is cut into 2^part_bits parts, one workgroup each
 };
 
@@ -47,21 +46,19 @@ struct SkArgs {
 // place of a record needs no global atomic (a returning global atomic per record measured 20 ms for 6e8 records, and an
 // add per wave to ONE global counter 28 ms: same-address atomics serialise in L2).  Per step a thread takes one packed
 // word (32 start positions): minimizer bucket of every valid k-mer start (W = k - SK_M + 1 m-mers per k-mer; template:
-// the window minimum is a fixed pattern of register moves), runs -> records; the step's records are counting-sorted by
-// coarse bucket in LDS and leave as one contiguous run per coarse bucket.
+// the window minimum is a fixed pattern of register moves), runs -> records, each stored at the LDS cursor of its
+// coarse region.  (A counting sort of the step's records in LDS, one contiguous run per coarse bucket on the way out,
+// measured 11.9 ms against this form's time: the two extra passes over the runs cost more than the partial lines.)
 template <int W>
 __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulonglong2 *__restrict__ recs1, uint32_t rstride,
                                                                    uint32_t *__restrict__ rcount1, uint32_t *__restrict__ part_kmers,
                                                                    int *__restrict__ overflow)
 {
     __shared__ uint32_t s_bk[SK_THREADS * (SK_PPT / 2)];     // 16-bit bucket of every position of the step
-    __shared__ ulonglong2 s_rec[SK_STAGE];
-    __shared__ uint8_t s_c[SK_STAGE];                        // coarse bucket of s_rec[i]
-    __shared__ uint32_t hist[256], start[256];
-    __shared__ uint64_t gbase[256];
+    __shared__ uint32_t cursor[SK_THREADS];                  // records written so far to coarse region c (2^b1 <= SK_THREADS)
     __shared__ uint32_t scratch[32];
     constexpr int NM = SK_PPT + W - 1;                 // m-mer positions a thread looks at
-    const int b1 = a.bb < 8 ? a.bb : 8, b2 = a.bb - b1;
+    const int b1 = a.b1, b2 = a.bb - b1;
     const uint32_t B1 = 1u << b1;
     const uint32_t vg = blockIdx.x;
     const uint32_t gen = vg >> a.part_bits, part = vg & ((1u << a.part_bits) - 1u);
@@ -70,8 +67,8 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     const uint64_t per_part = (w_hi - w_lo + (1u << a.part_bits) - 1) >> a.part_bits;
     const uint64_t w_a = min(w_lo + (uint64_t)part * per_part, w_hi), w_b = min(w_a + per_part, w_hi);
     const uint16_t *my_bk = reinterpret_cast<const uint16_t *>(s_bk) + threadIdx.x * SK_PPT;
-    uint32_t my_fill = 0;                              // thread t: records written so far to coarse region t
-    const uint64_t my_region = ((uint64_t)vg * B1 + threadIdx.x) * rstride;
+    cursor[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t n_valid = 0;
     bool over = false;
     for (uint64_t wbase = w_a; wbase < w_b; wbase += SK_THREADS) {
@@ -136,64 +133,27 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
         }
         // ends of runs: the next head, the next invalid start, or the end of the word
         const uint64_t bnd = (uint64_t)(heads | ~valid) | (1ull << SK_PPT);
-        uint32_t n_rec;
-        const uint32_t base = block_scan_sum((uint32_t)__popc(heads), scratch, &n_rec);
-        // sub-steps of at most SK_STAGE records (one, unless k is close to 11 and nearly every start opens a run)
-        for (uint32_t sub0 = 0; sub0 < n_rec; sub0 += SK_STAGE) {
-            if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-            __syncthreads();
-            {   // count per coarse bucket
-                uint32_t hd = heads, idx = base - sub0;
-                while (hd) {
-                    const int i = __ffs(hd) - 1;
-                    hd &= hd - 1;
-                    if (idx < (uint32_t)SK_STAGE) atomicAdd(&hist[my_bk[i] >> b2], 1u);
-                    idx++;
-                }
-            }
-            __syncthreads();
-            const uint32_t c_cnt = threadIdx.x < 256 ? hist[threadIdx.x] : 0u;
-            uint32_t n_here;
-            const uint32_t st = block_scan_sum(c_cnt, scratch, &n_here);
-            if (threadIdx.x < 256) {
-                start[threadIdx.x] = st;
-                hist[threadIdx.x] = 0;                 // now the running rank inside the coarse bucket
-                const bool fits = (uint64_t)my_fill + c_cnt <= rstride;
-                if (!fits) over = true;
-                gbase[threadIdx.x] = (fits && threadIdx.x < B1) ? my_region + my_fill : ~0ull;
-                if (fits) my_fill += c_cnt;
-            }
-            __syncthreads();
-            {   // place
-                uint32_t hd = heads, idx = base - sub0;
-                while (hd) {
-                    const int i = __ffs(hd) - 1;
-                    hd &= hd - 1;
-                    if (idx < (uint32_t)SK_STAGE) {
-                        const uint32_t len = (uint32_t)__ffsll((unsigned long long)(bnd >> (i + 1)));
-                        const uint32_t bkt = my_bk[i];
-                        const uint32_t c = bkt >> b2;
-                        ulonglong2 rec;
-                        rec.x = i ? ((w0 << (2 * i)) | (w1 >> (64 - 2 * i))) : w0;
-                        rec.y = ((w1 << (2 * i)) & ~0xffffull) | ((uint64_t)(bkt & ((1u << b2) - 1u)) << 8) | len;
-                        const uint32_t pos = start[c] + atomicAdd(&hist[c], 1u);
-                        s_rec[pos] = rec;
-                        s_c[pos] = (uint8_t)c;
-                    }
-                    idx++;
-                }
-            }
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n_here; i += SK_THREADS) {
-                const uint32_t c = s_c[i];
-                const uint64_t gb = gbase[c];
-                if (gb != ~0ull) recs1[gb + (i - start[c])] = s_rec[i];
-            }
-            __syncthreads();
+        // The runs of a lane leave one per round (a lane has ~6, at most 32): the slot in the coarse region comes from the
+        // workgroup's LDS cursor of that region, the record goes straight to its place.  A region's lines fill up in
+        // cursor order, 8 records each, and a workgroup keeps 256 of them open: they complete in L2.
+        uint32_t hd = heads;
+        while (hd) {
+            const int i = __ffs(hd) - 1;
+            hd &= hd - 1;
+            const uint32_t len = (uint32_t)__ffsll((unsigned long long)(bnd >> (i + 1)));
+            const uint32_t bkt = my_bk[i];
+            const uint32_t c = bkt >> b2;
+            ulonglong2 rec;
+            rec.x = i ? ((w0 << (2 * i)) | (w1 >> (64 - 2 * i))) : w0;
+            rec.y = ((w1 << (2 * i)) & ~0xffffull) | ((uint64_t)(bkt & ((1u << b2) - 1u)) << 8) | len;
+            const uint32_t slot = atomicAdd(&cursor[c], 1u);
+            if (slot < rstride) recs1[((uint64_t)vg * B1 + c) * rstride + slot] = rec;
+            else over = true;
         }
     }
+    __syncthreads();
     if (over) atomicExch(overflow, 1);
-    if (threadIdx.x < B1) rcount1[(uint64_t)vg * B1 + threadIdx.x] = my_fill;
+    if (threadIdx.x < B1) rcount1[(uint64_t)vg * B1 + threadIdx.x] = min(cursor[threadIdx.x], rstride);
     uint32_t total;
     (void)block_scan_sum(n_valid, scratch, &total);
     if (threadIdx.x == 0) part_kmers[vg] = total;
@@ -210,17 +170,17 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
 // first sorted by length (a counting sort through LDS), so that the lanes of a wave roll for about the same number of
 // steps -- unsorted, half of the lanes idle.
 __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglong2 *__restrict__ recs1, uint32_t rstride,
-                                                                    const uint32_t *__restrict__ rcount1, uint64_t n_regions, int k, int bb,
+                                                                    const uint32_t *__restrict__ rcount1, uint64_t n_regions, int k, int bb, int b1,
                                                                     uint64_t kstride, uint64_t *__restrict__ keys, uint64_t *__restrict__ off,
                                                                     uint32_t *__restrict__ len_out, int *__restrict__ overflow)
 {
     __shared__ uint64_t skeys[SK2_TILE_KEYS];
     __shared__ ulonglong2 srec[SK2_THREADS];
-    constexpr int NF = 1 << (SK_MAX_BITS - 8);          // fine buckets of a region
+    constexpr int NF = 64;          // fine buckets of a region
     __shared__ uint32_t gbase[NF];                      // relative to the region's first key
     __shared__ uint32_t hist[NF], start[NF], lhist[64], lstart[64];
     __shared__ uint32_t scratch[32];
-    const int b1 = bb < 8 ? bb : 8, b2 = bb - b1;
+    const int b2 = bb - b1;
     const uint32_t B2 = 1u << b2;
     const int up = 64 - 2 * k;
     const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
@@ -318,18 +278,18 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
 // gives every record its rank inside its fine bucket, kept in bits of y that hold bases no k-mer reaches) and written
 // from there; regions too large for that are swept twice (count, then place; the second sweep comes from L2).
 // Segment vg * 2^bb + bucket = recs2[off[..] .. + len[..]) in RECORDS.
-template <bool STAGED>
+template <bool STAGED, int MAXR>
 __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(const ulonglong2 *__restrict__ recs1, uint32_t rstride,
-                                                                            const uint32_t *__restrict__ rcount1, uint64_t n_regions, int bb,
+                                                                            const uint32_t *__restrict__ rcount1, uint64_t n_regions, int bb, int b1,
                                                                             ulonglong2 *__restrict__ recs2, uint64_t *__restrict__ off,
                                                                             uint32_t *__restrict__ len_out)
 {
-    constexpr int NF = 1 << (SK_MAX_BITS - 8);
+    constexpr int NF = 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     ulonglong2 *srec = reinterpret_cast<ulonglong2 *>(lds_raw);          // [rstride] when STAGED
     __shared__ uint32_t hist[NF], start[NF];
     __shared__ uint32_t scratch[32];
-    const int b1 = bb < 8 ? bb : 8, b2 = bb - b1;
+    const int b2 = bb - b1;
     const uint32_t B2 = 1u << b2;
     constexpr uint64_t RANK_MASK = 0x3ffffull << 16;
     for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
@@ -341,14 +301,14 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
         __syncthreads();
         if (STAGED) {
             // all of a thread's loads are in flight before the first one is used
-            ulonglong2 in[SK2_MAXR];
+            ulonglong2 in[MAXR > 0 ? MAXR : 1];
 #pragma unroll
-            for (int j = 0; j < SK2_MAXR; j++) {
+            for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
                 in[j] = i < n ? rr[i] : make_ulonglong2(0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < SK2_MAXR; j++) {
+            for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
                 if (i < n) {
                     const uint32_t rank = atomicAdd(&hist[(uint32_t)(in[j].y >> 8) & 0xffu], 1u);
@@ -370,17 +330,17 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
         }
         __syncthreads();
         if (STAGED) {
-            // in-place permutation of the LDS image through registers (a thread holds its <= SK2_MAXR records), then the
+            // in-place permutation of the LDS image through registers (a thread holds its <= MAXR records), then the
             // sorted region leaves with full-line stores: scattered 16-byte stores ran into the L2 request rate
-            ulonglong2 mine[SK2_MAXR];
+            ulonglong2 mine[MAXR > 0 ? MAXR : 1];
 #pragma unroll
-            for (int j = 0; j < SK2_MAXR; j++) {
+            for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
                 mine[j] = i < n ? srec[i] : make_ulonglong2(0, 0);
             }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < SK2_MAXR; j++) {
+            for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
                 if (i < n)
                     srec[start[(uint32_t)(mine[j].y >> 8) & 0xffu] + ((uint32_t)(mine[j].y >> 16) & 0x3ffffu)] =
@@ -419,15 +379,17 @@ static void launch_sk1(hipStream_t s, const SkArgs &a, ulonglong2 *recs1, uint32
 }
 
 int superkmer_max_bits() { return SK_MAX_BITS; }
+int superkmer_coarse_bits(int bb) { return bb < 9 ? bb : 9; }      // 512 regions per genome part: a region's records fit 40 KB of LDS at 5 Mbp
 int superkmer_lmax() { return SK_LMAX; }
 
-void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int part_bits, void *recs1, uint32_t rstride, uint32_t *rcount1,
+void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int b1, int part_bits, void *recs1, uint32_t rstride, uint32_t *rcount1,
                          uint32_t *part_kmers, int *overflow)
 {
     if (!L.total_syms || !L.n_genomes) return;
     SkArgs a;
     a.sym2 = L.sym2; a.inv = L.inv; a.total_syms = L.total_syms; a.genome_sym_off = L.genome_sym_off;
     a.n_genomes = L.n_genomes; a.k = L.k; a.bb = L.bb;
+    a.b1 = b1;
     a.part_bits = part_bits;
     ulonglong2 *r = reinterpret_cast<ulonglong2 *>(recs1);
     switch (L.k - SK_M + 1) {
@@ -440,34 +402,40 @@ void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int part_bits, void
     }
 }
 
-void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb,
+void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb, int b1,
                          uint64_t kstride, uint64_t *keys, uint64_t *off, uint32_t *len, int *overflow)
 {
     if (!n_regions) return;
     const uint32_t grid = (uint32_t)(n_regions < 256u * 32u ? n_regions : 256u * 32u);
     hipLaunchKernelGGL(superkmer_l2_kernel, dim3(grid), dim3(SK2_THREADS), 0, s, reinterpret_cast<const ulonglong2 *>(recs1), rstride, rcount1,
-                       n_regions, k, bb, kstride, keys, off, len, overflow);
+                       n_regions, k, bb, b1, kstride, keys, off, len, overflow);
 }
 
-void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb,
+template <int MAXR>
+static void launch_l2r_staged(hipStream_t s, uint32_t grid, const ulonglong2 *r1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb,
+                              int b1, ulonglong2 *r2, uint64_t *off, uint32_t *len)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(superkmer_l2_records_kernel<true, MAXR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  96 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((superkmer_l2_records_kernel<true, MAXR>), dim3(grid), dim3(SK2R_THREADS), (size_t)rstride * 16, s, r1, rstride, rcount1,
+                       n_regions, bb, b1, r2, off, len);
+}
+
+void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb, int b1,
                                  void *recs2, uint64_t *off, uint32_t *len)
 {
     if (!n_regions) return;
     const uint32_t grid = (uint32_t)(n_regions < 256u * 32u ? n_regions : 256u * 32u);
-    const size_t lds = (size_t)rstride * 16;
     const ulonglong2 *r1 = reinterpret_cast<const ulonglong2 *>(recs1);
     ulonglong2 *r2 = reinterpret_cast<ulonglong2 *>(recs2);
-    if (rstride <= (uint32_t)SK2_MAXR * SK2R_THREADS) {             // <= 80 KB: two workgroups per CU
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(superkmer_l2_records_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      96 * 1024);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(superkmer_l2_records_kernel<true>, dim3(grid), dim3(SK2R_THREADS), lds, s, r1, rstride, rcount1, n_regions, bb, r2, off, len);
-    } else {
-        hipLaunchKernelGGL(superkmer_l2_records_kernel<false>, dim3(grid), dim3(SK2R_THREADS), 0, s, r1, rstride, rcount1, n_regions, bb, r2, off, len);
-    }
+    // the region in LDS: up to 3072 records (48 KB, three workgroups per CU), up to 5120 (80 KB, two), else two sweeps
+    if (rstride <= 6u * SK2R_THREADS) launch_l2r_staged<6>(s, grid, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len);
+    else if (rstride <= 10u * SK2R_THREADS) launch_l2r_staged<10>(s, grid, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len);
+    else hipLaunchKernelGGL((superkmer_l2_records_kernel<false, 0>), dim3(grid), dim3(SK2R_THREADS), 0, s, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len);
 }
 
 void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int k, int bb, int sb, uint32_t *bucket_of, uint32_t *col_of)
