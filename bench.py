@@ -179,15 +179,25 @@ def kernel_table(ctx, n_cols, n_rows, n_local):
     return kernels
 
 
-def roofline_of(kernels, traffic_of=None):
+def roofline_of(kernels, traffic_of=None, occurrences=None, words=1):
     dom = max((n for n in kernels if "algo_GBps" in kernels[n]), key=lambda n: kernels[n]["avg_ms"] * kernels[n]["launches"], default=None)
     if not dom:
         return None
     a = kernels[dom]["algo_GBps"]
     traffic = traffic_of(dom) if traffic_of else None
-    return {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": "committed PMC passes of this workload (profiles/hbm_traffic.json)" if traffic else None,
-            "avg_launch_ms": kernels[dom]["avg_ms"]}
+    r = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
+         "traffic": traffic, "traffic_source": "committed PMC passes of this workload (profiles/hbm_traffic.json)" if traffic else None,
+         "avg_launch_ms": kernels[dom]["avg_ms"]}
+    if dom == "dict_build" and occurrences:
+        # dict_build IS stage 3 of SURVEY.md 8(d) (key + dictionary probe + output bit = 2W + 0.125 bytes per occurrence); in the
+        # record form it reaches the k-mers through ~2 bytes per occurrence of run records, so the bytes it moves
+        # ("moved") are far below the stage's figure and the kernel is bound by instruction issue, not by HBM
+        byts = (16.0 * words + 0.125) * occurrences
+        g = byts / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        r.update({"achieved": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "bytes_per_occurrence": 16.0 * words + 0.125,
+                  "definition": "SURVEY.md 8(d) stage 3 bytes per k-mer occurrence x occurrences of the launch / its duration",
+                  "moved_GBps": a, "moved_bytes": kernels[dom]["algo_bytes"]})
+    return r
 
 
 def committed_traffic(args, genomes):
@@ -379,11 +389,13 @@ def main():
         elapsed, kernels = count_leg(D, ctx, args, batch, args.steps, args.warmup)
         n_cols = n_rows = 0
         xfer = None
-    occ_total = D.sum_i(batch.n_occurrences)
+    batch_occ = batch.n_occurrences
+    occ_total = D.sum_i(batch_occ)
     syms_total = D.sum_i(batch.n_symbols)
     input_bytes = batch.input_bytes
     batch.free()
-    roofline = roofline_of(kernels, committed_traffic(args, n_mine) if (world == 1 and args.mode == "P" and args.stage == "matrix") else None)
+    roofline = roofline_of(kernels, committed_traffic(args, n_mine) if (world == 1 and args.mode == "P" and args.stage == "matrix") else None,
+                           occurrences=batch_occ, words=1 if args.k <= 32 else 2)
     filt_txt = "singleton filter" if not args.keep_singletons else "singletons kept"
     out = None
     if rank == 0:

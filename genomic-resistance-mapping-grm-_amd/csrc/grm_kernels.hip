@@ -1216,50 +1216,78 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
         seg_bounds(a.seg, (uint64_t)g * B + b, s0, n);
         if (FLAGS) f0 = a.in_flag_off[(uint64_t)g * B + b];
     }
-    // record form: decoding constants, and a wave-private table of the (up to 8) genomes a wave pools
+    // record form: decoding constants, and a wave-private table of the 16 sub-segments (8 genomes x 2 length classes) a wave pools
     const int kk = REC ? a.k : 1;
     const int up = 64 - 2 * kk, rcshift = 2 * (kk - 1);
     const uint64_t kmask = kk == 32 ? ~0ull : ((1ull << (2 * kk)) - 1);
-    uint64_t *tabD = reinterpret_cast<uint64_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES) + 8 * wave;
-    uint32_t *tabS = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)nw * 64) + 8 * wave;
+    uint64_t *tabD = reinterpret_cast<uint64_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES) + 16 * wave;
+    uint32_t *tabS = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)nw * 128) + 16 * wave;
     for (uint32_t r = 0; r < n_rows; r++) {
         if (REC) {
             // Record form.  A record holds a run of 1..8 consecutive k-mers with their bases; ONE LANE decodes one record
-            // (first k-mer by a shift and a reverse complement, the others by rolling both words) and takes its up to 8
-            // keys to the table.  The records of the wave's genomes of this word-row are pooled, 8 genomes at a time, so
-            // that the lanes of the last instruction of a genome are not left idle: lane -> (genome, record) through the
-            // running totals of the pooled segments.
+            // (first k-mer by a shift and a reverse complement, the others by rolling both words) and takes its keys to
+            // the table.  A segment holds its records of at most 4 k-mers first: those go four keys at a time, the others
+            // eight at a time (one size for all would leave a third of the key slots empty).  The records of the wave's
+            // genomes of this word-row are pooled, 8 genomes at a time and class by class, so that the lanes of the last
+            // instruction of a genome are not left idle: lane -> (class, genome, record) through the running totals of
+            // the 16 pooled sub-segments.
             const uint32_t row_first = (r * 64u) << pb;
             for (uint32_t j0 = 0; j0 < per_row && !full; j0 += 8) {
-                const uint32_t vgj = row_first + (uint32_t)wave + (j0 + (uint32_t)lane) * (uint32_t)nw;
+                const uint32_t jj = (uint32_t)lane & 7u, cls = ((uint32_t)lane >> 3) & 1u;
+                const uint32_t vgj = row_first + (uint32_t)wave + (j0 + jj) * (uint32_t)nw;
                 uint64_t sj = 0, nj = 0;
-                if (lane < 8 && j0 + (uint32_t)lane < per_row && vgj < GV) seg_bounds(a.seg, (uint64_t)vgj * B + b, sj, nj);
-                const uint32_t n32 = (uint32_t)nj;
+                if (lane < 16 && j0 + jj < per_row && vgj < GV) seg_bounds(a.seg, (uint64_t)vgj * B + b, sj, nj);
+                const uint32_t n_all = (uint32_t)nj & 0xffffu, n_short = (uint32_t)nj >> 16;
+                const uint32_t n32 = cls ? n_all - n_short : n_short;
                 const uint32_t inc = wave_scan_incl_dpp(n32);
-                const uint32_t cumj = inc - n32;
+                const uint32_t cume = inc - n32;
                 const uint32_t N = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                if (lane < 8) {
-                    tabD[lane] = sj - cumj;
+                if (lane < 16) {
+                    tabD[lane] = sj + (cls ? n_short : 0u) - cume;
                     tabS[lane] = 63u - ((vgj >> pb) & 63u);
                 }
-                const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 1), t2 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 2),
-                               t3 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 3), t4 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 4),
-                               t5 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 5), t6 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 6),
-                               t7 = (uint32_t)__builtin_amdgcn_readlane((int)cumj, 7);
-                // (the records of the next 64 lanes are requested before the current ones go to the table)
-                auto fetch = [&](uint32_t q, ulonglong2 &rec, uint32_t &sh) {
-                    const uint32_t j = (uint32_t)(q >= t1) + (uint32_t)(q >= t2) + (uint32_t)(q >= t3) + (uint32_t)(q >= t4) +
-                                       (uint32_t)(q >= t5) + (uint32_t)(q >= t6) + (uint32_t)(q >= t7);
-                    rec = q < N ? a.recs[tabD[j] + q] : make_ulonglong2(0, 0);
-                    sh = tabS[j];
+                uint32_t th[16];
+#pragma unroll
+                for (int e = 1; e < 16; e++) th[e] = (uint32_t)__builtin_amdgcn_readlane((int)cume, e);
+                const uint32_t NA = th[8];           // records of the short class in the pool
+                auto fetch = [&](uint32_t q, uint32_t q_end, int e0, ulonglong2 &rec, uint32_t &sh) {
+                    uint32_t e = (uint32_t)e0;
+#pragma unroll
+                    for (int i = 1; i < 8; i++) e += (uint32_t)(q >= th[e0 + i]);
+                    rec = q < q_end ? a.recs[tabD[e] + q] : make_ulonglong2(0, 0);
+                    sh = tabS[e];
                 };
                 ulonglong2 rec_n;
                 uint32_t sh_n;
-                fetch((uint32_t)lane, rec_n, sh_n);
-                for (uint32_t q0 = 0; q0 < N && !full; q0 += 64) {
+                // ---- the short records: four keys per lane ----
+                fetch((uint32_t)lane, NA, 0, rec_n, sh_n);
+                for (uint32_t q0 = 0; q0 < NA && !full; q0 += 64) {
                     const ulonglong2 rec = rec_n;
                     const uint32_t sh = sh_n;
-                    fetch(q0 + 64u + (uint32_t)lane, rec_n, sh_n);
+                    fetch(q0 + 64u + (uint32_t)lane, NA, 0, rec_n, sh_n);
+                    const unsigned long long bit = 1ull << sh;
+                    const uint32_t len = (uint32_t)(rec.y & 0xffu);
+                    uint64_t fwd = rec.x >> up;
+                    uint64_t rc = revcomp_m(fwd, kk);
+                    uint64_t rest = kk < 32 ? ((rec.x << (2 * kk)) | (rec.y >> up)) : rec.y;
+                    uint64_t kv[4];
+                    kv[0] = len ? (fwd < rc ? fwd : rc) : EMPTY_KEY;
+#pragma unroll
+                    for (int t = 1; t < 4; t++) {
+                        const uint64_t sy = rest >> 62;
+                        rest <<= 2;
+                        fwd = ((fwd << 2) | sy) & kmask;
+                        rc = (rc >> 2) | ((sy ^ 2ull) << rcshift);
+                        kv[t] = (uint32_t)t < len ? (fwd < rc ? fwd : rc) : EMPTY_KEY;
+                    }
+                    dict_probe<4, false>(w, kv, 0u, r * 64u + 63u - sh, r, bit);      // (the lane's genome: sizes the retry on overflow)
+                }
+                // ---- the long ones: eight ----
+                fetch(NA + (uint32_t)lane, N, 8, rec_n, sh_n);
+                for (uint32_t q0 = NA; q0 < N && !full; q0 += 64) {
+                    const ulonglong2 rec = rec_n;
+                    const uint32_t sh = sh_n;
+                    fetch(q0 + 64u + (uint32_t)lane, N, 8, rec_n, sh_n);
                     const unsigned long long bit = 1ull << sh;
                     const uint32_t len = (uint32_t)(rec.y & 0xffu);
                     uint64_t fwd = rec.x >> up;
@@ -1275,7 +1303,7 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                         rc = (rc >> 2) | ((sy ^ 2ull) << rcshift);
                         kv[t] = (uint32_t)t < len ? (fwd < rc ? fwd : rc) : EMPTY_KEY;
                     }
-                    dict_probe<8, false>(w, kv, 0u, r * 64u + 63u - sh, r, bit);      // (the lane's genome: sizes the retry on overflow)
+                    dict_probe<8, false>(w, kv, 0u, r * 64u + 63u - sh, r, bit);
                 }
             }
         } else {
@@ -1902,8 +1930,7 @@ void set_table_tuning(int kif, int threads)
 }
 void launch_dict_build(hipStream_t s, const DictArgs &a)
 {
-    // record form: + a 96-byte table of the pooled genomes per wave
-    const size_t lds = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (a.recs ? (size_t)(g_table_threads / 64) * 96 : 0);
+    const size_t lds = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES;
     const dim3 grid(1u << (a.bb + a.sb)), block(g_table_threads);     // 256 / 512 / 1024 threads: the wave count divides 64
 #define GRM_LAUNCH_DICT(K, T, F, R) hipLaunchKernelGGL((dict_build_kernel<K, T, F, R>), grid, block, lds, s, a)
     if (a.in_flags) {                   // union over ranks: not a hot kernel, one instance
@@ -1911,7 +1938,7 @@ void launch_dict_build(hipStream_t s, const DictArgs &a)
         return;
     }
     if (a.recs) {                       // one record (up to 8 keys) per lane; 8 waves (the instance's launch bound)
-        const size_t lds_r = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (size_t)(TABLE_THREADS / 64) * 96;
+        const size_t lds_r = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (size_t)(TABLE_THREADS / 64) * 192;      // + the pool table of every wave
         hipLaunchKernelGGL((dict_build_kernel<8, 512, false, true>), grid, dim3(TABLE_THREADS), lds_r, s, a);
         return;
     }

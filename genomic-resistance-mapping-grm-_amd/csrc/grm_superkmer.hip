@@ -277,17 +277,22 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
 // bucket, in place of the region in a second buffer.  STAGED: the region is read once into LDS (a returning LDS atomic
 // gives every record its rank inside its fine bucket, kept in bits of y that hold bases no k-mer reaches) and written
 // from there; regions too large for that are swept twice (count, then place; the second sweep comes from L2).
-// Segment vg * 2^bb + bucket = recs2[off[..] .. + len[..]) in RECORDS.
+// Inside a fine bucket the records of at most 4 k-mers stand first: dict_build takes those four keys at a time and the
+// others eight at a time, which leaves 17 % of its key slots empty instead of 33 %.
+// Segment vg * 2^bb + bucket = recs2[off[..] .. + (len[..] & 0xffff)) in RECORDS, the first len[..] >> 16 of them short.
+// bin of a record: 2 * fine bucket + (more than 4 k-mers)
+__device__ __forceinline__ uint32_t rec_bin(uint64_t y) { return (((uint32_t)(y >> 8) & 0xffu) << 1) | (uint32_t)((y & 0xffu) > 4u); }
+
 template <bool STAGED, int MAXR>
 __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(const ulonglong2 *__restrict__ recs1, uint32_t rstride,
                                                                             const uint32_t *__restrict__ rcount1, uint64_t n_regions, int bb, int b1,
                                                                             ulonglong2 *__restrict__ recs2, uint64_t *__restrict__ off,
                                                                             uint32_t *__restrict__ len_out)
 {
-    constexpr int NF = 64;
+    constexpr int NF = 64, NB = 2 * NF;                 // bins: (fine bucket, length class)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     ulonglong2 *srec = reinterpret_cast<ulonglong2 *>(lds_raw);          // [rstride] when STAGED
-    __shared__ uint32_t hist[NF], start[NF];
+    __shared__ uint32_t hist[NB], start[NB];
     __shared__ uint32_t scratch[32];
     const int b2 = bb - b1;
     const uint32_t B2 = 1u << b2;
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
         const ulonglong2 *rr = recs1 + region * rstride;
         ulonglong2 *out = recs2 + region * rstride;
         const uint64_t seg0 = region << b2;
-        if (threadIdx.x < NF) hist[threadIdx.x] = 0;
+        if (threadIdx.x < NB) hist[threadIdx.x] = 0;
         __syncthreads();
         if (STAGED) {
             // all of a thread's loads are in flight before the first one is used
@@ -311,22 +316,26 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
             for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
                 if (i < n) {
-                    const uint32_t rank = atomicAdd(&hist[(uint32_t)(in[j].y >> 8) & 0xffu], 1u);
+                    const uint32_t rank = atomicAdd(&hist[rec_bin(in[j].y)], 1u);
                     srec[i] = make_ulonglong2(in[j].x, (in[j].y & ~RANK_MASK) | ((uint64_t)rank << 16));
                 }
             }
         } else {
-            for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) atomicAdd(&hist[(uint32_t)(rr[i].y >> 8) & 0xffu], 1u);
+            for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) atomicAdd(&hist[rec_bin(rr[i].y)], 1u);
         }
         __syncthreads();
-        const uint32_t cnt = threadIdx.x < B2 ? hist[threadIdx.x] : 0u;
+        const uint32_t cnt = threadIdx.x < 2 * B2 ? hist[threadIdx.x] : 0u;
         uint32_t total;
         const uint32_t pre = block_scan_sum(cnt, scratch, &total);
-        if (threadIdx.x < B2) {
+        const uint32_t cnt_long = __shfl_down(cnt, 1);         // (of the bin after this one)
+        if (threadIdx.x < 2 * B2) {
             start[threadIdx.x] = pre;
             hist[threadIdx.x] = 0;                     // (two-sweep form: now the running rank)
-            off[seg0 + threadIdx.x] = region * rstride + pre;
-            len_out[seg0 + threadIdx.x] = cnt;
+            if (!(threadIdx.x & 1u)) {                 // bin 2f: the short records of fine bucket f, followed by its long ones
+                const uint32_t f = threadIdx.x >> 1;
+                off[seg0 + f] = region * rstride + pre;
+                len_out[seg0 + f] = (cnt + cnt_long) | (cnt << 16);
+            }
         }
         __syncthreads();
         if (STAGED) {
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
             for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
                 if (i < n)
-                    srec[start[(uint32_t)(mine[j].y >> 8) & 0xffu] + ((uint32_t)(mine[j].y >> 16) & 0x3ffffu)] =
+                    srec[start[rec_bin(mine[j].y)] + ((uint32_t)(mine[j].y >> 16) & 0x3ffffu)] =
                         make_ulonglong2(mine[j].x, mine[j].y & ~RANK_MASK);
             }
             __syncthreads();
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
         } else {
             for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) {
                 const ulonglong2 rec = rr[i];
-                const uint32_t f = (uint32_t)(rec.y >> 8) & 0xffu;
+                const uint32_t f = rec_bin(rec.y);
                 out[start[f] + atomicAdd(&hist[f], 1u)] = rec;
             }
         }
