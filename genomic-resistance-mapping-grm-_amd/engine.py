@@ -369,6 +369,7 @@ class Batch:
     # the exchange as one all-gather of fixed-stride records (see include/grm_kmer.h)
     @property
     def bucket_bits(self):
+        """bucket geometry as ranks compare it: the bucket bits in the low byte, + 0x100 for minimizer buckets"""
         return int(self.ctx.L.grm_batch_bucket_bits(self.h))
 
     def exchange_layout(self, n_max, words, bucket_bits):

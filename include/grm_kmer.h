@@ -165,8 +165,10 @@ int  grm_batch_fill(grm_batch *, grm_matrix **out);
  * grm_exchange_layout gives the offsets and the record stride (a multiple of 16 bytes); every rank writes its record
  * with grm_batch_export_dict_ordered, the host all-gathers n_ranks * stride bytes, and
  * grm_batch_set_global_dict_gathered builds the global dictionary from the gathered payload (counts / bucket_bits:
- * host arrays with n_local and grm_batch_bucket_bits of every rank).  Replaces the k-mer delivery between Ray's MPI
- * ranks (src/app.py:1310). */
+ * host arrays with n_local and grm_batch_bucket_bits of every rank).  grm_batch_bucket_bits returns the bucket geometry
+ * as ranks compare it: the bucket bits in the low byte, + 0x100 when the buckets are minimizer buckets (the record form
+ * of the partition); grm_exchange_layout reads the low byte only, so pass the largest low byte of any rank.  Replaces
+ * the k-mer delivery between Ray's MPI ranks (src/app.py:1310). */
 void grm_exchange_layout(uint64_t n_max, int words, int bucket_bits, uint64_t *flags_off, uint64_t *boff_off, uint64_t *stride);
 int  grm_batch_bucket_bits(const grm_batch *);
 int  grm_batch_export_dict_ordered(grm_batch *, void *dev_record, uint64_t flags_off, uint64_t boff_off);
