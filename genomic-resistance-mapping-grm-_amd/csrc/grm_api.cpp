@@ -687,6 +687,10 @@ struct grm_batch {
     bool rec_mode = false, rec_failed = false, rec_dict = false;
     uint32_t rec_rstride = 0;
     uint64_t rec_kstride = 0, rec_regions = 0;
+    int rec_b1 = 0;                // coarse bits of the record regions
+    uint32_t rec_need = 0;         // what the dictionary launch that gave the record form up estimated for its fullest bucket ...
+    int rec_need_bb = 0;           // ... of 2^rec_need_bb
+    int rec_bb_hint = -1, rec_bb_hint_k = 0;   // bucket bits a dictionary of this batch needed last time (more buckets instead of sub-buckets)
     int rec_part_bits = 0;         // genomes are cut into 2^rec_part_bits parts (segment index: virtual genome * 2^bb + bucket)
     bool slack_failed = false;     // a slack-layout partition of this batch overflowed: dense layout from then on
     DevBuf d_marks;                // one bit per segment: left to the workgroup form of the dedup
@@ -1009,6 +1013,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     b->k = k;
     b->abundance_min = abundance_min;
     b->deduped = false;
+    b->rec_mode = b->rec_dict = false;
 
     if (b->n_tiles == 0 || G == 0) {
         b->total_syms = b->total_keys = 0;
@@ -1061,6 +1066,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     if (k > 32) return GRM_OK;       // two-word k-mers: the caller continues on grm_wide_hash.hip / grm_wide.hip
     b->bb = pick_bucket_bits(c, max_g);
     b->rec_mode = false;
+    b->rec_dict = false;
     b->cap_log2 = pick_cap_log2(c);
 
     // ---- record form (grm_superkmer.hip): buckets by minimizer; level 1 moves runs of consecutive k-mers as 16-byte
@@ -1070,6 +1076,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     // segment sizes inside a region.
     if (k >= SK_M && abundance_min == 1 && !want_counts && c->opt_records != 0 && !b->rec_failed && c->opt_dense_layout <= 0) {
         int bbr = c->opt_bucket_bits >= 0 ? b->bb : b->bb + (c->opt_rec_bucket_shift >= 0 ? c->opt_rec_bucket_shift : 1);
+        if (c->opt_bucket_bits < 0 && b->rec_bb_hint > bbr && b->rec_bb_hint_k == k) bbr = b->rec_bb_hint;
         bbr = std::min(bbr, superkmer_max_bits());
         const int b1r = superkmer_coarse_bits(bbr);
         // one workgroup per genome part owns the part's regions: enough parts to fill the device when genomes are few
@@ -1117,7 +1124,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
                                     ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << b->cap_log2) * 8 <= MATRIX_S_LIMIT &&
                                     b->d_recs2.ensure((n_regions * rstride64 + 4) * 16) == hipSuccess;
             if (!by_records) (void)hipGetLastError();
-            b->rec_rstride = rstride; b->rec_kstride = kstride; b->rec_regions = n_regions;
+            b->rec_rstride = rstride; b->rec_kstride = kstride; b->rec_regions = n_regions; b->rec_b1 = b1r;
             int l2_idx = -1;
             if (by_records) {
                 TimeScope t(c, "superkmer_l2", b->total_syms);        // (units: the record count, once it is known)
@@ -1373,6 +1380,30 @@ struct DictCtrl {
 struct DictOut {
     DevBuf *keys, *flags, *wg_base, *wg_cnt;
 };
+// a launch holds fewer than 2^32 threads: at most 2^22 workgroups of 512
+static const int DICT_MAX_WG_BITS = 22;
+
+// run_dict_ladder -> grm_batch_local_dict: the record form would need many sub-buckets, each of which decodes every record
+// of its bucket again; the key form (sub-bucket workgroups only re-read and skip keys) is the cheaper way then
+static const int GRM_INTERNAL_WANT_KEY_FORM = -1000;
+
+// record form: the same records in 2^new_bb buckets -- level 2 again (the records carry more bucket bits than are in use)
+static int batch_rebucket(grm_batch *b, int new_bb)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    const uint64_t n_seg = (((uint64_t)b->n_genomes << b->rec_part_bits)) << new_bb;
+    HIPCHK(c, b->d_off.ensure((n_seg + 1) * 8));
+    HIPCHK(c, b->d_len.ensure((n_seg + 1) * 4));
+    {
+        TimeScope t(c, "superkmer_l2_again", 0);
+        launch_superkmer_l2_records(s, b->d_recs.p, b->rec_rstride, b->d_counts1.as<uint32_t>(), b->rec_regions, new_bb, b->rec_b1, b->d_recs2.p,
+                                    b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>());
+    }
+    HIPCHK(c, hipGetLastError());
+    b->bb = new_bb;
+    return GRM_OK;
+}
 static int run_dict_ladder(grm_batch *b, DictArgs a, uint64_t total_keys, int sb, bool want_bits, const DictOut &out, const char *tname,
                            int *sb_out, uint64_t *n_out, bool *bits_out, int *launches)
 {
@@ -1382,7 +1413,7 @@ static int run_dict_ladder(grm_batch *b, DictArgs a, uint64_t total_keys, int sb
     const size_t n_rows = ((size_t)a.n_genomes + 63) / 64;
     HIPCHK(c, b->d_ctrl.ensure(sizeof(DictCtrl)));
     for (int attempt = 0;; attempt++) {
-        if (a.bb + sb > 24) return fail(c, GRM_ERR_OVERFLOW, "%s: bucket union does not fit the LDS table even with 2^%d sub-buckets", tname, sb);
+        if (a.bb + sb > DICT_MAX_WG_BITS) return fail(c, GRM_ERR_OVERFLOW, "%s: bucket union does not fit the LDS table even with 2^%d sub-buckets", tname, sb);
         const uint32_t n_wg = 1u << (a.bb + sb);
         // every workgroup holds at most max_fill entries, and there are no more entries than keys
         const uint64_t out_cap = std::min<uint64_t>(total_keys, (uint64_t)n_wg * max_fill) + 64;
@@ -1426,6 +1457,31 @@ static int run_dict_ladder(grm_batch *b, DictArgs a, uint64_t total_keys, int sb
         // distinct k-mers; aim at 70 % of the usable table so that the estimate's error does not cost a third launch
         int step = 1;
         while (step < 24 && ((uint64_t)h.need >> step) > (uint64_t)max_fill * 7 / 10) step++;
+        bool more_buckets = false;
+        if (a.recs && b->rec_dict && c->opt_sub_bits < 0 && c->opt_bucket_bits < 0) {
+            // record form: every sub-bucket workgroup would decode ALL records of its bucket, so more BUCKETS come first
+            // (level 2 again, 6 ms) as far as the records' bucket bits and the presence words allow
+            int more = std::min(step, std::min(superkmer_max_bits(), b->rec_b1 + 7) - a.bb);
+            if (step > std::min(superkmer_max_bits(), b->rec_b1 + 7) - a.bb + 2) more = 0;      // hopeless: straight to the key form
+            while (more > 0 && ((size_t)1 << (a.bb + more + sb)) * n_rows * cap * 8 > MATRIX_S_LIMIT) more--;
+            if (more > 0) {
+                int rc = batch_rebucket(b, a.bb + more);
+                if (rc) return rc;
+                a.bb = b->bb;
+                a.seg.off = b->d_off.as<uint64_t>();
+                a.seg.len = b->d_len.as<uint32_t>();
+                // `need` extrapolates the fill linearly over the genomes, far too much for a pan-genome whose distinct
+                // k-mers saturate early: the new buckets are tried before any sub-bucket is added
+                step = 0;
+                more_buckets = true;
+            } else if (sb + step > 2) {
+                b->rec_need = h.need;                    // (of the fullest of 2^a.bb minimizer buckets)
+                b->rec_need_bb = a.bb;
+                return GRM_INTERNAL_WANT_KEY_FORM;       // no bucket bits left and more than 4 sub-buckets asked for: see the caller
+            }
+        }
+        if (a.bb + sb + step > DICT_MAX_WG_BITS) step = DICT_MAX_WG_BITS - a.bb - sb;      // as many sub-buckets as a launch allows before giving up
+        if (step <= 0 && !more_buckets) return fail(c, GRM_ERR_OVERFLOW, "%s: bucket union does not fit the LDS table even with 2^%d sub-buckets", tname, sb);
         sb += step;
     }
 }
@@ -1440,7 +1496,7 @@ static int batch_expand_keys(grm_batch *b)
     HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 16, s));
     {
         TimeScope t(c, "superkmer_l2_keys", b->total_syms);
-        launch_superkmer_l2(s, b->d_recs.p, b->rec_rstride, b->d_counts1.as<uint32_t>(), b->rec_regions, b->k, b->bb, superkmer_coarse_bits(b->bb), b->rec_kstride,
+        launch_superkmer_l2(s, b->d_recs.p, b->rec_rstride, b->d_counts1.as<uint32_t>(), b->rec_regions, b->k, b->bb, b->rec_b1, b->rec_kstride,
                             b->d_keys.as<uint64_t>(), b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->t_flag.as<int>());
     }
     HIPCHK(c, hipGetLastError());
@@ -1486,6 +1542,22 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
     a.n_genomes = G; a.bb = b->bb; a.cap_log2 = b->cap_log2;
     const DictOut out = {&b->d_local_keys, &b->d_local_flags, &b->d_wg_base, &b->d_wg_cnt};
     int rc = run_dict_ladder(b, a, b->total_keys, sb, c->opt_no_slots <= 0, out, "dict_build", &sb, &b->n_local, &b->have_bits, &b->dict_launches);
+    if (rc == GRM_INTERNAL_WANT_KEY_FORM) {
+        b->rec_failed = true;                // this batch holds too many distinct k-mers per minimizer bucket: key form from now on
+        rc = batch_partition_impl(b, b->k, b->abundance_min, false);
+        if (rc) return rc;
+        if (c->opt_sub_bits < 0) {
+            // what the failed launch learnt sizes the key form's first attempt: its fullest minimizer bucket held about twice an
+            // average one, and hashed buckets are even
+            const uint64_t per_bucket = b->rec_need_bb >= b->bb ? ((uint64_t)b->rec_need << (b->rec_need_bb - b->bb)) / 2
+                                                                : ((uint64_t)b->rec_need >> (b->bb - b->rec_need_bb)) / 2;
+            const uint32_t cap = 1u << b->cap_log2, max_fill = cap - (cap >> 3);
+            int s0 = 0;
+            while (s0 < DICT_MAX_WG_BITS - b->bb && (per_bucket >> s0) > (uint64_t)max_fill * 7 / 10) s0++;
+            b->sb_hint = s0; b->sb_hint_k = b->k; b->sb_hint_bb = b->bb; b->sb_hint_amin = b->abundance_min;
+        }
+        return grm_batch_local_dict(b, n_local);
+    }
     if (rc) return rc;
     if (b->rec_mode && !b->have_bits) {
         // the probing form of the fill reads key segments, genome by genome
@@ -1501,6 +1573,7 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
         }
     }
     b->sb_dict = sb;
+    if (b->rec_mode && c->opt_bucket_bits < 0) { b->rec_bb_hint = b->bb; b->rec_bb_hint_k = b->k; }
     if (c->opt_sub_bits < 0) { b->sb_hint = sb; b->sb_hint_k = b->k; b->sb_hint_bb = b->bb; b->sb_hint_amin = b->abundance_min; }
     b->have_local = true;
     if (n_local) *n_local = b->n_local;
@@ -1659,7 +1732,7 @@ static int dict_attach(grm_batch *b, uint64_t *n_kmers)
     // probing form.  sub-bucket count for the fill: keep the mean dictionary slice under 1/4 of the table
     int sb = c->opt_sub_bits >= 0 ? c->opt_sub_bits : 0;
     const uint64_t cap = 1ull << b->cap_log2;
-    while (b->bb + sb < 24 && (b->n_dict >> (b->bb + sb)) > cap / 4) sb++;
+    while (b->bb + sb < DICT_MAX_WG_BITS && (b->n_dict >> (b->bb + sb)) > cap / 4) sb++;
     int rc = bucketise_dict(b, sb);
     if (rc) return rc;
     b->have_global = true;
@@ -1750,32 +1823,38 @@ extern "C" int grm_batch_set_global_dict_gathered(grm_batch *b, const void *dev_
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int words = b->k > 32 ? 2 : 1;
-    int bb_max = 0;
-    bool same_bb = true;
+    int bb_max = 0, bb_min = 255;
+    bool same_kind = true;                 // hashed buckets or minimizer buckets, the same on every rank
     uint64_t total = 0;
     for (int r = 0; r < n_ranks; r++) {
         bb_max = std::max(bb_max, bucket_bits[r] & 0xff);
-        same_bb = same_bb && bucket_bits[r] == bucket_bits[0];
+        bb_min = std::min(bb_min, bucket_bits[r] & 0xff);
+        same_kind = same_kind && (bucket_bits[r] & ~0xff) == (bucket_bits[0] & ~0xff);
         if (counts[r] > n_max) return fail(c, GRM_ERR_ARG, "grm_batch_set_global_dict_gathered: rank %d holds more than n_max entries", r);
         total += counts[r];
     }
     uint64_t flags_off, boff_off, stride;
     grm_exchange_layout(n_max, words, bb_max, &flags_off, &boff_off, &stride);
     const uint8_t *payload = (const uint8_t *)dev_payload;
-    if (words == 1 && same_bb && n_ranks <= 63 && total && c->opt_no_union <= 0) {
-        const uint32_t B = 1u << bb_max;
+    if (words == 1 && same_kind && n_ranks <= 63 && total && c->opt_no_union <= 0) {
+        // ranks may have ended with different bucket counts (a rank whose tables overflowed took more): the union runs over
+        // the coarsest, in which every rank's buckets nest
+        RankShifts shifts;
+        memset(&shifts, 0, sizeof shifts);
+        for (int r = 0; r < n_ranks; r++) shifts.d[r] = (uint8_t)((bucket_bits[r] & 0xff) - bb_min);
+        const uint32_t B = 1u << bb_min;
         const uint64_t n_seg = (uint64_t)n_ranks * B;
         HIPCHK(c, b->t_u_off.ensure(n_seg * 8));
         HIPCHK(c, b->t_u_len.ensure(n_seg * 4));
         HIPCHK(c, b->t_u_foff.ensure(n_seg * 8));
-        launch_union_segments(s, payload, (uint32_t)n_ranks, stride, flags_off, boff_off, B, b->t_u_off.as<uint64_t>(), b->t_u_len.as<uint32_t>(),
-                              b->t_u_foff.as<uint64_t>());
+        launch_union_segments(s, payload, (uint32_t)n_ranks, stride, flags_off, boff_off, B, shifts, b->t_u_off.as<uint64_t>(),
+                              b->t_u_len.as<uint32_t>(), b->t_u_foff.as<uint64_t>());
         HIPCHK(c, hipGetLastError());
         DictArgs a;
         memset(&a, 0, sizeof a);
         a.keys = (const uint64_t *)payload;
         a.seg.off = b->t_u_off.as<uint64_t>(); a.seg.len = b->t_u_len.as<uint32_t>(); a.seg.stride = 0;
-        a.n_genomes = (uint32_t)n_ranks; a.bb = bb_max; a.cap_log2 = b->cap_log2;
+        a.n_genomes = (uint32_t)n_ranks; a.bb = bb_min; a.cap_log2 = b->cap_log2;
         a.in_flags = payload; a.in_flag_off = b->t_u_foff.as<uint64_t>();
         const DictOut out = {&b->t_u_keys, &b->t_u_flags, &b->t_u_wg_base, &b->t_u_wg_cnt};
         int sb = 0;
@@ -1861,7 +1940,7 @@ extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
         if (e2 != hipSuccess) { rc = fail(c, GRM_ERR_HIP, "matrix_fill: %s", hipGetErrorString(e2)); break; }
         if (!ov) break;
-        if (b->bb + b->sb_fill >= 24) { rc = fail(c, GRM_ERR_OVERFLOW, "matrix_fill: dictionary slice does not fit the LDS table"); break; }
+        if (b->bb + b->sb_fill >= DICT_MAX_WG_BITS) { rc = fail(c, GRM_ERR_OVERFLOW, "matrix_fill: dictionary slice does not fit the LDS table"); break; }
         rc = bucketise_dict(b, b->sb_fill + 1);
         if (rc) break;
     }

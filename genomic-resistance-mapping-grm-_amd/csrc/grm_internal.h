@@ -162,9 +162,12 @@ void launch_dict_export_ordered(hipStream_t s, const uint64_t *keys, const uint8
                                 const uint64_t *ord_off, uint32_t n_wg, int sb, uint64_t *out_keys, uint8_t *out_flags, uint32_t *bucket_off);
 void launch_bucket_offsets(hipStream_t s, const uint64_t *ord_off, int sb, uint32_t n_buckets, uint32_t *bucket_off);
 // segment arrays of the rank union over a gathered payload (rank r at r * stride bytes: keys, flags at flags_off, bucket
-// offsets at boff_off): key index (in uint64 units of the payload), length, byte offset of the flags
+// offsets at boff_off): key index (in uint64 units of the payload), length, byte offset of the flags.  The union runs over
+// n_buckets = 2^(smallest bucket bits of any rank); shifts.d[r] = rank r's bucket bits minus that (a bucket is the TOP
+// bits of a hash, so a rank's finer buckets nest inside the coarser ones, in order)
+struct RankShifts { uint8_t d[64]; };
 void launch_union_segments(hipStream_t s, const uint8_t *payload, uint32_t n_ranks, uint64_t stride, uint64_t flags_off, uint64_t boff_off,
-                           uint32_t n_buckets, uint64_t *off, uint32_t *len, uint64_t *flag_off);
+                           uint32_t n_buckets, const RankShifts &shifts, uint64_t *off, uint32_t *len, uint64_t *flag_off);
 // column of every local entry: position of its key in the sorted global dictionary, 0xffffffff if filtered / absent
 // (prefix_first: scratch of 2^20 + 2 uint32)
 void launch_dict_entry_cols(hipStream_t s, const uint64_t *dict, uint64_t n_dict, const uint64_t *entry_keys, uint64_t n_entries, int k,

@@ -1400,14 +1400,16 @@ __global__ void dict_bucket_offsets_kernel(const uint64_t *__restrict__ ord_off,
         bucket_off[b] = (uint32_t)ord_off[(uint64_t)b << sb];
 }
 __global__ void union_segments_kernel(const uint8_t *__restrict__ payload, uint32_t n_ranks, uint64_t stride, uint64_t flags_off,
-                                      uint64_t boff_off, uint32_t n_buckets, uint64_t *__restrict__ off, uint32_t *__restrict__ len,
-                                      uint64_t *__restrict__ flag_off)
+                                      uint64_t boff_off, uint32_t n_buckets, RankShifts shifts, uint64_t *__restrict__ off,
+                                      uint32_t *__restrict__ len, uint64_t *__restrict__ flag_off)
 {
     const uint64_t total = (uint64_t)n_ranks * n_buckets;
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = idx / n_buckets, b = idx % n_buckets;
         const uint32_t *boff = reinterpret_cast<const uint32_t *>(payload + r * stride + boff_off);
-        const uint32_t o0 = boff[b], o1 = boff[b + 1];
+        // a rank that used 2^d times as many buckets: its buckets b * 2^d .. (b + 1) * 2^d - 1 are this bucket (bucket = TOP bits)
+        const int d = shifts.d[r];
+        const uint32_t o0 = boff[b << d], o1 = boff[(b + 1) << d];
         off[idx] = r * (stride / 8) + o0;
         len[idx] = o1 - o0;
         flag_off[idx] = r * stride + flags_off + o0;
@@ -1964,10 +1966,10 @@ void launch_dict_export_ordered(hipStream_t s, const uint64_t *keys, const uint8
     launch_bucket_offsets(s, ord_off, sb, n_wg >> sb, bucket_off);
 }
 void launch_union_segments(hipStream_t s, const uint8_t *payload, uint32_t n_ranks, uint64_t stride, uint64_t flags_off, uint64_t boff_off,
-                           uint32_t n_buckets, uint64_t *off, uint32_t *len, uint64_t *flag_off)
+                           uint32_t n_buckets, const RankShifts &shifts, uint64_t *off, uint32_t *len, uint64_t *flag_off)
 {
     hipLaunchKernelGGL(union_segments_kernel, dim3(grid_for((uint64_t)n_ranks * n_buckets, 256)), dim3(256), 0, s, payload, n_ranks, stride,
-                       flags_off, boff_off, n_buckets, off, len, flag_off);
+                       flags_off, boff_off, n_buckets, shifts, off, len, flag_off);
 }
 void launch_dict_entry_cols(hipStream_t s, const uint64_t *dict, uint64_t n_dict, const uint64_t *entry_keys, uint64_t n_entries, int k,
                             uint32_t *prefix_first /* 2^20 + 2 entries */, uint32_t *entry_col)

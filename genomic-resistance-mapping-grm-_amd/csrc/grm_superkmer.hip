@@ -8,7 +8,7 @@
 // level 1 as ONE 16-byte record that carries its own bases:
 //     x            bases 0..31 of the run, MSB-first
 //     y[63..34]    bases 32..46                        (len + k - 1 <= 47 bases)
-//     y[15..8]     fine bucket (the bucket bits below the 8 coarse ones)
+//     y[14..8]     7 bucket bits below the coarse ones (level 2 uses the top bb - b1 of them)
 //     y[7..0]      len = k-mers in the run (1..16)
 // so 8 B per k-mer become ~2 B between the levels.  Level 2 owns a (genome part, coarse bucket) region: it sorts the
 // region's records by fine bucket and EXPANDS them to canonical k-mers on the way out, leaving the same bucket-sorted
@@ -25,7 +25,9 @@ namespace grm {
 constexpr int SK_THREADS = 1024;
 constexpr int SK_PPT = 32;                            // k-mer start positions per thread and step: one packed word
 constexpr int SK_LMAX = 8;                            // k-mers per record: what one lane of dict_build (record form) decodes at a time
-constexpr int SK_MAX_BITS = 14;                       // at most 9 coarse bits (SK_THREADS cursors), the fine field of a record has 8 bits; NF fine buckets in level 2
+constexpr int SK_FINE_BITS = 7;                       // a record carries 7 bucket bits below the coarse ones, whatever the bucket count in use:
+                                                      // level 2 takes the top bb - b1 of them, so more buckets only need level 2 again
+constexpr int SK_MAX_BITS = 9 + SK_FINE_BITS;         // at most 9 coarse bits (SK_THREADS cursors) + the fine field
 constexpr int SK2_THREADS = 256;
 constexpr int SK2R_THREADS = 512;                     // level 2, records only
 constexpr int SK2_TILE_KEYS = SK2_THREADS * SK_LMAX;                // one record per thread: at most 4096 keys = 32 KB of LDS per tile
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     __shared__ uint32_t cursor[SK_THREADS];                  // records written so far to coarse region c (2^b1 <= SK_THREADS)
     __shared__ uint32_t scratch[32];
     constexpr int NM = SK_PPT + W - 1;                 // m-mer positions a thread looks at
-    const int b1 = a.b1, b2 = a.bb - b1;
+    const int b1 = a.b1;
     const uint32_t B1 = 1u << b1;
     const uint32_t vg = blockIdx.x;
     const uint32_t gen = vg >> a.part_bits, part = vg & ((1u << a.part_bits) - 1u);
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
             }
             uint32_t bk[SK_PPT];
 #pragma unroll
-            for (int i = 0; i < SK_PPT; i++) bk[i] = minimizer_bucket(min(h[i], h[i + W - SPAN]), a.bb);
+            for (int i = 0; i < SK_PPT; i++) bk[i] = minimizer_bucket(min(h[i], h[i + W - SPAN]), b1 + SK_FINE_BITS);
 #pragma unroll
             for (int i = 0; i < SK_PPT; i++) {
                 const bool vi = (valid >> i) & 1u;
@@ -142,10 +144,10 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
             hd &= hd - 1;
             const uint32_t len = (uint32_t)__ffsll((unsigned long long)(bnd >> (i + 1)));
             const uint32_t bkt = my_bk[i];
-            const uint32_t c = bkt >> b2;
+            const uint32_t c = bkt >> SK_FINE_BITS;
             ulonglong2 rec;
             rec.x = i ? ((w0 << (2 * i)) | (w1 >> (64 - 2 * i))) : w0;
-            rec.y = ((w1 << (2 * i)) & ~0xffffull) | ((uint64_t)(bkt & ((1u << b2) - 1u)) << 8) | len;
+            rec.y = ((w1 << (2 * i)) & ~0xffffull) | ((uint64_t)(bkt & ((1u << SK_FINE_BITS) - 1u)) << 8) | len;
             const uint32_t slot = atomicAdd(&cursor[c], 1u);
             if (slot < rstride) recs1[((uint64_t)vg * B1 + c) * rstride + slot] = rec;
             else over = true;
@@ -158,6 +160,9 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     (void)block_scan_sum(n_valid, scratch, &total);
     if (threadIdx.x == 0) part_kmers[vg] = total;
 }
+
+// fine bucket of a record when 2^b2 fine buckets are in use: the top b2 of its SK_FINE_BITS
+__device__ __forceinline__ uint32_t rec_fine(uint64_t y, int b2) { return (((uint32_t)(y >> 8) & 0x7fu) >> (SK_FINE_BITS - b2)); }
 
 // ---- level 2 -----------------------------------------------------------------------------------------------------
 // One workgroup per (virtual genome, coarse bucket) region at a time.  Pass A adds up the k-mers per fine bucket (the
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
 {
     __shared__ uint64_t skeys[SK2_TILE_KEYS];
     __shared__ ulonglong2 srec[SK2_THREADS];
-    constexpr int NF = 64;          // fine buckets of a region
+    constexpr int NF = 1 << SK_FINE_BITS;          // fine buckets of a region, at most
     __shared__ uint32_t gbase[NF];                      // relative to the region's first key
     __shared__ uint32_t hist[NF], start[NF], lhist[64], lstart[64];
     __shared__ uint32_t scratch[32];
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += SK2_THREADS) {
             const uint64_t y = rr[i].y;
-            atomicAdd(&hist[(uint32_t)(y >> 8) & 0xffu], (uint32_t)(y & 0xffu));
+            atomicAdd(&hist[rec_fine(y, b2)], (uint32_t)(y & 0xffu));
         }
         __syncthreads();
         const uint32_t cnt = threadIdx.x < B2 ? hist[threadIdx.x] : 0u;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
             if (threadIdx.x < 64) lhist[threadIdx.x] = 0;
             __syncthreads();
             const uint32_t ln = (uint32_t)(rec.y & 0xffu);               // 0 for the padding of the last tile
-            const uint32_t fine = (uint32_t)(rec.y >> 8) & 0xffu;
+            const uint32_t fine = rec_fine(rec.y, b2);
             const uint32_t frank = ln ? atomicAdd(&hist[fine], ln) : 0u;  // first k-mer of the record inside its fine bucket
             const uint32_t lrank = atomicAdd(&lhist[ln & 63u], 1u);
             __syncthreads();
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
                 const ulonglong2 r2 = srec[threadIdx.x];
                 const uint32_t l2 = (uint32_t)(r2.y & 0xffu);
                 if (l2) {
-                    uint32_t at = start[(uint32_t)(r2.y >> 8) & 0xffu] + ((uint32_t)(r2.y >> 16) & 0x3ffffu);
+                    uint32_t at = start[rec_fine(r2.y, b2)] + ((uint32_t)(r2.y >> 16) & 0x3ffffu);
                     uint64_t fwd = r2.x >> up;
                     uint64_t rc = revcomp_m(fwd, k);
                     // the bases after the first k-mer, MSB-aligned (at most 15 are used)
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
 // others eight at a time, which leaves 17 % of its key slots empty instead of 33 %.
 // Segment vg * 2^bb + bucket = recs2[off[..] .. + (len[..] & 0xffff)) in RECORDS, the first len[..] >> 16 of them short.
 // bin of a record: 2 * fine bucket + (more than 4 k-mers)
-__device__ __forceinline__ uint32_t rec_bin(uint64_t y) { return (((uint32_t)(y >> 8) & 0xffu) << 1) | (uint32_t)((y & 0xffu) > 4u); }
+__device__ __forceinline__ uint32_t rec_bin(uint64_t y, int b2) { return (rec_fine(y, b2) << 1) | (uint32_t)((y & 0xffu) > 4u); }
 
 template <bool STAGED, int MAXR>
 __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(const ulonglong2 *__restrict__ recs1, uint32_t rstride,
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
                                                                             ulonglong2 *__restrict__ recs2, uint64_t *__restrict__ off,
                                                                             uint32_t *__restrict__ len_out)
 {
-    constexpr int NF = 64, NB = 2 * NF;                 // bins: (fine bucket, length class)
+    constexpr int NF = 1 << SK_FINE_BITS, NB = 2 * NF;  // bins: (fine bucket, length class)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     ulonglong2 *srec = reinterpret_cast<ulonglong2 *>(lds_raw);          // [rstride] when STAGED
     __shared__ uint32_t hist[NB], start[NB];
@@ -316,12 +321,12 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
             for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
                 if (i < n) {
-                    const uint32_t rank = atomicAdd(&hist[rec_bin(in[j].y)], 1u);
+                    const uint32_t rank = atomicAdd(&hist[rec_bin(in[j].y, b2)], 1u);
                     srec[i] = make_ulonglong2(in[j].x, (in[j].y & ~RANK_MASK) | ((uint64_t)rank << 16));
                 }
             }
         } else {
-            for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) atomicAdd(&hist[rec_bin(rr[i].y)], 1u);
+            for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) atomicAdd(&hist[rec_bin(rr[i].y, b2)], 1u);
         }
         __syncthreads();
         const uint32_t cnt = threadIdx.x < 2 * B2 ? hist[threadIdx.x] : 0u;
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
             for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
                 if (i < n)
-                    srec[start[rec_bin(mine[j].y)] + ((uint32_t)(mine[j].y >> 16) & 0x3ffffu)] =
+                    srec[start[rec_bin(mine[j].y, b2)] + ((uint32_t)(mine[j].y >> 16) & 0x3ffffu)] =
                         make_ulonglong2(mine[j].x, mine[j].y & ~RANK_MASK);
             }
             __syncthreads();
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
         } else {
             for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) {
                 const ulonglong2 rec = rr[i];
-                const uint32_t f = rec_bin(rec.y);
+                const uint32_t f = rec_bin(rec.y, b2);
                 out[start[f] + atomicAdd(&hist[f], 1u)] = rec;
             }
         }

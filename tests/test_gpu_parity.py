@@ -121,6 +121,7 @@ def test_medium_pangenome_all_paths(ctx):
     {"rec_part_bits": 2}, {"rec_part_bits": 3, "rec_keys": 1},  # genomes cut into parts (one workgroup each)
     {"rec_bucket_shift": 1}, {"bucket_bits": 6}, {"bucket_bits": 9, "sub_bits": 1},
     {"rec_part_bits": 1, "no_slots": 1},               # probing fill asked of a partition in parts: falls back to the key form
+    {"cap_log2": 7}, {"cap_log2": 8, "rec_bucket_shift": 0},   # record form: tables overflow -> more buckets (level 2 again), then sub-buckets
 ])
 def test_medium_with_forced_geometry(ctx, opts):
     genomes = _medium_genomes(n=5, length=120_000, seed=9)
@@ -888,7 +889,8 @@ def test_gathered_exchange_in_one_process(ctx, k, opts):
     """the exchange records of three "ranks" (three batches of one context) laid out as an all-gather would leave
     them; every batch builds the global dictionary from the payload (rank union in LDS tables, or the sort of
     everything with no_union / k > 32; cap_log2 8 forces the union through its sizing ladder) and fills its rows:
-    stacked, they are the oracle's matrix.  One rank uses another bucket geometry in a second round (general path)."""
+    stacked, they are the oracle's matrix.  One rank uses another bucket count in a second round: its finer or coarser
+    buckets nest in the others', the union runs over the coarsest."""
     import torch
     dev = torch.device("cuda", 0)
     pg = synth.PanGenome(genome_len=150_000, n_snps=1500, n_accessory=8, accessory_len=1500, seed=77, n_contigs=2)
@@ -916,7 +918,8 @@ def test_gathered_exchange_in_one_process(ctx, k, opts):
                     n_locals.append(b.local_dict())
                     bbs.append(b.bucket_bits)
                     batches.append(b)
-                assert (len(set(bbs)) > 1) == odd_geometry
+                if not opts:
+                    assert (len(set(bbs)) > 1) == odd_geometry      # (small tables: a rank may have taken more buckets)
                 n_max = max(1, max(n_locals))
                 flags_off, boff_off, stride = batches[0].exchange_layout(n_max, words, max(v & 0xff for v in bbs))
                 payload = torch.empty(len(shards) * stride, dtype=torch.uint8, device=dev)
