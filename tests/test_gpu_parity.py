@@ -152,6 +152,25 @@ def test_record_form_over_k(ctx, k):
                 ctx.set_option(name, -1)
 
 
+def test_record_form_gives_way_to_the_key_form_on_repeats(ctx):
+    """repeat-rich genomes: nearly all k-mers of a genome share a handful of minimizers, so a few record regions would hold
+    most of its records -- the partition raises its overflow flag and is redone in the key form (hashed k-mers spread
+    evenly whatever the sequence); the batch stays there for later runs"""
+    rng = np.random.RandomState(4)
+    genomes = []
+    for g in range(3):
+        unit = cases.rand_seq(rng, 37)
+        genomes.append([cases.fasta([("rep%d" % g, unit * 6000 + cases.rand_seq(rng, 20_000) + "AC" * 40_000)], width=80)])
+    ctx.timing(True)
+    try:
+        ctx.timing_reset()
+        _check(ctx, genomes, 31, 1, False)
+        names = [n for n, _, _ in ctx.timings()]
+        assert "superkmer_l1" in names and "kmer_scatter_l1" in names, names        # tried, then redone
+    finally:
+        ctx.timing(False)
+
+
 def test_parser_stress_layouts(ctx):
     """single-line sequences spanning many 16 KiB tiles, headers longer than a tile, headers that
     straddle tile boundaries, CRLF, blank lines, no trailing newline, lowercase / N runs"""
