@@ -2712,16 +2712,21 @@ static int wide_hash_global(grm_batch *b, const uint64_t *hi, const uint64_t *lo
         HIPCHK(c, hipMemcpyAsync(&W.U, W.pos.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
     }
-    // every local entry learns its column (binary search of its (hi, lo) among the sorted entries)
+    // every local entry learns its column: from the sort's order when the sorted entries are the local ones (one GPU),
+    // else by a binary search of its (hi, lo) among the sorted entries of all ranks
+    W.own_dict = n && hi == W.loc_hi.as<uint64_t>() && lo == W.loc_lo.as<uint64_t>() && n == W.n_local;
     HIPCHK(c, W.entry_col.ensure((W.n_local + 1) * 4));
-    if (W.n_local) {
+    if (W.n_local && W.own_dict) {
+        TimeScope t(c, "wh_entry_cols", W.n_local);
+        launch_wh_cols_from_order(s, W.idx2.as<uint32_t>(), W.keep.as<uint32_t>(), W.pos.as<uint32_t>(), n, W.entry_col.as<uint32_t>());
+        HIPCHK(c, hipGetLastError());
+    } else if (W.n_local) {
         TimeScope t(c, "wh_entry_cols", W.n_local);
         if (n) launch_wh_entry_cols(s, W.t_b.as<uint64_t>(), W.t_a.as<uint64_t>(), W.keep.as<uint32_t>(), W.pos.as<uint32_t>(), n,
                                     W.loc_hi.as<uint64_t>(), W.loc_lo.as<uint64_t>(), W.n_local, W.entry_col.as<uint32_t>());
         else HIPCHK(c, hipMemsetAsync(W.entry_col.p, 0xff, W.n_local * 4, s));
         HIPCHK(c, hipGetLastError());
     }
-    W.own_dict = n && hi == W.loc_hi.as<uint64_t>() && lo == W.loc_lo.as<uint64_t>() && n == W.n_local;
     W.have_global = true;
     return GRM_OK;
 }

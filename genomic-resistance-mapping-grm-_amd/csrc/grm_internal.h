@@ -275,6 +275,8 @@ void launch_wh_select(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo,
                       uint64_t *dict);
 void launch_wh_entry_cols(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
                           const uint64_t *e_hi, const uint64_t *e_lo, uint64_t n_entries, uint32_t *entry_col);
+// one GPU (the sorted entries are the local ones): entry_col[order[i]] = keep[i] ? pos[i] : 0xffffffff
+void launch_wh_cols_from_order(hipStream_t s, const uint32_t *order, const uint32_t *keep, const uint32_t *pos, uint64_t n, uint32_t *entry_col);
 hipError_t wh_set_max_dynamic_lds();
 
 }  // namespace grm

@@ -21,8 +21,8 @@
 
 namespace grm {
 
-constexpr int WH_PPT = 16;                       // start positions / keys per thread
-constexpr int WH_THREADS = 256;
+constexpr int WH_PPT = 8;                        // start positions / keys per thread
+constexpr int WH_THREADS = 512;                  // 8 waves per tile, two tiles (64 KiB of keys each) per CU
 constexpr int WH_TILE = WH_THREADS * WH_PPT;     // 4096 keys staged in LDS
 // thread t owns bucket t of a tile (grm_internal.h, "Bucket ownership by thread id"); this path stays <= 2^13 buckets
 static_assert(WH_THREADS >= (1 << L1_MAX_BITS) && WH_THREADS >= (1 << (MAX_HIST_BITS - L1_MAX_BITS)), "one thread per bucket of a level");
@@ -48,14 +48,14 @@ struct WideArgs {
     int bb;
 };
 
-// the 16 start positions p0 .. p0+15 of a thread; calls f(i, key) for the valid ones
+// the WH_PPT start positions p0 .. of a thread; calls f(i, key) for the valid ones
 template <typename F>
 __device__ __forceinline__ uint32_t wide_positions(const WideArgs &a, uint64_t p0, F &&f)
 {
     const int64_t nv = (int64_t)a.total_syms - a.k + 1 - (int64_t)p0;
     if (nv <= 0) return 0;
     const uint64_t grp = p0 >> 6;
-    uint32_t valid = (uint32_t)(valid_starts(a.inv[grp], a.inv[grp + 1], a.k) >> (p0 & 63)) & 0xffffu;
+    uint32_t valid = (uint32_t)(valid_starts(a.inv[grp], a.inv[grp + 1], a.k) >> (p0 & 63)) & ((1u << WH_PPT) - 1u);
     if (nv < WH_PPT) valid &= (1u << nv) - 1;
     if (valid) {
         const uint64_t wi = p0 >> 5;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l1_kernel(WideArgs a, int b1b
     const uint32_t gen0 = genome_of(a.genome_sym_off, a.n_genomes, p_first);
     const bool uniform = a.genome_sym_off[gen0 + 1] > p_last;
     if (uniform) {
-        hist[threadIdx.x] = 0;          // WH_THREADS == 256 >= B1
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
         K128 kv[WH_PPT];
         uint32_t bk[WH_PPT], rk[WH_PPT];
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l1_kernel(WideArgs a, int b1b
         const uint32_t c = threadIdx.x < B1 ? hist[threadIdx.x] : 0u;
         uint32_t n_tile;
         const uint32_t st = block_scan_sum(c, scratch, &n_tile);
-        start[threadIdx.x] = st;
+        if (threadIdx.x < 256) start[threadIdx.x] = st;
         if (c) {
             const uint64_t cidx = (uint64_t)gen0 * B1 + threadIdx.x;
             const uint64_t region0 = region_stride ? cidx * region_stride
@@ -460,6 +460,13 @@ __global__ void wide_select_kernel(const uint64_t *__restrict__ s_hi, const uint
         dict[2ull * c + 1] = s_lo[i];
     }
 }
+// one GPU: the sorted entries ARE the local entries, each exactly once, and order[i] is the local index of sorted entry i
+__global__ void wide_cols_from_order_kernel(const uint32_t *__restrict__ order, const uint32_t *__restrict__ keep,
+                                            const uint32_t *__restrict__ pos, uint64_t n, uint32_t *__restrict__ entry_col)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        entry_col[order[i]] = keep[i] ? pos[i] : 0xffffffffu;
+}
 // column of every local entry: binary search of its (hi, lo) among the n sorted entries of all ranks; the first entry of
 // its run says whether the k-mer was kept and which column it got (0xffffffff: filtered out)
 __global__ void wide_entry_cols_kernel(const uint64_t *__restrict__ s_hi, const uint64_t *__restrict__ s_lo,
@@ -539,6 +546,12 @@ void launch_wh_select(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo,
     if (!n) return;
     uint64_t g = (n + 255) / 256;
     hipLaunchKernelGGL(wide_select_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, s_hi, s_lo, keep, pos, n, dict);
+}
+void launch_wh_cols_from_order(hipStream_t s, const uint32_t *order, const uint32_t *keep, const uint32_t *pos, uint64_t n, uint32_t *entry_col)
+{
+    if (!n) return;
+    const uint64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(wide_cols_from_order_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, order, keep, pos, n, entry_col);
 }
 void launch_wh_entry_cols(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint32_t *keep, const uint32_t *pos, uint64_t n,
                           const uint64_t *e_hi, const uint64_t *e_lo, uint64_t n_entries, uint32_t *entry_col)
