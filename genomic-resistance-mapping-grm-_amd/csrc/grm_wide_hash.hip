@@ -252,8 +252,7 @@ __global__ __launch_bounds__(WH_THREADS) void wide_l2_kernel(const ulonglong2 *_
 
 // ---- per-bucket dictionary with 16-byte keys ---------------------------------------------------
 // returns the slot of (hi, lo), inserting it if absent; 0xffffffff when the table is full
-__device__ __forceinline__ uint32_t wide_find_or_insert(uint64_t *tlo, uint64_t *thi, uint32_t cap_mask, uint64_t hi, uint64_t lo,
-                                                        uint64_t h, bool *inserted)
+__device__ __forceinline__ uint32_t wide_find_or_insert(ulonglong2 *tkey, uint32_t cap_mask, uint64_t hi, uint64_t lo, uint64_t h, bool *inserted)
 {
     uint32_t slot = hash_slot(h, cap_mask);
     uint32_t probes = 0;
@@ -261,17 +260,19 @@ __device__ __forceinline__ uint32_t wide_find_or_insert(uint64_t *tlo, uint64_t 
     // every lane goes round this loop until it is done; a lane that meets a claimed-but-unpublished
     // slot re-reads it next time round (the claimer published in the meantime or will soon)
     for (uint32_t guard = 0; guard < 64u * (cap_mask + 1); guard++) {
-        uint64_t cur = __hip_atomic_load(&tlo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned long long *plo = reinterpret_cast<unsigned long long *>(&tkey[slot].x);
+        unsigned long long *phi = reinterpret_cast<unsigned long long *>(&tkey[slot].y);
+        uint64_t cur = __hip_atomic_load(plo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == WH_EMPTY) {
-            cur = atomicCAS((unsigned long long *)&tlo[slot], (unsigned long long)WH_EMPTY, (unsigned long long)lo);
+            cur = atomicCAS(plo, (unsigned long long)WH_EMPTY, (unsigned long long)lo);
             if (cur == WH_EMPTY) {                                   // claimed: publish hi
-                __hip_atomic_store(&thi[slot], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(phi, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 *inserted = true;
                 return slot;
             }
         }
         if (cur == lo) {
-            const uint64_t ch = __hip_atomic_load(&thi[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint64_t ch = __hip_atomic_load(phi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ch == hi) return slot;
             if (ch == WH_PENDING) continue;                          // not published yet: look again
         }
@@ -298,8 +299,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t cap = 1u << cap_log2, cap_mask = cap - 1;
-    uint64_t *tlo = reinterpret_cast<uint64_t *>(lds_raw);
-    uint64_t *thi = reinterpret_cast<uint64_t *>(lds_raw + (size_t)cap * 8);
+    ulonglong2 *tkey = reinterpret_cast<ulonglong2 *>(lds_raw);        // slot = (lo, hi): one 16-byte LDS read per probe
     unsigned long long *words = reinterpret_cast<unsigned long long *>(lds_raw + (size_t)cap * 16);
     uint16_t *meta = reinterpret_cast<uint16_t *>(lds_raw + (size_t)cap * 24);
     uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 26);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
     const uint32_t B = 1u << bb;
     const uint32_t b = wg >> sb, sub = wg & ((1u << sb) - 1);
     const uint32_t G = n_genomes, n_rows = (G + 63) >> 6;
-    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tlo[i] = WH_EMPTY; thi[i] = WH_PENDING; words[i] = 0; meta[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tkey[i] = make_ulonglong2(WH_EMPTY, WH_PENDING); words[i] = 0; meta[i] = 0; }
     if (threadIdx.x == 0) { full = 0; n_distinct = 0; }
     __syncthreads();
     const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;        // nw = 8: divides 64
@@ -330,43 +330,41 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
             if (g + nw < G) seg_of(g + nw, s0_next, n_next);
             if (g < G && !full) {
                 const unsigned long long bit = 1ull << (63 - (g & 63));
-                for (uint64_t i0 = lane; i0 < n && !full; i0 += 64 * 2) {
-                    ulonglong2 kv[2];
-                    uint64_t hv[2];
-                    uint32_t sl[2];
+                constexpr int KJ = 2;                    // keys per lane in flight (segments hold ~300 keys: four leave the second round mostly empty)
+                for (uint64_t i0 = lane; i0 < n && !full; i0 += 64 * KJ) {
+                    ulonglong2 kv[KJ];
+                    uint64_t hv[KJ];
+                    uint32_t sl[KJ];
 #pragma unroll
-                    for (int j = 0; j < 2; j++) {
+                    for (int j = 0; j < KJ; j++) {
                         const uint64_t i = i0 + 64u * j;
                         kv[j] = i < n ? keys[s0 + i] : make_ulonglong2(WH_EMPTY, WH_EMPTY);
+                    }
+#pragma unroll
+                    for (int j = 0; j < KJ; j++) {
                         hv[j] = mix128(kv[j].y, kv[j].x);
                         sl[j] = hash_slot(hv[j], cap_mask);
                     }
                     // first and second probe slot in the straight-line part: a key that sits one slot past its home
                     // must not go through the divergent insertion loop for every genome
-                    uint64_t cl[2][2], ch[2][2];
+                    ulonglong2 c0[KJ], c1[KJ];
 #pragma unroll
-                    for (int p = 0; p < 2; p++)
+                    for (int j = 0; j < KJ; j++) {
+                        c0[j] = tkey[sl[j]];
+                        c1[j] = tkey[(sl[j] + 1) & cap_mask];
+                    }
 #pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            const uint32_t at = (sl[j] + p) & cap_mask;
-                            cl[p][j] = tlo[at]; ch[p][j] = thi[at];
-                        }
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
+                    for (int j = 0; j < KJ; j++) {
                         const bool real = !(kv[j].x == WH_EMPTY && kv[j].y == WH_EMPTY);
                         if (!real) continue;
                         if (sb && hash_sub(hv[j], bb, sb) != sub) continue;
                         uint32_t slot = sl[j];
-                        bool done = false;
-#pragma unroll
-                        for (int p = 1; p >= 0; p--) {
-                            const bool hit = cl[p][j] == kv[j].x && ch[p][j] == kv[j].y;
-                            if (hit) slot = (sl[j] + p) & cap_mask;
-                            done |= hit;
-                        }
-                        if (!done) {
+                        const bool hit0 = c0[j].x == kv[j].x && c0[j].y == kv[j].y;
+                        const bool hit1 = c1[j].x == kv[j].x && c1[j].y == kv[j].y;
+                        if (hit1) slot = (sl[j] + 1) & cap_mask;
+                        if (!(hit0 | hit1)) {
                             bool ins;
-                            slot = wide_find_or_insert(tlo, thi, cap_mask, kv[j].y, kv[j].x, hv[j], &ins);
+                            slot = wide_find_or_insert(tkey, cap_mask, kv[j].y, kv[j].x, hv[j], &ins);
                             bool over = slot == 0xffffffffu;
                             if (!over && ins) {
                                 const uint32_t id = atomicAdd(&n_distinct, 1u);
@@ -391,7 +389,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
         __syncthreads();
         if (full) break;         // read between two barriers: uniform
         for (uint32_t slot = threadIdx.x; slot < cap; slot += blockDim.x) {
-            if (tlo[slot] == WH_EMPTY) continue;
+            if (tkey[slot].x == WH_EMPTY) continue;
             const unsigned long long wd = words[slot];
             const uint32_t m = meta[slot];
             if (matrix_s) matrix_s[(((uint64_t)wg * n_rows + r) << cap_log2) + (m & WMETA_ID)] = wd;
@@ -410,11 +408,11 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
     }
     const uint64_t out0 = (uint64_t)wg * cap;
     for (uint32_t slot = threadIdx.x; slot < cap; slot += blockDim.x) {
-        const uint64_t lo = tlo[slot];
-        if (lo == WH_EMPTY) continue;
+        const ulonglong2 key = tkey[slot];
+        if (key.x == WH_EMPTY) continue;
         const uint32_t m = meta[slot];
-        stage_lo[out0 + (m & WMETA_ID)] = lo;
-        stage_hi[out0 + (m & WMETA_ID)] = thi[slot];
+        stage_lo[out0 + (m & WMETA_ID)] = key.x;
+        stage_hi[out0 + (m & WMETA_ID)] = key.y;
         stage_flags[out0 + (m & WMETA_ID)] = (m & WMETA_MULTI) ? 2 : 1;
     }
     if (threadIdx.x == 0) stage_cnt[wg] = n_distinct;
