@@ -216,6 +216,19 @@ GRM_HD uint64_t pelem_combine(uint64_t a, uint64_t b)
     const uint32_t ch = pelem_ch(a) + ((ea ? ea : T_HDR) == T_SEQ ? b_after_seq : b_after_hdr);
     return pelem_make(eb ? eb : ea, cs, ch);
 }
+// the same element in 32 bits for a scan inside ONE 16 KiB tile (counts <= 16384 < 2^15): half the cross-lane moves
+GRM_HD uint32_t pelem32_make(int ev, uint32_t cs, uint32_t ch) { return ((uint32_t)ev << 30) | (cs << 15) | ch; }
+GRM_HD int pelem32_ev(uint32_t e) { return (int)(e >> 30); }
+GRM_HD uint32_t pelem32_cs(uint32_t e) { return (e >> 15) & 0x7fffu; }
+GRM_HD uint32_t pelem32_ch(uint32_t e) { return e & 0x7fffu; }
+GRM_HD uint32_t pelem32_combine(uint32_t a, uint32_t b)
+{
+    const int ea = pelem32_ev(a), eb = pelem32_ev(b);
+    const uint32_t b_after_seq = pelem32_cs(b), b_after_hdr = pelem32_ch(b);
+    const uint32_t cs = pelem32_cs(a) + ((ea ? ea : T_SEQ) == T_SEQ ? b_after_seq : b_after_hdr);
+    const uint32_t ch = pelem32_ch(a) + ((ea ? ea : T_HDR) == T_SEQ ? b_after_seq : b_after_hdr);
+    return pelem32_make(eb ? eb : ea, cs, ch);
+}
 
 // ---- FASTQ (4-line records: header, sequence, '+', quality) -------------------------------
 // A byte's role depends on its line index mod 4 ("phase").  Header lines (phase 0) emit one

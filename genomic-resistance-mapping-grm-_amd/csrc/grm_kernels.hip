@@ -36,12 +36,12 @@ namespace grm {
 struct TileChunks {
     uint32_t w[ROUNDS_PER_TILE][4];
     uint32_t ek[ROUNDS_PER_TILE], sep[ROUNDS_PER_TILE], unk[ROUNDS_PER_TILE];
-    uint64_t pre[ROUNDS_PER_TILE];     // exclusive prefix element of the chunk within the tile
-    uint64_t total;                    // element of the whole tile
+    uint32_t pre[ROUNDS_PER_TILE];     // exclusive prefix element (pelem32) of the chunk within the tile
+    uint32_t total;                    // element of the whole tile
 };
 
 template <int R>
-__device__ __forceinline__ void tile_round(const uint4 &v, uint32_t edge, int lane, TileChunks &tc, uint64_t &elem)
+__device__ __forceinline__ void tile_round(const uint4 &v, uint32_t edge, int lane, TileChunks &tc, uint32_t &elem)
 {
     tc.w[R][0] = v.x; tc.w[R][1] = v.y; tc.w[R][2] = v.z; tc.w[R][3] = v.w;
     uint32_t nl, gt, cr;
@@ -52,12 +52,13 @@ __device__ __forceinline__ void tile_round(const uint4 &v, uint32_t edge, int la
     uint32_t ek, sep, unk;
     chunk_classify(nl, gt, cr, ls, T_NONE, ek, sep, unk);
     tc.ek[R] = ek; tc.sep[R] = sep; tc.unk[R] = unk;
-    elem = pelem_make(chunk_last_event(ls, gt), __popc(ek) + __popc(unk), __popc(ek));
+    elem = pelem32_make(chunk_last_event(ls, gt), __popc(ek) + __popc(unk), __popc(ek));
 }
 
-__device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint32_t tile, uint64_t *partial /* LDS [16] */,
+__device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint32_t tile, uint64_t *partial64 /* LDS [16] */,
                                           TileChunks &tc)
 {
+    uint32_t *partial = reinterpret_cast<uint32_t *>(partial64);        // 32-bit elements: one cross-lane move per scan step
     const int lane = lane_id(), wave = wave_id();
     uint4 v[ROUNDS_PER_TILE];
     uint32_t edge[ROUNDS_PER_TILE];
@@ -67,7 +68,7 @@ __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint3
         v[r] = *reinterpret_cast<const uint4 *>(raw + base);
         edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;   // lanes > 0 ask their neighbour
     }
-    uint64_t inc[ROUNDS_PER_TILE];
+    uint32_t inc[ROUNDS_PER_TILE];
     tile_round<0>(v[0], edge[0], lane, tc, inc[0]);
     tile_round<1>(v[1], edge[1], lane, tc, inc[1]);
     tile_round<2>(v[2], edge[2], lane, tc, inc[2]);
@@ -76,8 +77,8 @@ __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint3
     for (int d = 1; d < 64; d <<= 1) {
 #pragma unroll
         for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-            const uint64_t o = __shfl_up(inc[r], d);
-            if (lane >= d) inc[r] = pelem_combine(o, inc[r]);
+            const uint32_t o = __shfl_up(inc[r], d);
+            if (lane >= d) inc[r] = pelem32_combine(o, inc[r]);
         }
     }
     if (lane == 63) {
@@ -87,23 +88,23 @@ __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint3
     __syncthreads();
     // prefix of this (round, wave) over the 16 wave partials, kept in scalars (no indexed array)
     static_assert(ROUNDS_PER_TILE == 4 && PARSE_THREADS == 256, "tile_scan assumes 4 rounds x 4 waves");
-    uint64_t acc = pelem_make(0, 0, 0);
-    uint64_t wp0 = acc, wp1 = acc, wp2 = acc, wp3 = acc;
+    uint32_t acc = pelem32_make(0, 0, 0);
+    uint32_t wp0 = acc, wp1 = acc, wp2 = acc, wp3 = acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         if (i == wave) wp0 = acc;
         if (i == 4 + wave) wp1 = acc;
         if (i == 8 + wave) wp2 = acc;
         if (i == 12 + wave) wp3 = acc;
-        acc = pelem_combine(acc, partial[i]);
+        acc = pelem32_combine(acc, partial[i]);
     }
     tc.total = acc;
-    uint64_t e0 = __shfl_up(inc[0], 1), e1 = __shfl_up(inc[1], 1), e2 = __shfl_up(inc[2], 1), e3 = __shfl_up(inc[3], 1);
-    if (lane == 0) e0 = e1 = e2 = e3 = pelem_make(0, 0, 0);
-    tc.pre[0] = pelem_combine(wp0, e0);
-    tc.pre[1] = pelem_combine(wp1, e1);
-    tc.pre[2] = pelem_combine(wp2, e2);
-    tc.pre[3] = pelem_combine(wp3, e3);
+    uint32_t e0 = __shfl_up(inc[0], 1), e1 = __shfl_up(inc[1], 1), e2 = __shfl_up(inc[2], 1), e3 = __shfl_up(inc[3], 1);
+    if (lane == 0) e0 = e1 = e2 = e3 = pelem32_make(0, 0, 0);
+    tc.pre[0] = pelem32_combine(wp0, e0);
+    tc.pre[1] = pelem32_combine(wp1, e1);
+    tc.pre[2] = pelem32_combine(wp2, e2);
+    tc.pre[3] = pelem32_combine(wp3, e3);
 }
 
 // FASTQ variant of the tile scan: the element carries the newline count mod 4 and the symbol
@@ -205,10 +206,10 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_summarize_kernel(
     } else {
         TileChunks tc;
         tile_scan(raw, tile, partial, tc);
-        s.v[0] = pelem_ch(tc.total);
-        s.v[1] = pelem_cs(tc.total) - pelem_ch(tc.total);
+        s.v[0] = pelem32_ch(tc.total);
+        s.v[1] = pelem32_cs(tc.total) - pelem32_ch(tc.total);
         s.v[2] = s.v[3] = 0;
-        s.tag = (uint32_t)pelem_ev(tc.total);
+        s.tag = (uint32_t)pelem32_ev(tc.total);
     }
     if (threadIdx.x == 0) sums[tile] = s;
 }
@@ -438,15 +439,15 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
         TileChunks tc;
         tile_scan(raw, tile, partial, tc);
         const int st = state == T_NONE ? T_SEQ : state;   // only before the first line start of a file
-        n_tile = st == T_SEQ ? pelem_cs(tc.total) : pelem_ch(tc.total);
+        n_tile = st == T_SEQ ? pelem32_cs(tc.total) : pelem32_ch(tc.total);
 #pragma unroll
         for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-            const int ev = pelem_ev(tc.pre[r]);
+            const int ev = pelem32_ev(tc.pre[r]);
             const int cin = ev ? ev : st;
             const uint32_t emit = tc.ek[r] | (cin == T_SEQ ? tc.unk[r] : 0u);
             uint32_t cs, ci;
             const int cnt = chunk_pack(tc.w[r], emit, tc.sep[r], cs, ci);
-            stream_insert(lead + (st == T_SEQ ? pelem_cs(tc.pre[r]) : pelem_ch(tc.pre[r])), cnt, cs, ci, or_sym, or_inv);
+            stream_insert(lead + (st == T_SEQ ? pelem32_cs(tc.pre[r]) : pelem32_ch(tc.pre[r])), cnt, cs, ci, or_sym, or_inv);
         }
     }
     __syncthreads();
