@@ -62,7 +62,7 @@ struct grm_ctx {
     int opt_dedup_cap_shift = -1; // > 0: wave-form dedup tables 2^shift times larger than the sizing rule asks for (measurements)
     int opt_dense_layout = -1;   // > 0: histogram-sized dense partition layout (tests, measurements)
     int opt_no_union = -1;       // > 0: gathered rank dictionaries are sorted as a whole (tests)
-    int opt_records = -1;        // 0: never use the record (minimizer) form of the partition (tests, measurements)
+    int opt_records = -1;        // 0: never use the record (minimizer) form of the partition; 1: also for 11 <= k < 19 (tests, measurements)
     int opt_rec_bucket_shift = -1; // record form: bucket bits on top of the key form's choice (default 1)
     int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
     int opt_rec_keys = -1;       // > 0: record form always expands to key segments in level 2 (tests, measurements)
@@ -1074,7 +1074,10 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     // Minimizer buckets are less even than hashed k-mers (a fine bucket holds ~30 minimizers of very different weight:
     // sigma ~25 % of the mean at 2^13 buckets), hence one more bucket bit than the key form and exact (not slack)
     // segment sizes inside a region.
-    if (k >= SK_M && abundance_min == 1 && !want_counts && c->opt_records != 0 && !b->rec_failed && c->opt_dense_layout <= 0) {
+    // (k < 19: a k-mer holds fewer than 9 m-mers and runs get short: measured at 300 x 5 Mbp, the record form takes 16.2 ms against
+    // 18.0 for the key form at k = 21, but 19.8 against 17.9 at k = 15 and 28.7 against 16.8 at k = 12 -- unless asked for)
+    if (k >= (c->opt_records > 0 ? SK_M : SK_M + 8) && abundance_min == 1 && !want_counts && c->opt_records != 0 && !b->rec_failed &&
+        c->opt_dense_layout <= 0) {
         int bbr = c->opt_bucket_bits >= 0 ? b->bb : b->bb + (c->opt_rec_bucket_shift >= 0 ? c->opt_rec_bucket_shift : 1);
         if (c->opt_bucket_bits < 0 && b->rec_bb_hint > bbr && b->rec_bb_hint_k == k) bbr = b->rec_bb_hint;
         bbr = std::min(bbr, superkmer_max_bits());

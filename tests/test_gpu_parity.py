@@ -142,7 +142,7 @@ def test_record_form_over_k(ctx, k):
     genomes = _medium_genomes(n=4, length=90_000, seed=21 + k)
     rng = np.random.RandomState(k)
     genomes.append([cases.fasta([("low", "ACGT" * 500 + "A" * 300 + cases.rand_seq(rng, 4000) + "N" * 40 + "CAG" * 400)], width=70)])
-    for opts in ({}, {"rec_keys": 1}):
+    for opts in ({"records": 1}, {"records": 1, "rec_keys": 1}):        # (records = 1: also below k = 19, where the key form is the default)
         try:
             for name, v in opts.items():
                 ctx.set_option(name, v)
