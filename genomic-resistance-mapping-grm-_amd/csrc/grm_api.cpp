@@ -1099,7 +1099,8 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         const uint64_t rstride64 = (uint64_t)(mean_r * 1.02 + 14.0 * std::sqrt(mean_r) + 32.0 + 15.0) / 16 * 16;     // mean + 7.5 sigma
         const uint64_t kstride = (uint64_t)(mean_k + 50.0 * std::sqrt(mean_k) + 256.0 + 15.0) / 16 * 16;
         // genomes of very different sizes would waste most of a layout sized for the largest one
-        bool rec = n_seg_r < 0xffffffffull && rstride64 < 0xffffffffull && kstride < 0xffffffffull &&
+        // (a segment's record count travels in 16 bits beside the count of its short records: only a forced, tiny bucket count gets near)
+        bool rec = n_seg_r < 0xffffffffull && rstride64 < 0xffffffffull && kstride < 0xffffffffull && mean_r / (double)(1u << (bbr - b1r)) < 16000.0 &&
                    (double)n_regions * (double)kstride <= 3.0 * (double)b->total_syms + 65536.0 * 1024.0;
         if (rec && b->d_recs.ensure((n_regions * rstride64 + 4) * 16) != hipSuccess) {
             (void)hipGetLastError();
