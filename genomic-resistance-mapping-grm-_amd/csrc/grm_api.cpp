@@ -1084,7 +1084,9 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         const int b1r = superkmer_coarse_bits(bbr);
         // one workgroup per genome part owns the part's regions: enough parts to fill the device when genomes are few
         int pbits = 0;
-        while (((uint64_t)G << pbits) < 512 && pbits < 6 && (max_g >> (pbits + 1)) >= 65536) pbits++;
+        // (one 1024-thread workgroup per CU and part: 128 genomes of 5 Mbp measured 7.6 / 7.5 / 8.3 / 10.2 ms per pass with 1 / 2 / 4 / 8
+        // parts per genome -- level 1 gains, level 2 and dict_build pay for the smaller segments)
+        while (((uint64_t)G << pbits) < 256 && pbits < 6 && (max_g >> (pbits + 1)) >= 65536) pbits++;
         if (c->opt_rec_part_bits >= 0) pbits = std::min(c->opt_rec_part_bits, 6);
         const uint64_t n_parts = (uint64_t)G << pbits;
         const uint64_t n_regions = n_parts << b1r, n_seg_r = n_parts << bbr;
