@@ -330,7 +330,10 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
             if (g + nw < G) seg_of(g + nw, s0_next, n_next);
             if (g < G && !full) {
                 const unsigned long long bit = 1ull << (63 - (g & 63));
-                constexpr int KJ = 2;                    // keys per lane in flight (segments hold ~300 keys: four leave the second round mostly empty)
+                // straight-line and predicated, as dict_build's probe (grm_kernels.hip): both probe slots of every key are
+                // read, a key found there ORs its bit in under a predicate; only a key that is in neither slot goes round
+                // the insertion loop (a bit mask of the lane's keys still to do, no per-key branches)
+                constexpr int KJ = 2;                    // keys per lane in flight (segments hold ~300 keys)
                 for (uint64_t i0 = lane; i0 < n && !full; i0 += 64 * KJ) {
                     ulonglong2 kv[KJ];
                     uint64_t hv[KJ];
@@ -345,41 +348,48 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                         hv[j] = mix128(kv[j].y, kv[j].x);
                         sl[j] = hash_slot(hv[j], cap_mask);
                     }
-                    // first and second probe slot in the straight-line part: a key that sits one slot past its home
-                    // must not go through the divergent insertion loop for every genome
                     ulonglong2 c0[KJ], c1[KJ];
 #pragma unroll
                     for (int j = 0; j < KJ; j++) {
                         c0[j] = tkey[sl[j]];
                         c1[j] = tkey[(sl[j] + 1) & cap_mask];
                     }
+                    uint32_t todo = 0;
 #pragma unroll
                     for (int j = 0; j < KJ; j++) {
-                        const bool real = !(kv[j].x == WH_EMPTY && kv[j].y == WH_EMPTY);
-                        if (!real) continue;
-                        if (sb && hash_sub(hv[j], bb, sb) != sub) continue;
-                        uint32_t slot = sl[j];
+                        const bool active = !(kv[j].x == WH_EMPTY && kv[j].y == WH_EMPTY) && (!sb || hash_sub(hv[j], bb, sb) == sub);
                         const bool hit0 = c0[j].x == kv[j].x && c0[j].y == kv[j].y;
                         const bool hit1 = c1[j].x == kv[j].x && c1[j].y == kv[j].y;
-                        if (hit1) slot = (sl[j] + 1) & cap_mask;
-                        if (!(hit0 | hit1)) {
-                            bool ins;
-                            slot = wide_find_or_insert(tkey, cap_mask, kv[j].y, kv[j].x, hv[j], &ins);
-                            bool over = slot == 0xffffffffu;
-                            if (!over && ins) {
+                        const uint32_t at = hit1 ? ((sl[j] + 1) & cap_mask) : sl[j];
+                        if (active && (hit0 | hit1)) __hip_atomic_fetch_or(&words[at], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        todo |= (uint32_t)(active && !(hit0 | hit1)) << j;
+                    }
+                    while (todo) {
+                        if (full) break;
+                        const int j = __ffs(todo) - 1;
+                        todo &= todo - 1;
+                        ulonglong2 key = kv[0];
+                        uint64_t h = hv[0];
+#pragma unroll
+                        for (int q = 1; q < KJ; q++) { if (j == q) { key = kv[q]; h = hv[q]; } }
+                        bool ins;
+                        const uint32_t slot = wide_find_or_insert(tkey, cap_mask, key.y, key.x, h, &ins);
+                        bool over = slot == 0xffffffffu;
+                        if (!over) {
+                            if (ins) {
                                 const uint32_t id = atomicAdd(&n_distinct, 1u);
                                 meta[slot] = (uint16_t)(id & WMETA_ID);
                                 if (birth && id < cap) birth[((uint64_t)wg << cap_log2) + id] = (uint16_t)r;
                                 over = id >= max_fill;
                             }
-                            if (over) {
-                                full = 1;
-                                const uint64_t est = (uint64_t)max_fill * G / (g + 1);
-                                atomicMax(need, (uint32_t)min(est, (uint64_t)0xffffffffu));
-                                if (slot == 0xffffffffu) continue;
-                            }
+                            __hip_atomic_fetch_or(&words[slot], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                        __hip_atomic_fetch_or(&words[slot], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (over) {
+                            full = 1;
+                            const uint64_t est = (uint64_t)max_fill * G / (g + 1);
+                            atomicMax(need, (uint32_t)min(est, (uint64_t)0xffffffffu));
+                            break;
+                        }
                     }
                 }
             }
