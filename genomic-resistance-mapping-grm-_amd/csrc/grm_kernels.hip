@@ -1094,9 +1094,10 @@ struct DictWave {
 // J keys per lane (EMPTY_KEY = none) against the table: the table is consulted four keys at a time (the 16-byte reads
 // of more keys than that at once cost more registers than the LDS latency they would hide).
 // several (FLAGS): bit j = key j is carried by several genomes inside its rank
-template <int J, bool FLAGS>
+// LIVE: the caller says which of the J keys exist (bit j of `live`) instead of marking the others with EMPTY_KEY
+template <int J, bool FLAGS, bool LIVE = false>
 __device__ __forceinline__ void dict_probe(const DictWave &w, const uint64_t (&kv)[J], uint32_t several, uint32_t g, uint32_t r,
-                                           unsigned long long bit)
+                                           unsigned long long bit, uint32_t live = 0)
 {
     uint32_t sl[J];
     uint32_t todo = 0;
@@ -1119,7 +1120,7 @@ __device__ __forceinline__ void dict_probe(const DictWave &w, const uint64_t (&k
 #pragma unroll
         for (int q = 0; q < GRP; q++) {
             const uint64_t key = kv[j0 + q];
-            const bool active = key != EMPTY_KEY && hs[q] == w.sub;
+            const bool active = (LIVE ? ((live >> (j0 + q)) & 1u) != 0 : key != EMPTY_KEY) && hs[q] == w.sub;
             uint32_t at = sl[j0 + q];
             const bool h0 = p0[q].x == key, h1 = p0[q].y == key, h2 = p1[q].x == key, h3 = p1[q].y == key;
             if (h1) at = sl[j0 + q] + 1;
@@ -1272,16 +1273,17 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                     uint64_t rc = revcomp_m(fwd, kk);
                     uint64_t rest = kk < 32 ? ((rec.x << (2 * kk)) | (rec.y >> up)) : rec.y;
                     uint64_t kv[4];
-                    kv[0] = len ? (fwd < rc ? fwd : rc) : EMPTY_KEY;
+                    kv[0] = fwd < rc ? fwd : rc;
 #pragma unroll
                     for (int t = 1; t < 4; t++) {
                         const uint64_t sy = rest >> 62;
                         rest <<= 2;
                         fwd = ((fwd << 2) | sy) & kmask;
                         rc = (rc >> 2) | ((sy ^ 2ull) << rcshift);
-                        kv[t] = (uint32_t)t < len ? (fwd < rc ? fwd : rc) : EMPTY_KEY;
+                        kv[t] = fwd < rc ? fwd : rc;          // (past the record's last k-mer: not live)
                     }
-                    dict_probe<4, false>(w, kv, 0u, r * 64u + 63u - sh, r, bit);      // (the lane's genome: sizes the retry on overflow)
+                    // (g argument: the lane's genome, sizes the retry on overflow)
+                    dict_probe<4, false, true>(w, kv, 0u, r * 64u + 63u - sh, r, bit, (1u << len) - 1u);
                 }
                 // ---- the long ones: eight ----
                 fetch(NA + (uint32_t)lane, N, 8, rec_n, sh_n);
@@ -1295,16 +1297,16 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                     uint64_t rc = revcomp_m(fwd, kk);
                     uint64_t rest = kk < 32 ? ((rec.x << (2 * kk)) | (rec.y >> up)) : rec.y;
                     uint64_t kv[8];
-                    kv[0] = len ? (fwd < rc ? fwd : rc) : EMPTY_KEY;
+                    kv[0] = fwd < rc ? fwd : rc;
 #pragma unroll
                     for (int t = 1; t < 8; t++) {
                         const uint64_t sy = rest >> 62;
                         rest <<= 2;
                         fwd = ((fwd << 2) | sy) & kmask;
                         rc = (rc >> 2) | ((sy ^ 2ull) << rcshift);
-                        kv[t] = (uint32_t)t < len ? (fwd < rc ? fwd : rc) : EMPTY_KEY;
+                        kv[t] = fwd < rc ? fwd : rc;
                     }
-                    dict_probe<8, false>(w, kv, 0u, r * 64u + 63u - sh, r, bit);
+                    dict_probe<8, false, true>(w, kv, 0u, r * 64u + 63u - sh, r, bit, (1u << len) - 1u);
                 }
             }
         } else {
