@@ -1151,10 +1151,7 @@ __device__ __forceinline__ void dict_probe(const DictWave &w, const uint64_t (&k
             atomicOr(&w.words[slot], (FLAGS && ((several >> j) & 1u)) ? (bit | 1ull) : bit);
         }
         if (over) {
-            *w.full = 1;
-            // what this workgroup would have needed: the fill it reached, scaled to all genomes
-            const uint64_t est = (uint64_t)w.max_fill * w.G / (g + 1);
-            atomicMax(w.need, (uint32_t)min(est, (uint64_t)0xffffffffu));
+            *w.full = 1;         // (what the workgroup would have needed is counted after the word-row loop: dict_build_kernel)
             break;
         }
     }
@@ -1358,7 +1355,65 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     }
     __syncthreads();
     if (full) {
-        if (threadIdx.x == 0) { atomicMax(a.overflow, 1); a.wg_cnt[wg] = 0; a.wg_base[wg] = 0; }
+        // The table overflowed.  What would this (bucket, sub-bucket) have needed?  Extrapolating the fill over the genomes
+        // is exact for unrelated genomes and 10-50x too much for a pan-genome, whose distinct k-mers saturate -- and every
+        // doubling of that estimate doubles the sub-bucket workgroups that re-read (record form: re-decode) the bucket.  So
+        // the workgroup COUNTS: all its keys once more into a HyperLogLog sketch (up to 4096 registers in the table's LDS,
+        // ~2 % error), and the host sizes the retry from the fullest workgroup's count.
+        const uint32_t HLL_M = cap < 4096u ? cap : 4096u;          // (a power of two >= 64; 4 of the table's 18 bytes per slot)
+        uint32_t *hll = reinterpret_cast<uint32_t *>(lds_raw);
+        uint64_t *scr64 = reinterpret_cast<uint64_t *>(lds_raw + (size_t)HLL_M * 4);
+        for (uint32_t i = threadIdx.x; i < HLL_M; i += blockDim.x) hll[i] = 0;
+        __syncthreads();
+        auto sketch = [&](uint64_t key) {
+            const uint64_t h = mix64(key);
+            if (sb && hash_sub(h, a.bb, sb) != w.sub) return;
+            const uint32_t lo = (uint32_t)h;
+            atomicMax(&hll[lo & (HLL_M - 1)], (uint32_t)__clz((lo >> 12) | 1u) - 11u);      // rank of the upper 20 bits: 1 .. 21
+        };
+        for (uint32_t vg = (uint32_t)wave; vg < GV; vg += (uint32_t)nw) {
+            uint64_t sv = 0, nv = 0;
+            seg_bounds(a.seg, (uint64_t)vg * B + b, sv, nv);
+            if (REC) {
+                nv &= 0xffffu;
+                for (uint64_t q0 = 0; q0 < nv; q0 += 64) {
+                    const ulonglong2 rec = q0 + lane < nv ? a.recs[sv + q0 + lane] : make_ulonglong2(0, 0);
+                    const uint32_t len = (uint32_t)(rec.y & 0xffu);
+                    uint64_t fwd = rec.x >> up;
+                    uint64_t rc = revcomp_m(fwd, kk);
+                    uint64_t rest = kk < 32 ? ((rec.x << (2 * kk)) | (rec.y >> up)) : rec.y;
+                    for (uint32_t t = 0; t < len; t++) {
+                        sketch(fwd < rc ? fwd : rc);
+                        const uint64_t sy = rest >> 62;
+                        rest <<= 2;
+                        fwd = ((fwd << 2) | sy) & kmask;
+                        rc = (rc >> 2) | ((sy ^ 2ull) << rcshift);
+                    }
+                }
+            } else {
+                for (uint64_t i = lane; i < nv; i += 64) sketch(a.keys[sv + i]);
+            }
+        }
+        __syncthreads();
+        // sum of 2^-register (in units of 2^-32) and the number of empty registers
+        uint64_t part = 0, zeros = 0;
+        for (uint32_t i = threadIdx.x; i < HLL_M; i += blockDim.x) {
+            const uint32_t m = hll[i];
+            part += 1ull << (32 - m);
+            zeros += m == 0;
+        }
+        uint64_t sum = 0, nz = 0;
+        (void)block_scan_sum64(part, scr64, &sum);
+        (void)block_scan_sum64(zeros, scr64, &nz);
+        if (threadIdx.x == 0) {
+            const double m = (double)HLL_M;
+            double est = 0.7213 / (1.0 + 1.079 / m) * m * m / ((double)sum / 4294967296.0);
+            if (est <= 2.5 * m && nz) est = m * log(m / (double)nz);             // small range: linear counting
+            atomicMax(a.need, (uint32_t)min(est * 1.05, 4.0e9));
+            atomicMax(a.overflow, 1);
+            a.wg_cnt[wg] = 0;
+            a.wg_base[wg] = 0;
+        }
         return;
     }
     if (threadIdx.x == 0) {
