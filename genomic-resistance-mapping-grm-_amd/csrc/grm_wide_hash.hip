@@ -385,9 +385,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                             __hip_atomic_fetch_or(&words[slot], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         if (over) {
-                            full = 1;
-                            const uint64_t est = (uint64_t)max_fill * G / (g + 1);
-                            atomicMax(need, (uint32_t)min(est, (uint64_t)0xffffffffu));
+                            full = 1;            // (what it would have needed is counted after the word-row loop)
                             break;
                         }
                     }
@@ -413,7 +411,42 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
     }
     __syncthreads();
     if (full) {
-        if (threadIdx.x == 0) { atomicExch(overflow, 1); stage_cnt[wg] = 0; }
+        // what the workgroup would have needed: all its keys once more through a HyperLogLog sketch in the abandoned table's
+        // LDS (see dict_build_kernel, grm_kernels.hip)
+        const uint32_t HLL_M = cap < 4096u ? cap : 4096u;
+        uint32_t *hll = reinterpret_cast<uint32_t *>(lds_raw);
+        uint64_t *scr64 = reinterpret_cast<uint64_t *>(lds_raw + (size_t)HLL_M * 4);
+        for (uint32_t i = threadIdx.x; i < HLL_M; i += blockDim.x) hll[i] = 0;
+        __syncthreads();
+        for (uint32_t gg = (uint32_t)wave; gg < G; gg += (uint32_t)nw) {
+            uint64_t sv = 0, nv = 0;
+            seg_of(gg, sv, nv);
+            for (uint64_t i = lane; i < nv; i += 64) {
+                const ulonglong2 key = keys[sv + i];
+                const uint64_t h = mix128(key.y, key.x);
+                if (sb && hash_sub(h, bb, sb) != sub) continue;
+                const uint32_t lo = (uint32_t)h;
+                atomicMax(&hll[lo & (HLL_M - 1)], (uint32_t)__clz((lo >> 12) | 1u) - 11u);
+            }
+        }
+        __syncthreads();
+        uint64_t part = 0, zeros = 0;
+        for (uint32_t i = threadIdx.x; i < HLL_M; i += blockDim.x) {
+            const uint32_t m = hll[i];
+            part += 1ull << (32 - m);
+            zeros += m == 0;
+        }
+        uint64_t sum = 0, nz = 0;
+        (void)block_scan_sum64(part, scr64, &sum);
+        (void)block_scan_sum64(zeros, scr64, &nz);
+        if (threadIdx.x == 0) {
+            const double m = (double)HLL_M;
+            double est = 0.7213 / (1.0 + 1.079 / m) * m * m / ((double)sum / 4294967296.0);
+            if (est <= 2.5 * m && nz) est = m * log(m / (double)nz);
+            atomicMax(need, (uint32_t)min(est * 1.05, 4.0e9));
+            atomicExch(overflow, 1);
+            stage_cnt[wg] = 0;
+        }
         return;
     }
     const uint64_t out0 = (uint64_t)wg * cap;
