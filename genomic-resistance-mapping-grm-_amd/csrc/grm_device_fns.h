@@ -146,6 +146,108 @@ GRM_HD uint32_t minimizer_bucket_of_kmer(uint64_t key, int k, int bb, int m_len 
     return minimizer_bucket(hmin, bb);
 }
 
+// ---- run records (record form of the partition): per-lane logic of grm_superkmer.hip and of dict_build's decoder ----
+constexpr int RUN_PPT = 32;          // k-mer start positions a thread takes per step: one packed word
+constexpr int RUN_LMAX = 8;          // k-mers per record
+constexpr int RUN_FINE_BITS = 7;     // bucket bits a record carries below the coarse ones
+
+// Buckets (nbits bits) of the 32 k-mers starting at the symbols of w0 (w1 = the next packed word), k = W + M - 1:
+// hashes of the 32 + W - 1 canonical M-mers (rolling forward / reverse-complement words), minimum over windows of W by
+// doubling (h[i] = min over [i, i + span)), then two overlapping spans.  Fully unrolled: everything stays in registers.
+template <int W, int M = 11>
+GRM_HD void run_buckets(uint64_t w0, uint64_t w1, int nbits, uint32_t (&bk)[RUN_PPT])
+{
+    constexpr int NM = RUN_PPT + W - 1;
+    uint32_t h[NM];
+    constexpr uint32_t mmask = (1u << (2 * M)) - 1;
+    uint32_t f = (uint32_t)(w0 >> (64 - 2 * (M - 1)));
+    uint32_t r = (uint32_t)(revcomp_m(f, M - 1) << 2);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < NM; q++) {
+        const int si = q + M - 1;               // index of the symbol that completes m-mer q (static)
+        const uint32_t s = si < 32 ? (uint32_t)(w0 >> (62 - 2 * si)) & 3u : (uint32_t)(w1 >> (62 - 2 * (si - 32))) & 3u;
+        f = ((f << 2) | s) & mmask;
+        r = (r >> 2) | ((s ^ 2u) << (2 * (M - 1)));
+        h[q] = minimizer_hash(f < r ? f : r);
+    }
+    constexpr int LV = W >= 16 ? 4 : W >= 8 ? 3 : W >= 4 ? 2 : W >= 2 ? 1 : 0;
+    constexpr int SPAN = 1 << LV;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int l = 0; l < LV; l++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < NM; i++)
+            if (i + (2 << l) <= NM) h[i] = h[i] < h[i + (1 << l)] ? h[i] : h[i + (1 << l)];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < RUN_PPT; i++) {
+        const uint32_t a = h[i], b = h[i + W - SPAN];
+        bk[i] = minimizer_bucket(a < b ? a : b, nbits);
+    }
+}
+// first positions of the runs of a word: a valid start whose predecessor is invalid, in another bucket, or RUN_LMAX or
+// more positions behind the last head (a record holds at most RUN_LMAX k-mers)
+GRM_HD uint32_t run_heads(uint32_t valid, const uint32_t (&bk)[RUN_PPT])
+{
+    uint32_t heads = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < RUN_PPT; i++) {
+        const bool vi = (valid >> i) & 1u;
+        const bool hd = vi && (i == 0 || !((valid >> (i > 0 ? i - 1 : 0)) & 1u) || bk[i] != bk[i > 0 ? i - 1 : 0]);
+        heads |= (uint32_t)hd << i;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = RUN_LMAX; i < RUN_PPT; i++) {
+        if (((valid >> i) & 1u) && ((heads >> (i + 1 - RUN_LMAX)) & ((1u << RUN_LMAX) - 1u)) == 0) heads |= 1u << i;
+    }
+    return heads;
+}
+// k-mers of the run that starts at position i: up to the next head, the next invalid start, or the end of the word
+GRM_HD uint32_t run_length(uint32_t heads, uint32_t valid, int i)
+{
+    const uint64_t bnd = (uint64_t)(heads | ~valid) | (1ull << RUN_PPT);
+    const uint64_t rest = bnd >> (i + 1);
+    return (uint32_t)__builtin_ctzll(rest) + 1u;
+}
+// the 16-byte record of a run: x = bases 0..31 from position i, y = the following bases | 7 fine bucket bits | length
+GRM_HD void run_record(uint64_t w0, uint64_t w1, int i, uint32_t len, uint32_t bucket, uint64_t &x, uint64_t &y)
+{
+    x = i ? ((w0 << (2 * i)) | (w1 >> (64 - 2 * i))) : w0;
+    y = ((w1 << (2 * i)) & ~0xffffull) | ((uint64_t)(bucket & ((1u << RUN_FINE_BITS) - 1u)) << 8) | len;
+}
+// decoder state of a record: forward / reverse-complement words of the current k-mer, and the bases after it, MSB-aligned
+struct RunDecoder {
+    uint64_t fwd, rc, rest;
+};
+GRM_HD RunDecoder run_open(uint64_t x, uint64_t y, int k)
+{
+    RunDecoder d;
+    const int up = 64 - 2 * k;
+    d.fwd = x >> up;
+    d.rc = revcomp_m(d.fwd, k);
+    d.rest = k < 32 ? ((x << (2 * k)) | (y >> up)) : y;
+    return d;
+}
+GRM_HD uint64_t run_canonical(const RunDecoder &d) { return d.fwd < d.rc ? d.fwd : d.rc; }
+GRM_HD void run_next(RunDecoder &d, uint64_t kmask, int rcshift)
+{
+    const uint64_t sy = d.rest >> 62;
+    d.rest <<= 2;
+    d.fwd = ((d.fwd << 2) | sy) & kmask;
+    d.rc = (d.rc >> 2) | ((sy ^ 2ull) << rcshift);
+}
+
 // ---- FASTA byte classification -------------------------------------------------------
 // 4-bit mask of the bytes of x that equal c (SWAR exact zero-byte test, then bit gather)
 GRM_HD uint32_t byte_eq_mask4(uint32_t x, uint32_t c)

@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     }
     // record form: decoding constants, and a wave-private table of the 16 sub-segments (8 genomes x 2 length classes) a wave pools
     const int kk = REC ? a.k : 1;
-    const int up = 64 - 2 * kk, rcshift = 2 * (kk - 1);
+    const int rcshift = 2 * (kk - 1);
     const uint64_t kmask = kk == 32 ? ~0ull : ((1ull << (2 * kk)) - 1);
     uint64_t *tabD = reinterpret_cast<uint64_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES) + 16 * wave;
     uint32_t *tabS = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)nw * 128) + 16 * wave;
@@ -1266,18 +1266,13 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                     fetch(q0 + 64u + (uint32_t)lane, NA, 0, rec_n, sh_n);
                     const unsigned long long bit = 1ull << sh;
                     const uint32_t len = (uint32_t)(rec.y & 0xffu);
-                    uint64_t fwd = rec.x >> up;
-                    uint64_t rc = revcomp_m(fwd, kk);
-                    uint64_t rest = kk < 32 ? ((rec.x << (2 * kk)) | (rec.y >> up)) : rec.y;
+                    RunDecoder dec = run_open(rec.x, rec.y, kk);
                     uint64_t kv[4];
-                    kv[0] = fwd < rc ? fwd : rc;
+                    kv[0] = run_canonical(dec);
 #pragma unroll
                     for (int t = 1; t < 4; t++) {
-                        const uint64_t sy = rest >> 62;
-                        rest <<= 2;
-                        fwd = ((fwd << 2) | sy) & kmask;
-                        rc = (rc >> 2) | ((sy ^ 2ull) << rcshift);
-                        kv[t] = fwd < rc ? fwd : rc;          // (past the record's last k-mer: not live)
+                        run_next(dec, kmask, rcshift);
+                        kv[t] = run_canonical(dec);          // (past the record's last k-mer: not live)
                     }
                     // (g argument: the lane's genome, sizes the retry on overflow)
                     dict_probe<4, false, true>(w, kv, 0u, r * 64u + 63u - sh, r, bit, (1u << len) - 1u);
@@ -1290,18 +1285,13 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                     fetch(q0 + 64u + (uint32_t)lane, N, 8, rec_n, sh_n);
                     const unsigned long long bit = 1ull << sh;
                     const uint32_t len = (uint32_t)(rec.y & 0xffu);
-                    uint64_t fwd = rec.x >> up;
-                    uint64_t rc = revcomp_m(fwd, kk);
-                    uint64_t rest = kk < 32 ? ((rec.x << (2 * kk)) | (rec.y >> up)) : rec.y;
+                    RunDecoder dec = run_open(rec.x, rec.y, kk);
                     uint64_t kv[8];
-                    kv[0] = fwd < rc ? fwd : rc;
+                    kv[0] = run_canonical(dec);
 #pragma unroll
                     for (int t = 1; t < 8; t++) {
-                        const uint64_t sy = rest >> 62;
-                        rest <<= 2;
-                        fwd = ((fwd << 2) | sy) & kmask;
-                        rc = (rc >> 2) | ((sy ^ 2ull) << rcshift);
-                        kv[t] = fwd < rc ? fwd : rc;
+                        run_next(dec, kmask, rcshift);
+                        kv[t] = run_canonical(dec);
                     }
                     dict_probe<8, false, true>(w, kv, 0u, r * 64u + 63u - sh, r, bit, (1u << len) - 1u);
                 }
@@ -1379,15 +1369,10 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                 for (uint64_t q0 = 0; q0 < nv; q0 += 64) {
                     const ulonglong2 rec = q0 + lane < nv ? a.recs[sv + q0 + lane] : make_ulonglong2(0, 0);
                     const uint32_t len = (uint32_t)(rec.y & 0xffu);
-                    uint64_t fwd = rec.x >> up;
-                    uint64_t rc = revcomp_m(fwd, kk);
-                    uint64_t rest = kk < 32 ? ((rec.x << (2 * kk)) | (rec.y >> up)) : rec.y;
+                    RunDecoder dec = run_open(rec.x, rec.y, kk);
                     for (uint32_t t = 0; t < len; t++) {
-                        sketch(fwd < rc ? fwd : rc);
-                        const uint64_t sy = rest >> 62;
-                        rest <<= 2;
-                        fwd = ((fwd << 2) | sy) & kmask;
-                        rc = (rc >> 2) | ((sy ^ 2ull) << rcshift);
+                        sketch(run_canonical(dec));
+                        run_next(dec, kmask, rcshift);
                     }
                 }
             } else {

@@ -24,9 +24,10 @@
 namespace grm {
 
 constexpr int SK_THREADS = 1024;
-constexpr int SK_PPT = 32;                            // k-mer start positions per thread and step: one packed word
-constexpr int SK_LMAX = 8;                            // k-mers per record: what one lane of dict_build (record form) decodes at a time
-constexpr int SK_FINE_BITS = 7;                       // a record carries 7 bucket bits below the coarse ones, whatever the bucket count in use:
+constexpr int SK_PPT = RUN_PPT;                       // k-mer start positions per thread and step: one packed word
+constexpr int SK_LMAX = RUN_LMAX;                     // k-mers per record: what one lane of dict_build (record form) decodes at a time
+static_assert(SK_M == 11, "run_buckets<W> is instantiated with its default m-mer length");
+constexpr int SK_FINE_BITS = RUN_FINE_BITS;           // a record carries 7 bucket bits below the coarse ones, whatever the bucket count in use:
                                                       // level 2 takes the top bb - b1 of them, so more buckets only need level 2 again
 constexpr int SK_MAX_BITS = 9 + SK_FINE_BITS;         // at most 9 coarse bits (SK_THREADS cursors) + the fine field
 constexpr int SK2_THREADS = 256;
@@ -60,7 +61,6 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     __shared__ uint32_t s_bk[SK_THREADS * (SK_PPT / 2)];     // 16-bit bucket of every position of the step
     __shared__ uint32_t cursor[SK_THREADS];                  // records written so far to coarse region c (2^b1 <= SK_THREADS)
     __shared__ uint32_t scratch[32];
-    constexpr int NM = SK_PPT + W - 1;                 // m-mer positions a thread looks at
     const int b1 = a.b1;
     const uint32_t B1 = 1u << b1;
     const uint32_t vg = blockIdx.x;
@@ -93,62 +93,26 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
         n_valid += (uint32_t)__popc(valid);
         uint32_t heads = 0;
         if (valid) {
-            // hashes of the canonical m-mers at positions 0 .. NM-1 (rolling forward / reverse-complement words)
-            uint32_t h[NM];
-            constexpr uint32_t mmask = (1u << (2 * SK_M)) - 1;
-            uint32_t f = (uint32_t)(w0 >> (64 - 2 * (SK_M - 1)));
-            uint32_t r = (uint32_t)(revcomp_m(f, SK_M - 1) << 2);
-#pragma unroll
-            for (int q = 0; q < NM; q++) {
-                const int si = q + SK_M - 1;               // index of the symbol that completes m-mer q (static)
-                const uint32_t s = si < 32 ? (uint32_t)(w0 >> (62 - 2 * si)) & 3u : (uint32_t)(w1 >> (62 - 2 * (si - 32))) & 3u;
-                f = ((f << 2) | s) & mmask;
-                r = (r >> 2) | ((s ^ 2u) << (2 * (SK_M - 1)));
-                h[q] = minimizer_hash(f < r ? f : r);
-            }
-            // minimum over windows of W: doubling (h[i] = min over [i, i + span)), then two overlapping spans
-            constexpr int LV = W >= 16 ? 4 : W >= 8 ? 3 : W >= 4 ? 2 : W >= 2 ? 1 : 0;
-            constexpr int SPAN = 1 << LV;
-#pragma unroll
-            for (int l = 0; l < LV; l++) {
-#pragma unroll
-                for (int i = 0; i < NM; i++)
-                    if (i + (2 << l) <= NM) h[i] = min(h[i], h[i + (1 << l)]);
-            }
             uint32_t bk[SK_PPT];
-#pragma unroll
-            for (int i = 0; i < SK_PPT; i++) bk[i] = minimizer_bucket(min(h[i], h[i + W - SPAN]), b1 + SK_FINE_BITS);
-#pragma unroll
-            for (int i = 0; i < SK_PPT; i++) {
-                const bool vi = (valid >> i) & 1u;
-                const bool hd = vi && (i == 0 || !((valid >> (i > 0 ? i - 1 : 0)) & 1u) || bk[i] != bk[i > 0 ? i - 1 : 0]);
-                heads |= (uint32_t)hd << i;
-            }
-            // a record holds at most SK_LMAX k-mers: a start with no head among the SK_LMAX positions up to it opens one
-#pragma unroll
-            for (int i = SK_LMAX; i < SK_PPT; i++) {
-                if (((valid >> i) & 1u) && ((heads >> (i + 1 - SK_LMAX)) & ((1u << SK_LMAX) - 1u)) == 0) heads |= 1u << i;
-            }
+            run_buckets<W>(w0, w1, b1 + SK_FINE_BITS, bk);
+            heads = run_heads(valid, bk);
             // the bucket of a run's first position is the only per-position value the emission needs, and it is
             // indexed by a run-time position: through LDS (each thread reads back its own 64 bytes)
 #pragma unroll
             for (int i = 0; i < SK_PPT; i += 2) s_bk[threadIdx.x * (SK_PPT / 2) + i / 2] = bk[i] | (bk[i + 1] << 16);
         }
-        // ends of runs: the next head, the next invalid start, or the end of the word
-        const uint64_t bnd = (uint64_t)(heads | ~valid) | (1ull << SK_PPT);
         // The runs of a lane leave one per round (a lane has ~6, at most 32): the slot in the coarse region comes from the
         // workgroup's LDS cursor of that region, the record goes straight to its place.  A region's lines fill up in
-        // cursor order, 8 records each, and a workgroup keeps 256 of them open: they complete in L2.
+        // cursor order, 8 records each, and a workgroup keeps 512 of them open: they complete in L2 (mostly).
         uint32_t hd = heads;
         while (hd) {
             const int i = __ffs(hd) - 1;
             hd &= hd - 1;
-            const uint32_t len = (uint32_t)__ffsll((unsigned long long)(bnd >> (i + 1)));
             const uint32_t bkt = my_bk[i];
             const uint32_t c = bkt >> SK_FINE_BITS;
-            ulonglong2 rec;
-            rec.x = i ? ((w0 << (2 * i)) | (w1 >> (64 - 2 * i))) : w0;
-            rec.y = ((w1 << (2 * i)) & ~0xffffull) | ((uint64_t)(bkt & ((1u << SK_FINE_BITS) - 1u)) << 8) | len;
+            uint64_t rx, ry;
+            run_record(w0, w1, i, run_length(heads, valid, i), bkt, rx, ry);
+            const ulonglong2 rec = make_ulonglong2(rx, ry);
             const uint32_t slot = atomicAdd(&cursor[c], 1u);
             if (slot < rstride) recs1[((uint64_t)vg * B1 + c) * rstride + slot] = rec;
             else over = true;
@@ -188,7 +152,6 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
     __shared__ uint32_t scratch[32];
     const int b2 = bb - b1;
     const uint32_t B2 = 1u << b2;
-    const int up = 64 - 2 * k;
     const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     const int rcshift = 2 * (k - 1);
     const int lane = lane_id(), wave = wave_id();
@@ -253,17 +216,11 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
                 const uint32_t l2 = (uint32_t)(r2.y & 0xffu);
                 if (l2) {
                     uint32_t at = start[rec_fine(r2.y, b2)] + ((uint32_t)(r2.y >> 16) & 0x3ffffu);
-                    uint64_t fwd = r2.x >> up;
-                    uint64_t rc = revcomp_m(fwd, k);
-                    // the bases after the first k-mer, MSB-aligned (at most 15 are used)
-                    uint64_t rest = k < 32 ? ((r2.x << (2 * k)) | (r2.y >> up)) : r2.y;
+                    RunDecoder dec = run_open(r2.x, r2.y, k);
                     for (uint32_t t = 0;; t++) {
-                        skeys[at++] = fwd < rc ? fwd : rc;
+                        skeys[at++] = run_canonical(dec);
                         if (t + 1 >= l2) break;
-                        const uint64_t s = rest >> 62;
-                        rest <<= 2;
-                        fwd = ((fwd << 2) | s) & mask;
-                        rc = (rc >> 2) | ((s ^ 2ull) << rcshift);
+                        run_next(dec, mask, rcshift);
                     }
                 }
             }

@@ -11,6 +11,9 @@
 
 using namespace grm;
 
+template <int W>
+static void emul_buckets(uint64_t w0, uint64_t w1, int nbits, uint32_t (&bk)[RUN_PPT]) { run_buckets<W>(w0, w1, nbits, bk); }
+
 extern "C" {
 
 // raw: tile-aligned image (multiple of 16 bytes), raw[-1] must be '\n' conceptually: the
@@ -262,4 +265,58 @@ uint32_t emul_bucket(uint64_t h, int bb) { return hash_bucket(h, bb); }
 uint32_t emul_sub(uint64_t h, int bb, int sb) { return hash_sub(h, bb, sb); }
 uint64_t emul_valid_starts(uint64_t i0, uint64_t i1, int k) { return valid_starts(i0, i1, k); }
 uint64_t emul_revcomp(uint64_t v, int m) { return revcomp_m(v, m); }
+
+// Record form of the partition (grm_superkmer.hip) with the kernels' own per-lane functions: every packed word -> buckets of
+// its 32 k-mer starts (run_buckets<W>), runs (run_heads / run_length), 16-byte records (run_record); every record is then
+// decoded the way dict_build does (run_open / run_next).  out_keys / out_bucket: one entry per decoded k-mer, in stream order
+// (bucket = the record's coarse bits | fine field at nbits = coarse_bits + RUN_FINE_BITS); out_len: one entry per record.
+uint64_t emul_runs(const uint64_t *sym2, const uint64_t *inv, uint64_t total_syms, int k, int coarse_bits, uint64_t *out_keys,
+                   uint32_t *out_bucket, uint64_t cap, uint32_t *out_len, uint64_t len_cap, uint64_t *n_records)
+{
+    uint64_t n = 0, nr = 0;
+    const int nbits = coarse_bits + RUN_FINE_BITS;
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const int rcshift = 2 * (k - 1);
+    const uint64_t n_words = (total_syms + 31) / 32;
+    for (uint64_t wi = 0; wi < n_words; wi++) {
+        const uint64_t p0 = wi << 5, grp = p0 >> 6;
+        const int64_t nv = (int64_t)total_syms - k + 1 - (int64_t)p0;
+        if (nv <= 0) break;
+        const uint64_t w0 = sym2[wi], w1 = sym2[wi + 1];
+        uint32_t valid = (uint32_t)valid_starts_at(inv[grp], inv[grp + 1], (int)(p0 & 63), k);
+        if (nv < RUN_PPT) valid &= (1u << nv) - 1;
+        if (!valid) continue;
+        uint32_t bk[RUN_PPT];
+        switch (k - 11 + 1) {
+#define CASE(W) case W: emul_buckets<W>(w0, w1, nbits, bk); break;
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+            CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22)
+#undef CASE
+            default: return ~0ull;
+        }
+        const uint32_t heads = run_heads(valid, bk);
+        for (int i = 0; i < RUN_PPT; i++) {
+            if (!((heads >> i) & 1u)) continue;
+            const uint32_t len = run_length(heads, valid, i);
+            uint64_t x, y;
+            run_record(w0, w1, i, len, bk[i], x, y);
+            if (nr < len_cap) out_len[nr] = (uint32_t)(y & 0xff);
+            nr++;
+            // every position of the run must be a valid start of the same bucket
+            for (uint32_t t = 0; t < len; t++)
+                if (!((valid >> (i + t)) & 1u) || bk[i + t] != bk[i]) return ~0ull - 1;
+            RunDecoder d = run_open(x, y, k);
+            const uint32_t bucket = ((bk[i] >> RUN_FINE_BITS) << RUN_FINE_BITS) | ((uint32_t)(y >> 8) & ((1u << RUN_FINE_BITS) - 1u));
+            for (uint32_t t = 0; t < (uint32_t)(y & 0xff); t++) {
+                if (n < cap) { out_keys[n] = run_canonical(d); out_bucket[n] = bucket; }
+                n++;
+                run_next(d, kmask, rcshift);
+            }
+        }
+    }
+    *n_records = nr;
+    return n;
+}
+
+uint32_t emul_minimizer_bucket_of_kmer(uint64_t key, int k, int nbits) { return minimizer_bucket_of_kmer(key, k, nbits); }
 }

@@ -44,6 +44,11 @@ def emul():
     L.emul_revcomp.argtypes = [C.c_uint64, C.c_int]
     L.emul_mix64.restype = C.c_uint64
     L.emul_mix64.argtypes = [C.c_uint64]
+    L.emul_runs.restype = C.c_uint64
+    L.emul_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                            C.POINTER(C.c_uint64)]
+    L.emul_minimizer_bucket_of_kmer.restype = C.c_uint32
+    L.emul_minimizer_bucket_of_kmer.argtypes = [C.c_uint64, C.c_int, C.c_int]
     return L
 
 
@@ -224,3 +229,39 @@ def test_wide_kmers_match_oracle(emul, k):
     got = got[order]
     uniq, counts = np.unique(got, axis=0, return_counts=True)
     assert uniq.shape == km.shape and (uniq == km).all() and (counts == ct).all()
+
+
+@pytest.mark.parametrize("k", [11, 12, 15, 21, 27, 31, 32])
+def test_run_records_decode_to_the_oracles_kmers(emul, k):
+    """record form of the partition, on the CPU with the kernels' own per-lane functions: the runs of equal minimizer bucket
+    of every packed word, as 16-byte records, decode to exactly the canonical k-mers the oracle counts; every k-mer of a
+    record has the record's bucket when that is re-derived from the k-mer alone (what the probing fill and the ranks rely
+    on); a record holds 1..8 k-mers"""
+    rng = np.random.RandomState(100 + k)
+    files = [cases.fasta([("a", cases.rand_seq(rng, 20_000)), ("b", "ACGT" * 300 + "A" * 200 + cases.rand_seq(rng, 3000) + "N" * 7 + "GATTACA" * 90)], width=70).encode(),
+             (">c\n" + cases.rand_seq(rng, 5000).lower() + "\n").encode()]
+    raw, nsym, direct = extract(emul, files, k)
+    ng = len(raw) // 64 + 8
+    sym2 = np.zeros(2 * ng, dtype=np.uint64)
+    inv = np.zeros(ng, dtype=np.uint64)
+    assert emul.emul_parse(raw.ctypes.data, len(raw), sym2.ctypes.data, inv.ctypes.data, ng) == nsym
+    cap = max(1, nsym)
+    keys = np.zeros(cap, dtype=np.uint64)
+    buckets = np.zeros(cap, dtype=np.uint32)
+    lens = np.zeros(cap, dtype=np.uint32)
+    n_rec = C.c_uint64(0)
+    coarse_bits = 9
+    n = emul.emul_runs(sym2.ctypes.data, inv.ctypes.data, nsym, k, coarse_bits, keys.ctypes.data, buckets.ctypes.data, cap,
+                       lens.ctypes.data, cap, C.byref(n_rec))
+    assert n == len(direct), n                                   # (a huge n: emul_runs found a run that is not one)
+    assert (keys[:n] == direct).all()                            # same k-mers, in stream order
+    km, ct, nocc = orc.count_genome(files, k)
+    vals, counts = np.unique(keys[:n], return_counts=True)
+    assert nocc == n and (vals == km[:, 0]).all() and (counts == ct).all()
+    lens = lens[:n_rec.value]
+    assert lens.sum() == n and lens.min() >= 1 and lens.max() <= 8
+    nbits = coarse_bits + 7
+    for i in rng.randint(0, n, size=400):
+        assert emul.emul_minimizer_bucket_of_kmer(int(keys[i]), k, nbits) == int(buckets[i])
+        # fewer buckets = the top bits (what level 2 and the union of ranks with different bucket counts rely on)
+        assert emul.emul_minimizer_bucket_of_kmer(int(keys[i]), k, nbits - 5) == int(buckets[i]) >> 5
