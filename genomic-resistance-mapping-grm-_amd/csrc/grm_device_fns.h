@@ -378,12 +378,48 @@ GRM_HD uint64_t fq_elem_combine(uint64_t a, uint64_t b)
 // the emitted symbols of one 16-byte chunk as bit strings: returns the count (0..16);
 // sym: 2 bits per symbol, first symbol most significant, in the low 2*count bits;
 // inv: bit i = symbol i is a separator / bad base.
+// 2-bit codes of the 4 bytes of x as one byte, first byte most significant; bad-base bits of the 4 bytes, first byte in bit 0
+GRM_HD uint32_t codes_of_word(uint32_t x)
+{
+    uint32_t c = (x >> 1) & 0x03030303u;
+    c = (c >> 24) | ((c >> 8) & 0xff00u) | ((c << 8) & 0xff0000u) | (c << 24);         // byte swap: first byte on top
+    return (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xffu;
+}
+GRM_HD uint32_t bad_of_word(uint32_t x)
+{
+    const uint32_t b = (x >> 3) & 0x01010101u;
+    return (b | (b >> 7) | (b >> 14) | (b >> 21)) & 0xfu;
+}
 GRM_HD int chunk_pack(const uint32_t w[4], uint32_t emit, uint32_t sep, uint32_t &sym, uint32_t &inv)
 {
+    emit &= 0xffffu;
+    sep &= emit;
+    const uint32_t holes = ~emit & 0xffffu;
+    if (sep == 0 && (holes & (holes - 1)) == 0) {
+        // nothing but bases, or all but ONE byte (the newline of an 80-column line): all 16 codes at once (SWAR), then the one
+        // hole is closed -- the byte-by-byte loop below spent ~160 instructions per chunk on what is the case of nearly every chunk
+        uint32_t s16 = (codes_of_word(w[0]) << 24) | (codes_of_word(w[1]) << 16) | (codes_of_word(w[2]) << 8) | codes_of_word(w[3]);
+        uint32_t b16 = bad_of_word(w[0]) | (bad_of_word(w[1]) << 4) | (bad_of_word(w[2]) << 8) | (bad_of_word(w[3]) << 12);
+        if (holes) {
+            const int j = __builtin_ctz(holes);                   // byte j is not a symbol: symbols j+1.. move up by one
+            const uint32_t low_mask = j == 15 ? 0u : (0x3fffffffu >> (2 * j));         // the symbols after j (2-bit groups, MSB-first)
+            const uint32_t high = j == 0 ? 0u : (s16 & ~(0xffffffffu >> (2 * j)));
+            s16 = (high >> 2) | (s16 & low_mask);
+            b16 = (b16 & ((1u << j) - 1u)) | ((b16 >> (j + 1)) << j);
+            sym = s16;                                            // 15 symbols in the low 30 bits
+            inv = b16;
+            return 15;
+        }
+        sym = s16;
+        inv = b16;
+        return 16;
+    }
     sym = 0; inv = 0;
     int n = 0;
     uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32), hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
+#endif
     for (int j = 0; j < 16; j++) {
         const uint32_t b = (uint32_t)lo & 0xffu;          // byte j (no indexed access: stays in registers)
         lo = (lo >> 8) | (hi << 56);
