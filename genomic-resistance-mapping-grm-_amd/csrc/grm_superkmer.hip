@@ -104,18 +104,27 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
         // The runs of a lane leave one per round (a lane has ~6, at most 32): the slot in the coarse region comes from the
         // workgroup's LDS cursor of that region, the record goes straight to its place.  A region's lines fill up in
         // cursor order, 8 records each, and a workgroup keeps 512 of them open: they complete in L2 (mostly).
+        // (two runs per round: both LDS atomics are in flight before either record is stored)
         uint32_t hd = heads;
         while (hd) {
             const int i = __ffs(hd) - 1;
             hd &= hd - 1;
-            const uint32_t bkt = my_bk[i];
-            const uint32_t c = bkt >> SK_FINE_BITS;
-            uint64_t rx, ry;
+            const bool two = hd != 0;
+            const int i2 = two ? __ffs(hd) - 1 : i;
+            hd &= hd - 1;                  // (0 & anything = 0)
+            const uint32_t bkt = my_bk[i], bkt2 = my_bk[i2];
+            const uint32_t c = bkt >> SK_FINE_BITS, c2 = bkt2 >> SK_FINE_BITS;
+            uint64_t rx, ry, rx2, ry2;
             run_record(w0, w1, i, run_length(heads, valid, i), bkt, rx, ry);
-            const ulonglong2 rec = make_ulonglong2(rx, ry);
+            run_record(w0, w1, i2, run_length(heads, valid, i2), bkt2, rx2, ry2);
             const uint32_t slot = atomicAdd(&cursor[c], 1u);
-            if (slot < rstride) recs1[((uint64_t)vg * B1 + c) * rstride + slot] = rec;
+            const uint32_t slot2 = two ? atomicAdd(&cursor[c2], 1u) : 0u;
+            if (slot < rstride) recs1[((uint64_t)vg * B1 + c) * rstride + slot] = make_ulonglong2(rx, ry);
             else over = true;
+            if (two) {
+                if (slot2 < rstride) recs1[((uint64_t)vg * B1 + c2) * rstride + slot2] = make_ulonglong2(rx2, ry2);
+                else over = true;
+            }
         }
     }
     __syncthreads();
