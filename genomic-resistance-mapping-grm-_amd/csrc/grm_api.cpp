@@ -66,6 +66,7 @@ struct grm_ctx {
     int opt_rec_bucket_shift = -1; // record form: bucket bits on top of the key form's choice (default 1)
     int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
     int opt_rec_keys = -1;       // > 0: record form always expands to key segments in level 2 (tests, measurements)
+    int opt_rec_memo = -1;       // record memo of dict_build: log2 of its slots (8..12), 0 = none, < 0 = default (10, with a 2^11 key table)
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
 // 64-bit words of a k-mer, most significant first: 1 (k <= 32), 2 (<= 64), 3 (<= 96), 4 (<= 128)
@@ -253,6 +254,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "rec_bucket_shift") c->opt_rec_bucket_shift = value;
     else if (n == "rec_part_bits") c->opt_rec_part_bits = value;
     else if (n == "rec_keys") c->opt_rec_keys = value;
+    else if (n == "rec_memo") c->opt_rec_memo = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
@@ -692,6 +694,7 @@ struct grm_batch {
     int rec_need_bb = 0;           // ... of 2^rec_need_bb
     int rec_bb_hint = -1, rec_bb_hint_k = 0;   // bucket bits a dictionary of this batch needed last time (more buckets instead of sub-buckets)
     int rec_part_bits = 0;         // genomes are cut into 2^rec_part_bits parts (segment index: virtual genome * 2^bb + bucket)
+    int rec_memo_log2 = 0;         // slots of dict_build's record memo (log2), 0 = none
     bool slack_failed = false;     // a slack-layout partition of this batch overflowed: dense layout from then on
     DevBuf d_marks;                // one bit per segment: left to the workgroup form of the dedup
     // dictionary
@@ -1126,8 +1129,12 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
             // the fill through the presence bits needs no keys at all: dict_build then decodes the records itself and
             // level 2 only sorts them by fine bucket; else (probing fill) level 2 expands them to key segments
             const size_t n_rows_b = ((size_t)G + 63) / 64;
+            // (dict_build's record memo takes LDS: with it the key table has 2^11 slots unless the caller says otherwise, so that
+            // two workgroups still share a CU)
+            b->rec_memo_log2 = c->opt_rec_memo < 0 ? 10 : c->opt_rec_memo == 0 ? 0 : std::min(12, std::max(8, c->opt_rec_memo));
+            const uint32_t cap_r = (b->rec_memo_log2 && c->opt_cap_log2 <= 0) ? 11u : b->cap_log2;
             const bool by_records = c->opt_no_slots <= 0 && c->opt_rec_keys <= 0 && n_rows_b <= 0xffffu &&
-                                    ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << b->cap_log2) * 8 <= MATRIX_S_LIMIT &&
+                                    ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << cap_r) * 8 <= MATRIX_S_LIMIT &&
                                     b->d_recs2.ensure((n_regions * rstride64 + 4) * 16) == hipSuccess;
             if (!by_records) (void)hipGetLastError();
             b->rec_rstride = rstride; b->rec_kstride = kstride; b->rec_regions = n_regions; b->rec_b1 = b1r;
@@ -1157,6 +1164,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
                 b->rec_part_bits = pbits;
                 b->rec_mode = true;
                 b->rec_dict = by_records;
+                if (by_records) b->cap_log2 = cap_r;
                 b->partitioned = true;
                 return GRM_OK;
             }
@@ -1377,6 +1385,7 @@ struct DictCtrl {
     unsigned long long n_out;
     int overflow;
     uint32_t need;
+    unsigned long long memo_stats[4];
 };
 
 
@@ -1439,6 +1448,8 @@ static int run_dict_ladder(grm_batch *b, DictArgs a, uint64_t total_keys, int sb
         a.out_cap = out_cap;
         DictCtrl *ctrl = b->d_ctrl.as<DictCtrl>();
         a.n_out = &ctrl->n_out; a.overflow = &ctrl->overflow; a.need = &ctrl->need;
+        static const bool memo_diag = getenv("GRM_MEMO_STATS") != nullptr;
+        a.memo_stats = memo_diag ? ctrl->memo_stats : nullptr;
         a.wg_base = out.wg_base->as<uint64_t>(); a.wg_cnt = out.wg_cnt->as<uint32_t>();
         a.matrix_s = bits ? b->d_matrix_s.as<uint64_t>() : nullptr;
         a.birth = bits ? b->d_birth.as<uint16_t>() : nullptr;
@@ -1451,6 +1462,10 @@ static int run_dict_ladder(grm_batch *b, DictArgs a, uint64_t total_keys, int sb
         DictCtrl h;
         HIPCHK(c, hipMemcpyAsync(&h, b->d_ctrl.p, sizeof h, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        if (memo_diag && a.memo_log2)
+            fprintf(stderr, "[grm] %s memo 2^%d: %llu (workgroup, row) ends with the memo on, mean records held %.1f, occurrences asked %llu found %llu; overflow %d\n",
+                    tname, a.memo_log2, h.memo_stats[3], h.memo_stats[3] ? (double)h.memo_stats[0] / (double)h.memo_stats[3] : 0.0, h.memo_stats[1],
+                    h.memo_stats[2], h.overflow);
         if (!h.overflow) {
             *sb_out = sb;
             *n_out = h.n_out;
@@ -1543,6 +1558,7 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
     a.keys = b->rec_dict ? nullptr : b->d_keys.as<uint64_t>();
     a.recs = b->rec_dict ? reinterpret_cast<const ulonglong2 *>(b->d_recs2.p) : nullptr;
     a.k = b->k;
+    a.memo_log2 = b->rec_dict ? b->rec_memo_log2 : 0;
     a.part_bits = b->rec_mode ? b->rec_part_bits : 0;
     a.seg = batch_segments(b);
     a.n_genomes = G; a.bb = b->bb; a.cap_log2 = b->cap_log2;

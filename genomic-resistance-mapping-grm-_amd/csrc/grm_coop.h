@@ -21,6 +21,15 @@ __device__ __forceinline__ void lds_barrier()
     __asm__ volatile("" ::: "memory");
 }
 
+// A read of LDS that must be done again every time it is written (another wave may have stored there).  Not `volatile`:
+// the compiler sends a volatile access through the FLAT path (flat_load + s_waitcnt vmcnt(0) lgkmcnt(0): an address-space
+// check per access, and every global load in flight is waited for); a relaxed workgroup-scope atomic load stays a ds_read.
+template <class T>
+__device__ __forceinline__ T lds_peek(const T *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // exclusive prefix sum of one value per lane inside a wave (DPP-free shuffle form)
 __device__ __forceinline__ uint32_t wave_scan_excl(uint32_t v)
 {

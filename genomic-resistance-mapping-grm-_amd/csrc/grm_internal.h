@@ -131,6 +131,9 @@ struct DictArgs {
     // seg counts records; k as given (keys == nullptr then)
     const ulonglong2 *recs;
     int k;
+    // record memo of the record form (grm_kernels.hip, "record memo"): 2^memo_log2 slots; 0 = none
+    int memo_log2;
+    unsigned long long *memo_stats;     // diagnostics (nullptr: none): sums over (workgroup, word-row) of records held, occurrences asked, found, and their number
     SegLayout seg;
     uint32_t n_genomes;
     int bb, sb;
@@ -156,6 +159,9 @@ struct DictArgs {
     const uint64_t *in_flag_off;
 };
 void launch_dict_build(hipStream_t s, const DictArgs &a);
+// records a memo of 2^memo_log2 slots holds (7/16 of the slots), and its LDS bytes: 24 per record, 4 per slot, 16 of counters
+constexpr uint32_t dict_memo_entries(int memo_log2) { return memo_log2 > 0 ? (7u << memo_log2) >> 4 : 0u; }
+constexpr size_t dict_memo_bytes(int memo_log2) { return memo_log2 > 0 ? (size_t)dict_memo_entries(memo_log2) * 24 + ((size_t)4 << memo_log2) + 16 : 0; }
 // local dictionary in bucket order: entries of workgroup wg copied to [ord_off[wg], ord_off[wg+1]) (ord_off = exclusive
 // scan of wg_cnt), and the first entry of every hash bucket (2^bb + 1 offsets)
 void launch_dict_export_ordered(hipStream_t s, const uint64_t *keys, const uint8_t *flags, const uint64_t *wg_base, const uint32_t *wg_cnt,

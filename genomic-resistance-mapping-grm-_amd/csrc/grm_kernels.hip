@@ -813,6 +813,13 @@ __global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t *__restri
 // ------------------------------------------------------------------------------------
 // LDS open-addressing table helpers (linear probing, 64-bit CAS = ds_cmpst_rtn_b64)
 // ------------------------------------------------------------------------------------
+// "this workgroup's table overflowed": a flag in LDS read inside loops.  (A volatile int would be read through the FLAT
+// path -- flat_load + s_waitcnt vmcnt(0), which also drains the global loads in flight; a relaxed atomic stays a ds_read.)
+struct LdsFlag {
+    int *p;
+    __device__ __forceinline__ operator bool() const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; }
+    __device__ __forceinline__ void set(int v) const { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+};
 // returns slot of key (inserting it if absent), or 0xffffffff when the table is full
 __device__ __forceinline__ uint32_t lds_find_or_insert(uint64_t *tkeys, uint32_t cap_mask, uint64_t key,
                                                        uint64_t h, bool *inserted)
@@ -821,7 +828,7 @@ __device__ __forceinline__ uint32_t lds_find_or_insert(uint64_t *tkeys, uint32_t
     for (uint32_t probe = 0; probe <= cap_mask; probe++) {
         // plain read first: almost every probe of a pan-genome finds its key already present,
         // and a ds_read_b64 is cheaper than a returning ds_cmpst_b64
-        uint64_t cur = *reinterpret_cast<volatile uint64_t *>(&tkeys[slot]);
+        uint64_t cur = lds_peek(&tkeys[slot]);
         if (cur == EMPTY_KEY)
             cur = atomicCAS((unsigned long long *)&tkeys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
         if (cur == EMPTY_KEY) { *inserted = true; return slot; }
@@ -866,19 +873,19 @@ __global__ __launch_bounds__(TABLE_THREADS) void bucket_dedup_kernel(
     uint64_t *tkeys = reinterpret_cast<uint64_t *>(lds_raw);
     uint32_t *tcnt = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 8);
     uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 12);   // [16] + flags
-    volatile int &full = *reinterpret_cast<volatile int *>(scratch + 16);
+    const LdsFlag full = {reinterpret_cast<int *>(scratch + 16)};
     for (uint64_t seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
         if (marks && !((marks[seg >> 5] >> (seg & 31)) & 1u)) continue;      // second pass: what the wave form left
         uint64_t s0, n;
         seg_bounds(seg_layout, seg, s0, n);
         for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tkeys[i] = EMPTY_KEY; tcnt[i] = 0; }
-        if (threadIdx.x == 0) full = 0;
+        if (threadIdx.x == 0) full.set(0);
         __syncthreads();
         for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
             const uint64_t key = keys[s0 + i];
             bool ins;
             const uint32_t slot = lds_find_or_insert(tkeys, cap_mask, key, mix64(key), &ins);
-            if (slot == 0xffffffffu) full = 1;
+            if (slot == 0xffffffffu) full.set(1);
             else atomicAdd(&tcnt[slot], 1u);
         }
         __syncthreads();
@@ -929,7 +936,7 @@ __device__ __forceinline__ bool dedup_insert4(uint64_t *tk, uint32_t *tc, const 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         sl[j] = hash_slot(mix64(kv[j]), MASK);
-        cur[j] = *reinterpret_cast<volatile uint64_t *>(&tk[sl[j]]);
+        cur[j] = lds_peek(&tk[sl[j]]);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -945,7 +952,7 @@ __device__ __forceinline__ bool dedup_insert4(uint64_t *tk, uint32_t *tc, const 
                 slot = 0xffffffffu;
                 uint32_t at = (sl[j] + 1) & MASK;
                 for (uint32_t probe = 0; probe < MASK; probe++, at = (at + 1) & MASK) {
-                    uint64_t c2 = *reinterpret_cast<volatile uint64_t *>(&tk[at]);
+                    uint64_t c2 = lds_peek(&tk[at]);
                     if (c2 == EMPTY_KEY)
                         c2 = atomicCAS((unsigned long long *)&tk[at], (unsigned long long)EMPTY_KEY, (unsigned long long)kv[j]);
                     if (c2 == EMPTY_KEY) { ins = true; slot = at; break; }
@@ -1068,7 +1075,7 @@ __device__ __forceinline__ uint32_t lds_pair_find_or_insert(uint64_t *tkeys, uin
 {
     uint32_t slot = hash_slot(h, cap_mask) & ~1u;
     for (uint32_t probe = 0; probe <= cap_mask; probe++) {
-        uint64_t cur = *reinterpret_cast<volatile uint64_t *>(&tkeys[slot]);
+        uint64_t cur = lds_peek(&tkeys[slot]);
         if (cur == EMPTY_KEY)
             cur = atomicCAS((unsigned long long *)&tkeys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
         if (cur == EMPTY_KEY) { *inserted = true; return slot; }
@@ -1082,7 +1089,7 @@ struct DictWave {
     uint64_t *tkeys;
     unsigned long long *words;
     uint16_t *meta;
-    volatile int *full;
+    LdsFlag full;
     uint32_t *n_distinct;
     uint32_t cap_mask, max_fill, cap_log2;
     uint32_t wg, sub, G;
@@ -1132,7 +1139,7 @@ __device__ __forceinline__ void dict_probe(const DictWave &w, const uint64_t (&k
         }
     }
     while (todo) {
-        if (*w.full) break;          // LDS flag: once the table is given up, stop probing it
+        if (w.full) break;           // LDS flag: once the table is given up, stop probing it
         const int j = __ffs(todo) - 1;
         todo &= todo - 1;
         uint64_t key = kv[0];
@@ -1151,7 +1158,7 @@ __device__ __forceinline__ void dict_probe(const DictWave &w, const uint64_t (&k
             atomicOr(&w.words[slot], (FLAGS && ((several >> j) & 1u)) ? (bit | 1ull) : bit);
         }
         if (over) {
-            *w.full = 1;         // (what the workgroup would have needed is counted after the word-row loop: dict_build_kernel)
+            w.full.set(1);       // (what the workgroup would have needed is counted after the word-row loop: dict_build_kernel)
             break;
         }
     }
@@ -1174,6 +1181,94 @@ __device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__
     dict_probe<J, FLAGS>(w, kv, several, g, r, bit);
 }
 
+// ---- record memo (record form) --------------------------------------------------------------------------------------
+// Genomes of one species share most of their sequence, and with it most of their run records: the SAME 16 bytes come
+// in from most genomes of a word-row.  The workgroup therefore keeps a small table of the distinct records it has met
+// (id = order of arrival) with one presence word per record; an occurrence of a held record costs one hash of 16 bytes,
+// one tag compare, one 16-byte compare and one OR -- instead of decoding its up to 8 k-mers and probing the key table
+// for each.  At the end of a word-row every held record is decoded ONCE and its word is ORed into its k-mers' words.
+// A record the table does not hold (table full, probe sequence too long, slot being written) goes the direct way, so
+// the memo is an accelerator and never a point of failure; a workgroup whose memo is full and rarely hit (unrelated
+// genomes) switches it off.
+constexpr uint32_t MEMO_NONE = 0xffffffffu, MEMO_LOCK = 0x0000ffffu;
+struct DictMemo {
+    uint32_t *slot;                 // [2^slot_log2]: 0 = empty, MEMO_LOCK = being written, else tag << 16 | id + 1
+    ulonglong2 *rec;                // [n_ent] the records, by id
+    unsigned long long *words;      // [n_ent] presence word of the current word-row
+    uint32_t *ctl;                  // [0] records held, [1] memo in use, [2] occurrences found, [3] occurrences asked (of the row)
+    uint32_t n_ent, smask;
+};
+__device__ __forceinline__ uint32_t memo_hash(uint64_t x, uint64_t y)
+{
+    const uint32_t h = mul24((uint32_t)x, 0x9E3779u) + mul24((uint32_t)(x >> 24), 0x85EBCBu) + mul24((uint32_t)(x >> 48), 0xC2B2AFu) +
+                       mul24((uint32_t)(y >> 40), 0xD6E8FFu) + mul24((uint32_t)(y >> 16), 0xA54FF5u) + mul24((uint32_t)y & 0xffffu, 0x3C6EF3u);
+    return h ^ (h >> 13);
+}
+// id of the record (x, y) in the memo, entering it when there is room; MEMO_NONE: not held, take the direct way
+__device__ __forceinline__ uint32_t memo_find_or_insert(const DictMemo &M, uint64_t x, uint64_t y)
+{
+    const uint32_t h = memo_hash(x, y);
+    const uint32_t tag = h >> 16;
+    uint32_t s = h & M.smask;
+    for (int p = 0; p < 6; p++) {
+        // (relaxed: the record is read through the id the slot word carries, and an acquire would also wait for the global
+        // loads in flight -- the next records)
+        uint32_t v = __hip_atomic_load(&M.slot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v == 0) {
+            if (__hip_atomic_load(&M.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= M.n_ent) return MEMO_NONE;
+            v = atomicCAS(&M.slot[s], 0u, MEMO_LOCK);
+            if (v == 0) {
+                const uint32_t id = atomicAdd(&M.ctl[0], 1u);
+                if (id >= M.n_ent) return MEMO_NONE;          // (the slot stays locked: whoever reaches it goes the direct way)
+                M.rec[id] = make_ulonglong2(x, y);
+                // the record before the slot word that publishes it: LDS only (a plain release would drain the global loads too)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                __hip_atomic_store(&M.slot[s], (tag << 16) | (id + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return id;
+            }
+        }
+        if (v == MEMO_LOCK) continue;       // being written (often by a lane of this wave with the same record): look again
+        if ((v >> 16) == tag) {
+            const uint32_t id = (v & 0xffffu) - 1u;
+            const ulonglong2 e = M.rec[id];
+            if (e.x == x && e.y == y) return id;
+        }
+        s = (s + 1) & M.smask;
+    }
+    return MEMO_NONE;
+}
+// one record per lane (rec.y == 0: none), genome bit `bit` of word-row r: through the memo, or J keys to the table
+template <int J>
+__device__ __forceinline__ void dict_take_record(const DictWave &w, const DictMemo &M, bool memo_on, const ulonglong2 rec, unsigned long long bit,
+                                                 uint32_t r, int kk, uint64_t kmask, int rcshift)
+{
+    bool direct = rec.y != 0;
+    if (memo_on) {
+        const uint32_t id = direct ? memo_find_or_insert(M, rec.x, rec.y) : MEMO_NONE;
+        const unsigned long long asked = __ballot(direct);
+        if (id != MEMO_NONE) {
+            atomicOr(&M.words[id], bit);
+            direct = false;
+        }
+        const unsigned long long left = __ballot(direct);
+        if (lane_id() == 0) {
+            atomicAdd(&M.ctl[2], (uint32_t)__popcll(asked) - (uint32_t)__popcll(left));
+            atomicAdd(&M.ctl[3], (uint32_t)__popcll(asked));
+        }
+        if (!left) return;
+    }
+    const uint32_t len = (uint32_t)(rec.y & 0xffu);
+    RunDecoder dec = run_open(rec.x, rec.y, kk);
+    uint64_t kv[J];
+    kv[0] = run_canonical(dec);
+#pragma unroll
+    for (int t = 1; t < J; t++) {
+        run_next(dec, kmask, rcshift);
+        kv[t] = run_canonical(dec);          // (past the record's last k-mer: not live)
+    }
+    dict_probe<J, false, true>(w, kv, 0u, 0u, r, bit, direct ? (1u << len) - 1u : 0u);
+}
+
 // MAXT: largest workgroup the instance is launched with (the 8-deep form needs more than the 128 VGPRs a
 // 1024-thread workgroup leaves per lane)
 template <int KIF, int MAXT, bool FLAGS, bool REC>
@@ -1185,7 +1280,7 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     unsigned long long *words = reinterpret_cast<unsigned long long *>(lds_raw + (size_t)cap * 8);
     uint16_t *meta = reinterpret_cast<uint16_t *>(lds_raw + (size_t)cap * 16);
     uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 18);   // [16] + flags
-    volatile int &full = *reinterpret_cast<volatile int *>(scratch + 16);
+    const LdsFlag full = {reinterpret_cast<int *>(scratch + 16)};
     uint32_t &n_distinct = scratch[17];
     uint64_t &out_base = *reinterpret_cast<uint64_t *>(scratch + 18);
     const uint32_t wg = blockIdx.x;
@@ -1194,7 +1289,7 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     const uint32_t b = wg >> sb;
     const uint32_t G = a.n_genomes, n_rows = (G + 63) >> 6;
     for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tkeys[i] = EMPTY_KEY; words[i] = 0; meta[i] = 0; }
-    if (threadIdx.x == 0) { full = 0; n_distinct = 0; }
+    if (threadIdx.x == 0) { full.set(0); n_distinct = 0; }
     __syncthreads();
     const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;     // nw divides 64 (launcher)
     // a genome may come in 2^part_bits parts ("virtual genomes" g, real genome g >> pb; record form of the partition)
@@ -1202,7 +1297,7 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     const uint32_t GV = G << pb;
     const uint32_t per_row = (64u << pb) / (uint32_t)nw;    // (virtual) genomes per wave per word-row
     DictWave w;
-    w.tkeys = tkeys; w.words = words; w.meta = meta; w.full = &full; w.n_distinct = &n_distinct;
+    w.tkeys = tkeys; w.words = words; w.meta = meta; w.full = full; w.n_distinct = &n_distinct;
     w.cap_mask = cap_mask; w.max_fill = cap - (cap >> 3); w.cap_log2 = a.cap_log2;
     w.wg = wg; w.sub = wg & ((1u << sb) - 1); w.G = G; w.bb = a.bb; w.sb = sb; w.birth = a.birth; w.need = a.need;
     // segment of the NEXT genome is fetched while the current one is processed (the two dependent
@@ -1221,6 +1316,37 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     const uint64_t kmask = kk == 32 ? ~0ull : ((1ull << (2 * kk)) - 1);
     uint64_t *tabD = reinterpret_cast<uint64_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES) + 16 * wave;
     uint32_t *tabS = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)nw * 128) + 16 * wave;
+    // record memo (REC, a.memo_log2 > 0): 2^memo_log2 slots for 7/16 of that many records, behind the waves' pool tables
+    DictMemo M;
+    M.smask = REC && a.memo_log2 ? (1u << a.memo_log2) - 1u : 0u;
+    M.n_ent = REC && a.memo_log2 ? dict_memo_entries(a.memo_log2) : 0u;
+    {
+        uint8_t *mb = lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)nw * 192;
+        M.rec = reinterpret_cast<ulonglong2 *>(mb);
+        M.words = reinterpret_cast<unsigned long long *>(mb + (size_t)M.n_ent * 16);
+        M.slot = reinterpret_cast<uint32_t *>(mb + (size_t)M.n_ent * 24);
+        M.ctl = M.slot + M.smask + 1;
+    }
+    if (REC && a.memo_log2) {
+        for (uint32_t i = threadIdx.x; i <= M.smask; i += blockDim.x) M.slot[i] = 0;
+        for (uint32_t i = threadIdx.x; i < M.n_ent; i += blockDim.x) M.words[i] = 0;
+        if (threadIdx.x == 0) { M.ctl[0] = 0; M.ctl[1] = 1; M.ctl[2] = 0; M.ctl[3] = 0; }
+        __syncthreads();
+    }
+    // record form: segment bounds of a wave's group of 8 (virtual) genomes x 2 length classes -- lane e < 16 holds those of genome e & 7
+    // (record segments come with offsets AND lengths -- regions leave gaps; read here without seg_bounds' cases, whose merges
+    // would make the compiler wait for the loads on the spot)
+    auto group_bounds = [&](uint32_t rr, uint32_t j0, uint64_t &sj, uint32_t &nj) {
+        const uint32_t jj = (uint32_t)lane & 7u;
+        const uint32_t vgj = ((rr * 64u) << pb) + (uint32_t)wave + (j0 + jj) * (uint32_t)nw;
+        const bool mine = rr < n_rows && lane < 16 && j0 + jj < per_row && vgj < GV;
+        const uint64_t at = mine ? (uint64_t)vgj * B + b : 0;
+        sj = mine ? a.seg.off[at] : 0ull;
+        nj = mine ? a.seg.len[at] : 0u;
+    };
+    uint64_t sj_n = 0;
+    uint32_t nj_n = 0;
+    if (REC) group_bounds(0, 0, sj_n, nj_n);
     for (uint32_t r = 0; r < n_rows; r++) {
         if (REC) {
             // Record form.  A record holds a run of 1..8 consecutive k-mers with their bases; ONE LANE decodes one record
@@ -1230,13 +1356,19 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
             // genomes of this word-row are pooled, 8 genomes at a time and class by class, so that the lanes of the last
             // instruction of a genome are not left idle: lane -> (class, genome, record) through the running totals of
             // the 16 pooled sub-segments.
-            const uint32_t row_first = (r * 64u) << pb;
+            const bool memo_on = a.memo_log2 && M.ctl[1];          // (changes between the barriers of a row's end only)
             for (uint32_t j0 = 0; j0 < per_row && !full; j0 += 8) {
                 const uint32_t jj = (uint32_t)lane & 7u, cls = ((uint32_t)lane >> 3) & 1u;
-                const uint32_t vgj = row_first + (uint32_t)wave + (j0 + jj) * (uint32_t)nw;
-                uint64_t sj = 0, nj = 0;
-                if (lane < 16 && j0 + jj < per_row && vgj < GV) seg_bounds(a.seg, (uint64_t)vgj * B + b, sj, nj);
-                const uint32_t n_all = (uint32_t)nj & 0xffffu, n_short = (uint32_t)nj >> 16;
+                const uint32_t vgj = ((r * 64u) << pb) + (uint32_t)wave + (j0 + jj) * (uint32_t)nw;
+                // this group's bounds were asked for a group ago; the next group's (the next word-row's first after this row's
+                // last) are asked for now.  (The asm makes the wait for sj / nj stand BEFORE the new loads are issued: the compiler
+                // waits with vmcnt(0) at the first use, which would otherwise take the new loads with it.)
+                const uint64_t sj = sj_n;
+                const uint32_t nj = nj_n;
+                __asm__ volatile("" ::"v"(sj), "v"(nj));
+                if (j0 + 8 < per_row) group_bounds(r, j0 + 8, sj_n, nj_n);
+                else group_bounds(r + 1, 0, sj_n, nj_n);
+                const uint32_t n_all = nj & 0xffffu, n_short = nj >> 16;
                 const uint32_t n32 = cls ? n_all - n_short : n_short;
                 const uint32_t inc = wave_scan_incl_dpp(n32);
                 const uint32_t cume = inc - n32;
@@ -1256,44 +1388,29 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                     rec = q < q_end ? a.recs[tabD[e] + q] : make_ulonglong2(0, 0);
                     sh = tabS[e];
                 };
-                ulonglong2 rec_n;
-                uint32_t sh_n;
-                // ---- the short records: four keys per lane ----
+                // One batch of 64 records is always in flight while the batch before it is worked on -- across the two classes
+                // as well: the first long records are asked for before the short ones are gone through.
+                ulonglong2 rec_n, rec_l;
+                uint32_t sh_n, sh_l;
                 fetch((uint32_t)lane, NA, 0, rec_n, sh_n);
+                fetch(NA + (uint32_t)lane, N, 8, rec_l, sh_l);
+                // ---- the short records: four keys per lane ----
                 for (uint32_t q0 = 0; q0 < NA && !full; q0 += 64) {
                     const ulonglong2 rec = rec_n;
                     const uint32_t sh = sh_n;
+                    __asm__ volatile("" ::"v"(rec.x), "v"(rec.y));      // (as above: wait for this batch, then ask for the next)
                     fetch(q0 + 64u + (uint32_t)lane, NA, 0, rec_n, sh_n);
-                    const unsigned long long bit = 1ull << sh;
-                    const uint32_t len = (uint32_t)(rec.y & 0xffu);
-                    RunDecoder dec = run_open(rec.x, rec.y, kk);
-                    uint64_t kv[4];
-                    kv[0] = run_canonical(dec);
-#pragma unroll
-                    for (int t = 1; t < 4; t++) {
-                        run_next(dec, kmask, rcshift);
-                        kv[t] = run_canonical(dec);          // (past the record's last k-mer: not live)
-                    }
-                    // (g argument: the lane's genome, sizes the retry on overflow)
-                    dict_probe<4, false, true>(w, kv, 0u, r * 64u + 63u - sh, r, bit, (1u << len) - 1u);
+                    dict_take_record<4>(w, M, memo_on, rec, 1ull << sh, r, kk, kmask, rcshift);
                 }
                 // ---- the long ones: eight ----
-                fetch(NA + (uint32_t)lane, N, 8, rec_n, sh_n);
+                rec_n = rec_l;
+                sh_n = sh_l;
                 for (uint32_t q0 = NA; q0 < N && !full; q0 += 64) {
                     const ulonglong2 rec = rec_n;
                     const uint32_t sh = sh_n;
+                    __asm__ volatile("" ::"v"(rec.x), "v"(rec.y));
                     fetch(q0 + 64u + (uint32_t)lane, N, 8, rec_n, sh_n);
-                    const unsigned long long bit = 1ull << sh;
-                    const uint32_t len = (uint32_t)(rec.y & 0xffu);
-                    RunDecoder dec = run_open(rec.x, rec.y, kk);
-                    uint64_t kv[8];
-                    kv[0] = run_canonical(dec);
-#pragma unroll
-                    for (int t = 1; t < 8; t++) {
-                        run_next(dec, kmask, rcshift);
-                        kv[t] = run_canonical(dec);
-                    }
-                    dict_probe<8, false, true>(w, kv, 0u, r * 64u + 63u - sh, r, bit, (1u << len) - 1u);
+                    dict_take_record<8>(w, M, memo_on, rec, 1ull << sh, r, kk, kmask, rcshift);
                 }
             }
         } else {
@@ -1329,6 +1446,35 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
         }
         __syncthreads();
         if (full) break;         // read between two barriers: uniform
+        if (REC && a.memo_log2 && M.ctl[1]) {
+            // the records the memo holds: each decoded once, its word of this row ORed into the words of its k-mers
+            const uint32_t held = min(M.ctl[0], M.n_ent), found = M.ctl[2], asked = M.ctl[3];
+            for (uint32_t t0 = 0; t0 < held; t0 += blockDim.x) {
+                const uint32_t t = t0 + threadIdx.x;
+                const unsigned long long wd = t < held ? M.words[t] : 0ull;
+                if (!__ballot(wd != 0)) continue;
+                ulonglong2 rec = make_ulonglong2(0, 0);
+                if (wd) {
+                    rec = M.rec[t];
+                    M.words[t] = 0;
+                }
+                dict_take_record<8>(w, M, false, rec, wd, r, kk, kmask, rcshift);
+            }
+            __syncthreads();
+            // full and hit by less than a quarter of the row's records: unrelated genomes, the memo only costs
+            if (threadIdx.x == 0) {
+                if (held >= M.n_ent && found * 4u < asked) M.ctl[1] = 0;
+                M.ctl[2] = 0;
+                M.ctl[3] = 0;
+                if (a.memo_stats) {         // (diagnostics, GRM_MEMO_STATS: records held, occurrences asked / found, rows with the memo on)
+                    atomicAdd(&a.memo_stats[0], (unsigned long long)held);
+                    atomicAdd(&a.memo_stats[1], (unsigned long long)asked);
+                    atomicAdd(&a.memo_stats[2], (unsigned long long)found);
+                    atomicAdd(&a.memo_stats[3], 1ull);
+                }
+            }
+            if (full) break;
+        }
         // end of the word-row: publish and clear the words of every occupied slot
         for (uint32_t slot = threadIdx.x; slot < cap; slot += blockDim.x) {
             if (tkeys[slot] == EMPTY_KEY) continue;
@@ -1983,7 +2129,8 @@ void launch_dict_build(hipStream_t s, const DictArgs &a)
         return;
     }
     if (a.recs) {                       // one record (up to 8 keys) per lane; 8 waves (the instance's launch bound)
-        const size_t lds_r = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (size_t)(TABLE_THREADS / 64) * 192;      // + the pool table of every wave
+        const size_t lds_r = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (size_t)(TABLE_THREADS / 64) * 192 +     // + the pool table of every wave
+                             dict_memo_bytes(a.memo_log2);                                                               // + the record memo
         hipLaunchKernelGGL((dict_build_kernel<8, 512, false, true>), grid, dim3(TABLE_THREADS), lds_r, s, a);
         return;
     }

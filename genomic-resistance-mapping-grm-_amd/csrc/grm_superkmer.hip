@@ -66,29 +66,40 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     const uint32_t vg = blockIdx.x;
     const uint32_t gen = vg >> a.part_bits, part = vg & ((1u << a.part_bits) - 1u);
     const uint64_t lo = a.genome_sym_off[gen], hi = a.genome_sym_off[gen + 1];
-    const uint64_t w_lo = lo >> 5, w_hi = (hi + 31) >> 5;
-    const uint64_t per_part = (w_hi - w_lo + (1u << a.part_bits) - 1) >> a.part_bits;
-    const uint64_t w_a = min(w_lo + (uint64_t)part * per_part, w_hi), w_b = min(w_a + per_part, w_hi);
+    // A thread's 32 start positions are a window of the GENOME (window j = positions lo + 32 j ...), not a word of the packed
+    // stream: runs end at window ends, so with stream-aligned windows the same sequence would be cut into different records
+    // in every genome (32 possible phases) -- and dict_build's record memo lives on genomes sharing their records.  The
+    // window's two words are funnel-shifted out of three stream words.
+    const int phase = (int)(lo & 31);
+    const uint64_t n_win = (hi - lo + 31) >> 5;
+    const uint64_t per_part = (n_win + (1u << a.part_bits) - 1) >> a.part_bits;
+    const uint64_t j_a = min((uint64_t)part * per_part, n_win), j_b = min(j_a + per_part, n_win);
     const uint16_t *my_bk = reinterpret_cast<const uint16_t *>(s_bk) + threadIdx.x * SK_PPT;
     cursor[threadIdx.x] = 0;
     __syncthreads();
     uint32_t n_valid = 0;
     bool over = false;
-    for (uint64_t wbase = w_a; wbase < w_b; wbase += SK_THREADS) {
-        const uint64_t wi = wbase + threadIdx.x;
-        const uint64_t p0 = wi << 5;
+    for (uint64_t jbase = j_a; jbase < j_b; jbase += SK_THREADS) {
+        const uint64_t j = jbase + threadIdx.x;
+        const uint64_t p0 = lo + (j << 5);
         uint32_t valid = 0;
         uint64_t w0 = 0, w1 = 0;
         const int64_t nv = (int64_t)a.total_syms - a.k + 1 - (int64_t)p0;
-        if (wi < w_b && nv > 0) {
-            const uint64_t grp = p0 >> 6;
-            w0 = a.sym2[wi];
-            w1 = a.sym2[wi + 1];
+        if (j < j_b && nv > 0) {
+            const uint64_t grp = p0 >> 6, wq = p0 >> 5;
+            const uint64_t u0 = a.sym2[wq], u1 = a.sym2[wq + 1];
+            if (phase) {
+                const uint64_t u2 = a.sym2[wq + 2];       // (the stream buffer ends with 16 words of slack)
+                w0 = (u0 << (2 * phase)) | (u1 >> (64 - 2 * phase));
+                w1 = (u1 << (2 * phase)) | (u2 >> (64 - 2 * phase));
+            } else {
+                w0 = u0;
+                w1 = u1;
+            }
             valid = (uint32_t)valid_starts_at(a.inv[grp], a.inv[grp + 1], (int)(p0 & 63), a.k);
             if (nv < SK_PPT) valid &= (1u << nv) - 1;
-            // the first and the last word of a genome also hold positions of its neighbours
-            if (p0 < lo) valid &= ~0u << (uint32_t)(lo - p0);
-            if (p0 + SK_PPT > hi) valid &= hi > p0 ? ((1u << (uint32_t)(hi - p0)) - 1u) : 0u;
+            // the last window of a genome also holds positions of the next one
+            if (p0 + SK_PPT > hi) valid &= (1u << (uint32_t)(hi - p0)) - 1u;
         }
         n_valid += (uint32_t)__popc(valid);
         uint32_t heads = 0;

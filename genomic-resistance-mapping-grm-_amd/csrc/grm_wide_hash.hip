@@ -303,14 +303,15 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
     unsigned long long *words = reinterpret_cast<unsigned long long *>(lds_raw + (size_t)cap * 16);
     uint16_t *meta = reinterpret_cast<uint16_t *>(lds_raw + (size_t)cap * 24);
     uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 26);
-    volatile int &full = *reinterpret_cast<volatile int *>(scratch + 16);
+    int *const full_p = reinterpret_cast<int *>(scratch + 16);        // (read with lds_peek: a volatile int would go through the flat path)
+    auto is_full = [&]() { return lds_peek(full_p) != 0; };
     uint32_t &n_distinct = scratch[17];
     const uint32_t wg = blockIdx.x;
     const uint32_t B = 1u << bb;
     const uint32_t b = wg >> sb, sub = wg & ((1u << sb) - 1);
     const uint32_t G = n_genomes, n_rows = (G + 63) >> 6;
     for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) { tkey[i] = make_ulonglong2(WH_EMPTY, WH_PENDING); words[i] = 0; meta[i] = 0; }
-    if (threadIdx.x == 0) { full = 0; n_distinct = 0; }
+    if (threadIdx.x == 0) { *full_p = 0; n_distinct = 0; }
     __syncthreads();
     const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;        // nw = 8: divides 64
     const uint32_t max_fill = cap - (cap >> 3);
@@ -328,13 +329,13 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
         for (uint32_t jr = 0; jr < per_row; jr++, g += nw) {
             uint64_t s0_next = 0, n_next = 0;
             if (g + nw < G) seg_of(g + nw, s0_next, n_next);
-            if (g < G && !full) {
+            if (g < G && !is_full()) {
                 const unsigned long long bit = 1ull << (63 - (g & 63));
                 // straight-line and predicated, as dict_build's probe (grm_kernels.hip): both probe slots of every key are
                 // read, a key found there ORs its bit in under a predicate; only a key that is in neither slot goes round
                 // the insertion loop (a bit mask of the lane's keys still to do, no per-key branches)
                 constexpr int KJ = 2;                    // keys per lane in flight (segments hold ~300 keys)
-                for (uint64_t i0 = lane; i0 < n && !full; i0 += 64 * KJ) {
+                for (uint64_t i0 = lane; i0 < n && !is_full(); i0 += 64 * KJ) {
                     ulonglong2 kv[KJ];
                     uint64_t hv[KJ];
                     uint32_t sl[KJ];
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                         todo |= (uint32_t)(active && !(hit0 | hit1)) << j;
                     }
                     while (todo) {
-                        if (full) break;
+                        if (is_full()) break;
                         const int j = __ffs(todo) - 1;
                         todo &= todo - 1;
                         ulonglong2 key = kv[0];
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                             __hip_atomic_fetch_or(&words[slot], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         if (over) {
-                            full = 1;            // (what it would have needed is counted after the word-row loop)
+                            __hip_atomic_store(full_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // (what it would have needed is counted after the word-row loop)
                             break;
                         }
                     }
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
             n = n_next;
         }
         __syncthreads();
-        if (full) break;         // read between two barriers: uniform
+        if (is_full()) break;    // read between two barriers: uniform
         for (uint32_t slot = threadIdx.x; slot < cap; slot += blockDim.x) {
             if (tkey[slot].x == WH_EMPTY) continue;
             const unsigned long long wd = words[slot];
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
         __syncthreads();
     }
     __syncthreads();
-    if (full) {
+    if (is_full()) {
         // what the workgroup would have needed: all its keys once more through a HyperLogLog sketch in the abandoned table's
         // LDS (see dict_build_kernel, grm_kernels.hip)
         const uint32_t HLL_M = cap < 4096u ? cap : 4096u;
