@@ -66,7 +66,7 @@ struct grm_ctx {
     int opt_rec_bucket_shift = -1; // record form: bucket bits on top of the key form's choice (default 1)
     int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
     int opt_rec_keys = -1;       // > 0: record form always expands to key segments in level 2 (tests, measurements)
-    int opt_rec_memo = -1;       // record memo of dict_build: log2 of its slots (8..12), 0 = none, < 0 = default (10, with a 2^11 key table)
+    int opt_rec_memo = -1;       // record memo of dict_build: log2 of its slots (8..11), 0 = none, < 0 = default (10, with a 2^11 key table)
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
 // 64-bit words of a k-mer, most significant first: 1 (k <= 32), 2 (<= 64), 3 (<= 96), 4 (<= 128)
@@ -1131,7 +1131,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
             const size_t n_rows_b = ((size_t)G + 63) / 64;
             // (dict_build's record memo takes LDS: with it the key table has 2^11 slots unless the caller says otherwise, so that
             // two workgroups still share a CU)
-            b->rec_memo_log2 = c->opt_rec_memo < 0 ? 10 : c->opt_rec_memo == 0 ? 0 : std::min(12, std::max(8, c->opt_rec_memo));
+            b->rec_memo_log2 = c->opt_rec_memo < 0 ? 10 : c->opt_rec_memo == 0 ? 0 : std::min(11, std::max(8, c->opt_rec_memo));
             const uint32_t cap_r = (b->rec_memo_log2 && c->opt_cap_log2 <= 0) ? 11u : b->cap_log2;
             const bool by_records = c->opt_no_slots <= 0 && c->opt_rec_keys <= 0 && n_rows_b <= 0xffffu &&
                                     ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << cap_r) * 8 <= MATRIX_S_LIMIT &&

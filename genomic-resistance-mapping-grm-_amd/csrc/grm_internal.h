@@ -159,9 +159,13 @@ struct DictArgs {
     const uint64_t *in_flag_off;
 };
 void launch_dict_build(hipStream_t s, const DictArgs &a);
-// records a memo of 2^memo_log2 slots holds (7/16 of the slots), and its LDS bytes: 24 per record, 4 per slot, 16 of counters
-constexpr uint32_t dict_memo_entries(int memo_log2) { return memo_log2 > 0 ? (7u << memo_log2) >> 4 : 0u; }
-constexpr size_t dict_memo_bytes(int memo_log2) { return memo_log2 > 0 ? (size_t)dict_memo_entries(memo_log2) * 24 + ((size_t)4 << memo_log2) + 16 : 0; }
+// record memo of dict_build's record form: 5/8 * 2^memo_log2 records; LDS bytes: 40 per record (the record, the table slots of its
+// k-mers, its word), twice 2^memo_log2 slots of 4 bytes, 32 of counters -- and 2 per slot of the key table (slot of every entry id)
+constexpr uint32_t dict_memo_entries(int memo_log2) { return memo_log2 > 0 ? (5u << memo_log2) >> 3 : 0u; }
+constexpr size_t dict_memo_bytes(int memo_log2, uint32_t cap_log2)
+{
+    return memo_log2 > 0 ? (size_t)dict_memo_entries(memo_log2) * 40 + ((size_t)8 << memo_log2) + 32 + ((size_t)2 << cap_log2) : 0;
+}
 // local dictionary in bucket order: entries of workgroup wg copied to [ord_off[wg], ord_off[wg+1]) (ord_off = exclusive
 // scan of wg_cnt), and the first entry of every hash bucket (2^bb + 1 offsets)
 void launch_dict_export_ordered(hipStream_t s, const uint64_t *keys, const uint8_t *flags, const uint64_t *wg_base, const uint32_t *wg_cnt,

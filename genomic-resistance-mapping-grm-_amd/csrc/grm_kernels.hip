@@ -1096,6 +1096,7 @@ struct DictWave {
     int bb, sb;
     uint16_t *birth;
     uint32_t *need;
+    uint16_t *sid;          // table slot of entry id (record form with the memo: the word-row's end goes by id); nullptr: not kept
 };
 
 // J keys per lane (EMPTY_KEY = none) against the table: the table is consulted four keys at a time (the 16-byte reads
@@ -1152,6 +1153,7 @@ __device__ __forceinline__ void dict_probe(const DictWave &w, const uint64_t (&k
             if (ins) {
                 const uint32_t id = atomicAdd(w.n_distinct, 1u);
                 w.meta[slot] = (uint16_t)(id & META_ID);
+                if (w.sid && id <= w.cap_mask) w.sid[id] = (uint16_t)slot;
                 if (w.birth && id <= w.cap_mask) w.birth[((uint64_t)w.wg << w.cap_log2) + id] = (uint16_t)r;
                 over = id >= w.max_fill;
             }
@@ -1185,18 +1187,20 @@ __device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__
 // Genomes of one species share most of their sequence, and with it most of their run records: the SAME 16 bytes come
 // in from most genomes of a word-row.  The workgroup therefore keeps a small table of the distinct records it has met
 // (id = order of arrival) with one presence word per record; an occurrence of a held record costs one hash of 16 bytes,
-// one tag compare, one 16-byte compare and one OR -- instead of decoding its up to 8 k-mers and probing the key table
-// for each.  At the end of a word-row every held record is decoded ONCE and its word is ORed into its k-mers' words.
-// A record the table does not hold (table full, probe sequence too long, slot being written) goes the direct way, so
-// the memo is an accelerator and never a point of failure; a workgroup whose memo is full and rarely hit (unrelated
-// genomes) switches it off.
+// one 16-byte read of its bucket of four slots, one 16-byte compare and one OR -- instead of decoding its up to 8 k-mers
+// and probing the key table for each.  At the end of a word-row the word of every held record goes to its k-mers' words.
+// A record the table does not hold (table or bucket full, slot being written) goes the direct way, so the memo is an
+// accelerator and never a point of failure; a workgroup whose memo is full and rarely hit (unrelated genomes) switches
+// it off.
 constexpr uint32_t MEMO_NONE = 0xffffffffu, MEMO_LOCK = 0x0000ffffu;
 struct DictMemo {
-    uint32_t *slot;                 // [2^slot_log2]: 0 = empty, MEMO_LOCK = being written, else tag << 16 | id + 1
+    uint32_t *slot;                 // buckets of 4 slots: 0 = empty, MEMO_LOCK = being written, else tag << 16 | id + 1
     ulonglong2 *rec;                // [n_ent] the records, by id
     unsigned long long *words;      // [n_ent] presence word of the current word-row
-    uint32_t *ctl;                  // [0] records held, [1] memo in use, [2] occurrences found, [3] occurrences asked (of the row)
-    uint32_t n_ent, smask;
+    ulonglong2 *kslot;              // [n_ent] table slots of the record's up to 8 k-mers (16 bits each, 0xffff = none), once resolved
+    uint32_t *ctl;                  // [0] records held, [1] memo in use, [2] occurrences that went the direct way, [3] occurrences (of
+                                    // the row), [4] records whose k-mer slots are resolved (ids below it)
+    uint32_t n_ent, bmask;          // bmask: buckets - 1
 };
 __device__ __forceinline__ uint32_t memo_hash(uint64_t x, uint64_t y)
 {
@@ -1204,39 +1208,131 @@ __device__ __forceinline__ uint32_t memo_hash(uint64_t x, uint64_t y)
                        mul24((uint32_t)(y >> 40), 0xD6E8FFu) + mul24((uint32_t)(y >> 16), 0xA54FF5u) + mul24((uint32_t)y & 0xffffu, 0x3C6EF3u);
     return h ^ (h >> 13);
 }
-// id of the record (x, y) in the memo, entering it when there is room; MEMO_NONE: not held, take the direct way
+// The common case, straight-line: the record's bucket holds it.  ORs `bit` into its word and returns true then.
+__device__ __forceinline__ bool memo_hit(const DictMemo &M, uint64_t x, uint64_t y, unsigned long long bit)
+{
+    const uint32_t h = memo_hash(x, y);
+    const uint32_t tag = h >> 16;
+    const uint4 v = *reinterpret_cast<const uint4 *>(&M.slot[(h & M.bmask) << 2]);
+    uint32_t e = 0;
+    e = (v.w >> 16) == tag ? v.w : e;
+    e = (v.z >> 16) == tag ? v.z : e;
+    e = (v.y >> 16) == tag ? v.y : e;
+    e = (v.x >> 16) == tag ? v.x : e;
+    const uint32_t idp = e & 0xffffu;                   // id + 1 of the first slot with the tag (0: an empty slot or none; 0xffff: being written)
+    bool ok = idp != 0u && idp != 0xffffu;
+    const uint32_t id = ok ? idp - 1u : 0u;
+    const ulonglong2 held = M.rec[id];
+    ok = ok && held.x == x && held.y == y;
+    if (ok) atomicOr(&M.words[id], bit);
+    return ok;
+}
+// The rest (first occurrence of a record, a slot being written, a second slot with the same tag): id of the record, entering
+// it when bucket and memo have room; MEMO_NONE: not held, take the direct way
 __device__ __forceinline__ uint32_t memo_find_or_insert(const DictMemo &M, uint64_t x, uint64_t y)
 {
     const uint32_t h = memo_hash(x, y);
     const uint32_t tag = h >> 16;
-    uint32_t s = h & M.smask;
-    for (int p = 0; p < 6; p++) {
-        // (relaxed: the record is read through the id the slot word carries, and an acquire would also wait for the global
-        // loads in flight -- the next records)
-        uint32_t v = __hip_atomic_load(&M.slot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (v == 0) {
-            if (__hip_atomic_load(&M.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= M.n_ent) return MEMO_NONE;
-            v = atomicCAS(&M.slot[s], 0u, MEMO_LOCK);
+    // (its bucket, then the next one: a record that lives there is found here at every occurrence -- rare, and far cheaper
+    // than the direct way)
+    uint32_t *bucket = &M.slot[(h & M.bmask) << 2];
+    uint32_t *const bucket2 = &M.slot[((h + 1u) & M.bmask) << 2];
+    for (int p = 0; p < 8; p++) {
+        bool again = false;
+        for (int q = 0; q < 4; q++) {
+            // (relaxed: the record is read through the id the slot word carries, and an acquire would also wait for the global
+            // loads in flight -- the next records)
+            uint32_t v = lds_peek(&bucket[q]);
             if (v == 0) {
-                const uint32_t id = atomicAdd(&M.ctl[0], 1u);
-                if (id >= M.n_ent) return MEMO_NONE;          // (the slot stays locked: whoever reaches it goes the direct way)
-                M.rec[id] = make_ulonglong2(x, y);
-                // the record before the slot word that publishes it: LDS only (a plain release would drain the global loads too)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                __hip_atomic_store(&M.slot[s], (tag << 16) | (id + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return id;
+                if (lds_peek(&M.ctl[0]) >= M.n_ent) return MEMO_NONE;
+                v = atomicCAS(&bucket[q], 0u, MEMO_LOCK);
+                if (v == 0) {
+                    const uint32_t id = atomicAdd(&M.ctl[0], 1u);
+                    if (id >= M.n_ent) return MEMO_NONE;          // (the slot stays locked: whoever reaches it goes the direct way)
+                    M.rec[id] = make_ulonglong2(x, y);
+                    // the record before the slot word that publishes it: LDS only (a plain release would drain the global loads too)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                    __hip_atomic_store(&bucket[q], (tag << 16) | (id + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return id;
+                }
+            }
+            if (v == MEMO_LOCK) {           // being written (often by a lane of this wave with the same record): look again
+                again = true;
+                break;
+            }
+            if ((v >> 16) == tag) {
+                const uint32_t id = (v & 0xffffu) - 1u;
+                const ulonglong2 e = M.rec[id];
+                if (e.x == x && e.y == y) return id;
             }
         }
-        if (v == MEMO_LOCK) continue;       // being written (often by a lane of this wave with the same record): look again
-        if ((v >> 16) == tag) {
-            const uint32_t id = (v & 0xffffu) - 1u;
-            const ulonglong2 e = M.rec[id];
-            if (e.x == x && e.y == y) return id;
+        if (!again) {
+            if (bucket == bucket2) return MEMO_NONE;       // eight other records
+            bucket = bucket2;
         }
-        s = (s + 1) & M.smask;
     }
     return MEMO_NONE;
 }
+// slot of `key` in the workgroup's table, entering it if absent (entry id, birth row, fill limit as in dict_probe);
+// 0xffffffff: the table is full (the flag is set)
+__device__ __forceinline__ uint32_t dict_slot_of(const DictWave &w, uint64_t key, uint32_t r)
+{
+    bool ins;
+    const uint32_t slot = lds_pair_find_or_insert(w.tkeys, w.cap_mask, key, mix64(key), &ins);
+    bool over = slot == 0xffffffffu;
+    if (!over && ins) {
+        const uint32_t id = atomicAdd(w.n_distinct, 1u);
+        w.meta[slot] = (uint16_t)(id & META_ID);
+        if (w.sid && id <= w.cap_mask) w.sid[id] = (uint16_t)slot;
+        if (w.birth && id <= w.cap_mask) w.birth[((uint64_t)w.wg << w.cap_log2) + id] = (uint16_t)r;
+        over = id >= w.max_fill;
+    }
+    if (over) w.full.set(1);
+    return slot;
+}
+// End of a word-row: the word of every held record goes to the words of its k-mers.  The table slots of a record's k-mers
+// are resolved when the record is met here for the first time (decoded, every k-mer of this sub-bucket found or entered)
+// and kept, 16 bits each: afterwards a record costs one 16-byte read and up to 8 ORs per word-row.
+__device__ __forceinline__ void memo_flush_row(const DictWave &w, const DictMemo &M, uint32_t r, int kk, uint64_t kmask, int rcshift)
+{
+    const uint32_t held = min(M.ctl[0], M.n_ent), known = M.ctl[4];
+    for (uint32_t t0 = 0; t0 < held; t0 += blockDim.x) {
+        const uint32_t t = t0 + threadIdx.x;
+        unsigned long long wd = 0;
+        if (t < held) {
+            wd = M.words[t];
+            if (wd) M.words[t] = 0;
+        }
+        ulonglong2 ks = make_ulonglong2(~0ull, ~0ull);
+        if (t < held && t >= known) {
+            const ulonglong2 rec = M.rec[t];
+            const uint32_t len = (uint32_t)(rec.y & 0xffu);
+            RunDecoder dec = run_open(rec.x, rec.y, kk);
+            for (uint32_t tt = 0; tt < len; tt++) {
+                if (w.full) break;
+                const uint64_t key = run_canonical(dec);
+                run_next(dec, kmask, rcshift);
+                if (w.sb && hash_sub(mix64(key), w.bb, w.sb) != w.sub) continue;
+                const uint32_t slot = dict_slot_of(w, key, r);
+                if (slot == 0xffffffffu) break;
+                const unsigned long long put = ~((unsigned long long)(0xffffu ^ slot) << (16 * (tt & 3)));
+                if (tt < 4) ks.x &= put;
+                else ks.y &= put;
+            }
+            M.kslot[t] = ks;
+        } else if (wd) {
+            ks = M.kslot[t];
+        }
+        if (wd) {
+#pragma unroll
+            for (int tt = 0; tt < 8; tt++) {
+                const uint32_t slot = (uint32_t)((tt < 4 ? ks.x : ks.y) >> (16 * (tt & 3))) & 0xffffu;
+                if (slot != 0xffffu) atomicOr(&w.words[slot], wd);
+            }
+        }
+    }
+}
+
 // one record per lane (rec.y == 0: none), genome bit `bit` of word-row r: through the memo, or J keys to the table
 template <int J>
 __device__ __forceinline__ void dict_take_record(const DictWave &w, const DictMemo &M, bool memo_on, const ulonglong2 rec, unsigned long long bit,
@@ -1244,18 +1340,16 @@ __device__ __forceinline__ void dict_take_record(const DictWave &w, const DictMe
 {
     bool direct = rec.y != 0;
     if (memo_on) {
+        if (direct && memo_hit(M, rec.x, rec.y, bit)) direct = false;
+        if (!__ballot(direct)) return;
         const uint32_t id = direct ? memo_find_or_insert(M, rec.x, rec.y) : MEMO_NONE;
-        const unsigned long long asked = __ballot(direct);
         if (id != MEMO_NONE) {
             atomicOr(&M.words[id], bit);
             direct = false;
         }
         const unsigned long long left = __ballot(direct);
-        if (lane_id() == 0) {
-            atomicAdd(&M.ctl[2], (uint32_t)__popcll(asked) - (uint32_t)__popcll(left));
-            atomicAdd(&M.ctl[3], (uint32_t)__popcll(asked));
-        }
         if (!left) return;
+        if (lane_id() == 0) atomicAdd(&M.ctl[2], (uint32_t)__popcll(left));
     }
     const uint32_t len = (uint32_t)(rec.y & 0xffu);
     RunDecoder dec = run_open(rec.x, rec.y, kk);
@@ -1299,7 +1393,7 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     DictWave w;
     w.tkeys = tkeys; w.words = words; w.meta = meta; w.full = full; w.n_distinct = &n_distinct;
     w.cap_mask = cap_mask; w.max_fill = cap - (cap >> 3); w.cap_log2 = a.cap_log2;
-    w.wg = wg; w.sub = wg & ((1u << sb) - 1); w.G = G; w.bb = a.bb; w.sb = sb; w.birth = a.birth; w.need = a.need;
+    w.wg = wg; w.sub = wg & ((1u << sb) - 1); w.G = G; w.bb = a.bb; w.sb = sb; w.birth = a.birth; w.need = a.need; w.sid = nullptr;
     // segment of the NEXT genome is fetched while the current one is processed (the two dependent
     // global round trips -- bounds, then keys -- would otherwise serialise per genome).  Wave w takes
     // genomes w, w + nw, ...: since nw divides 64 that sequence walks the word-rows in step with the
@@ -1316,30 +1410,32 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     const uint64_t kmask = kk == 32 ? ~0ull : ((1ull << (2 * kk)) - 1);
     uint64_t *tabD = reinterpret_cast<uint64_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES) + 16 * wave;
     uint32_t *tabS = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)nw * 128) + 16 * wave;
-    // record memo (REC, a.memo_log2 > 0): 2^memo_log2 slots for 7/16 of that many records, behind the waves' pool tables
+    // record memo (REC, a.memo_log2 > 0): 5/8 * 2^memo_log2 records, twice 2^memo_log2 slots, behind the waves' pool tables
     DictMemo M;
-    M.smask = REC && a.memo_log2 ? (1u << a.memo_log2) - 1u : 0u;
+    M.bmask = REC && a.memo_log2 ? (1u << (a.memo_log2 - 1)) - 1u : 0u;          // 2^(memo_log2 + 1) slots in buckets of 4
     M.n_ent = REC && a.memo_log2 ? dict_memo_entries(a.memo_log2) : 0u;
     {
         uint8_t *mb = lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)nw * 192;
         M.rec = reinterpret_cast<ulonglong2 *>(mb);
-        M.words = reinterpret_cast<unsigned long long *>(mb + (size_t)M.n_ent * 16);
-        M.slot = reinterpret_cast<uint32_t *>(mb + (size_t)M.n_ent * 24);
-        M.ctl = M.slot + M.smask + 1;
+        M.kslot = reinterpret_cast<ulonglong2 *>(mb + (size_t)M.n_ent * 16);
+        M.words = reinterpret_cast<unsigned long long *>(mb + (size_t)M.n_ent * 32);
+        M.slot = reinterpret_cast<uint32_t *>(mb + (size_t)M.n_ent * 40);
+        M.ctl = M.slot + ((size_t)(M.bmask + 1) << 2);
     }
+    w.sid = REC && a.memo_log2 ? reinterpret_cast<uint16_t *>(M.ctl + 8) : nullptr;          // [cap]
     if (REC && a.memo_log2) {
-        for (uint32_t i = threadIdx.x; i <= M.smask; i += blockDim.x) M.slot[i] = 0;
+        for (uint32_t i = threadIdx.x; i < (M.bmask + 1) << 2; i += blockDim.x) M.slot[i] = 0;
         for (uint32_t i = threadIdx.x; i < M.n_ent; i += blockDim.x) M.words[i] = 0;
-        if (threadIdx.x == 0) { M.ctl[0] = 0; M.ctl[1] = 1; M.ctl[2] = 0; M.ctl[3] = 0; }
+        if (threadIdx.x == 0) { M.ctl[0] = 0; M.ctl[1] = 1; M.ctl[2] = 0; M.ctl[3] = 0; M.ctl[4] = 0; }
         __syncthreads();
     }
-    // record form: segment bounds of a wave's group of 8 (virtual) genomes x 2 length classes -- lane e < 16 holds those of genome e & 7
+    // record form: segment bounds of a wave's group of 8 (virtual) genomes -- lane e holds those of genome e & 7
     // (record segments come with offsets AND lengths -- regions leave gaps; read here without seg_bounds' cases, whose merges
     // would make the compiler wait for the loads on the spot)
     auto group_bounds = [&](uint32_t rr, uint32_t j0, uint64_t &sj, uint32_t &nj) {
         const uint32_t jj = (uint32_t)lane & 7u;
         const uint32_t vgj = ((rr * 64u) << pb) + (uint32_t)wave + (j0 + jj) * (uint32_t)nw;
-        const bool mine = rr < n_rows && lane < 16 && j0 + jj < per_row && vgj < GV;
+        const bool mine = rr < n_rows && j0 + jj < per_row && vgj < GV;          // (every lane: those of genome lane & 7)
         const uint64_t at = mine ? (uint64_t)vgj * B + b : 0;
         sj = mine ? a.seg.off[at] : 0ull;
         nj = mine ? a.seg.len[at] : 0u;
@@ -1368,7 +1464,43 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                 __asm__ volatile("" ::"v"(sj), "v"(nj));
                 if (j0 + 8 < per_row) group_bounds(r, j0 + 8, sj_n, nj_n);
                 else group_bounds(r + 1, 0, sj_n, nj_n);
-                const uint32_t n_all = nj & 0xffffu, n_short = nj >> 16;
+                if (memo_on) {
+                    // With the memo an occurrence is a lookup whatever its length: no classes, no pooling.  The 8 lanes
+                    // l & 7 == e take the records of genome e, 8 at a time (128 contiguous bytes); two batches are in flight.
+                    const uint32_t n_mine = nj & 0xffffu;
+                    uint32_t n_max = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) n_max = max(n_max, (uint32_t)__builtin_amdgcn_readlane((int)n_mine, e));
+                    const unsigned long long bit = 1ull << (63u - ((vgj >> pb) & 63u));
+                    {
+                        uint32_t n_sum = 0;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) n_sum += (uint32_t)__builtin_amdgcn_readlane((int)n_mine, e);
+                        if (lane == 0) atomicAdd(&M.ctl[3], n_sum);
+                    }
+                    // Four batches of 64 records are in flight per wave (the reads are 128-byte pieces of segments that lie
+                    // megabytes apart: latency, not bandwidth, is what they cost).  The loads are unconditional (index clamped,
+                    // validity applied at use) and the batches sit in four fixed registers, so that the wait for one batch
+                    // is a counted s_waitcnt that leaves the younger three in flight.
+                    const ulonglong2 *seg = a.recs + sj;
+                    const uint32_t i_mine = (uint32_t)lane >> 3, n_last = n_mine ? n_mine - 1u : 0u;
+                    ulonglong2 q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) q[u] = seg[min(i_mine + 8u * u, n_last)];
+                    for (uint32_t i = 0; i < n_max && !full; i += 32) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (i + 8u * u >= n_max) break;
+                            ulonglong2 rec = q[u];
+                            __asm__ volatile("" ::"v"(rec.x), "v"(rec.y));      // (the wait stands here, before the next load is issued)
+                            q[u] = seg[min(i_mine + i + 8u * u + 32u, n_last)];
+                            if (i_mine + i + 8u * u >= n_mine) rec.y = 0;
+                            dict_take_record<8>(w, M, true, rec, bit, r, kk, kmask, rcshift);
+                        }
+                    }
+                    continue;
+                }
+                const uint32_t n_all = lane < 16 ? nj & 0xffffu : 0u, n_short = lane < 16 ? nj >> 16 : 0u;
                 const uint32_t n32 = cls ? n_all - n_short : n_short;
                 const uint32_t inc = wave_scan_incl_dpp(n32);
                 const uint32_t cume = inc - n32;
@@ -1400,7 +1532,7 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                     const uint32_t sh = sh_n;
                     __asm__ volatile("" ::"v"(rec.x), "v"(rec.y));      // (as above: wait for this batch, then ask for the next)
                     fetch(q0 + 64u + (uint32_t)lane, NA, 0, rec_n, sh_n);
-                    dict_take_record<4>(w, M, memo_on, rec, 1ull << sh, r, kk, kmask, rcshift);
+                    dict_take_record<4>(w, M, false, rec, 1ull << sh, r, kk, kmask, rcshift);
                 }
                 // ---- the long ones: eight ----
                 rec_n = rec_l;
@@ -1410,7 +1542,7 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                     const uint32_t sh = sh_n;
                     __asm__ volatile("" ::"v"(rec.x), "v"(rec.y));
                     fetch(q0 + 64u + (uint32_t)lane, N, 8, rec_n, sh_n);
-                    dict_take_record<8>(w, M, memo_on, rec, 1ull << sh, r, kk, kmask, rcshift);
+                    dict_take_record<8>(w, M, false, rec, 1ull << sh, r, kk, kmask, rcshift);
                 }
             }
         } else {
@@ -1447,25 +1579,15 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
         __syncthreads();
         if (full) break;         // read between two barriers: uniform
         if (REC && a.memo_log2 && M.ctl[1]) {
-            // the records the memo holds: each decoded once, its word of this row ORed into the words of its k-mers
-            const uint32_t held = min(M.ctl[0], M.n_ent), found = M.ctl[2], asked = M.ctl[3];
-            for (uint32_t t0 = 0; t0 < held; t0 += blockDim.x) {
-                const uint32_t t = t0 + threadIdx.x;
-                const unsigned long long wd = t < held ? M.words[t] : 0ull;
-                if (!__ballot(wd != 0)) continue;
-                ulonglong2 rec = make_ulonglong2(0, 0);
-                if (wd) {
-                    rec = M.rec[t];
-                    M.words[t] = 0;
-                }
-                dict_take_record<8>(w, M, false, rec, wd, r, kk, kmask, rcshift);
-            }
+            const uint32_t held = min(M.ctl[0], M.n_ent), asked = M.ctl[3], found = asked - min(asked, M.ctl[2]);
+            memo_flush_row(w, M, r, kk, kmask, rcshift);
             __syncthreads();
             // full and hit by less than a quarter of the row's records: unrelated genomes, the memo only costs
             if (threadIdx.x == 0) {
                 if (held >= M.n_ent && found * 4u < asked) M.ctl[1] = 0;
                 M.ctl[2] = 0;
                 M.ctl[3] = 0;
+                M.ctl[4] = held;
                 if (a.memo_stats) {         // (diagnostics, GRM_MEMO_STATS: records held, occurrences asked / found, rows with the memo on)
                     atomicAdd(&a.memo_stats[0], (unsigned long long)held);
                     atomicAdd(&a.memo_stats[1], (unsigned long long)asked);
@@ -1475,7 +1597,21 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
             }
             if (full) break;
         }
-        // end of the word-row: publish and clear the words of every occupied slot
+        // end of the word-row: publish and clear the words of every occupied slot (by entry id where the slots of the ids are kept)
+        if (w.sid) {
+            const uint32_t nd = min(n_distinct, cap);
+            for (uint32_t id = threadIdx.x; id < nd; id += blockDim.x) {
+                const uint32_t slot = w.sid[id];
+                const unsigned long long wd = words[slot];
+                if (a.matrix_s) a.matrix_s[(((uint64_t)wg * n_rows + r) << a.cap_log2) + id] = wd;
+                if (wd) {
+                    const uint32_t m = meta[slot];
+                    const bool multi = (m & META_SEEN) || (wd & (wd - 1));
+                    meta[slot] = (uint16_t)(m | META_SEEN | (multi ? META_MULTI : 0u));
+                    words[slot] = 0;
+                }
+            }
+        } else
         for (uint32_t slot = threadIdx.x; slot < cap; slot += blockDim.x) {
             if (tkeys[slot] == EMPTY_KEY) continue;
             const unsigned long long wd = words[slot];
@@ -2130,7 +2266,7 @@ void launch_dict_build(hipStream_t s, const DictArgs &a)
     }
     if (a.recs) {                       // one record (up to 8 keys) per lane; 8 waves (the instance's launch bound)
         const size_t lds_r = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (size_t)(TABLE_THREADS / 64) * 192 +     // + the pool table of every wave
-                             dict_memo_bytes(a.memo_log2);                                                               // + the record memo
+                             dict_memo_bytes(a.memo_log2, a.cap_log2);                                                               // + the record memo
         hipLaunchKernelGGL((dict_build_kernel<8, 512, false, true>), grid, dim3(TABLE_THREADS), lds_r, s, a);
         return;
     }

@@ -79,7 +79,14 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     __syncthreads();
     uint32_t n_valid = 0;
     bool over = false;
-    for (uint64_t jbase = j_a; jbase < j_b; jbase += SK_THREADS) {
+    // Related genomes are the same sequence at the same window numbers: started together, their workgroups would store to the
+    // same places of their (equally laid out) regions at the same time.  Each workgroup starts its round through the part's
+    // steps somewhere else.
+    const uint32_t n_steps = (uint32_t)((j_b - j_a + SK_THREADS - 1) / SK_THREADS);
+    const uint32_t rot = n_steps ? (uint32_t)((vg * 0x9E3779B1u) >> 8) % n_steps : 0u;
+    for (uint32_t it = 0; it < n_steps; it++) {
+        const uint32_t st = it + rot < n_steps ? it + rot : it + rot - n_steps;
+        const uint64_t jbase = j_a + (uint64_t)st * SK_THREADS;
         const uint64_t j = jbase + threadIdx.x;
         const uint64_t p0 = lo + (j << 5);
         uint32_t valid = 0;
