@@ -122,6 +122,8 @@ def test_medium_pangenome_all_paths(ctx):
     {"rec_bucket_shift": 1}, {"bucket_bits": 6}, {"bucket_bits": 9, "sub_bits": 1},
     {"rec_part_bits": 1, "no_slots": 1},               # probing fill asked of a partition in parts: falls back to the key form
     {"cap_log2": 7}, {"cap_log2": 8, "rec_bucket_shift": 0},   # record form: tables overflow -> more buckets (level 2 again), then sub-buckets
+    {"rec_memo": 0}, {"rec_memo": 8}, {"rec_memo": 11},        # dict_build's record memo: none, smallest, largest
+    {"rec_memo": 8, "cap_log2": 9}, {"rec_memo": 9, "sub_bits": 2}, {"rec_memo": 10, "rec_part_bits": 2, "bucket_bits": 7},
 ])
 def test_medium_with_forced_geometry(ctx, opts):
     genomes = _medium_genomes(n=5, length=120_000, seed=9)
@@ -150,6 +152,36 @@ def test_record_form_over_k(ctx, k):
         finally:
             for name in opts:
                 ctx.set_option(name, -1)
+
+
+@pytest.mark.parametrize("opts", [{}, {"rec_memo": 8, "bucket_bits": 5}, {"rec_memo": 0}, {"rec_memo": 9, "bucket_bits": 9, "sub_bits": 1}])
+def test_record_memo_over_word_rows(ctx, opts):
+    """dict_build's record memo over several word-rows (150 related genomes = 3 rows: records met in row 0 are found again in
+    rows 1 and 2, their k-mers' table slots resolved once), with a memo far too small for its bucket (most occurrences go
+    the direct way next to the held ones), and with sub-buckets (a record's k-mers belong to different workgroups)"""
+    pg = synth.PanGenome(genome_len=24_000, n_snps=900, n_accessory=6, accessory_len=900, seed=77, n_contigs=2)
+    genomes = [[pg.genome(i).tobytes()] for i in range(150)]
+    try:
+        for name, v in opts.items():
+            ctx.set_option(name, v)
+        _check(ctx, genomes, 31, 1, True)
+        _check(ctx, genomes, 23, 1, False)
+    finally:
+        for name in opts:
+            ctx.set_option(name, -1)
+
+
+def test_record_memo_switches_itself_off_on_unrelated_genomes(ctx):
+    """unrelated genomes share no records: a small memo fills up in the first genomes, is hardly ever hit and is given up
+    by its workgroup after a word-row (the pooled two-class form takes over) -- same matrix"""
+    genomes = [[synth.random_genome(i, genome_len=16_000, seed=4321).tobytes()] for i in range(140)]
+    try:
+        ctx.set_option("rec_memo", 8)
+        ctx.set_option("bucket_bits", 4)
+        _check(ctx, genomes, 31, 1, False)
+    finally:
+        ctx.set_option("rec_memo", -1)
+        ctx.set_option("bucket_bits", -1)
 
 
 def test_record_form_gives_way_to_the_key_form_on_repeats(ctx):
