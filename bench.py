@@ -188,15 +188,22 @@ def roofline_of(kernels, traffic_of=None, occurrences=None, words=1):
     r = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
          "traffic": traffic, "traffic_source": "committed PMC passes of this workload (profiles/hbm_traffic.json)" if traffic else None,
          "avg_launch_ms": kernels[dom]["avg_ms"]}
-    if dom == "dict_build" and occurrences:
-        # dict_build IS stage 3 of SURVEY.md 8(d) (key + dictionary probe + output bit = 2W + 0.125 bytes per occurrence); in the
-        # record form it reaches the k-mers through ~2 bytes per occurrence of run records, so the bytes it moves
-        # ("moved") are far below the stage's figure and the kernel is bound by instruction issue, not by HBM
-        byts = (16.0 * words + 0.125) * occurrences
-        g = byts / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        r.update({"achieved": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "bytes_per_occurrence": 16.0 * words + 0.125,
-                  "definition": "SURVEY.md 8(d) stage 3 bytes per k-mer occurrence x occurrences of the launch / its duration",
-                  "moved_GBps": a, "moved_bytes": kernels[dom]["algo_bytes"]})
+    # SURVEY.md 8(d) prices the stages of a straightforward extract / sort / fill pipeline per k-mer occurrence (W = 8 B per word):
+    # 1 + W extract, 4W partition + sort, 2W + 1/8 fill.  The record form reaches the k-mers through ~3 bytes per occurrence of run
+    # records, so a kernel here moves far fewer bytes than the stage it stands for: `achieved` / `frac` above are the bytes THIS
+    # design's kernel must move over its duration; `survey_stage` is the stage's model bytes over the same
+    # duration (above 1.0: the kernel is done sooner than HBM at its peak could move the model's bytes).
+    stage = {"superkmer_l1": ("extract (write W) + first partition pass (read W + write W)", 3 * 8.0 * words),
+             "kmer_scatter_l1": ("extract (write W) + first partition pass (read W + write W)", 3 * 8.0 * words),
+             "dict_build": ("fill: key + dictionary probe + output bit", 16.0 * words + 0.125)}.get(dom)
+    if stage and occurrences:
+        g = stage[1] * occurrences / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        r["survey_stage"] = {"stage": stage[0], "bytes_per_occurrence": stage[1], "achieved": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4)}
+    limits = {"superkmer_l1": "VALU issue: 4.2e9 wave instructions = 6.8 of its 9.9 ms (minimizers of 52 m-mers per 32 positions in registers); "
+                              "writes 1.57x its records as partial lines (profiles/r02/final_sq_counters.csv, final_pmc_hbm.csv)",
+              "dict_build": "latency of 128-byte reads of segments megabytes apart + LDS lookups, 4 waves per SIMD (profiles/r02/final_sq_counters.csv)"}
+    if dom in limits and traffic:           # (the committed profile is of this very workload)
+        r["limited_by"] = limits[dom]
     return r
 
 
