@@ -7,7 +7,7 @@
 // minimizer partitions [EXT]).  A run of up to 8 consecutive valid k-mer starts with the same bucket travels through
 // level 1 as ONE 16-byte record that carries its own bases:
 //     x            bases 0..31 of the run, MSB-first
-//     y[63..34]    bases 32..46                        (len + k - 1 <= 39 bases)
+//     y[63..34]    bases 32..46                        (len + k - 1 <= 39 bases; y[33..16]: the bases that follow in the window, unused)
 //     y[14..8]     7 bucket bits below the coarse ones (level 2 uses the top bb - b1 of them)
 //     y[7..0]      len = k-mers in the run (1..8)
 // so 8 B per k-mer become ~3 B.  Level 2 owns a (genome part, coarse bucket) region: it sorts the region's records by fine
@@ -48,8 +48,8 @@ struct SkArgs {
 // ---- level 1 -----------------------------------------------------------------------------------------------------
 // One workgroup per (genome, part) = "virtual genome" vg: it owns the part's 2^b1 coarse regions of records1, so the
 // place of a record needs no global atomic (a returning global atomic per record measured 20 ms for 6e8 records, and an
-// add per wave to ONE global counter 28 ms: same-address atomics serialise in L2).  Per step a thread takes one packed
-// word (32 start positions): minimizer bucket of every valid k-mer start (W = k - SK_M + 1 m-mers per k-mer; template:
+// add per wave to ONE global counter 28 ms: same-address atomics serialise in L2).  Per step a thread takes one window
+// of 32 start positions of its genome (below): minimizer bucket of every valid k-mer start (W = k - SK_M + 1 m-mers per k-mer; template:
 // the window minimum is a fixed pattern of register moves), runs -> records, each stored at the LDS cursor of its
 // coarse region.  (A counting sort of the step's records in LDS, one contiguous run per coarse bucket on the way out,
 // measured 11.9 ms against this form's time: the two extra passes over the runs cost more than the partial lines.)
