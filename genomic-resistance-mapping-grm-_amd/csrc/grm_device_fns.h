@@ -148,7 +148,7 @@ GRM_HD uint32_t minimizer_bucket_of_kmer(uint64_t key, int k, int bb, int m_len 
 
 // ---- run records (record form of the partition): per-lane logic of grm_superkmer.hip and of dict_build's decoder ----
 constexpr int RUN_PPT = 32;          // k-mer start positions a thread takes per step: one packed word
-constexpr int RUN_LMAX = 8;          // k-mers per record
+constexpr int RUN_LMAX = 16;         // k-mers per record (k + 15 <= 47 bases fit x and y[63..34])
 constexpr int RUN_FINE_BITS = 7;     // bucket bits a record carries below the coarse ones
 
 // Buckets (nbits bits) of the 32 k-mers starting at the symbols of w0 (w1 = the next packed word), k = W + M - 1:

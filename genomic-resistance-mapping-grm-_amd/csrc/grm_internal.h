@@ -159,12 +159,13 @@ struct DictArgs {
     const uint64_t *in_flag_off;
 };
 void launch_dict_build(hipStream_t s, const DictArgs &a);
-// record memo of dict_build's record form: 5/8 * 2^memo_log2 records; LDS bytes: 40 per record (the record, the table slots of its
-// k-mers, its word), twice 2^memo_log2 slots of 4 bytes, 32 of counters -- and 2 per slot of the key table (slot of every entry id)
-constexpr uint32_t dict_memo_entries(int memo_log2) { return memo_log2 > 0 ? (5u << memo_log2) >> 3 : 0u; }
+// record memo of dict_build's record form: 15/32 * 2^memo_log2 records; LDS bytes: 56 per record (the record, the 16 table slots of
+// its k-mers, its word), twice 2^memo_log2 slots of 4 bytes, 32 of counters -- and 2 per slot of the key table (slot of every entry
+// id).  (2^10: 480 records, 39.2 KB; with the 2048-slot key table 77.7 KB: two workgroups share a CU.)
+constexpr uint32_t dict_memo_entries(int memo_log2) { return memo_log2 > 0 ? (15u << memo_log2) >> 5 : 0u; }
 constexpr size_t dict_memo_bytes(int memo_log2, uint32_t cap_log2)
 {
-    return memo_log2 > 0 ? (size_t)dict_memo_entries(memo_log2) * 40 + ((size_t)8 << memo_log2) + 32 + ((size_t)2 << cap_log2) : 0;
+    return memo_log2 > 0 ? (size_t)dict_memo_entries(memo_log2) * 56 + ((size_t)8 << memo_log2) + 32 + ((size_t)2 << cap_log2) : 0;
 }
 // local dictionary in bucket order: entries of workgroup wg copied to [ord_off[wg], ord_off[wg+1]) (ord_off = exclusive
 // scan of wg_cnt), and the first entry of every hash bucket (2^bb + 1 offsets)

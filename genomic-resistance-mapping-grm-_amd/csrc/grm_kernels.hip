@@ -1197,7 +1197,7 @@ struct DictMemo {
     uint32_t *slot;                 // buckets of 4 slots: 0 = empty, MEMO_LOCK = being written, else tag << 16 | id + 1
     ulonglong2 *rec;                // [n_ent] the records, by id
     unsigned long long *words;      // [n_ent] presence word of the current word-row
-    ulonglong2 *kslot;              // [n_ent] table slots of the record's up to 8 k-mers (16 bits each, 0xffff = none), once resolved
+    ulonglong2 *kslot;              // [2 n_ent] table slots of the record's up to 16 k-mers (16 bits each, 0xffff = none), once resolved
     uint32_t *ctl;                  // [0] records held, [1] memo in use, [2] occurrences that went the direct way, [3] occurrences (of
                                     // the row), [4] records whose k-mer slots are resolved (ids below it)
     uint32_t n_ent, bmask;          // bmask: buckets - 1
@@ -1303,7 +1303,7 @@ __device__ __forceinline__ void memo_flush_row(const DictWave &w, const DictMemo
             wd = M.words[t];
             if (wd) M.words[t] = 0;
         }
-        ulonglong2 ks = make_ulonglong2(~0ull, ~0ull);
+        unsigned long long k0 = ~0ull, k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;          // (four scalars: an indexed array would live in scratch)
         if (t < held && t >= known) {
             const ulonglong2 rec = M.rec[t];
             const uint32_t len = (uint32_t)(rec.y & 0xffu);
@@ -1316,17 +1316,23 @@ __device__ __forceinline__ void memo_flush_row(const DictWave &w, const DictMemo
                 const uint32_t slot = dict_slot_of(w, key, r);
                 if (slot == 0xffffffffu) break;
                 const unsigned long long put = ~((unsigned long long)(0xffffu ^ slot) << (16 * (tt & 3)));
-                if (tt < 4) ks.x &= put;
-                else ks.y &= put;
+                const uint32_t qd = tt >> 2;
+                k0 &= qd == 0u ? put : ~0ull;
+                k1 &= qd == 1u ? put : ~0ull;
+                k2 &= qd == 2u ? put : ~0ull;
+                k3 &= qd == 3u ? put : ~0ull;
             }
-            M.kslot[t] = ks;
+            M.kslot[2 * t] = make_ulonglong2(k0, k1);
+            M.kslot[2 * t + 1] = make_ulonglong2(k2, k3);
         } else if (wd) {
-            ks = M.kslot[t];
+            const ulonglong2 lo = M.kslot[2 * t], hi = M.kslot[2 * t + 1];
+            k0 = lo.x; k1 = lo.y; k2 = hi.x; k3 = hi.y;
         }
         if (wd) {
 #pragma unroll
-            for (int tt = 0; tt < 8; tt++) {
-                const uint32_t slot = (uint32_t)((tt < 4 ? ks.x : ks.y) >> (16 * (tt & 3))) & 0xffffu;
+            for (int tt = 0; tt < RUN_LMAX; tt++) {
+                const unsigned long long kq = tt < 4 ? k0 : tt < 8 ? k1 : tt < 12 ? k2 : k3;
+                const uint32_t slot = (uint32_t)(kq >> (16 * (tt & 3))) & 0xffffu;
                 if (slot != 0xffffu) atomicOr(&w.words[slot], wd);
             }
         }
@@ -1361,12 +1367,24 @@ __device__ __forceinline__ void dict_take_record(const DictWave &w, const DictMe
         kv[t] = run_canonical(dec);          // (past the record's last k-mer: not live)
     }
     dict_probe<J, false, true>(w, kv, 0u, 0u, r, bit, direct ? (1u << len) - 1u : 0u);
+    if (J == 8 && RUN_LMAX > 8) {
+        // a record holds up to 16 k-mers: the second eight, where a lane of the wave has them
+        const uint32_t live2 = direct ? ((1u << len) - 1u) >> 8 : 0u;
+        if (!__ballot(live2 != 0)) return;
+        uint64_t kv2[J];
+#pragma unroll
+        for (int t = 0; t < J; t++) {
+            run_next(dec, kmask, rcshift);
+            kv2[t] = run_canonical(dec);
+        }
+        dict_probe<J, false, true>(w, kv2, 0u, 0u, r, bit, live2);
+    }
 }
 
 // MAXT: largest workgroup the instance is launched with (the 8-deep form needs more than the 128 VGPRs a
 // 1024-thread workgroup leaves per lane)
 template <int KIF, int MAXT, bool FLAGS, bool REC>
-__global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
+__global__ __launch_bounds__(MAXT, 4) void dict_build_kernel(const DictArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t cap = 1u << a.cap_log2, cap_mask = cap - 1;
@@ -1410,7 +1428,7 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
     const uint64_t kmask = kk == 32 ? ~0ull : ((1ull << (2 * kk)) - 1);
     uint64_t *tabD = reinterpret_cast<uint64_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES) + 16 * wave;
     uint32_t *tabS = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)nw * 128) + 16 * wave;
-    // record memo (REC, a.memo_log2 > 0): 5/8 * 2^memo_log2 records, twice 2^memo_log2 slots, behind the waves' pool tables
+    // record memo (REC, a.memo_log2 > 0): 15/32 * 2^memo_log2 records, twice 2^memo_log2 slots, behind the waves' pool tables
     DictMemo M;
     M.bmask = REC && a.memo_log2 ? (1u << (a.memo_log2 - 1)) - 1u : 0u;          // 2^(memo_log2 + 1) slots in buckets of 4
     M.n_ent = REC && a.memo_log2 ? dict_memo_entries(a.memo_log2) : 0u;
@@ -1418,8 +1436,8 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
         uint8_t *mb = lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)nw * 192;
         M.rec = reinterpret_cast<ulonglong2 *>(mb);
         M.kslot = reinterpret_cast<ulonglong2 *>(mb + (size_t)M.n_ent * 16);
-        M.words = reinterpret_cast<unsigned long long *>(mb + (size_t)M.n_ent * 32);
-        M.slot = reinterpret_cast<uint32_t *>(mb + (size_t)M.n_ent * 40);
+        M.words = reinterpret_cast<unsigned long long *>(mb + (size_t)M.n_ent * 48);
+        M.slot = reinterpret_cast<uint32_t *>(mb + (size_t)M.n_ent * 56);
         M.ctl = M.slot + ((size_t)(M.bmask + 1) << 2);
     }
     w.sid = REC && a.memo_log2 ? reinterpret_cast<uint16_t *>(M.ctl + 8) : nullptr;          // [cap]
@@ -1487,16 +1505,19 @@ __global__ __launch_bounds__(MAXT) void dict_build_kernel(const DictArgs a)
                     ulonglong2 q[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) q[u] = seg[min(i_mine + 8u * u, n_last)];
+                    // (the four steps written out: left to the unroller, a body this size stays a loop and q[] goes to scratch)
+                    auto step = [&](ulonglong2 &qu, uint32_t at) {
+                        ulonglong2 rec = qu;
+                        __asm__ volatile("" ::"v"(rec.x), "v"(rec.y));      // (the wait stands here, before the next load is issued)
+                        qu = seg[min(i_mine + at + 32u, n_last)];
+                        if (i_mine + at >= n_mine) rec.y = 0;
+                        dict_take_record<8>(w, M, true, rec, bit, r, kk, kmask, rcshift);
+                    };
                     for (uint32_t i = 0; i < n_max && !full; i += 32) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            if (i + 8u * u >= n_max) break;
-                            ulonglong2 rec = q[u];
-                            __asm__ volatile("" ::"v"(rec.x), "v"(rec.y));      // (the wait stands here, before the next load is issued)
-                            q[u] = seg[min(i_mine + i + 8u * u + 32u, n_last)];
-                            if (i_mine + i + 8u * u >= n_mine) rec.y = 0;
-                            dict_take_record<8>(w, M, true, rec, bit, r, kk, kmask, rcshift);
-                        }
+                        step(q[0], i);
+                        if (i + 8u < n_max) step(q[1], i + 8u);
+                        if (i + 16u < n_max) step(q[2], i + 16u);
+                        if (i + 24u < n_max) step(q[3], i + 24u);
                     }
                     continue;
                 }

@@ -259,7 +259,7 @@ def test_run_records_decode_to_the_oracles_kmers(emul, k):
     vals, counts = np.unique(keys[:n], return_counts=True)
     assert nocc == n and (vals == km[:, 0]).all() and (counts == ct).all()
     lens = lens[:n_rec.value]
-    assert lens.sum() == n and lens.min() >= 1 and lens.max() <= 8
+    assert lens.sum() == n and lens.min() >= 1 and lens.max() <= 16
     nbits = coarse_bits + 7
     for i in rng.randint(0, n, size=400):
         assert emul.emul_minimizer_bucket_of_kmer(int(keys[i]), k, nbits) == int(buckets[i])
