@@ -127,7 +127,7 @@ void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const SegLayout &se
 struct DictArgs {
     const uint64_t *keys;
     int part_bits;          // segments of 2^part_bits parts per genome: segment index = ((genome << part_bits) + part) * 2^bb + bucket
-    // record form: the segments hold the 16-byte run records of grm_superkmer.hip (1..8 k-mers each) instead of keys,
+    // record form: the segments hold the 16-byte run records of grm_superkmer.hip (1..16 k-mers each) instead of keys,
     // seg counts records; k as given (keys == nullptr then)
     const ulonglong2 *recs;
     int k;

@@ -1187,7 +1187,7 @@ __device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__
 // Genomes of one species share most of their sequence, and with it most of their run records: the SAME 16 bytes come
 // in from most genomes of a word-row.  The workgroup therefore keeps a small table of the distinct records it has met
 // (id = order of arrival) with one presence word per record; an occurrence of a held record costs one hash of 16 bytes,
-// one 16-byte read of its bucket of four slots, one 16-byte compare and one OR -- instead of decoding its up to 8 k-mers
+// one 16-byte read of its bucket of four slots, one 16-byte compare and one OR -- instead of decoding its up to 16 k-mers
 // and probing the key table for each.  At the end of a word-row the word of every held record goes to its k-mers' words.
 // A record the table does not hold (table or bucket full, slot being written) goes the direct way, so the memo is an
 // accelerator and never a point of failure; a workgroup whose memo is full and rarely hit (unrelated genomes) switches
@@ -1292,7 +1292,7 @@ __device__ __forceinline__ uint32_t dict_slot_of(const DictWave &w, uint64_t key
 }
 // End of a word-row: the word of every held record goes to the words of its k-mers.  The table slots of a record's k-mers
 // are resolved when the record is met here for the first time (decoded, every k-mer of this sub-bucket found or entered)
-// and kept, 16 bits each: afterwards a record costs one 16-byte read and up to 8 ORs per word-row.
+// and kept, 16 bits each: afterwards a record costs two 16-byte reads and up to 16 ORs per word-row.
 __device__ __forceinline__ void memo_flush_row(const DictWave &w, const DictMemo &M, uint32_t r, int kk, uint64_t kmask, int rcshift)
 {
     const uint32_t held = min(M.ctl[0], M.n_ent), known = M.ctl[4];
@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(MAXT, 4) void dict_build_kernel(const DictArgs a)
     if (REC) group_bounds(0, 0, sj_n, nj_n);
     for (uint32_t r = 0; r < n_rows; r++) {
         if (REC) {
-            // Record form.  A record holds a run of 1..8 consecutive k-mers with their bases; ONE LANE decodes one record
+            // Record form.  A record holds a run of 1..16 consecutive k-mers with their bases; ONE LANE decodes one record
             // (first k-mer by a shift and a reverse complement, the others by rolling both words) and takes its keys to
             // the table.  A segment holds its records of at most 4 k-mers first: those go four keys at a time, the others
             // eight at a time (one size for all would leave a third of the key slots empty).  The records of the wave's
@@ -2285,7 +2285,7 @@ void launch_dict_build(hipStream_t s, const DictArgs &a)
         GRM_LAUNCH_DICT(4, 1024, true, false);
         return;
     }
-    if (a.recs) {                       // one record (up to 8 keys) per lane; 8 waves (the instance's launch bound)
+    if (a.recs) {                       // one record (up to 16 keys) per lane; 8 waves (the instance's launch bound)
         const size_t lds_r = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (size_t)(TABLE_THREADS / 64) * 192 +     // + the pool table of every wave
                              dict_memo_bytes(a.memo_log2, a.cap_log2);                                                               // + the record memo
         hipLaunchKernelGGL((dict_build_kernel<8, 512, false, true>), grid, dim3(TABLE_THREADS), lds_r, s, a);

@@ -4,13 +4,13 @@
 // level 1, read and written by level 2, read by the consumer -- 160 GB per 1000 x 5 Mbp.  Here the bucket of a k-mer
 // is a function of its MINIMIZER -- the canonical 11-mer with the smallest hash among the k - 10 it contains -- so
 // consecutive k-mers of a sequence share their bucket for (k - 9) / 2 positions on average (what DSK itself does with its
-// minimizer partitions [EXT]).  A run of up to 8 consecutive valid k-mer starts with the same bucket travels through
+// minimizer partitions [EXT]).  A run of up to 16 consecutive valid k-mer starts with the same bucket travels through
 // level 1 as ONE 16-byte record that carries its own bases:
 //     x            bases 0..31 of the run, MSB-first
-//     y[63..34]    bases 32..46                        (len + k - 1 <= 39 bases; y[33..16]: the bases that follow in the window, unused)
+//     y[63..34]    bases 32..46                        (len + k - 1 <= 47 bases; y[33..16]: the bases that follow in the window, unused)
 //     y[14..8]     7 bucket bits below the coarse ones (level 2 uses the top bb - b1 of them)
-//     y[7..0]      len = k-mers in the run (1..8)
-// so 8 B per k-mer become ~3 B.  Level 2 owns a (genome part, coarse bucket) region: it sorts the region's records by fine
+//     y[7..0]      len = k-mers in the run (1..16)
+// so 8 B per k-mer become ~2.2 B.  Level 2 owns a (genome part, coarse bucket) region: it sorts the region's records by fine
 // bucket (and short / long) for dict_build's record form, which decodes them itself; for a consumer that needs keys (the
 // probing fill) a second form of level 2 EXPANDS them to canonical k-mers on the way out, leaving the same bucket-sorted
 // key segments as the key form.  A k-mer and its reverse
@@ -32,7 +32,7 @@ constexpr int SK_FINE_BITS = RUN_FINE_BITS;           // a record carries 7 buck
 constexpr int SK_MAX_BITS = 9 + SK_FINE_BITS;         // at most 9 coarse bits (SK_THREADS cursors) + the fine field
 constexpr int SK2_THREADS = 256;
 constexpr int SK2R_THREADS = 512;                     // level 2, records only
-constexpr int SK2_TILE_KEYS = SK2_THREADS * SK_LMAX;                // one record per thread: at most 4096 keys = 32 KB of LDS per tile
+constexpr int SK2_TILE_KEYS = SK2_THREADS * SK_LMAX;                // one record per thread: at most 256 x 16 keys = 32 KB of LDS per tile
 
 struct SkArgs {
     const uint64_t *sym2;
@@ -163,7 +163,7 @@ __device__ __forceinline__ uint32_t rec_fine(uint64_t y, int b2) { return (((uin
 // records are requested before the current one is worked on).  A record's k-mers go to ONE fine bucket, so the rank of
 // the record inside its bucket (one returning LDS atomic per record) places all of them.  A lane rolls through its record
 // (forward and reverse-complement words, as the key form's extraction does) and stores the canonical k-mers into the
-// tile's LDS image, which leaves as one contiguous run per fine bucket.  Records hold 1..8 k-mers: the tile's records are
+// tile's LDS image, which leaves as one contiguous run per fine bucket.  Records hold 1..16 k-mers: the tile's records are
 // first sorted by length (a counting sort through LDS), so that the lanes of a wave roll for about the same number of
 // steps -- unsorted, a third of the lanes idle.
 __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglong2 *__restrict__ recs1, uint32_t rstride,
