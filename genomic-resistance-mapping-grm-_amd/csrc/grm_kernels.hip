@@ -1296,45 +1296,41 @@ __device__ __forceinline__ uint32_t dict_slot_of(const DictWave &w, uint64_t key
 __device__ __forceinline__ void memo_flush_row(const DictWave &w, const DictMemo &M, uint32_t r, int kk, uint64_t kmask, int rcshift)
 {
     const uint32_t held = min(M.ctl[0], M.n_ent), known = M.ctl[4];
-    for (uint32_t t0 = 0; t0 < held; t0 += blockDim.x) {
-        const uint32_t t = t0 + threadIdx.x;
-        unsigned long long wd = 0;
-        if (t < held) {
-            wd = M.words[t];
-            if (wd) M.words[t] = 0;
-        }
+    // records met for the first time in this word-row: one lane resolves one record
+    for (uint32_t t = known + threadIdx.x; t < held; t += blockDim.x) {
         unsigned long long k0 = ~0ull, k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;          // (four scalars: an indexed array would live in scratch)
-        if (t < held && t >= known) {
-            const ulonglong2 rec = M.rec[t];
-            const uint32_t len = (uint32_t)(rec.y & 0xffu);
-            RunDecoder dec = run_open(rec.x, rec.y, kk);
-            for (uint32_t tt = 0; tt < len; tt++) {
-                if (w.full) break;
-                const uint64_t key = run_canonical(dec);
-                run_next(dec, kmask, rcshift);
-                if (w.sb && hash_sub(mix64(key), w.bb, w.sb) != w.sub) continue;
-                const uint32_t slot = dict_slot_of(w, key, r);
-                if (slot == 0xffffffffu) break;
-                const unsigned long long put = ~((unsigned long long)(0xffffu ^ slot) << (16 * (tt & 3)));
-                const uint32_t qd = tt >> 2;
-                k0 &= qd == 0u ? put : ~0ull;
-                k1 &= qd == 1u ? put : ~0ull;
-                k2 &= qd == 2u ? put : ~0ull;
-                k3 &= qd == 3u ? put : ~0ull;
-            }
-            M.kslot[2 * t] = make_ulonglong2(k0, k1);
-            M.kslot[2 * t + 1] = make_ulonglong2(k2, k3);
-        } else if (wd) {
-            const ulonglong2 lo = M.kslot[2 * t], hi = M.kslot[2 * t + 1];
-            k0 = lo.x; k1 = lo.y; k2 = hi.x; k3 = hi.y;
+        const ulonglong2 rec = M.rec[t];
+        const uint32_t len = (uint32_t)(rec.y & 0xffu);
+        RunDecoder dec = run_open(rec.x, rec.y, kk);
+        for (uint32_t tt = 0; tt < len; tt++) {
+            if (w.full) break;
+            const uint64_t key = run_canonical(dec);
+            run_next(dec, kmask, rcshift);
+            if (w.sb && hash_sub(mix64(key), w.bb, w.sb) != w.sub) continue;
+            const uint32_t slot = dict_slot_of(w, key, r);
+            if (slot == 0xffffffffu) break;
+            const unsigned long long put = ~((unsigned long long)(0xffffu ^ slot) << (16 * (tt & 3)));
+            const uint32_t qd = tt >> 2;
+            k0 &= qd == 0u ? put : ~0ull;
+            k1 &= qd == 1u ? put : ~0ull;
+            k2 &= qd == 2u ? put : ~0ull;
+            k3 &= qd == 3u ? put : ~0ull;
         }
-        if (wd) {
+        M.kslot[2 * t] = make_ulonglong2(k0, k1);
+        M.kslot[2 * t + 1] = make_ulonglong2(k2, k3);
+    }
+    if (held > known) lds_barrier();         // (uniform: both read between the caller's barriers)
+    // every held record: two lanes (of one wave) take its word to the slots of its first and its second eight k-mers
+    for (uint32_t t2 = threadIdx.x; t2 < 2u * held; t2 += blockDim.x) {
+        const uint32_t t = t2 >> 1, half = t2 & 1u;
+        const unsigned long long wd = M.words[t];
+        if (!wd) continue;
+        const ulonglong2 ks = M.kslot[2 * t + half];
+        if (half == 0) M.words[t] = 0;           // (its partner lane has read the word: same instruction, same wave)
 #pragma unroll
-            for (int tt = 0; tt < RUN_LMAX; tt++) {
-                const unsigned long long kq = tt < 4 ? k0 : tt < 8 ? k1 : tt < 12 ? k2 : k3;
-                const uint32_t slot = (uint32_t)(kq >> (16 * (tt & 3))) & 0xffffu;
-                if (slot != 0xffffu) atomicOr(&w.words[slot], wd);
-            }
+        for (int tt = 0; tt < 8; tt++) {
+            const uint32_t slot = (uint32_t)((tt < 4 ? ks.x : ks.y) >> (16 * (tt & 3))) & 0xffffu;
+            if (slot != 0xffffu) atomicOr(&w.words[slot], wd);
         }
     }
 }
