@@ -151,25 +151,33 @@ constexpr int RUN_PPT = 32;          // k-mer start positions a thread takes per
 constexpr int RUN_LMAX = 16;         // k-mers per record (k + 15 <= 47 bases fit x and y[63..34])
 constexpr int RUN_FINE_BITS = 7;     // bucket bits a record carries below the coarse ones
 
+// `len` symbols (len <= 16) from symbol offset `off` of the 64 symbols held MSB-first in the four words d[0..3]; with off and
+// len known at compile time (unrolled callers) this is one bit-field extract, or a funnel shift and a mask
+GRM_HD uint32_t sym_field(const uint32_t (&d)[4], int off, int len)
+{
+    const int b = 2 * off, j = b >> 5, sh = b & 31, nb = 2 * len;
+    const uint64_t win = ((uint64_t)d[j] << 32) | (uint64_t)(j + 1 < 4 ? d[j + 1] : 0u);
+    return (uint32_t)(win >> (64 - sh - nb)) & ((1u << nb) - 1u);
+}
 // Buckets (nbits bits) of the 32 k-mers starting at the symbols of w0 (w1 = the next packed word), k = W + M - 1:
-// hashes of the 32 + W - 1 canonical M-mers (rolling forward / reverse-complement words), minimum over windows of W by
-// doubling (h[i] = min over [i, i + span)), then two overlapping spans.  Fully unrolled: everything stays in registers.
+// hashes of the 32 + W - 1 canonical M-mers (fields of the two words and of their reverse complement), minimum over windows of W
+// by doubling (h[i] = min over [i, i + span)), then two overlapping spans.  Fully unrolled: everything stays in registers.
 template <int W, int M = 11>
 GRM_HD void run_buckets(uint64_t w0, uint64_t w1, int nbits, uint32_t (&bk)[RUN_PPT])
 {
     constexpr int NM = RUN_PPT + W - 1;
+    static_assert(NM + M - 1 <= 64, "the m-mers of a thread's window lie inside its two words");
     uint32_t h[NM];
-    constexpr uint32_t mmask = (1u << (2 * M)) - 1;
-    uint32_t f = (uint32_t)(w0 >> (64 - 2 * (M - 1)));
-    uint32_t r = (uint32_t)(revcomp_m(f, M - 1) << 2);
+    // m-mer q = symbols q .. q + M - 1 of (w0 : w1); its reverse complement = symbols 64 - M - q .. of the reverse complement of
+    // the 64 symbols, rc(w1) : rc(w0).  Both are fields at fixed offsets: no rolling words.
+    const uint64_t r1 = revcomp_m(w1, 32), r0 = revcomp_m(w0, 32);
+    const uint32_t df[4] = {(uint32_t)(w0 >> 32), (uint32_t)w0, (uint32_t)(w1 >> 32), (uint32_t)w1};
+    const uint32_t dr[4] = {(uint32_t)(r1 >> 32), (uint32_t)r1, (uint32_t)(r0 >> 32), (uint32_t)r0};
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int q = 0; q < NM; q++) {
-        const int si = q + M - 1;               // index of the symbol that completes m-mer q (static)
-        const uint32_t s = si < 32 ? (uint32_t)(w0 >> (62 - 2 * si)) & 3u : (uint32_t)(w1 >> (62 - 2 * (si - 32))) & 3u;
-        f = ((f << 2) | s) & mmask;
-        r = (r >> 2) | ((s ^ 2u) << (2 * (M - 1)));
+        const uint32_t f = sym_field(df, q, M), r = sym_field(dr, 64 - M - q, M);
         h[q] = minimizer_hash(f < r ? f : r);
     }
     constexpr int LV = W >= 16 ? 4 : W >= 8 ? 3 : W >= 4 ? 2 : W >= 2 ? 1 : 0;
@@ -205,11 +213,20 @@ GRM_HD uint32_t run_heads(uint32_t valid, const uint32_t (&bk)[RUN_PPT])
         const bool hd = vi && (i == 0 || !((valid >> (i > 0 ? i - 1 : 0)) & 1u) || bk[i] != bk[i > 0 ? i - 1 : 0]);
         heads |= (uint32_t)hd << i;
     }
+    if (2 * RUN_LMAX >= RUN_PPT && (RUN_LMAX & (RUN_LMAX - 1)) == 0) {
+        // at most ONE start can be RUN_LMAX positions behind the last head (a second one would lie beyond the word): the lowest
+        // valid start that no head of the RUN_LMAX positions up to it covers
+        uint32_t cover = heads;
+        for (int d = 1; d < RUN_LMAX; d <<= 1) cover |= cover << d;          // bit i: a head in [i - RUN_LMAX + 1, i]
+        const uint32_t cand = valid & ~cover & ~((1u << RUN_LMAX) - 1u);
+        heads |= cand & (0u - cand);
+    } else {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = RUN_LMAX; i < RUN_PPT; i++) {
-        if (((valid >> i) & 1u) && ((heads >> (i + 1 - RUN_LMAX)) & ((1u << RUN_LMAX) - 1u)) == 0) heads |= 1u << i;
+        for (int i = RUN_LMAX; i < RUN_PPT; i++) {
+            if (((valid >> i) & 1u) && ((heads >> (i + 1 - RUN_LMAX)) & ((1u << RUN_LMAX) - 1u)) == 0) heads |= 1u << i;
+        }
     }
     return heads;
 }
