@@ -66,6 +66,7 @@ struct grm_ctx {
     int opt_rec_bucket_shift = -1; // record form: bucket bits on top of the key form's choice (default 1)
     int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
     int opt_rec_keys = -1;       // > 0: record form always expands to key segments in level 2 (tests, measurements)
+    int opt_rec_coarse = -1;     // record form: coarse bucket bits of level 1 (tests, measurements); < 0 = min(bucket bits, 9)
     int opt_rec_memo = -1;       // record memo of dict_build: log2 of its slots (8..11), 0 = none, < 0 = default (10, with a 2^11 key table)
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
@@ -255,6 +256,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "rec_part_bits") c->opt_rec_part_bits = value;
     else if (n == "rec_keys") c->opt_rec_keys = value;
     else if (n == "rec_memo") c->opt_rec_memo = value;
+    else if (n == "rec_coarse") c->opt_rec_coarse = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else return fail(c, GRM_ERR_ARG, "unknown option %s", name);
@@ -1084,7 +1086,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         int bbr = c->opt_bucket_bits >= 0 ? b->bb : b->bb + (c->opt_rec_bucket_shift >= 0 ? c->opt_rec_bucket_shift : 1);
         if (c->opt_bucket_bits < 0 && b->rec_bb_hint > bbr && b->rec_bb_hint_k == k) bbr = b->rec_bb_hint;
         bbr = std::min(bbr, superkmer_max_bits());
-        const int b1r = superkmer_coarse_bits(bbr);
+        const int b1r = c->opt_rec_coarse > 0 ? std::max(bbr - 7, std::min(c->opt_rec_coarse, superkmer_coarse_bits(bbr))) : superkmer_coarse_bits(bbr);
         // one workgroup per genome part owns the part's regions: enough parts to fill the device when genomes are few
         int pbits = 0;
         // (one 1024-thread workgroup per CU and part: 128 genomes of 5 Mbp measured 7.6 / 7.5 / 8.3 / 10.2 ms per pass with 1 / 2 / 4 / 8
