@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 G
 
 # algorithmic bytes per unit for each kernel (DESIGN.md "Kernels"); unit = what TimeScope counts
 ALGO_BYTES = {
-    "parse_summarize": 1.0,          # per input byte: read 1
-    "parse_pack": 1.0 + 0.375,       # per input byte: read 1, write 2+1 bits per symbol (<= byte count)
+    "parse_summarize": 1.0 + 0.25,   # per input byte: read 1, write the 4-byte scan prefix of every 16-byte chunk
+    "parse_pack": 1.0 + 0.25 + 0.375,    # per input byte: read 1 + that prefix, write 2+1 bits per symbol (<= byte count)
     "kmer_hist": 0.375,              # per symbol: read packed stream
     "kmer_scatter_l1": 0.375 + 8.0,  # key form, per k-mer occurrence: read packed stream, write one u64 key
     "kmer_scatter_l2": 16.0,         # key form, per key: read 8, write 8 (second radix level)

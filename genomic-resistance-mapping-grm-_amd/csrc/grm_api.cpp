@@ -672,7 +672,7 @@ struct grm_batch {
     DevBuf d_genome_tile_off; // u32[n_genomes+1]
     DevBuf d_tile_meta;       // u8[n_tiles]: TILE_META_FIRST | TILE_META_FASTQ
     // parse products
-    DevBuf d_sums, d_tile_off, d_tile_state, d_sym2, d_inv, d_genome_sym_off, d_scan_scratch;
+    DevBuf d_sums, d_tile_off, d_tile_state, d_sym2, d_inv, d_genome_sym_off, d_scan_scratch, d_chunk_pre;
     uint64_t total_syms = 0;
     std::vector<uint64_t> h_genome_sym_off;
     // partition products
@@ -1042,11 +1042,12 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         HIPCHK(c, b->d_inv.ensure(max_groups * 8));
         HIPCHK(c, b->d_genome_sym_off.ensure(((size_t)G + 1) * 8));
         HIPCHK(c, b->d_scan_scratch.ensure(parse_scan_scratch_bytes(b->n_tiles)));
+        HIPCHK(c, b->d_chunk_pre.ensure(parse_chunk_pre_bytes(b->n_tiles)));
     }
     // (no memset of the packed stream: parse_pack's companion kernel zeroes the groups that need it)
     {
         TimeScope t(c, "parse_summarize", b->raw_bytes);
-        launch_parse_summarize(s, raw, b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_sums.as<TileSummary>());
+        launch_parse_summarize(s, raw, b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_sums.as<TileSummary>(), b->d_chunk_pre.as<uint32_t>());
     }
     {
         TimeScope t(c, "parse_scan", b->n_tiles);
@@ -1057,7 +1058,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     {
         TimeScope t(c, "parse_pack", b->raw_bytes);
         launch_parse_pack(s, raw, b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_tile_off.as<uint64_t>(), b->d_tile_state.as<uint8_t>(),
-                          b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>());
+                          b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>(), b->d_sums.as<TileSummary>(), b->d_chunk_pre.as<uint32_t>());
     }
     HIPCHK(c, hipGetLastError());
     b->h_genome_sym_off.resize(G + 1);

@@ -68,13 +68,15 @@ struct KmerLaunch {
     uint32_t groups_per_thread;
 };
 
-void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, TileSummary *sums);
+// chunk_pre (optional): the exclusive prefix element of every 16-byte chunk of every tile, for parse_pack (parse_chunk_pre_bytes)
+void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, TileSummary *sums, uint32_t *chunk_pre);
+size_t parse_chunk_pre_bytes(uint32_t n_tiles);
 void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles, const uint8_t *tile_meta, uint64_t *tile_off,
                        uint8_t *tile_state, const uint32_t *genome_tile_off, uint32_t n_genomes,
                        uint64_t *genome_sym_off, void *scratch);
 size_t parse_scan_scratch_bytes(uint32_t n_tiles);
 void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, const uint64_t *tile_off,
-                       const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv);
+                       const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv, const TileSummary *sums, const uint32_t *chunk_pre);
 void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
 int scatter_b1_bits(int bb);
 void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *coarse_off,

@@ -107,6 +107,26 @@ __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint3
     tc.pre[3] = pelem32_combine(wp3, e3);
 }
 
+// the tile's chunks classified, WITHOUT the scan: the exclusive prefix element of every chunk comes from the caller (parse_pack reads
+// what parse_summarize's scan of the same tile left in chunk_pre)
+__device__ __forceinline__ void tile_rounds(const uint8_t *__restrict__ raw, uint32_t tile, TileChunks &tc)
+{
+    const int lane = lane_id();
+    uint4 v[ROUNDS_PER_TILE];
+    uint32_t edge[ROUNDS_PER_TILE];
+#pragma unroll
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
+        v[r] = *reinterpret_cast<const uint4 *>(raw + base);
+        edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;
+    }
+    uint32_t unused;
+    tile_round<0>(v[0], edge[0], lane, tc, unused);
+    tile_round<1>(v[1], edge[1], lane, tc, unused);
+    tile_round<2>(v[2], edge[2], lane, tc, unused);
+    tile_round<3>(v[3], edge[3], lane, tc, unused);
+}
+
 // FASTQ variant of the tile scan: the element carries the newline count mod 4 and the symbol
 // count for each of the 4 possible starting line phases (fq_elem_* in grm_device_fns.h).
 struct TileChunksFq {
@@ -191,7 +211,7 @@ __device__ __forceinline__ void tile_scan_fq(const uint8_t *__restrict__ raw, ui
 // FASTQ: {v[s] = symbols when the tile starts in line phase s, tag = 4 | newlines mod 4}.
 __global__ __launch_bounds__(PARSE_THREADS) void parse_summarize_kernel(
     const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint8_t *__restrict__ tile_meta,
-    TileSummary *__restrict__ sums)
+    TileSummary *__restrict__ sums, uint32_t *__restrict__ chunk_pre)
 {
     __shared__ uint64_t partial[ROUNDS_PER_TILE * (PARSE_THREADS / 64)];
     const uint32_t tile = blockIdx.x;
@@ -206,6 +226,12 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_summarize_kernel(
     } else {
         TileChunks tc;
         tile_scan(raw, tile, partial, tc);
+        // the exclusive prefix element of every 16-byte chunk: parse_pack needs exactly these and would otherwise repeat the
+        // whole scan (4 bytes per 16 of input, against ~240 of its ~450 instructions per chunk)
+        if (chunk_pre) {
+#pragma unroll
+            for (int r = 0; r < ROUNDS_PER_TILE; r++) chunk_pre[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x] = tc.pre[r];
+        }
         s.v[0] = pelem32_ch(tc.total);
         s.v[1] = pelem32_cs(tc.total) - pelem32_ch(tc.total);
         s.v[2] = s.v[3] = 0;
@@ -407,7 +433,7 @@ __global__ void parse_prezero_kernel(const uint64_t *__restrict__ tile_off, uint
 __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
     const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint8_t *__restrict__ tile_meta,
     const uint64_t *__restrict__ tile_off, const uint8_t *__restrict__ tile_state, uint64_t *__restrict__ sym2,
-    uint64_t *__restrict__ inv)
+    uint64_t *__restrict__ inv, const TileSummary *__restrict__ sums, const uint32_t *__restrict__ chunk_pre)
 {
     constexpr int MAX_GROUPS = TILE_BYTES / 64 + 2;
     __shared__ uint64_t partial[ROUNDS_PER_TILE * (PARSE_THREADS / 64)];
@@ -437,9 +463,19 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
         }
     } else {
         TileChunks tc;
-        tile_scan(raw, tile, partial, tc);
         const int st = state == T_NONE ? T_SEQ : state;   // only before the first line start of a file
-        n_tile = st == T_SEQ ? pelem32_cs(tc.total) : pelem32_ch(tc.total);
+        if (chunk_pre) {
+            // the scan of this tile was done by parse_summarize: its per-chunk prefixes and the tile's totals are read back
+            tile_rounds(raw, tile, tc);
+#pragma unroll
+            for (int r = 0; r < ROUNDS_PER_TILE; r++) tc.pre[r] = chunk_pre[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x];
+            const TileSummary ts = sums[tile];
+            n_tile = st == T_SEQ ? ts.v[0] + ts.v[1] : ts.v[0];
+            __syncthreads();                              // (orders the zeroing above, as the scan's barrier does)
+        } else {
+            tile_scan(raw, tile, partial, tc);
+            n_tile = st == T_SEQ ? pelem32_cs(tc.total) : pelem32_ch(tc.total);
+        }
 #pragma unroll
         for (int r = 0; r < ROUNDS_PER_TILE; r++) {
             const int ev = pelem32_ev(tc.pre[r]);
@@ -2129,10 +2165,11 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap = 256u 
     return (uint32_t)(g > cap ? cap : g);
 }
 
-void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, TileSummary *sums)
+void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, TileSummary *sums, uint32_t *chunk_pre)
 {
-    hipLaunchKernelGGL(parse_summarize_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, sums);
+    hipLaunchKernelGGL(parse_summarize_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, sums, chunk_pre);
 }
+size_t parse_chunk_pre_bytes(uint32_t n_tiles) { return (size_t)n_tiles * ROUNDS_PER_TILE * PARSE_THREADS * 4; }
 // scratch: n_tiles * 20 B (tile prefixes) + n_blocks * (20 + 1 + 8) B + 8 B
 size_t parse_scan_scratch_bytes(uint32_t n_tiles)
 {
@@ -2158,11 +2195,11 @@ void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles,
                        genome_sym_off);
 }
 void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, const uint64_t *tile_off,
-                       const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv)
+                       const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv, const TileSummary *sums, const uint32_t *chunk_pre)
 {
     hipLaunchKernelGGL(parse_prezero_kernel, dim3(((uint64_t)n_tiles + 256) / 256), dim3(256), 0, s, tile_off, n_tiles, sym2, inv);
     hipLaunchKernelGGL(parse_pack_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, tile_off,
-                       tile_state, sym2, inv);
+                       tile_state, sym2, inv, sums, chunk_pre);
 }
 
 static KmerArgs make_args(const KmerLaunch &L)
