@@ -199,8 +199,8 @@ def roofline_of(kernels, traffic_of=None, occurrences=None, words=1):
     if stage and occurrences:
         g = stage[1] * occurrences / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
         r["survey_stage"] = {"stage": stage[0], "bytes_per_occurrence": stage[1], "achieved": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4)}
-    limits = {"superkmer_l1": "VALU issue: 3.5e9 wave instructions = 5.7 of its 7.6 ms (minimizers of 52 m-mers per 32 positions in registers); "
-                              "writes 1.65x its records as partial lines (profiles/r02/final_sq_counters.csv, final_pmc_hbm.csv)",
+    limits = {"superkmer_l1": "VALU issue: 3.5e9 wave instructions = 5.7 of its 7.7 ms (minimizers of 52 m-mers per 32 positions in registers); "
+                              "writes 1.66x its records as partial lines (profiles/r02/final_sq_counters.csv, final_pmc_hbm.csv)",
               "dict_build": "latency of 128-byte reads of segments megabytes apart + LDS lookups, 4 waves per SIMD (profiles/r02/final_sq_counters.csv)"}
     if dom in limits and traffic:           # (the committed profile is of this very workload)
         r["limited_by"] = limits[dom]
