@@ -291,3 +291,23 @@ def test_kover_split_on_the_device(tmp_path):
         assert (m.sum_rows(some) == dense[some].sum(axis=0)).all()
         assert (m.column_counts() == dense.sum(axis=0)).all()
         m.free()
+
+
+def test_bench_starts_its_ranks_itself():
+    """`bench.py --gpus 2` as the driver runs it for N > 1 (here: both ranks on cuda:0 over gloo, GRM_BENCH_REHEARSAL=1): the parent
+    starts the ranks, rank 0 prints ONE line with n_gpus = 2, and the strong-scaling headline (the same genome set split over the
+    ranks in word-row blocks) ends with the same columns as the one-rank run"""
+    import json
+    common = ["--genomes", "160", "--genome-len", "150000", "--steps", "1", "--warmup", "1", "--no-e2e", "--no-random", "--cpu-genomes", "0"]
+    one = _run([os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common)
+    two = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env={"GRM_BENCH_REHEARSAL": "1"})
+    l1 = [l for l in one.stdout.splitlines() if l.startswith("{")]
+    l2 = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(l1) == 1 and len(l2) == 1, (one.stdout, two.stdout)
+    a, b = json.loads(l1[0]), json.loads(l2[0])
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2
+    assert b["scaling"] == "strong" and b["config"]["genomes_total"] == 160
+    assert a["config"]["columns"] == b["config"]["columns"] > 0
+    assert b["collective"]["world_size_seen"] == 2 and b["collective"]["allgather_calls"] >= 1
+    for line in (a, b):
+        assert line["roofline"] and line["unit"] == "k-mers/s" and line["value"] > 0
