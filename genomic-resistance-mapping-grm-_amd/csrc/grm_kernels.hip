@@ -2319,9 +2319,12 @@ void launch_dict_build(hipStream_t s, const DictArgs &a)
         return;
     }
     if (a.recs) {                       // one record (up to 16 keys) per lane; 8 waves (the instance's launch bound)
-        const size_t lds_r = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (size_t)(TABLE_THREADS / 64) * 192 +     // + the pool table of every wave
-                             dict_memo_bytes(a.memo_log2, a.cap_log2);                                                               // + the record memo
-        hipLaunchKernelGGL((dict_build_kernel<8, 512, false, true>), grid, dim3(TABLE_THREADS), lds_r, s, a);
+        const size_t lds_t = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES + (size_t)(TABLE_THREADS / 64) * 192;      // + the pool table of every wave
+        DictArgs b = a;
+        // (a caller-forced table of 2^13 slots leaves no room for the record memo inside the 159 KB a workgroup may allocate: none then)
+        if (lds_t + dict_memo_bytes(b.memo_log2, b.cap_log2) > (size_t)159 * 1024) b.memo_log2 = 0;
+        const size_t lds_r = lds_t + dict_memo_bytes(b.memo_log2, b.cap_log2);                                              // + the record memo
+        hipLaunchKernelGGL((dict_build_kernel<8, 512, false, true>), grid, dim3(TABLE_THREADS), lds_r, s, b);
         return;
     }
     const int kif = (g_table_threads > 512 && g_dict_kif > 4) ? 4 : g_dict_kif;

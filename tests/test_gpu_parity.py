@@ -124,6 +124,7 @@ def test_medium_pangenome_all_paths(ctx):
     {"cap_log2": 7}, {"cap_log2": 8, "rec_bucket_shift": 0},   # record form: tables overflow -> more buckets (level 2 again), then sub-buckets
     {"rec_memo": 0}, {"rec_memo": 8}, {"rec_memo": 11},        # dict_build's record memo: none, smallest, largest
     {"rec_memo": 8, "cap_log2": 9}, {"rec_memo": 9, "sub_bits": 2}, {"rec_memo": 10, "rec_part_bits": 2, "bucket_bits": 7},
+    {"cap_log2": 13}, {"cap_log2": 12, "rec_memo": 11},        # forced big tables: the memo only where it fits beside them
 ])
 def test_medium_with_forced_geometry(ctx, opts):
     genomes = _medium_genomes(n=5, length=120_000, seed=9)
