@@ -236,7 +236,7 @@ def test_run_records_decode_to_the_oracles_kmers(emul, k):
     """record form of the partition, on the CPU with the kernels' own per-lane functions: the runs of equal minimizer bucket
     of every packed word, as 16-byte records, decode to exactly the canonical k-mers the oracle counts; every k-mer of a
     record has the record's bucket when that is re-derived from the k-mer alone (what the probing fill and the ranks rely
-    on); a record holds 1..8 k-mers"""
+    on); a record holds 1..16 k-mers, and the low-complexity stretches make some reach the 16"""
     rng = np.random.RandomState(100 + k)
     files = [cases.fasta([("a", cases.rand_seq(rng, 20_000)), ("b", "ACGT" * 300 + "A" * 200 + cases.rand_seq(rng, 3000) + "N" * 7 + "GATTACA" * 90)], width=70).encode(),
              (">c\n" + cases.rand_seq(rng, 5000).lower() + "\n").encode()]
@@ -259,7 +259,7 @@ def test_run_records_decode_to_the_oracles_kmers(emul, k):
     vals, counts = np.unique(keys[:n], return_counts=True)
     assert nocc == n and (vals == km[:, 0]).all() and (counts == ct).all()
     lens = lens[:n_rec.value]
-    assert lens.sum() == n and lens.min() >= 1 and lens.max() <= 16
+    assert lens.sum() == n and lens.min() >= 1 and lens.max() == 16
     nbits = coarse_bits + 7
     for i in rng.randint(0, n, size=400):
         assert emul.emul_minimizer_bucket_of_kmer(int(keys[i]), k, nbits) == int(buckets[i])
