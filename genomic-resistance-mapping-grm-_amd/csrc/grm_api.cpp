@@ -67,7 +67,7 @@ struct grm_ctx {
     int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
     int opt_rec_keys = -1;       // > 0: record form always expands to key segments in level 2 (tests, measurements)
     int opt_rec_coarse = -1;     // record form: coarse bucket bits of level 1 (tests, measurements); < 0 = min(bucket bits, 9)
-    int opt_rec_memo = -1;       // record memo of dict_build: log2 of its slots (8..11), 0 = none, < 0 = default (10, with a 2^11 key table)
+    int opt_rec_memo = -1;       // record memo of dict_build: log2 of its size base (8..11; 15/32 of 2^that records), 0 = none, < 0 = default (10, with a 2^11 key table)
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
 // 64-bit words of a k-mer, most significant first: 1 (k <= 32), 2 (<= 64), 3 (<= 96), 4 (<= 128)

@@ -1516,7 +1516,7 @@ __global__ __launch_bounds__(MAXT, 4) void dict_build_kernel(const DictArgs a)
                 else group_bounds(r + 1, 0, sj_n, nj_n);
                 if (memo_on) {
                     // With the memo an occurrence is a lookup whatever its length: no classes, no pooling.  The 8 lanes
-                    // l & 7 == e take the records of genome e, 8 at a time (128 contiguous bytes); two batches are in flight.
+                    // l & 7 == e take the records of genome e, 8 at a time (128 contiguous bytes); four batches are in flight (below).
                     const uint32_t n_mine = nj & 0xffffu;
                     uint32_t n_max = 0;
 #pragma unroll
