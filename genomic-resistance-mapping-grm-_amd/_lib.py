@@ -19,6 +19,7 @@ _U64P = C.POINTER(C.c_uint64)
 PROTOTYPES = [
     ("grm_create", _P, [C.c_int, C.c_int]),
     ("grm_destroy", None, [_P]),
+    ("grm_ctx_live_handles", C.c_int, [_P]),
     ("grm_last_error", C.c_char_p, [_P]),
     ("grm_version", C.c_char_p, []),
     ("grm_set_option", C.c_int, [_P, C.c_char_p, C.c_int]),
@@ -82,6 +83,7 @@ PROTOTYPES = [
     ("grm_batch_n_occurrences", C.c_uint64, [_P]),
     ("grm_batch_input_bytes", C.c_uint64, [_P]),
     ("grm_batch_n_local", C.c_uint64, [_P]),
+    ("grm_batch_memo_stats", C.c_int, [_P, _U64P]),
     ("grm_batch_genome_set", C.c_int, [_P, C.c_int, _PP]),
     ("grm_batch_free", None, [_P]),
 ]

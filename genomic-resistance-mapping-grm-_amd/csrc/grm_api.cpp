@@ -39,6 +39,12 @@ struct TimingRec {
 };
 
 struct grm_ctx {
+    // Lifetime: the owner (grm_create / grm_destroy) holds one reference and every handle made from the context (batch, matrix,
+    // k-mer set, dictionary accumulator) holds another: grm_destroy with handles still alive only drops the owner's, and the
+    // streams go when the last handle is freed.  (Python finalises a Batch kept alive by a traceback AFTER its Context was closed:
+    // its free then synchronised a stream of a deleted context -- round 2's aborts at process exit.)
+    std::atomic<int> refs{1};
+    std::atomic<bool> owner_gone{false};
     int device = 0;
     hipStream_t stream = nullptr;
     // uploads run on their own stream: grm_batch_upload of the NEXT batch may be called from a
@@ -67,7 +73,27 @@ struct grm_ctx {
     int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
     int opt_rec_keys = -1;       // > 0: record form always expands to key segments in level 2 (tests, measurements)
     int opt_rec_coarse = -1;     // record form: coarse bucket bits of level 1 (tests, measurements); < 0 = min(bucket bits, 9)
+    int opt_memo_stats = -1;     // > 0: dict_build counts what its record memo held / was asked / found (grm_batch_memo_stats)
     int opt_rec_memo = -1;       // record memo of dict_build: log2 of its size base (8..11; 15/32 of 2^that records), 0 = none, < 0 = default (10, with a 2^11 key table)
+};
+static void ctx_release(grm_ctx *c);
+static inline void ctx_retain(grm_ctx *c) { c->refs.fetch_add(1, std::memory_order_relaxed); }
+// a handle's reference to its context (NULL for host-only objects)
+struct CtxRef {
+    grm_ctx *p = nullptr;
+    CtxRef() = default;
+    CtxRef(const CtxRef &) = delete;
+    CtxRef &operator=(const CtxRef &) = delete;
+    CtxRef &operator=(grm_ctx *c)
+    {
+        if (c) ctx_retain(c);
+        if (p) ctx_release(p);
+        p = c;
+        return *this;
+    }
+    ~CtxRef() { if (p) ctx_release(p); }
+    operator grm_ctx *() const { return p; }
+    grm_ctx *operator->() const { return p; }
 };
 static inline int c_opt_wide_sort(const grm_ctx *c) { return c->opt_wide_sort; }
 // 64-bit words of a k-mer, most significant first: 1 (k <= 32), 2 (<= 64), 3 (<= 96), 4 (<= 128)
@@ -222,9 +248,9 @@ extern "C" grm_ctx *grm_create(int device_ordinal, int n_streams)
     return c;
 }
 
-extern "C" void grm_destroy(grm_ctx *c)
+static void ctx_release(grm_ctx *c)
 {
-    if (!c) return;
+    if (c->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
     (void)hipSetDevice(c->device);
     for (auto &r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -232,6 +258,16 @@ extern "C" void grm_destroy(grm_ctx *c)
     g_pool.trim();
     delete c;
 }
+
+extern "C" void grm_destroy(grm_ctx *c)
+{
+    if (!c) return;
+    if (c->owner_gone.exchange(true)) return;      // (a second grm_destroy while handles keep the context alive)
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    ctx_release(c);
+}
+extern "C" int grm_ctx_live_handles(const grm_ctx *c) { return c ? c->refs.load() - (c->owner_gone.load() ? 0 : 1) : 0; }
 
 extern "C" const char *grm_last_error(grm_ctx *c) { return c ? c->err.c_str() : "no context (no HIP device?)"; }
 
@@ -256,6 +292,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "rec_part_bits") c->opt_rec_part_bits = value;
     else if (n == "rec_keys") c->opt_rec_keys = value;
     else if (n == "rec_memo") c->opt_rec_memo = value;
+    else if (n == "memo_stats") c->opt_memo_stats = value;
     else if (n == "rec_coarse") c->opt_rec_coarse = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
@@ -316,7 +353,7 @@ static hipError_t d2h(grm_ctx *c, void *dst, const void *src, size_t bytes)
 }
 
 struct grm_kmer_set {
-    grm_ctx *ctx = nullptr;
+    CtxRef ctx;
     int k = 0, words = 1;
     uint64_t occurrences = 0;
     size_t n = 0;
@@ -328,7 +365,7 @@ struct grm_kmer_set {
 };
 
 struct grm_matrix {
-    grm_ctx *ctx = nullptr;
+    CtxRef ctx;
     int k = 0, words = 1, n_genomes = 0;
     size_t n_rows = 0, n_kmers = 0;
     DevBuf d_kmers, d_data, d_errors;     // d_errors: per-column error counts of the last grm_matrix_risk_errors
@@ -656,7 +693,7 @@ static int wide_stage_global(grm_batch *b, const void *dev_keys, const void *dev
 static int wide_stage_fill(grm_batch *b, grm_matrix **out);
 
 struct grm_batch {
-    grm_ctx *ctx = nullptr;
+    CtxRef ctx;
     WideSorted *wide = nullptr;      // two-word (k > 32) sort path buffers, created on first use
     MultiSorted *multi = nullptr;    // three- / four-word (k > 64) sort path buffers
     WideHash *whash = nullptr;       // two-word hash-partition path buffers
@@ -697,6 +734,7 @@ struct grm_batch {
     int rec_bb_hint = -1, rec_bb_hint_k = 0;   // bucket bits a dictionary of this batch needed last time (more buckets instead of sub-buckets)
     int rec_part_bits = 0;         // genomes are cut into 2^rec_part_bits parts (segment index: virtual genome * 2^bb + bucket)
     int rec_memo_log2 = 0;         // slots of dict_build's record memo (log2), 0 = none
+    uint64_t memo_stats[4] = {0, 0, 0, 0};   // of the last dictionary launch with the "memo_stats" option: see grm_batch_memo_stats
     bool slack_failed = false;     // a slack-layout partition of this batch overflowed: dense layout from then on
     DevBuf d_marks;                // one bit per segment: left to the workgroup form of the dedup
     // dictionary
@@ -1096,14 +1134,12 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         if (c->opt_rec_part_bits >= 0) pbits = std::min(c->opt_rec_part_bits, 6);
         const uint64_t n_parts = (uint64_t)G << pbits;
         const uint64_t n_regions = n_parts << b1r, n_seg_r = n_parts << bbr;
-        // records per region: a run ends where the minimizer changes (2 / (w + 1) per position for the w m-mers of a
-        // k-mer) or at the end of a thread's 32 positions, and runs of roughly geometric length are cut every
-        // superkmer_lmax() k-mers; k-mers per region: ~0.05 distinct minimizers per position, sigma of a region =
-        // 1.39 x its share / sqrt(its minimizers) (both simulated)
+        // records per region: a run ends where the minimizer occurrence changes -- 2 / (w + 1) per position for the w m-mers
+        // of a k-mer -- or at a base that is none (0.005: contig ends, N runs); k-mers per region: ~0.05 distinct minimizers per
+        // position, sigma of a region = 1.39 x its share / sqrt(its minimizers) (both simulated)
         const int w = k - SK_M + 1;
         const double mean_k = (double)((max_g >> pbits) >> b1r) + 1.0;
-        const double d0 = 2.0 / (w + 1) + 1.0 / 32;                       // runs per position before the cap on their length
-        const double mean_r = mean_k * (d0 * (1.0 + 1.0 / (std::exp(superkmer_lmax() * d0) - 1.0)) + 0.005);
+        const double mean_r = mean_k * (2.0 / (w + 1) + 0.005);
         const uint64_t rstride64 = (uint64_t)(mean_r * 1.02 + 14.0 * std::sqrt(mean_r) + 32.0 + 15.0) / 16 * 16;     // mean + 7.5 sigma
         const uint64_t kstride = (uint64_t)(mean_k + 50.0 * std::sqrt(mean_k) + 256.0 + 15.0) / 16 * 16;
         // genomes of very different sizes would waste most of a layout sized for the largest one
@@ -1146,7 +1182,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
                 TimeScope t(c, "superkmer_l2", b->total_syms);        // (units: the record count, once it is known)
                 l2_idx = t.idx;
                 launch_superkmer_l2_records(s, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, bbr, b1r, b->d_recs2.p,
-                                            b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>());
+                                            b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->t_flag.as<int>());
             } else {
                 HIPCHK(c, b->d_keys.ensure((n_regions * kstride + 4) * 8));
                 TimeScope t(c, "superkmer_l2_keys", b->total_syms);
@@ -1381,6 +1417,12 @@ extern "C" uint64_t grm_batch_n_symbols(const grm_batch *b) { return b ? b->tota
 extern "C" uint64_t grm_batch_n_occurrences(const grm_batch *b) { return b ? b->total_keys : 0; }
 extern "C" uint64_t grm_batch_input_bytes(const grm_batch *b) { return b ? b->input_bytes : 0; }
 extern "C" uint64_t grm_batch_n_local(const grm_batch *b) { return b ? b->n_local : 0; }
+extern "C" int grm_batch_memo_stats(const grm_batch *b, uint64_t *out4)
+{
+    if (!b || !out4) return GRM_ERR_ARG;
+    for (int i = 0; i < 4; i++) out4[i] = b->memo_stats[i];
+    return GRM_OK;
+}
 
 // ---- dictionary of the local genomes ------------------------------------------------------
 // device control block of dict_build: { n_out u64, overflow i32, need u32 }
@@ -1411,12 +1453,21 @@ static int batch_rebucket(grm_batch *b, int new_bb)
     grm_ctx *c = b->ctx;
     hipStream_t s = c->stream;
     const uint64_t n_seg = (((uint64_t)b->n_genomes << b->rec_part_bits)) << new_bb;
+    // launch contract of level 2: it writes off / len for EVERY segment of the new bucket count and the records of every region.
+    // (Round 2's memory fault of 10:25 -- DESIGN.md 7b -- was this launch in its first, uncommitted form: level 2 run again for
+    // 2^new_bb buckets into off / len arrays still sized for the old count, a linear overrun that faulted at the first unmapped
+    // 2 MiB boundary behind them.)
     HIPCHK(c, b->d_off.ensure((n_seg + 1) * 8));
     HIPCHK(c, b->d_len.ensure((n_seg + 1) * 4));
+    HIPCHK(c, b->t_flag.ensure(32));
+    if (new_bb < b->rec_b1 || new_bb > b->rec_b1 + 7 || b->d_off.bytes < (n_seg + 1) * 8 || b->d_len.bytes < (n_seg + 1) * 4 ||
+        b->d_recs2.bytes < (b->rec_regions * (uint64_t)b->rec_rstride + 4) * 16 || b->d_counts1.bytes < (b->rec_regions + 1) * 4)
+        return fail(c, GRM_ERR_STATE, "internal: level 2 asked for 2^%d buckets over buffers sized for fewer", new_bb);
+    HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 4, s));
     {
         TimeScope t(c, "superkmer_l2_again", 0);
         launch_superkmer_l2_records(s, b->d_recs.p, b->rec_rstride, b->d_counts1.as<uint32_t>(), b->rec_regions, new_bb, b->rec_b1, b->d_recs2.p,
-                                    b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>());
+                                    b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->t_flag.as<int>());
     }
     HIPCHK(c, hipGetLastError());
     b->bb = new_bb;
@@ -1445,13 +1496,23 @@ static int run_dict_ladder(grm_batch *b, DictArgs a, uint64_t total_keys, int sb
             HIPCHK(c, b->d_matrix_s.ensure(ms_bytes));
             HIPCHK(c, b->d_birth.ensure((size_t)n_wg * cap * 2));
         }
+        // launch contract: one workgroup per (bucket, sub-bucket) and fewer than 2^32 threads per launch; every array the kernel
+        // indexes by workgroup or by (virtual genome, bucket) covers THIS bucket count
+        const uint64_t n_seg_in = ((uint64_t)a.n_genomes << a.part_bits) << a.bb;
+        if (a.bb + sb > DICT_MAX_WG_BITS || out.wg_base->bytes < (size_t)n_wg * 8 || out.wg_cnt->bytes < ((size_t)n_wg + 1) * 4 ||
+            out.keys->bytes < out_cap * 8 || out.flags->bytes < out_cap ||
+            (bits && (b->d_matrix_s.bytes < ms_bytes || b->d_birth.bytes < (size_t)n_wg * cap * 2)) ||
+            (a.seg.off == b->d_off.as<uint64_t>() && a.seg.off && b->d_off.bytes < n_seg_in * 8) ||
+            (a.seg.len == b->d_len.as<uint32_t>() && a.seg.len && b->d_len.bytes < n_seg_in * 4))
+            return fail(c, GRM_ERR_STATE, "internal: %s launch of 2^%d workgroups over buffers sized for fewer", tname, a.bb + sb);
         HIPCHK(c, hipMemsetAsync(b->d_ctrl.p, 0, sizeof(DictCtrl), s));
         a.sb = sb;
         a.out_keys = out.keys->as<uint64_t>(); a.out_flags = out.flags->as<uint8_t>();
         a.out_cap = out_cap;
         DictCtrl *ctrl = b->d_ctrl.as<DictCtrl>();
         a.n_out = &ctrl->n_out; a.overflow = &ctrl->overflow; a.need = &ctrl->need;
-        static const bool memo_diag = getenv("GRM_MEMO_STATS") != nullptr;
+        static const bool memo_env = getenv("GRM_MEMO_STATS") != nullptr;
+        const bool memo_diag = memo_env || c->opt_memo_stats > 0;
         a.memo_stats = memo_diag ? ctrl->memo_stats : nullptr;
         a.wg_base = out.wg_base->as<uint64_t>(); a.wg_cnt = out.wg_cnt->as<uint32_t>();
         a.matrix_s = bits ? b->d_matrix_s.as<uint64_t>() : nullptr;
@@ -1465,7 +1526,8 @@ static int run_dict_ladder(grm_batch *b, DictArgs a, uint64_t total_keys, int sb
         DictCtrl h;
         HIPCHK(c, hipMemcpyAsync(&h, b->d_ctrl.p, sizeof h, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
-        if (memo_diag && a.memo_log2)
+        if (memo_diag) for (int i = 0; i < 4; i++) b->memo_stats[i] = a.memo_log2 ? h.memo_stats[i] : 0;
+        if (memo_env && a.memo_log2)
             fprintf(stderr, "[grm] %s memo 2^%d: %llu (workgroup, row) ends with the memo on, mean records held %.1f, occurrences asked %llu found %llu; overflow %d\n",
                     tname, a.memo_log2, h.memo_stats[3], h.memo_stats[3] ? (double)h.memo_stats[0] / (double)h.memo_stats[3] : 0.0, h.memo_stats[1],
                     h.memo_stats[2], h.overflow);
@@ -2065,7 +2127,7 @@ extern "C" int grm_merge_counted_sets(grm_ctx *c, grm_kmer_set *const *sets, int
 // column carried by several genomes -- the multi-GPU merge, applied over time instead of over ranks)
 // and fills that chunk's word-rows.  grm_matrix_stack_rows puts the row blocks together.
 struct grm_dict_accum {
-    grm_ctx *ctx = nullptr;
+    CtxRef ctx;
     int words = 0;                 // 0 until the first batch is added
     uint64_t n = 0, cap = 0;
     DevBuf keys, flags;

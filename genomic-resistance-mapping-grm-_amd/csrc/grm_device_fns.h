@@ -115,17 +115,16 @@ GRM_HD uint32_t hash_sub(uint64_t h, int bb, int sb)
 GRM_HD uint32_t hash_slot(uint64_t h, uint32_t cap_mask) { return (uint32_t)h & cap_mask; }
 
 // ---- minimizers (record form of the partition, grm_superkmer.hip) ----------------------------
-// order of the canonical m-mers (x < 2^22): the smallest hash inside a k-mer is its minimizer
-GRM_HD uint32_t minimizer_hash(uint32_t x)
+// Order of the canonical m-mers (x < 2^22): the m-mer with the smallest value inside a k-mer is its minimizer.  The order
+// only has to look random, and it is evaluated for every symbol: ONE full-rate multiply-add, of which the top 24 bits
+// count (the constant term keeps poly-A, x = 0, from being the smallest m-mer of every genome).
+constexpr int MINIMIZER_ORDER_BITS = 24;
+GRM_HD uint32_t minimizer_hash(uint32_t x) { return mul24(x, 0x9E3779u) + 0x7F4A7C15u; }      // order = result >> 8
+// bucket of a k-mer from the order value (24 bits) of its minimizer.  The minimum of k - 10 values crowds towards 0, so
+// the bucket is NOT its top bits: the value is hashed once more (per run, not per position).
+GRM_HD uint32_t minimizer_bucket(uint32_t order, int bb)
 {
-    const uint32_t t = mul24(x, 0x9E3779u);
-    return mul24(t >> 10, 0x85EBCBu) + t;
-}
-// bucket of a k-mer from the hash of its minimizer.  The minimum of k - 10 hashes crowds towards 0, so the bucket is
-// NOT its top bits: the value is hashed once more.
-GRM_HD uint32_t minimizer_bucket(uint32_t hmin, int bb)
-{
-    const uint32_t t = mul24(hmin ^ (hmin >> 24), 0xC2B2AFu);
+    const uint32_t t = mul24(order ^ (order >> 11), 0xC2B2AFu) + mul24(order >> 5, 0x85EBCBu);
     return (t >> 1) >> (31 - bb);
 }
 
@@ -133,23 +132,39 @@ GRM_HD uint32_t minimizer_bucket(uint32_t hmin, int bb)
 GRM_HD uint32_t minimizer_bucket_of_kmer(uint64_t key, int k, int bb, int m_len = 11)
 {
     const uint32_t mmask = (1u << (2 * m_len)) - 1;
-    uint32_t f = 0, r = 0, hmin = ~0u;
+    uint32_t f = 0, r = 0, omin = ~0u;
     for (int j = 0; j < k; j++) {
         const uint32_t s = (uint32_t)(key >> (2 * (k - 1 - j))) & 3u;
         f = ((f << 2) | s) & mmask;
         r = (r >> 2) | ((s ^ 2u) << (2 * (m_len - 1)));
         if (j >= m_len - 1) {
-            const uint32_t h = minimizer_hash(f < r ? f : r);
-            hmin = h < hmin ? h : hmin;
+            const uint32_t o = minimizer_hash(f < r ? f : r) >> (32 - MINIMIZER_ORDER_BITS);
+            omin = o < omin ? o : omin;
         }
     }
-    return minimizer_bucket(hmin, bb);
+    return minimizer_bucket(omin, bb);
 }
 
 // ---- run records (record form of the partition): per-lane logic of grm_superkmer.hip and of dict_build's decoder ----
+// A RUN is a maximal stretch of consecutive valid k-mer starts that share their minimizer OCCURRENCE (the leftmost m-mer
+// with the smallest order value among the W = k - M + 1 the k-mer contains).  Where a run starts and ends is a property of
+// the sequence around it (2 W - 1 m-mers), not of where a thread's window or a contig begins: the same sequence gives the
+// same runs in every genome, however its assembly is cut, ordered or shifted by an indel upstream.  A run holds at most W
+// k-mers (all contain the one m-mer), i.e. at most 2 k - M = 53 bases at k = 32, and travels as ONE 16-byte record
+//     x            bases 0..31 of the run, MSB-first
+//     y[63..22]    bases 32..52; bits behind the run's last base are 0
+//     y[21..12]    0
+//     y[11..5]     7 bucket bits below the coarse ones
+//     y[4..0]      k-mers in the run (1..22)
+// stored STRAND-CANONICALLY: in the orientation in which the minimizer m-mer is its own canonical form (M is odd: an
+// m-mer is never its own reverse complement).  A contig and its reverse complement therefore give the same records; the
+// decoder emits min(forward, reverse complement) of every k-mer, so the orientation needs no flag.
 constexpr int RUN_PPT = 32;          // k-mer start positions a thread takes per step: one packed word
-constexpr int RUN_LMAX = 16;         // k-mers per record (k + 15 <= 47 bases fit x and y[63..34])
+constexpr int RUN_LMAX = 22;         // k-mers per record: W at k = 32
 constexpr int RUN_FINE_BITS = 7;     // bucket bits a record carries below the coarse ones
+constexpr int RUN_LEN_BITS = 5;
+GRM_HD uint32_t run_len(uint64_t y) { return (uint32_t)y & ((1u << RUN_LEN_BITS) - 1u); }
+GRM_HD uint32_t run_fine(uint64_t y) { return ((uint32_t)y >> RUN_LEN_BITS) & ((1u << RUN_FINE_BITS) - 1u); }
 
 // `len` symbols (len <= 16) from symbol offset `off` of the 64 symbols held MSB-first in the four words d[0..3]; with off and
 // len known at compile time (unrolled callers) this is one bit-field extract, or a funnel shift and a mask
@@ -159,89 +174,115 @@ GRM_HD uint32_t sym_field(const uint32_t (&d)[4], int off, int len)
     const uint64_t win = ((uint64_t)d[j] << 32) | (uint64_t)(j + 1 < 4 ? d[j + 1] : 0u);
     return (uint32_t)(win >> (64 - sh - nb)) & ((1u << nb) - 1u);
 }
-// Buckets (nbits bits) of the 32 k-mers starting at the symbols of w0 (w1 = the next packed word), k = W + M - 1:
-// hashes of the 32 + W - 1 canonical M-mers (fields of the two words and of their reverse complement), minimum over windows of W
-// by doubling (h[i] = min over [i, i + span)), then two overlapping spans.  Fully unrolled: everything stays in registers.
-template <int W, int M = 11>
-GRM_HD void run_buckets(uint64_t w0, uint64_t w1, int nbits, uint32_t (&bk)[RUN_PPT])
+GRM_HD uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
 {
-    constexpr int NM = RUN_PPT + W - 1;
-    static_assert(NM + M - 1 <= 64, "the m-mers of a thread's window lie inside its two words");
+    const uint32_t ab = a < b ? a : b;          // (the backend fuses the pair into v_min3_u32)
+    return ab < c ? ab : c;
+}
+// Minimizer of the 33 k-mers that start at positions -1 .. 31 of a window: w0 = the packed word of positions 0..31, w1 the
+// next one, prev2 = the 2-bit code of position -1.  val[i + 1], for the k-mer at position i:
+//     bits 31..8   order value of its minimizer
+//     bits  6..1   position of the minimizer occurrence, + 1 (0 .. 31 + W)
+//     bit   0      1 = the reverse complement of that m-mer is the canonical one
+// Equal order values resolve to the leftmost occurrence (the position is part of the compared word).  Hashes of the 32 + W
+// canonical M-mers (fields at fixed offsets of the two words and of their reverse complement: no rolling words), window
+// minimum over W by spans of 3 and 9 (v_min3_u32).  Fully unrolled: everything stays in registers.
+template <int W, int M = 11>
+GRM_HD void run_minimizers(uint64_t w0, uint64_t w1, uint32_t prev2, uint32_t (&val)[RUN_PPT + 1])
+{
+    constexpr int NM = RUN_PPT + W;              // m-mers at positions -1 .. 31 + W - 1
+    static_assert(RUN_PPT + W - 1 + M <= 64, "the m-mers of a thread's window lie inside its two words");
+    static_assert(W >= 1 && W <= 27, "window minimum by spans of 1, 3 or 9");
     uint32_t h[NM];
     // m-mer q = symbols q .. q + M - 1 of (w0 : w1); its reverse complement = symbols 64 - M - q .. of the reverse complement of
-    // the 64 symbols, rc(w1) : rc(w0).  Both are fields at fixed offsets: no rolling words.
+    // the 64 symbols, rc(w1) : rc(w0)
     const uint64_t r1 = revcomp_m(w1, 32), r0 = revcomp_m(w0, 32);
     const uint32_t df[4] = {(uint32_t)(w0 >> 32), (uint32_t)w0, (uint32_t)(w1 >> 32), (uint32_t)w1};
     const uint32_t dr[4] = {(uint32_t)(r1 >> 32), (uint32_t)r1, (uint32_t)(r0 >> 32), (uint32_t)r0};
+    constexpr uint32_t KEEP = ~0u << (32 - MINIMIZER_ORDER_BITS);
+    {
+        // position -1: the symbol before the window, then the first M - 1 of w0
+        const uint32_t f = (prev2 << (2 * (M - 1))) | sym_field(df, 0, M - 1);
+        const uint32_t r = (sym_field(dr, 64 - (M - 1), M - 1) << 2) | (prev2 ^ 2u);
+        h[0] = (minimizer_hash(f < r ? f : r) & KEEP) | (uint32_t)(r < f);
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int q = 0; q < NM; q++) {
+    for (int q = 0; q < NM - 1; q++) {
         const uint32_t f = sym_field(df, q, M), r = sym_field(dr, 64 - M - q, M);
-        h[q] = minimizer_hash(f < r ? f : r);
+        h[q + 1] = (minimizer_hash(f < r ? f : r) & KEEP) | ((uint32_t)(q + 1) << 1) | (uint32_t)(r < f);
     }
-    constexpr int LV = W >= 16 ? 4 : W >= 8 ? 3 : W >= 4 ? 2 : W >= 2 ? 1 : 0;
-    constexpr int SPAN = 1 << LV;
+    constexpr int S = W <= 3 ? 1 : W <= 9 ? 3 : 9;
+    if (S >= 3) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int l = 0; l < LV; l++) {
+        for (int i = 0; i + 2 < NM; i++) h[i] = min3u(h[i], h[i + 1], h[i + 2]);             // [i, i + 3)
+    }
+    if (S >= 9) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int i = 0; i < NM; i++)
-            if (i + (2 << l) <= NM) h[i] = h[i] < h[i + (1 << l)] ? h[i] : h[i + (1 << l)];
+        for (int i = 0; i + 8 < NM; i++) h[i] = min3u(h[i], h[i + 3], h[i + 6]);             // [i, i + 9)
     }
+    constexpr int MID = S < W - S ? S : W - S;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < RUN_PPT; i++) {
-        const uint32_t a = h[i], b = h[i + W - SPAN];
-        bk[i] = minimizer_bucket(a < b ? a : b, nbits);
-    }
+    for (int i = 0; i <= RUN_PPT; i++) val[i] = min3u(h[i], h[i + MID], h[i + W - S]);     // [i, i + W)
 }
-// first positions of the runs of a word: a valid start whose predecessor is invalid, in another bucket, or RUN_LMAX or
-// more positions behind the last head (a record holds at most RUN_LMAX k-mers)
-GRM_HD uint32_t run_heads(uint32_t valid, const uint32_t (&bk)[RUN_PPT])
+// first positions of the runs of a window: a valid start whose predecessor is invalid or has another minimizer occurrence.
+// valid: bit i = position i is a valid k-mer start; prev_valid: position -1 is one (of the same genome)
+GRM_HD uint32_t run_heads(uint32_t valid, bool prev_valid, const uint32_t (&val)[RUN_PPT + 1])
 {
-    uint32_t heads = 0;
+    uint32_t differs = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < RUN_PPT; i++) {
-        const bool vi = (valid >> i) & 1u;
-        const bool hd = vi && (i == 0 || !((valid >> (i > 0 ? i - 1 : 0)) & 1u) || bk[i] != bk[i > 0 ? i - 1 : 0]);
-        heads |= (uint32_t)hd << i;
-    }
-    if (2 * RUN_LMAX >= RUN_PPT && (RUN_LMAX & (RUN_LMAX - 1)) == 0) {
-        // at most ONE start can be RUN_LMAX positions behind the last head (a second one would lie beyond the word): the lowest
-        // valid start that no head of the RUN_LMAX positions up to it covers
-        uint32_t cover = heads;
-        for (int d = 1; d < RUN_LMAX; d <<= 1) cover |= cover << d;          // bit i: a head in [i - RUN_LMAX + 1, i]
-        const uint32_t cand = valid & ~cover & ~((1u << RUN_LMAX) - 1u);
-        heads |= cand & (0u - cand);
-    } else {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int i = RUN_LMAX; i < RUN_PPT; i++) {
-            if (((valid >> i) & 1u) && ((heads >> (i + 1 - RUN_LMAX)) & ((1u << RUN_LMAX) - 1u)) == 0) heads |= 1u << i;
-        }
-    }
-    return heads;
+    for (int i = 0; i < RUN_PPT; i++) differs |= (uint32_t)(val[i + 1] != val[i]) << i;
+    return valid & (differs | ~((valid << 1) | (uint32_t)prev_valid));
 }
-// k-mers of the run that starts at position i: up to the next head, the next invalid start, or the end of the word
+// positions at the front of a window that continue a run begun before it (0 when position 0 starts a run or is no k-mer start)
+GRM_HD uint32_t run_lead(uint32_t valid, uint32_t heads)
+{
+    return (uint32_t)__builtin_ctz((heads | ~valid) | 0x80000000u);
+}
+// k-mers of the run that starts at position i, inside the window: up to the next head, the next invalid start, or the end of the
+// window -- a run that reaches the end goes on for run_lead() of the next window
 GRM_HD uint32_t run_length(uint32_t heads, uint32_t valid, int i)
 {
     const uint64_t bnd = (uint64_t)(heads | ~valid) | (1ull << RUN_PPT);
     const uint64_t rest = bnd >> (i + 1);
     return (uint32_t)__builtin_ctzll(rest) + 1u;
 }
-// the 16-byte record of a run: x = bases 0..31 from position i, y = the following bases | 7 fine bucket bits | length
-GRM_HD void run_record(uint64_t w0, uint64_t w1, int i, uint32_t len, uint32_t bucket, uint64_t &x, uint64_t &y)
+// The 16-byte record of the run of `len` k-mers that starts at position i of the window (w0, w1, w2: the window's word and
+// the two after it): its len + k - 1 bases, reverse-complemented when `flip`; fine = the 7 bucket bits below the coarse ones
+GRM_HD void run_record(uint64_t w0, uint64_t w1, uint64_t w2, int i, uint32_t len, int k, bool flip, uint32_t fine, uint64_t &x, uint64_t &y)
 {
-    x = i ? ((w0 << (2 * i)) | (w1 >> (64 - 2 * i))) : w0;
-    y = ((w1 << (2 * i)) & ~0xffffull) | ((uint64_t)(bucket & ((1u << RUN_FINE_BITS) - 1u)) << 8) | len;
+    const int span = (int)len + k - 1;              // 11 .. 53 bases
+    uint64_t a = i ? ((w0 << (2 * i)) | (w1 >> (64 - 2 * i))) : w0;
+    uint64_t b = i ? ((w1 << (2 * i)) | (w2 >> (64 - 2 * i))) : w1;
+    if (span <= 32) {
+        a &= ~0ull << (64 - 2 * span);
+        b = 0;
+    } else {
+        b &= ~0ull << (128 - 2 * span);
+    }
+    if (flip) {
+        // reverse complement of the 64 bases a : b = rc(b) : rc(a); the run's bases are its LAST `span` ones
+        const uint64_t hi = revcomp_m(b, 32), lo = revcomp_m(a, 32);
+        const int sh = 2 * (64 - span);              // 22 .. 106
+        if (sh >= 64) {
+            a = lo << (sh - 64);
+            b = 0;
+        } else {
+            a = (hi << sh) | (lo >> (64 - sh));
+            b = lo << sh;
+        }
+    }
+    x = a;
+    y = b | ((uint64_t)(fine & ((1u << RUN_FINE_BITS) - 1u)) << RUN_LEN_BITS) | len;
 }
 // decoder state of a record: forward / reverse-complement words of the current k-mer, and the bases after it, MSB-aligned
 struct RunDecoder {
@@ -253,7 +294,7 @@ GRM_HD RunDecoder run_open(uint64_t x, uint64_t y, int k)
     const int up = 64 - 2 * k;
     d.fwd = x >> up;
     d.rc = revcomp_m(d.fwd, k);
-    d.rest = k < 32 ? ((x << (2 * k)) | (y >> up)) : y;
+    d.rest = k < 32 ? ((x << (2 * k)) | (y >> up)) : y;       // (at most W - 1 = k - 11 of its bases are read: all above y's low fields)
     return d;
 }
 GRM_HD uint64_t run_canonical(const RunDecoder &d) { return d.fwd < d.rc ? d.fwd : d.rc; }

@@ -84,7 +84,7 @@ void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *
 void launch_sum_u32(hipStream_t s, const uint32_t *in, uint64_t n, uint64_t *out);
 // record form of the partition (grm_superkmer.hip; 11 <= k <= 32): buckets by minimizer.  Genome g is cut into
 // 2^part_bits parts ("virtual genomes" vg = (g << part_bits) + part).
-//   level 1: runs of consecutive k-mers with one bucket -> 16-byte records, sorted by the coarse bucket bits:
+//   level 1: runs of consecutive k-mers with one minimizer occurrence -> 16-byte records, sorted by the coarse bucket bits:
 //            region (vg, coarse) = recs1[(vg * 2^b1 + coarse) * rstride ..], rcount1[..] records; part_kmers[vg] = k-mer
 //            occurrences of the part; *overflow = 1 when a region would exceed rstride
 //   level 2: records -> canonical k-mers, sorted by the fine bits: segment vg * 2^bb + bucket = keys[off[..] .. + len[..]),
@@ -95,8 +95,9 @@ void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, con
                          uint64_t kstride, uint64_t *keys, uint64_t *off, uint32_t *len, int *overflow);
 //   level 2, records only: the region's records sorted by the fine bits, region r again at r * rstride of recs2: segment
 //            vg * 2^bb + bucket = recs2[off[..] .. + len[..]) (in records; dict_build decodes them, DictArgs::recs)
+//            *overflow = 1 when a segment holds more than 65535 records (its count travels in 16 bits)
 void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb, int b1,
-                                 void *recs2, uint64_t *off, uint32_t *len);
+                                 void *recs2, uint64_t *off, uint32_t *len, int *overflow);
 // (bucket << sb) | sub of dictionary keys under minimizer buckets (launch_dict_bucket_ids for the hashed ones)
 void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int k, int bb, int sb, uint32_t *bucket_of, uint32_t *col_of);
 int superkmer_max_bits();
@@ -129,7 +130,7 @@ void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const SegLayout &se
 struct DictArgs {
     const uint64_t *keys;
     int part_bits;          // segments of 2^part_bits parts per genome: segment index = ((genome << part_bits) + part) * 2^bb + bucket
-    // record form: the segments hold the 16-byte run records of grm_superkmer.hip (1..16 k-mers each) instead of keys,
+    // record form: the segments hold the 16-byte run records of grm_superkmer.hip (1..22 k-mers each) instead of keys,
     // seg counts records; k as given (keys == nullptr then)
     const ulonglong2 *recs;
     int k;
@@ -161,13 +162,13 @@ struct DictArgs {
     const uint64_t *in_flag_off;
 };
 void launch_dict_build(hipStream_t s, const DictArgs &a);
-// record memo of dict_build's record form: 15/32 * 2^memo_log2 records; LDS bytes: 56 per record (the record, the 16 table slots of
+// record memo of dict_build's record form: 13/32 * 2^memo_log2 records; LDS bytes: 72 per record (the record, the 24 table slots of
 // its k-mers, its word), twice 2^memo_log2 slots of 4 bytes, 32 of counters -- and 2 per slot of the key table (slot of every entry
-// id).  (2^10: 480 records, 39.2 KB; with the 2048-slot key table 77.7 KB: two workgroups share a CU.)
-constexpr uint32_t dict_memo_entries(int memo_log2) { return memo_log2 > 0 ? (15u << memo_log2) >> 5 : 0u; }
+// id).  (2^10: 416 records, 42.3 KB; with the 2048-slot key table 78.9 KB: two workgroups share a CU.)
+constexpr uint32_t dict_memo_entries(int memo_log2) { return memo_log2 > 0 ? (13u << memo_log2) >> 5 : 0u; }
 constexpr size_t dict_memo_bytes(int memo_log2, uint32_t cap_log2)
 {
-    return memo_log2 > 0 ? (size_t)dict_memo_entries(memo_log2) * 56 + ((size_t)8 << memo_log2) + 32 + ((size_t)2 << cap_log2) : 0;
+    return memo_log2 > 0 ? (size_t)dict_memo_entries(memo_log2) * 72 + ((size_t)8 << memo_log2) + 32 + ((size_t)2 << cap_log2) : 0;
 }
 // local dictionary in bucket order: entries of workgroup wg copied to [ord_off[wg], ord_off[wg+1]) (ord_off = exclusive
 // scan of wg_cnt), and the first entry of every hash bucket (2^bb + 1 offsets)

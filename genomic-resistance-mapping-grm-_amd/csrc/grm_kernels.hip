@@ -1233,7 +1233,7 @@ struct DictMemo {
     uint32_t *slot;                 // buckets of 4 slots: 0 = empty, MEMO_LOCK = being written, else tag << 16 | id + 1
     ulonglong2 *rec;                // [n_ent] the records, by id
     unsigned long long *words;      // [n_ent] presence word of the current word-row
-    ulonglong2 *kslot;              // [2 n_ent] table slots of the record's up to 16 k-mers (16 bits each, 0xffff = none), once resolved
+    uint32_t *kslot;                // [12 n_ent] table slots of the record's up to 22 k-mers (16 bits each, 0xffff = none; 24 per record), once resolved
     uint32_t *ctl;                  // [0] records held, [1] memo in use, [2] occurrences that went the direct way, [3] occurrences (of
                                     // the row), [4] records whose k-mer slots are resolved (ids below it)
     uint32_t n_ent, bmask;          // bmask: buckets - 1
@@ -1328,15 +1328,15 @@ __device__ __forceinline__ uint32_t dict_slot_of(const DictWave &w, uint64_t key
 }
 // End of a word-row: the word of every held record goes to the words of its k-mers.  The table slots of a record's k-mers
 // are resolved when the record is met here for the first time (decoded, every k-mer of this sub-bucket found or entered)
-// and kept, 16 bits each: afterwards a record costs two 16-byte reads and up to 16 ORs per word-row.
+// and kept, 16 bits each: afterwards a record costs three 4-byte reads and up to 6 ORs per lane and word-row.
 __device__ __forceinline__ void memo_flush_row(const DictWave &w, const DictMemo &M, uint32_t r, int kk, uint64_t kmask, int rcshift)
 {
     const uint32_t held = min(M.ctl[0], M.n_ent), known = M.ctl[4];
     // records met for the first time in this word-row: one lane resolves one record
     for (uint32_t t = known + threadIdx.x; t < held; t += blockDim.x) {
-        unsigned long long k0 = ~0ull, k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;          // (four scalars: an indexed array would live in scratch)
+        unsigned long long k0 = ~0ull, k1 = ~0ull, k2 = ~0ull, k3 = ~0ull, k4 = ~0ull, k5 = ~0ull;   // (scalars: an indexed array would live in scratch)
         const ulonglong2 rec = M.rec[t];
-        const uint32_t len = (uint32_t)(rec.y & 0xffu);
+        const uint32_t len = run_len(rec.y);
         RunDecoder dec = run_open(rec.x, rec.y, kk);
         for (uint32_t tt = 0; tt < len; tt++) {
             if (w.full) break;
@@ -1351,21 +1351,26 @@ __device__ __forceinline__ void memo_flush_row(const DictWave &w, const DictMemo
             k1 &= qd == 1u ? put : ~0ull;
             k2 &= qd == 2u ? put : ~0ull;
             k3 &= qd == 3u ? put : ~0ull;
+            k4 &= qd == 4u ? put : ~0ull;
+            k5 &= qd == 5u ? put : ~0ull;
         }
-        M.kslot[2 * t] = make_ulonglong2(k0, k1);
-        M.kslot[2 * t + 1] = make_ulonglong2(k2, k3);
+        ulonglong2 *ks = reinterpret_cast<ulonglong2 *>(M.kslot + 12 * t);
+        ks[0] = make_ulonglong2(k0, k1);
+        ks[1] = make_ulonglong2(k2, k3);
+        ks[2] = make_ulonglong2(k4, k5);
     }
     if (held > known) lds_barrier();         // (uniform: both read between the caller's barriers)
-    // every held record: two lanes (of one wave) take its word to the slots of its first and its second eight k-mers
-    for (uint32_t t2 = threadIdx.x; t2 < 2u * held; t2 += blockDim.x) {
-        const uint32_t t = t2 >> 1, half = t2 & 1u;
+    // every held record: four lanes (of one wave) take its word to the slots of six of its k-mers each
+    for (uint32_t t4 = threadIdx.x; t4 < 4u * held; t4 += blockDim.x) {
+        const uint32_t t = t4 >> 2, qr = t4 & 3u;
         const unsigned long long wd = M.words[t];
         if (!wd) continue;
-        const ulonglong2 ks = M.kslot[2 * t + half];
-        if (half == 0) M.words[t] = 0;           // (its partner lane has read the word: same instruction, same wave)
+        const uint32_t *ks = M.kslot + 12 * t + 3 * qr;
+        const uint32_t s0 = ks[0], s1 = ks[1], s2 = ks[2];
+        if (qr == 0) M.words[t] = 0;             // (its partner lanes have read the word: same instruction, same wave)
 #pragma unroll
-        for (int tt = 0; tt < 8; tt++) {
-            const uint32_t slot = (uint32_t)((tt < 4 ? ks.x : ks.y) >> (16 * (tt & 3))) & 0xffffu;
+        for (int tt = 0; tt < 6; tt++) {
+            const uint32_t slot = ((tt < 2 ? s0 : tt < 4 ? s1 : s2) >> (16 * (tt & 1))) & 0xffffu;
             if (slot != 0xffffu) atomicOr(&w.words[slot], wd);
         }
     }
@@ -1389,7 +1394,7 @@ __device__ __forceinline__ void dict_take_record(const DictWave &w, const DictMe
         if (!left) return;
         if (lane_id() == 0) atomicAdd(&M.ctl[2], (uint32_t)__popcll(left));
     }
-    const uint32_t len = (uint32_t)(rec.y & 0xffu);
+    const uint32_t len = run_len(rec.y);
     RunDecoder dec = run_open(rec.x, rec.y, kk);
     uint64_t kv[J];
     kv[0] = run_canonical(dec);
@@ -1399,17 +1404,20 @@ __device__ __forceinline__ void dict_take_record(const DictWave &w, const DictMe
         kv[t] = run_canonical(dec);          // (past the record's last k-mer: not live)
     }
     dict_probe<J, false, true>(w, kv, 0u, 0u, r, bit, direct ? (1u << len) - 1u : 0u);
-    if (J == 8 && RUN_LMAX > 8) {
-        // a record holds up to 16 k-mers: the second eight, where a lane of the wave has them
-        const uint32_t live2 = direct ? ((1u << len) - 1u) >> 8 : 0u;
-        if (!__ballot(live2 != 0)) return;
-        uint64_t kv2[J];
+    if (J == 8) {
+        // a record holds up to 22 k-mers: the second and third eight, where a lane of the wave has them
+#pragma unroll 1
+        for (uint32_t done = 8; done < (uint32_t)RUN_LMAX; done += 8) {
+            const uint32_t live2 = direct ? ((1u << len) - 1u) >> done : 0u;
+            if (!__ballot(live2 != 0)) return;
+            uint64_t kv2[J];
 #pragma unroll
-        for (int t = 0; t < J; t++) {
-            run_next(dec, kmask, rcshift);
-            kv2[t] = run_canonical(dec);
+            for (int t = 0; t < J; t++) {
+                run_next(dec, kmask, rcshift);
+                kv2[t] = run_canonical(dec);
+            }
+            dict_probe<J, false, true>(w, kv2, 0u, 0u, r, bit, live2 & 0xffu);
         }
-        dict_probe<J, false, true>(w, kv2, 0u, 0u, r, bit, live2);
     }
 }
 
@@ -1467,9 +1475,9 @@ __global__ __launch_bounds__(MAXT, 4) void dict_build_kernel(const DictArgs a)
     {
         uint8_t *mb = lds_raw + (size_t)cap * 18 + TABLE_SCRATCH_BYTES + (size_t)nw * 192;
         M.rec = reinterpret_cast<ulonglong2 *>(mb);
-        M.kslot = reinterpret_cast<ulonglong2 *>(mb + (size_t)M.n_ent * 16);
-        M.words = reinterpret_cast<unsigned long long *>(mb + (size_t)M.n_ent * 48);
-        M.slot = reinterpret_cast<uint32_t *>(mb + (size_t)M.n_ent * 56);
+        M.kslot = reinterpret_cast<uint32_t *>(mb + (size_t)M.n_ent * 16);
+        M.words = reinterpret_cast<unsigned long long *>(mb + (size_t)M.n_ent * 64);
+        M.slot = reinterpret_cast<uint32_t *>(mb + (size_t)M.n_ent * 72);
         M.ctl = M.slot + ((size_t)(M.bmask + 1) << 2);
     }
     w.sid = REC && a.memo_log2 ? reinterpret_cast<uint16_t *>(M.ctl + 8) : nullptr;          // [cap]
@@ -1495,7 +1503,7 @@ __global__ __launch_bounds__(MAXT, 4) void dict_build_kernel(const DictArgs a)
     if (REC) group_bounds(0, 0, sj_n, nj_n);
     for (uint32_t r = 0; r < n_rows; r++) {
         if (REC) {
-            // Record form.  A record holds a run of 1..16 consecutive k-mers with their bases; ONE LANE decodes one record
+            // Record form.  A record holds a run of 1..22 consecutive k-mers with their bases; ONE LANE decodes one record
             // (first k-mer by a shift and a reverse complement, the others by rolling both words) and takes its keys to
             // the table.  A segment holds its records of at most 4 k-mers first: those go four keys at a time, the others
             // eight at a time (one size for all would leave a third of the key slots empty).  The records of the wave's
@@ -1703,7 +1711,7 @@ __global__ __launch_bounds__(MAXT, 4) void dict_build_kernel(const DictArgs a)
                 nv &= 0xffffu;
                 for (uint64_t q0 = 0; q0 < nv; q0 += 64) {
                     const ulonglong2 rec = q0 + lane < nv ? a.recs[sv + q0 + lane] : make_ulonglong2(0, 0);
-                    const uint32_t len = (uint32_t)(rec.y & 0xffu);
+                    const uint32_t len = run_len(rec.y);
                     RunDecoder dec = run_open(rec.x, rec.y, kk);
                     for (uint32_t t = 0; t < len; t++) {
                         sketch(run_canonical(dec));

@@ -2,20 +2,18 @@
 //
 // The key form (grm_kernels.hip, levels 1 and 2) moves every canonical k-mer through HBM as an 8-byte key: written by
 // level 1, read and written by level 2, read by the consumer -- 160 GB per 1000 x 5 Mbp.  Here the bucket of a k-mer
-// is a function of its MINIMIZER -- the canonical 11-mer with the smallest hash among the k - 10 it contains -- so
-// consecutive k-mers of a sequence share their bucket for (k - 9) / 2 positions on average (what DSK itself does with its
-// minimizer partitions [EXT]).  A run of up to 16 consecutive valid k-mer starts with the same bucket travels through
-// level 1 as ONE 16-byte record that carries its own bases:
-//     x            bases 0..31 of the run, MSB-first
-//     y[63..34]    bases 32..46                        (len + k - 1 <= 47 bases; y[33..16]: the bases that follow in the window, unused)
-//     y[14..8]     7 bucket bits below the coarse ones (level 2 uses the top bb - b1 of them)
-//     y[7..0]      len = k-mers in the run (1..16)
-// so 8 B per k-mer become ~2.2 B.  Level 2 owns a (genome part, coarse bucket) region: it sorts the region's records by fine
-// bucket (and short / long) for dict_build's record form, which decodes them itself; for a consumer that needs keys (the
-// probing fill) a second form of level 2 EXPANDS them to canonical k-mers on the way out, leaving the same bucket-sorted
-// key segments as the key form.  A k-mer and its reverse
-// complement contain the same canonical 11-mers, so the bucket is a function of the canonical k-mer, on every rank alike
-// (minimizer_bucket_of_kmer re-derives it from a key where a consumer has only the key).
+// is a function of its MINIMIZER -- the canonical 11-mer with the smallest order value among the k - 10 it contains -- so
+// consecutive k-mers of a sequence share their bucket (what DSK itself does with its minimizer partitions [EXT]).  A RUN =
+// the consecutive valid k-mer starts that share one minimizer OCCURRENCE (a super-k-mer: at most k - 10 k-mers, 11 on
+// average at k = 31) travels as ONE 16-byte record that carries its own bases (layout: grm_device_fns.h, "run records"):
+// 8 B per k-mer become ~1.5 B.  Where a run starts and ends depends on the sequence alone, and a record is stored in the
+// orientation in which its minimizer is canonical: genomes that share a stretch of sequence share its records whatever the
+// contig order, strand or an indel upstream -- which is what dict_build's record memo lives on.
+// Level 2 owns a (genome part, coarse bucket) region: it sorts the region's records by fine bucket (and short / long) for
+// dict_build's record form, which decodes them itself; for a consumer that needs keys (the probing fill) a second form of
+// level 2 EXPANDS them to canonical k-mers on the way out, leaving the same bucket-sorted key segments as the key form.
+// A k-mer and its reverse complement contain the same canonical 11-mers, so the bucket is a function of the canonical
+// k-mer, on every rank alike (minimizer_bucket_of_kmer re-derives it from a key where a consumer has only the key).
 #include "grm_internal.h"
 #include "grm_device_fns.h"
 #include "grm_coop.h"
@@ -25,14 +23,20 @@ namespace grm {
 
 constexpr int SK_THREADS = 1024;
 constexpr int SK_PPT = RUN_PPT;                       // k-mer start positions per thread and step: one packed word
-constexpr int SK_LMAX = RUN_LMAX;                     // k-mers per record: what one lane of dict_build (record form) decodes at a time
-static_assert(SK_M == 11, "run_buckets<W> is instantiated with its default m-mer length");
+constexpr int SK_LMAX = RUN_LMAX;                     // k-mers per record, at most
+static_assert(SK_M == 11, "run_minimizers<W> is instantiated with its default m-mer length");
 constexpr int SK_FINE_BITS = RUN_FINE_BITS;           // a record carries 7 bucket bits below the coarse ones, whatever the bucket count in use:
                                                       // level 2 takes the top bb - b1 of them, so more buckets only need level 2 again
-constexpr int SK_MAX_BITS = 9 + SK_FINE_BITS;         // at most 9 coarse bits (SK_THREADS cursors) + the fine field
+constexpr int SK_MAX_COARSE = 9;
+constexpr int SK_MAX_BITS = SK_MAX_COARSE + SK_FINE_BITS;         // at most 9 coarse bits (cursors) + the fine field
+// A wave takes 63 consecutive windows per step; its lane 63 works on the window AFTER them (the next wave's, or the next
+// step's, first) only to say how far the run that crosses into it goes on.
+constexpr int SK_WAVE_WINDOWS = 63;
+constexpr int SK_STEP_WINDOWS = (SK_THREADS / 64) * SK_WAVE_WINDOWS;
+constexpr size_t SK_L1_LDS = (size_t)SK_PPT * SK_THREADS * 4 + ((size_t)4 << SK_MAX_COARSE) + 128;
 constexpr int SK2_THREADS = 256;
 constexpr int SK2R_THREADS = 512;                     // level 2, records only
-constexpr int SK2_TILE_KEYS = SK2_THREADS * SK_LMAX;                // one record per thread: at most 256 x 16 keys = 32 KB of LDS per tile
+constexpr int SK2_TILE_KEYS = SK2_THREADS * SK_LMAX;                // one record per thread: at most 256 x 22 keys = 44 KB of LDS per tile
 
 struct SkArgs {
     const uint64_t *sym2;
@@ -49,112 +53,111 @@ struct SkArgs {
 // One workgroup per (genome, part) = "virtual genome" vg: it owns the part's 2^b1 coarse regions of records1, so the
 // place of a record needs no global atomic (a returning global atomic per record measured 20 ms for 6e8 records, and an
 // add per wave to ONE global counter 28 ms: same-address atomics serialise in L2).  Per step a thread takes one window
-// of 32 start positions of its genome (below): minimizer bucket of every valid k-mer start (W = k - SK_M + 1 m-mers per k-mer; template:
-// the window minimum is a fixed pattern of register moves), runs -> records, each stored at the LDS cursor of its
-// coarse region.  (A counting sort of the step's records in LDS, one contiguous run per coarse bucket on the way out,
-// measured 11.9 ms against this form's time: the two extra passes over the runs cost more than the partial lines.)
+// = one word of the packed stream = 32 k-mer start positions: minimizer of every start (template on W = k - SK_M + 1:
+// the window minimum is a fixed pattern of register moves), run heads where the minimizer occurrence changes.  A run
+// belongs to the window it STARTS in; the one that crosses the window's end goes on for as many positions as the next
+// window's thread (the lane to the right) finds in front of its first head.  Each run leaves as one record, stored at the
+// LDS cursor of its coarse region.
 template <int W>
 __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulonglong2 *__restrict__ recs1, uint32_t rstride,
                                                                    uint32_t *__restrict__ rcount1, uint32_t *__restrict__ part_kmers,
                                                                    int *__restrict__ overflow)
 {
-    __shared__ uint32_t s_bk[SK_THREADS * (SK_PPT / 2)];     // 16-bit bucket of every position of the step
-    __shared__ uint32_t cursor[SK_THREADS];                  // records written so far to coarse region c (2^b1 <= SK_THREADS)
-    __shared__ uint32_t scratch[32];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint32_t *s_val = reinterpret_cast<uint32_t *>(lds_raw);          // [SK_PPT][SK_THREADS]: minimizer word of every position of the step
+    uint32_t *cursor = s_val + SK_PPT * SK_THREADS;                   // records written so far to coarse region c
+    uint32_t *scratch = cursor + (1u << SK_MAX_COARSE);
     const int b1 = a.b1;
     const uint32_t B1 = 1u << b1;
     const uint32_t vg = blockIdx.x;
     const uint32_t gen = vg >> a.part_bits, part = vg & ((1u << a.part_bits) - 1u);
     const uint64_t lo = a.genome_sym_off[gen], hi = a.genome_sym_off[gen + 1];
-    // A thread's 32 start positions are a window of the GENOME (window j = positions lo + 32 j ...), not a word of the packed
-    // stream: runs end at window ends, so with stream-aligned windows the same sequence would be cut into different records
-    // in every genome (32 possible phases) -- and dict_build's record memo lives on genomes sharing their records.  The
-    // window's two words are funnel-shifted out of three stream words.
-    const int phase = (int)(lo & 31);
-    const uint64_t n_win = (hi - lo + 31) >> 5;
+    // positions that may start a k-mer of this genome: [lo, p_end)
+    const uint64_t last = a.total_syms >= (uint64_t)a.k ? a.total_syms - a.k + 1 : 0;
+    const uint64_t p_end = hi < last ? hi : last;
+    // the genome's windows (words of the stream), cut into parts
+    const uint64_t jw_lo = lo >> 5, jw_hi = hi > lo ? (hi + 31) >> 5 : jw_lo;
+    const uint64_t n_win = jw_hi - jw_lo;
     const uint64_t per_part = (n_win + (1u << a.part_bits) - 1) >> a.part_bits;
-    const uint64_t j_a = min((uint64_t)part * per_part, n_win), j_b = min(j_a + per_part, n_win);
-    const uint16_t *my_bk = reinterpret_cast<const uint16_t *>(s_bk) + threadIdx.x * SK_PPT;
-    cursor[threadIdx.x] = 0;
+    const uint64_t j_a = jw_lo + min((uint64_t)part * per_part, n_win), j_b = min(j_a + per_part, jw_hi);
+    for (uint32_t c = threadIdx.x; c < B1; c += SK_THREADS) cursor[c] = 0;
     __syncthreads();
+    const int lane = lane_id(), wave = wave_id();
+    uint32_t *my_val = s_val + threadIdx.x;
     uint32_t n_valid = 0;
     bool over = false;
-    // Related genomes are the same sequence at the same window numbers: started together, their workgroups would store to the
-    // same places of their (equally laid out) regions at the same time.  Each workgroup starts its round through the part's
-    // steps somewhere else.
-    const uint32_t n_steps = (uint32_t)((j_b - j_a + SK_THREADS - 1) / SK_THREADS);
+    // Related genomes are the same sequence at about the same window numbers: started together, their workgroups would store
+    // to the same places of their (equally laid out) regions at the same time.  Each workgroup starts its round through the
+    // part's steps somewhere else.
+    const uint32_t n_steps = (uint32_t)((j_b - j_a + SK_STEP_WINDOWS - 1) / SK_STEP_WINDOWS);
     const uint32_t rot = n_steps ? (uint32_t)((vg * 0x9E3779B1u) >> 8) % n_steps : 0u;
     for (uint32_t it = 0; it < n_steps; it++) {
         const uint32_t st = it + rot < n_steps ? it + rot : it + rot - n_steps;
-        const uint64_t jbase = j_a + (uint64_t)st * SK_THREADS;
-        const uint64_t j = jbase + threadIdx.x;
-        const uint64_t p0 = lo + (j << 5);
-        uint32_t valid = 0;
-        uint64_t w0 = 0, w1 = 0;
-        const int64_t nv = (int64_t)a.total_syms - a.k + 1 - (int64_t)p0;
-        if (j < j_b && nv > 0) {
-            const uint64_t grp = p0 >> 6, wq = p0 >> 5;
-            const uint64_t u0 = a.sym2[wq], u1 = a.sym2[wq + 1];
-            if (phase) {
-                const uint64_t u2 = a.sym2[wq + 2];       // (the stream buffer ends with 16 words of slack)
-                w0 = (u0 << (2 * phase)) | (u1 >> (64 - 2 * phase));
-                w1 = (u1 << (2 * phase)) | (u2 >> (64 - 2 * phase));
+        const uint64_t j = j_a + (uint64_t)st * SK_STEP_WINDOWS + (uint32_t)(wave * SK_WAVE_WINDOWS + lane);
+        uint32_t valid = 0, heads = 0;
+        uint64_t w0 = 0, w1 = 0, w2 = 0;
+        if (j <= j_b) {              // (j_b itself: only for the run that crosses into it; the stream buffers end with slack words)
+            const uint64_t p0 = j << 5;
+            // bit t of vs: position p0 - 1 + t starts a k-mer (t = 0 .. 32; k <= 32 keeps all 33 inside the 64 flags read)
+            uint64_t vs;
+            if (p0) {
+                const uint64_t q = p0 - 1;
+                vs = valid_starts_at(a.inv[q >> 6], a.inv[(q >> 6) + 1], (int)(q & 63), a.k);
             } else {
-                w0 = u0;
-                w1 = u1;
+                vs = valid_starts_at(a.inv[0], a.inv[1], 0, a.k) << 1;
             }
-            valid = (uint32_t)valid_starts_at(a.inv[grp], a.inv[grp + 1], (int)(p0 & 63), a.k);
-            if (nv < SK_PPT) valid &= (1u << nv) - 1;
-            // the last window of a genome also holds positions of the next one
-            if (p0 + SK_PPT > hi) valid &= (1u << (uint32_t)(hi - p0)) - 1u;
-        }
-        n_valid += (uint32_t)__popc(valid);
-        uint32_t heads = 0;
-        if (valid) {
-            uint32_t bk[SK_PPT];
-            run_buckets<W>(w0, w1, b1 + SK_FINE_BITS, bk);
-            heads = run_heads(valid, bk);
-            // the bucket of a run's first position is the only per-position value the emission needs, and it is
-            // indexed by a run-time position: through LDS (each thread reads back its own 64 bytes)
+            // ... of THIS genome: lo <= p0 - 1 + t < p_end
+            const uint64_t t_lo = lo + 1 > p0 ? lo + 1 - p0 : 0, t_hi = p_end + 1 > p0 ? p_end + 1 - p0 : 0;
+            const uint64_t keep = (t_hi >= 33 ? (1ull << 33) - 1 : (1ull << t_hi) - 1) & ~(t_lo >= 33 ? (1ull << 33) - 1 : (1ull << t_lo) - 1);
+            vs &= keep;
+            valid = (uint32_t)(vs >> 1);
+            if (valid) {
+                w0 = a.sym2[j];
+                w1 = a.sym2[j + 1];
+                w2 = a.sym2[j + 2];
+                const uint32_t prev2 = j ? (uint32_t)a.sym2[j - 1] & 3u : 0u;
+                uint32_t val[SK_PPT + 1];
+                run_minimizers<W>(w0, w1, prev2, val);
+                heads = run_heads(valid, (vs & 1u) != 0, val);
+                // the minimizer word of a run's first position is the only per-position value the emission needs, and it is
+                // indexed by a run-time position: through LDS (each thread reads back its own column)
 #pragma unroll
-            for (int i = 0; i < SK_PPT; i += 2) s_bk[threadIdx.x * (SK_PPT / 2) + i / 2] = bk[i] | (bk[i + 1] << 16);
+                for (int i = 0; i < SK_PPT; i++) my_val[i * SK_THREADS] = val[i + 1];
+            }
         }
-        // The runs of a lane leave one per round (a lane has ~6, at most 32): the slot in the coarse region comes from the
+        // how far the run that crosses into the window of the lane to the right goes on there
+        const uint32_t lead_next = __shfl_down(run_lead(valid, heads), 1);
+        const bool mine = lane < SK_WAVE_WINDOWS && j < j_b;
+        if (mine) n_valid += (uint32_t)__popc(valid);
+        // The runs of a lane leave one per round (a lane has ~3.5, at most 32): the slot in the coarse region comes from the
         // workgroup's LDS cursor of that region, the record goes straight to its place.  A region's lines fill up in
         // cursor order, 8 records each, and a workgroup keeps 512 of them open: they complete in L2 (mostly).
-        // (two runs per round: both LDS atomics are in flight before either record is stored)
-        uint32_t hd = heads;
+        uint32_t hd = mine ? heads : 0u;
         while (hd) {
             const int i = __ffs(hd) - 1;
             hd &= hd - 1;
-            const bool two = hd != 0;
-            const int i2 = two ? __ffs(hd) - 1 : i;
-            hd &= hd - 1;                  // (0 & anything = 0)
-            const uint32_t bkt = my_bk[i], bkt2 = my_bk[i2];
-            const uint32_t c = bkt >> SK_FINE_BITS, c2 = bkt2 >> SK_FINE_BITS;
-            uint64_t rx, ry, rx2, ry2;
-            run_record(w0, w1, i, run_length(heads, valid, i), bkt, rx, ry);
-            run_record(w0, w1, i2, run_length(heads, valid, i2), bkt2, rx2, ry2);
+            const uint32_t v = my_val[i * SK_THREADS];
+            uint32_t len = run_length(heads, valid, i);
+            if (i + (int)len == SK_PPT) len += lead_next;
+            const uint32_t bkt = minimizer_bucket(v >> (32 - MINIMIZER_ORDER_BITS), b1 + SK_FINE_BITS);
+            const uint32_t c = bkt >> SK_FINE_BITS;
+            uint64_t rx, ry;
+            run_record(w0, w1, w2, i, len, a.k, (v & 1u) != 0, bkt, rx, ry);
             const uint32_t slot = atomicAdd(&cursor[c], 1u);
-            const uint32_t slot2 = two ? atomicAdd(&cursor[c2], 1u) : 0u;
             if (slot < rstride) recs1[((uint64_t)vg * B1 + c) * rstride + slot] = make_ulonglong2(rx, ry);
             else over = true;
-            if (two) {
-                if (slot2 < rstride) recs1[((uint64_t)vg * B1 + c2) * rstride + slot2] = make_ulonglong2(rx2, ry2);
-                else over = true;
-            }
         }
     }
     __syncthreads();
     if (over) atomicExch(overflow, 1);
-    if (threadIdx.x < B1) rcount1[(uint64_t)vg * B1 + threadIdx.x] = min(cursor[threadIdx.x], rstride);
+    for (uint32_t c = threadIdx.x; c < B1; c += SK_THREADS) rcount1[(uint64_t)vg * B1 + c] = min(cursor[c], rstride);
     uint32_t total;
     (void)block_scan_sum(n_valid, scratch, &total);
     if (threadIdx.x == 0) part_kmers[vg] = total;
 }
 
 // fine bucket of a record when 2^b2 fine buckets are in use: the top b2 of its SK_FINE_BITS
-__device__ __forceinline__ uint32_t rec_fine(uint64_t y, int b2) { return (((uint32_t)(y >> 8) & 0x7fu) >> (SK_FINE_BITS - b2)); }
+__device__ __forceinline__ uint32_t rec_fine(uint64_t y, int b2) { return run_fine(y) >> (SK_FINE_BITS - b2); }
 
 // ---- level 2 -----------------------------------------------------------------------------------------------------
 // One workgroup per (virtual genome, coarse bucket) region at a time.  Pass A adds up the k-mers per fine bucket (the
@@ -165,7 +168,8 @@ __device__ __forceinline__ uint32_t rec_fine(uint64_t y, int b2) { return (((uin
 // (forward and reverse-complement words, as the key form's extraction does) and stores the canonical k-mers into the
 // tile's LDS image, which leaves as one contiguous run per fine bucket.  Records hold 1..16 k-mers: the tile's records are
 // first sorted by length (a counting sort through LDS), so that the lanes of a wave roll for about the same number of
-// steps -- unsorted, a third of the lanes idle.
+// steps -- unsorted, a third of the lanes idle.  (The rank of a record inside its fine bucket travels beside it in LDS: a record
+// has no spare bits, and none that differ between two genomes with the same run.)
 __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglong2 *__restrict__ recs1, uint32_t rstride,
                                                                     const uint32_t *__restrict__ rcount1, uint64_t n_regions, int k, int bb, int b1,
                                                                     uint64_t kstride, uint64_t *__restrict__ keys, uint64_t *__restrict__ off,
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
 {
     __shared__ uint64_t skeys[SK2_TILE_KEYS];
     __shared__ ulonglong2 srec[SK2_THREADS];
+    __shared__ uint32_t srank[SK2_THREADS];
     constexpr int NF = 1 << SK_FINE_BITS;          // fine buckets of a region, at most
     __shared__ uint32_t gbase[NF];                      // relative to the region's first key
     __shared__ uint32_t hist[NF], start[NF], lhist[64], lstart[64];
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += SK2_THREADS) {
             const uint64_t y = rr[i].y;
-            atomicAdd(&hist[rec_fine(y, b2)], (uint32_t)(y & 0xffu));
+            atomicAdd(&hist[rec_fine(y, b2)], run_len(y));
         }
         __syncthreads();
         const uint32_t cnt = threadIdx.x < B2 ? hist[threadIdx.x] : 0u;
@@ -217,10 +222,10 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
             if (threadIdx.x < NF) hist[threadIdx.x] = 0;
             if (threadIdx.x < 64) lhist[threadIdx.x] = 0;
             __syncthreads();
-            const uint32_t ln = (uint32_t)(rec.y & 0xffu);               // 0 for the padding of the last tile
+            const uint32_t ln = run_len(rec.y);                          // 0 for the padding of the last tile
             const uint32_t fine = rec_fine(rec.y, b2);
             const uint32_t frank = ln ? atomicAdd(&hist[fine], ln) : 0u;  // first k-mer of the record inside its fine bucket
-            const uint32_t lrank = atomicAdd(&lhist[ln & 63u], 1u);
+            const uint32_t lrank = atomicAdd(&lhist[ln], 1u);
             __syncthreads();
             if (wave == 0) {
                 const uint32_t c = lhist[lane];
@@ -234,15 +239,15 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
                 gbase[threadIdx.x] = my_next;
                 my_next += c2;
             }
-            // by length: thread j continues with the j-th shortest record (the rank inside the fine bucket travels in
-            // bits of y that hold bases no k-mer of the record reaches)
-            srec[lstart[ln & 63u] + lrank] = make_ulonglong2(rec.x, (rec.y & ~(0x3ffffull << 16)) | ((uint64_t)frank << 16));
+            // by length: thread j continues with the j-th shortest record
+            srec[lstart[ln] + lrank] = rec;
+            srank[lstart[ln] + lrank] = frank;
             __syncthreads();
             {
                 const ulonglong2 r2 = srec[threadIdx.x];
-                const uint32_t l2 = (uint32_t)(r2.y & 0xffu);
+                const uint32_t l2 = run_len(r2.y);
                 if (l2) {
-                    uint32_t at = start[rec_fine(r2.y, b2)] + ((uint32_t)(r2.y >> 16) & 0x3ffffu);
+                    uint32_t at = start[rec_fine(r2.y, b2)] + srank[threadIdx.x];
                     RunDecoder dec = run_open(r2.x, r2.y, k);
                     for (uint32_t t = 0;; t++) {
                         skeys[at++] = run_canonical(dec);
@@ -265,28 +270,28 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
 
 // Level 2 without the expansion (dict_build decodes the records itself, record form): the region's records sorted by fine
 // bucket, in place of the region in a second buffer.  STAGED: the region is read once into LDS (a returning LDS atomic
-// gives every record its rank inside its fine bucket, kept in bits of y that hold bases no k-mer reaches) and written
+// gives every record its rank inside its fine bucket, kept in a 16-bit array beside the records) and written
 // from there; regions too large for that are swept twice (count, then place; the second sweep comes from L2).
-// Inside a fine bucket the records of at most 4 k-mers stand first: dict_build takes those four keys at a time and the
-// others eight at a time, which leaves 17 % of its key slots empty instead of 33 %.
+// Inside a fine bucket the records of at most 4 k-mers stand first: without its memo dict_build takes those four keys at a
+// time and the others eight at a time.
 // Segment vg * 2^bb + bucket = recs2[off[..] .. + (len[..] & 0xffff)) in RECORDS, the first len[..] >> 16 of them short.
 // bin of a record: 2 * fine bucket + (more than 4 k-mers)
-__device__ __forceinline__ uint32_t rec_bin(uint64_t y, int b2) { return (rec_fine(y, b2) << 1) | (uint32_t)((y & 0xffu) > 4u); }
+__device__ __forceinline__ uint32_t rec_bin(uint64_t y, int b2) { return (rec_fine(y, b2) << 1) | (uint32_t)(run_len(y) > 4u); }
 
 template <bool STAGED, int MAXR>
 __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(const ulonglong2 *__restrict__ recs1, uint32_t rstride,
                                                                             const uint32_t *__restrict__ rcount1, uint64_t n_regions, int bb, int b1,
                                                                             ulonglong2 *__restrict__ recs2, uint64_t *__restrict__ off,
-                                                                            uint32_t *__restrict__ len_out)
+                                                                            uint32_t *__restrict__ len_out, int *__restrict__ overflow)
 {
     constexpr int NF = 1 << SK_FINE_BITS, NB = 2 * NF;  // bins: (fine bucket, length class)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     ulonglong2 *srec = reinterpret_cast<ulonglong2 *>(lds_raw);          // [rstride] when STAGED
+    uint16_t *srank = reinterpret_cast<uint16_t *>(lds_raw + (size_t)rstride * 16);      // [rstride] (rstride < 2^16 when STAGED)
     __shared__ uint32_t hist[NB], start[NB];
     __shared__ uint32_t scratch[32];
     const int b2 = bb - b1;
     const uint32_t B2 = 1u << b2;
-    constexpr uint64_t RANK_MASK = 0x3ffffull << 16;
     for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
         const uint32_t n = min(rcount1[region], rstride);
         const ulonglong2 *rr = recs1 + region * rstride;
@@ -306,8 +311,8 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
             for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
                 if (i < n) {
-                    const uint32_t rank = atomicAdd(&hist[rec_bin(in[j].y, b2)], 1u);
-                    srec[i] = make_ulonglong2(in[j].x, (in[j].y & ~RANK_MASK) | ((uint64_t)rank << 16));
+                    srank[i] = (uint16_t)atomicAdd(&hist[rec_bin(in[j].y, b2)], 1u);
+                    srec[i] = in[j];
                 }
             }
         } else {
@@ -325,6 +330,8 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
                 const uint32_t f = threadIdx.x >> 1;
                 off[seg0 + f] = region * rstride + pre;
                 len_out[seg0 + f] = (cnt + cnt_long) | (cnt << 16);
+                // (a segment's record count travels in 16 bits beside the count of its short ones: the host falls back to the key form)
+                if (cnt + cnt_long > 0xffffu) atomicExch(overflow, 1);
             }
         }
         __syncthreads();
@@ -332,18 +339,18 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
             // in-place permutation of the LDS image through registers (a thread holds its <= MAXR records), then the
             // sorted region leaves with full-line stores: scattered 16-byte stores ran into the L2 request rate
             ulonglong2 mine[MAXR > 0 ? MAXR : 1];
+            uint32_t rank[MAXR > 0 ? MAXR : 1];
 #pragma unroll
             for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
                 mine[j] = i < n ? srec[i] : make_ulonglong2(0, 0);
+                rank[j] = i < n ? srank[i] : 0u;
             }
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
-                if (i < n)
-                    srec[start[rec_bin(mine[j].y, b2)] + ((uint32_t)(mine[j].y >> 16) & 0x3ffffu)] =
-                        make_ulonglong2(mine[j].x, mine[j].y & ~RANK_MASK);
+                if (i < n) srec[start[rec_bin(mine[j].y, b2)] + rank[j]] = mine[j];
             }
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) out[i] = srec[i];
@@ -373,12 +380,17 @@ __global__ void minimizer_bucket_ids_kernel(const uint64_t *__restrict__ dict, u
 template <int W>
 static void launch_sk1(hipStream_t s, const SkArgs &a, ulonglong2 *recs1, uint32_t rstride, uint32_t *rcount1, uint32_t *part_kmers, int *overflow)
 {
-    hipLaunchKernelGGL(superkmer_l1_kernel<W>, dim3(a.n_genomes << a.part_bits), dim3(SK_THREADS), 0, s, a, recs1, rstride, rcount1, part_kmers,
-                       overflow);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(superkmer_l1_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_L1_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(superkmer_l1_kernel<W>, dim3(a.n_genomes << a.part_bits), dim3(SK_THREADS), SK_L1_LDS, s, a, recs1, rstride, rcount1,
+                       part_kmers, overflow);
 }
 
 int superkmer_max_bits() { return SK_MAX_BITS; }
-int superkmer_coarse_bits(int bb) { return bb < 9 ? bb : 9; }      // 512 regions per genome part: a region's records fit 40 KB of LDS at 5 Mbp
+int superkmer_coarse_bits(int bb) { return bb < SK_MAX_COARSE ? bb : SK_MAX_COARSE; }      // 512 regions per genome part: a region's ~1000 records (5 Mbp) fit LDS
 int superkmer_lmax() { return SK_LMAX; }
 
 void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int b1, int part_bits, void *recs1, uint32_t rstride, uint32_t *rcount1,
@@ -412,7 +424,7 @@ void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, con
 
 template <int MAXR>
 static void launch_l2r_staged(hipStream_t s, uint32_t grid, const ulonglong2 *r1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb,
-                              int b1, ulonglong2 *r2, uint64_t *off, uint32_t *len)
+                              int b1, ulonglong2 *r2, uint64_t *off, uint32_t *len, int *overflow)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -420,21 +432,23 @@ static void launch_l2r_staged(hipStream_t s, uint32_t grid, const ulonglong2 *r1
                                   96 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((superkmer_l2_records_kernel<true, MAXR>), dim3(grid), dim3(SK2R_THREADS), (size_t)rstride * 16, s, r1, rstride, rcount1,
-                       n_regions, bb, b1, r2, off, len);
+    // the records and, beside them, their 16-bit ranks
+    hipLaunchKernelGGL((superkmer_l2_records_kernel<true, MAXR>), dim3(grid), dim3(SK2R_THREADS), (size_t)rstride * 18, s, r1, rstride, rcount1,
+                       n_regions, bb, b1, r2, off, len, overflow);
 }
 
 void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb, int b1,
-                                 void *recs2, uint64_t *off, uint32_t *len)
+                                 void *recs2, uint64_t *off, uint32_t *len, int *overflow)
 {
     if (!n_regions) return;
     const uint32_t grid = (uint32_t)(n_regions < 256u * 32u ? n_regions : 256u * 32u);
     const ulonglong2 *r1 = reinterpret_cast<const ulonglong2 *>(recs1);
     ulonglong2 *r2 = reinterpret_cast<ulonglong2 *>(recs2);
-    // the region in LDS: up to 3072 records (48 KB, three workgroups per CU), up to 5120 (80 KB, two), else two sweeps
-    if (rstride <= 6u * SK2R_THREADS) launch_l2r_staged<6>(s, grid, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len);
-    else if (rstride <= 10u * SK2R_THREADS) launch_l2r_staged<10>(s, grid, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len);
-    else hipLaunchKernelGGL((superkmer_l2_records_kernel<false, 0>), dim3(grid), dim3(SK2R_THREADS), 0, s, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len);
+    // the region in LDS: up to 1536 records (27 KB, five workgroups per CU), 3072 (54 KB, two), 5120 (90 KB, one), else two sweeps
+    if (rstride <= 3u * SK2R_THREADS) launch_l2r_staged<3>(s, grid, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len, overflow);
+    else if (rstride <= 6u * SK2R_THREADS) launch_l2r_staged<6>(s, grid, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len, overflow);
+    else if (rstride <= 10u * SK2R_THREADS) launch_l2r_staged<10>(s, grid, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len, overflow);
+    else hipLaunchKernelGGL((superkmer_l2_records_kernel<false, 0>), dim3(grid), dim3(SK2R_THREADS), 0, s, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len, overflow);
 }
 
 void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int k, int bb, int sb, uint32_t *bucket_of, uint32_t *col_of)

@@ -6,6 +6,7 @@ The reference has no in-process API for this path: Kover calls
 device-resident form.  numpy arrays out, plain pointers in: PyTorch is not needed here.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -31,9 +32,21 @@ class Context:
         if not self.h:
             raise GrmError(-2, "grm_create(%d) failed: no usable HIP device (there is no CPU fallback)" % device)
         self.device = device
+        self._children = weakref.WeakSet()      # live Batch / Matrix / KmerSet / DictAccum objects of this context
+
+    def _adopt(self, child):
+        self._children.add(child)
+        return child
 
     def close(self):
+        """Frees every handle made from this context that is still alive, then the context.  (The library also counts
+        references -- a handle freed after grm_destroy is safe -- but freeing in order returns the HBM right away.)"""
         if self.h:
+            for child in list(self._children):
+                try:
+                    child.free()
+                except Exception:
+                    pass
             self.L.grm_destroy(self.h)
             self.h = None
 
@@ -126,6 +139,7 @@ class Context:
 class KmerSet:
     def __init__(self, ctx, h):
         self.ctx, self.h = ctx, h
+        ctx._adopt(self)
 
     def __len__(self):
         return self.ctx.L.grm_kmer_set_size(self.h)
@@ -173,6 +187,7 @@ class Matrix:
 
     def __init__(self, ctx, h):
         self.ctx, self.h = ctx, h
+        ctx._adopt(self)
 
     @property
     def n_kmers(self):
@@ -288,6 +303,7 @@ class DictAccum:
 
     def __init__(self, ctx, h):
         self.ctx, self.h = ctx, h
+        ctx._adopt(self)
 
     def add(self, batch):
         self.ctx._chk(self.ctx.L.grm_dict_accum_add(self.h, batch.h))
@@ -300,6 +316,12 @@ class DictAccum:
             self.ctx.L.grm_dict_accum_free(self.h)
             self.h = None
 
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
 
 class Batch:
     """device-resident batch of genomes: parse -> partition -> dictionary -> presence bits"""
@@ -310,6 +332,7 @@ class Batch:
         ctx._chk(ctx.L.grm_batch_create(ctx.h, n_genomes, C.byref(h)))
         self.h = h
         self.n_genomes = n_genomes
+        ctx._adopt(self)
 
     def add(self, genome_index, data):
         buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else None
@@ -407,6 +430,15 @@ class Batch:
         """entries of the last local dictionary (distinct k-mers of this batch's genomes)"""
         return int(self.ctx.L.grm_batch_n_local(self.h))
 
+    def memo_stats(self):
+        """record memo of the last dictionary launch (ctx.set_option("memo_stats", 1)) -> dict, or None without a memo"""
+        v = (C.c_uint64 * 4)()
+        self.ctx._chk(self.ctx.L.grm_batch_memo_stats(self.h, v))
+        held, asked, found, ends = (int(x) for x in v)
+        if not ends:
+            return None
+        return {"records_held_mean": held / ends, "occurrences": asked, "found": found, "hit_rate": found / asked if asked else 0.0}
+
     def free(self):
         if self.h:
             self.ctx.L.grm_batch_free(self.h)
@@ -430,6 +462,9 @@ class HostMatrix(Matrix):
         def _chk(self, rc):
             if rc != 0:
                 raise GrmError(rc, "host-only matrix")
+
+        def _adopt(self, child):
+            return child
 
     def __init__(self, kmers, data, n_genomes, k):
         L = _lib.load()

@@ -17,11 +17,14 @@
  *   - every function returns 0 on success or a negative grm_status; grm_last_error(ctx)
  *     returns a message owned by the ctx (valid until the next call on that ctx).
  *   - k-mers are 2-bit packed, first base most significant, A=0 C=1 T=2 G=3 (GATB),
- *     canonical = min(forward, reverse complement); `words` uint64 per k-mer, most significant
- *     first (1 for k<=32, 2 for 33<=k<=64).  Inputs: FASTA or 4-line FASTQ, optionally gzip.
+ *     canonical = min(forward, reverse complement); `words` = ceil(k / 32) uint64 per k-mer, most significant
+ *     first (k = 1 .. 128, the reference's range: bin/kover/kover:114).  Inputs: FASTA or 4-line FASTQ, optionally gzip.
  *   - matrix: uint64 [n_rows][n_kmers] row-major, genome i -> row i/64, bit 63-(i%64)
  *     (bin/kover/core/kover/utils.py:133-156); columns ascending by k-mer value.
  *   - a grm_ctx is single-caller; HIP streams inside are the parallelism.
+ *   - lifetime: every handle made from a context (grm_batch, grm_matrix, grm_kmer_set, grm_dict_accum) holds a
+ *     reference to it.  grm_destroy drops the owner's reference; the device streams are released when the last
+ *     handle has been freed, so handles may be freed after grm_destroy (a caller that unwinds on an error does).
  *   - plain pointers and sizes only: no Python / torch types cross this boundary.
  *     Arguments named dev_* are HIP device pointers on the ctx's device.
  */
@@ -56,6 +59,8 @@ typedef struct grm_batch grm_batch;
 /* device_ordinal >= 0: HIP device.  There is no CPU mode: -1 is rejected (GRM_ERR_NO_DEVICE). */
 grm_ctx    *grm_create(int device_ordinal, int n_streams);
 void        grm_destroy(grm_ctx *);
+/* handles made from the context that have not been freed yet */
+int         grm_ctx_live_handles(const grm_ctx *);
 const char *grm_last_error(grm_ctx *);
 const char *grm_version(void);
 /* tuning knobs (mainly for tests): name in {"groups_per_thread","bucket_bits","cap_log2",
@@ -193,6 +198,9 @@ uint64_t grm_batch_n_symbols(const grm_batch *);
 uint64_t grm_batch_n_occurrences(const grm_batch *);     /* valid k-mer windows */
 uint64_t grm_batch_input_bytes(const grm_batch *);
 uint64_t grm_batch_n_local(const grm_batch *);           /* entries of the last local dictionary */
+/* record memo of the last dictionary launch (option "memo_stats" = 1; zeros when the launch had no memo): sums over
+ * (workgroup, word-row) of { records held, record occurrences asked, occurrences found in the memo, (workgroup, word-row) count } */
+int      grm_batch_memo_stats(const grm_batch *, uint64_t *out4);
 /* per-genome distinct k-mers after the last partition (+dedup): sorted set for genome g */
 int  grm_batch_genome_set(grm_batch *, int genome_index, grm_kmer_set **out);
 void grm_batch_free(grm_batch *);

@@ -12,7 +12,7 @@
 using namespace grm;
 
 template <int W>
-static void emul_buckets(uint64_t w0, uint64_t w1, int nbits, uint32_t (&bk)[RUN_PPT]) { run_buckets<W>(w0, w1, nbits, bk); }
+static void emul_minimizers(uint64_t w0, uint64_t w1, uint32_t prev2, uint32_t (&val)[RUN_PPT + 1]) { run_minimizers<W>(w0, w1, prev2, val); }
 
 extern "C" {
 
@@ -266,53 +266,90 @@ uint32_t emul_sub(uint64_t h, int bb, int sb) { return hash_sub(h, bb, sb); }
 uint64_t emul_valid_starts(uint64_t i0, uint64_t i1, int k) { return valid_starts(i0, i1, k); }
 uint64_t emul_revcomp(uint64_t v, int m) { return revcomp_m(v, m); }
 
-// Record form of the partition (grm_superkmer.hip) with the kernels' own per-lane functions: every packed word -> buckets of
-// its 32 k-mer starts (run_buckets<W>), runs (run_heads / run_length), 16-byte records (run_record); every record is then
-// decoded the way dict_build does (run_open / run_next).  out_keys / out_bucket: one entry per decoded k-mer, in stream order
-// (bucket = the record's coarse bits | fine field at nbits = coarse_bits + RUN_FINE_BITS); out_len: one entry per record.
-uint64_t emul_runs(const uint64_t *sym2, const uint64_t *inv, uint64_t total_syms, int k, int coarse_bits, uint64_t *out_keys,
-                   uint32_t *out_bucket, uint64_t cap, uint32_t *out_len, uint64_t len_cap, uint64_t *n_records)
+// Record form of the partition (grm_superkmer.hip) with the kernels' own per-lane functions, window by window as level 1 goes
+// through the genome [lo, hi) of the stream: minimizer words of the 33 k-mer starts (run_minimizers<W>), run heads, the lead
+// of the next window (what the lane to the right reports), 16-byte records (run_record); every record is then decoded the way
+// dict_build does (run_open / run_next).  out_keys / out_bucket: one entry per decoded k-mer, record after record in decode
+// order (bucket at nbits = coarse_bits + RUN_FINE_BITS, from the record's minimizer); out_rec: per record {length, flipped,
+// x lo, x hi, y lo, y hi} (6 uint32).  Returns the number of k-mers; ~0 - code on an inconsistency.
+uint64_t emul_runs(const uint64_t *sym2, const uint64_t *inv, uint64_t total_syms, uint64_t lo, uint64_t hi, int k, int coarse_bits,
+                   uint64_t *out_keys, uint32_t *out_bucket, uint64_t cap, uint32_t *out_rec, uint64_t rec_cap, uint64_t *n_records)
 {
     uint64_t n = 0, nr = 0;
     const int nbits = coarse_bits + RUN_FINE_BITS;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     const int rcshift = 2 * (k - 1);
-    const uint64_t n_words = (total_syms + 31) / 32;
-    for (uint64_t wi = 0; wi < n_words; wi++) {
-        const uint64_t p0 = wi << 5, grp = p0 >> 6;
-        const int64_t nv = (int64_t)total_syms - k + 1 - (int64_t)p0;
-        if (nv <= 0) break;
-        const uint64_t w0 = sym2[wi], w1 = sym2[wi + 1];
-        uint32_t valid = (uint32_t)valid_starts_at(inv[grp], inv[grp + 1], (int)(p0 & 63), k);
-        if (nv < RUN_PPT) valid &= (1u << nv) - 1;
-        if (!valid) continue;
-        uint32_t bk[RUN_PPT];
-        switch (k - 11 + 1) {
-#define CASE(W) case W: emul_buckets<W>(w0, w1, nbits, bk); break;
-            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
-            CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22)
-#undef CASE
-            default: return ~0ull;
+    const uint64_t last = total_syms >= (uint64_t)k ? total_syms - k + 1 : 0;
+    const uint64_t p_end = hi < last ? hi : last;
+    const uint64_t jw_lo = lo >> 5, jw_hi = hi > lo ? (hi + 31) >> 5 : jw_lo;
+    struct Win { uint32_t valid, heads, lead; uint32_t val[RUN_PPT + 1]; };
+    auto window = [&](uint64_t j, Win &w) -> bool {
+        const uint64_t p0 = j << 5;
+        uint64_t vs;
+        if (p0) {
+            const uint64_t q = p0 - 1;
+            vs = valid_starts_at(inv[q >> 6], inv[(q >> 6) + 1], (int)(q & 63), k);
+        } else {
+            vs = valid_starts_at(inv[0], inv[1], 0, k) << 1;
         }
-        const uint32_t heads = run_heads(valid, bk);
+        const uint64_t t_lo = lo + 1 > p0 ? lo + 1 - p0 : 0, t_hi = p_end + 1 > p0 ? p_end + 1 - p0 : 0;
+        const uint64_t keep = (t_hi >= 33 ? (1ull << 33) - 1 : (1ull << t_hi) - 1) & ~(t_lo >= 33 ? (1ull << 33) - 1 : (1ull << t_lo) - 1);
+        vs &= keep;
+        w.valid = (uint32_t)(vs >> 1);
+        w.heads = 0;
+        if (w.valid) {
+            const uint32_t prev2 = j ? (uint32_t)sym2[j - 1] & 3u : 0u;
+            switch (k - 11 + 1) {
+#define CASE(W) case W: emul_minimizers<W>(sym2[j], sym2[j + 1], prev2, w.val); break;
+                CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+                CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22)
+#undef CASE
+                default: return false;
+            }
+            w.heads = run_heads(w.valid, (vs & 1u) != 0, w.val);
+        }
+        w.lead = run_lead(w.valid, w.heads);
+        return true;
+    };
+    Win cur, nxt;
+    if (jw_hi > jw_lo && !window(jw_lo, cur)) return ~0ull;
+    for (uint64_t j = jw_lo; j < jw_hi; j++) {
+        if (!window(j + 1, nxt)) return ~0ull;               // (the window after the genome's last: nothing valid, lead 0)
+        const uint64_t w0 = sym2[j], w1 = sym2[j + 1], w2 = sym2[j + 2];
         for (int i = 0; i < RUN_PPT; i++) {
-            if (!((heads >> i) & 1u)) continue;
-            const uint32_t len = run_length(heads, valid, i);
-            uint64_t x, y;
-            run_record(w0, w1, i, len, bk[i], x, y);
-            if (nr < len_cap) out_len[nr] = (uint32_t)(y & 0xff);
-            nr++;
-            // every position of the run must be a valid start of the same bucket
+            if (!((cur.heads >> i) & 1u)) continue;
+            uint32_t len = run_length(cur.heads, cur.valid, i);
+            // every position of the run inside the window: a valid start with the head's minimizer occurrence
             for (uint32_t t = 0; t < len; t++)
-                if (!((valid >> (i + t)) & 1u) || bk[i + t] != bk[i]) return ~0ull - 1;
+                if (!((cur.valid >> (i + t)) & 1u) || cur.val[i + 1 + t] != cur.val[i + 1]) return ~0ull - 1;
+            if (i + (int)len == RUN_PPT) {
+                // the part in the next window: the same minimizer occurrence, one word further (its position field counts from there)
+                for (uint32_t t = 0; t < nxt.lead; t++) {
+                    if (!((nxt.valid >> t) & 1u)) return ~0ull - 2;
+                    if ((nxt.val[t + 1] >> 8) != (cur.val[i + 1] >> 8) || (nxt.val[t + 1] & 1u) != (cur.val[i + 1] & 1u)) return ~0ull - 3;
+                    if (((nxt.val[t + 1] >> 1) & 63u) + RUN_PPT != ((cur.val[i + 1] >> 1) & 63u)) return ~0ull - 4;
+                }
+                len += nxt.lead;
+            }
+            if (len > (uint32_t)(k - 11 + 1)) return ~0ull - 5;        // a run shares one m-mer: at most W k-mers
+            const uint32_t v = cur.val[i + 1];
+            const uint32_t bucket = minimizer_bucket(v >> (32 - MINIMIZER_ORDER_BITS), nbits);
+            uint64_t x, y;
+            run_record(w0, w1, w2, i, len, k, (v & 1u) != 0, bucket, x, y);
+            if (run_len(y) != len || run_fine(y) != (bucket & ((1u << RUN_FINE_BITS) - 1u)) || ((y >> 12) & 0x3ffu)) return ~0ull - 6;
+            if (nr < rec_cap) {
+                uint32_t *o = out_rec + 6 * nr;
+                o[0] = len; o[1] = v & 1u; o[2] = (uint32_t)x; o[3] = (uint32_t)(x >> 32); o[4] = (uint32_t)y; o[5] = (uint32_t)(y >> 32);
+            }
+            nr++;
             RunDecoder d = run_open(x, y, k);
-            const uint32_t bucket = ((bk[i] >> RUN_FINE_BITS) << RUN_FINE_BITS) | ((uint32_t)(y >> 8) & ((1u << RUN_FINE_BITS) - 1u));
-            for (uint32_t t = 0; t < (uint32_t)(y & 0xff); t++) {
+            for (uint32_t t = 0; t < len; t++) {
                 if (n < cap) { out_keys[n] = run_canonical(d); out_bucket[n] = bucket; }
                 n++;
                 run_next(d, kmask, rcshift);
             }
         }
+        cur = nxt;
     }
     *n_records = nr;
     return n;

@@ -185,6 +185,66 @@ def test_record_memo_switches_itself_off_on_unrelated_genomes(ctx):
         ctx.set_option("bucket_bits", -1)
 
 
+def _realistic_genomes(n, length, seed, **kw):
+    pg = synth.realistic(genome_len=length, seed=seed, n_snps=length // 100, n_accessory=6, accessory_len=1500, **kw)
+    return [[pg.genome(i).tobytes()] for i in range(n)]
+
+
+@pytest.mark.parametrize("k", [31, 21])
+def test_realistic_assemblies_bit_exact(ctx, k):
+    """GRM's real inputs (src/app.py:576-583): every genome its own contigs, cut at its own places, in its own order, each on a
+    random strand, with indels between the strains -- no two genomes share a coordinate frame.  Bit-exact against the oracle, on
+    the record form with and without its memo, in parts, and on the key form"""
+    genomes = _realistic_genomes(70, 60_000, 31, indel_sites=40, contigs=(3, 9))
+    for opts in ({}, {"rec_memo": 0}, {"rec_part_bits": 2}, {"records": 0}):
+        try:
+            for name, v in opts.items():
+                ctx.set_option(name, v)
+            _check(ctx, genomes, k, 1, True)
+        finally:
+            for name in opts:
+                ctx.set_option(name, -1)
+
+
+def test_record_memo_survives_frame_and_strand(ctx):
+    """the same strains once as in round 2's generator (one coordinate frame, forward strand) and once as real assemblies
+    (contigs cut anywhere, shuffled, on random strands, indels): run records are cut where the SEQUENCE says and stored
+    strand-canonically, so dict_build's memo finds nearly every record occurrence in both"""
+    rates = {}
+    for name, kw in (("one frame", dict(indel_sites=0, contigs=None, shuffle_contigs=False, random_strand=False, n_contigs=1)),
+                     ("assemblies", dict(indel_sites=30, contigs=(10, 30)))):
+        genomes = _realistic_genomes(128, 300_000, 77, **kw)
+        b = ctx.batch(len(genomes))
+        for g, files in enumerate(genomes):
+            b.add(g, files[0])
+        b.upload()
+        try:
+            ctx.set_option("memo_stats", 1)
+            m = b.run(31, 1, True)
+            st = b.memo_stats()
+        finally:
+            ctx.set_option("memo_stats", -1)
+        assert st is not None and st["occurrences"] > 1_000_000
+        rates[name] = st["hit_rate"]
+        m.free()
+        b.free()
+    assert rates["one frame"] > 0.95, rates
+    assert rates["assemblies"] > 0.93, rates             # (a contig end or an indel costs the two runs around it)
+    assert rates["assemblies"] > rates["one frame"] - 0.04, rates
+
+
+def test_hundred_unrelated_genomes_through_the_matrix_path(ctx):
+    """the shape of round 2's memory fault (bench.py --mode R --genomes 100: unrelated genomes through the record form's
+    overflow ladder -- more buckets via level 2 again, then the key form), reduced to what the oracle checks in seconds"""
+    genomes = [[synth.random_genome(i, genome_len=400_000, seed=99).tobytes()] for i in range(100)]
+    _check(ctx, genomes, 31, 1, False)
+    try:
+        ctx.set_option("cap_log2", 9)                   # small tables: the ladder has to climb (more buckets, then sub-buckets / key form)
+        _check(ctx, genomes, 31, 1, True)
+    finally:
+        ctx.set_option("cap_log2", -1)
+
+
 def test_record_form_gives_way_to_the_key_form_on_repeats(ctx):
     """repeat-rich genomes: nearly all k-mers of a genome share a handful of minimizers, so a few record regions would hold
     most of its records -- the partition raises its overflow flag and is redone in the key form (hashed k-mers spread
