@@ -10,6 +10,12 @@ Legs of one invocation (rank 0 prints ONE JSON line):
                 N>1: configs[2] -- the SAME 1000-genome set split over the ranks in blocks of whole
                 word-rows (128,...,104 at N=8), ONE dictionary all-gather over RCCL; "scaling": "strong".
                 The weak form (1000 genomes per GPU) is measured too and reported under "weak".
+  realistic     N=1: the same 1000 strains as real assemblies -- every genome cut into its own 20-100 contigs at its own places,
+                contigs in random order and on random strands, ~1 indel site per 10 kbp (GRM's inputs: src/app.py:576-583) --
+                through the same pass: ms per pass, kernel table, hit rate of dict_build's record memo.
+  c5            N=1: BASELINE configs[4] -- 500 genomes, k=63 (two-word k-mers), singletons kept; pass + gzip-5 .kover writer.
+  c4            N=1: BASELINE configs[3] at full depth for 8 genomes -- 150 bp reads, 100x, 0.5 % errors, FASTQ, k=21,
+                abundance-min 2: the counting stage, one genome's solid set compared with the CPU restatement.
   random_acgt   counting stage (parse -> partition -> per-genome dedup + count, matrix not materialised;
                 SURVEY 8(d) C2(R)) on 1000 independent uniform-ACGT genomes (split over the ranks for N>1,
                 no collective): bases/s and its own roofline.
@@ -61,7 +67,7 @@ def parse_args():
     ap.add_argument("--genomes", type=int, default=1000, help="genomes of the set (N=1 / strong) or per GPU (weak)")
     ap.add_argument("--weak-only", action="store_true", help="N>1: only the weak form (--genomes per GPU) as the headline")
     ap.add_argument("--genome-len", type=int, default=5_000_000)
-    ap.add_argument("--mode", default="P", choices=["P", "R"], help="generator of the headline leg")
+    ap.add_argument("--mode", default="P", choices=["P", "R", "X"], help="generator of the headline leg (X = realistic assemblies)")
     ap.add_argument("--stage", default="matrix", choices=["matrix", "count"],
                     help="headline leg: whole path to the matrix, or the counting stage only")
     ap.add_argument("--k", type=int, default=31)
@@ -70,6 +76,11 @@ def parse_args():
     ap.add_argument("--no-random", action="store_true", help="skip the random-ACGT counting leg")
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the weak-scaling leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> .kover end-to-end leg")
+    ap.add_argument("--no-realistic", action="store_true", help="skip the realistic-assemblies leg")
+    ap.add_argument("--no-c4", action="store_true", help="skip the reads leg (BASELINE configs[3])")
+    ap.add_argument("--no-c5", action="store_true", help="skip the k=63 leg (BASELINE configs[4])")
+    ap.add_argument("--only", default=None, choices=["headline", "realistic", "c4", "c5", "random"],
+                    help="run ONE leg (profiling); for any leg but the headline, the headline shrinks to 16 genomes")
     ap.add_argument("--cpu-genomes", type=int, default=-1,
                     help="genomes the CPU restatement is timed on (default: all of the e2e set; 0 = skip)")
     ap.add_argument("--gzip", type=int, default=4)
@@ -199,11 +210,13 @@ def roofline_of(kernels, traffic_of=None, occurrences=None, words=1):
     if stage and occurrences:
         g = stage[1] * occurrences / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
         r["survey_stage"] = {"stage": stage[0], "bytes_per_occurrence": stage[1], "achieved": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4)}
-    limits = {"superkmer_l1": "VALU issue: 3.5e9 wave instructions = 5.7 of its 7.7 ms (minimizers of 52 m-mers per 32 positions in registers); "
-                              "writes 1.66x its records as partial lines (profiles/r02/final_sq_counters.csv, final_pmc_hbm.csv)",
-              "dict_build": "latency of 128-byte reads of segments megabytes apart + LDS lookups, 4 waves per SIMD (profiles/r02/final_sq_counters.csv)"}
-    if dom in limits and traffic:           # (the committed profile is of this very workload)
-        r["limited_by"] = limits[dom]
+    if traffic:           # (the committed profile is of this very workload): what bounds the kernel, as read from that profile
+        try:
+            lj = json.load(open(os.path.join(ROOT, "profiles", "limits.json")))
+            if dom in lj.get("limited_by", {}):
+                r["limited_by"] = {"text": lj["limited_by"][dom], "profile_commit": lj.get("commit"), "source": lj.get("source")}
+        except (OSError, ValueError):
+            pass
     return r
 
 
@@ -225,6 +238,9 @@ def make_batch(ctx, synth, mode, base, n, genome_len, keep=None):
     batch = ctx.batch(n)
     if mode == "P":
         pg = synth.PanGenome(genome_len=genome_len, seed=1234)
+        gen = lambda i: pg.genome(base + i)
+    elif mode == "X":
+        pg = synth.realistic(genome_len=genome_len, seed=1234)
         gen = lambda i: pg.genome(base + i)
     else:
         gen = lambda i: synth.random_genome(base + i, genome_len=genome_len, seed=1234)
@@ -282,6 +298,258 @@ def count_leg(D, ctx, args, batch, steps, warmup):
     return elapsed, kernel_table(ctx, 0, 0, 0)
 
 
+def realistic_leg(D, Dm, ctx, synth, args):
+    """the headline pass over the same strains given as real assemblies (own contigs per genome, shuffled, random strands, indels)"""
+    b = make_batch(ctx, synth, "X", 0, args.genomes, args.genome_len)
+    el, n_cols, n_rows, kernels, _ = matrix_leg(D, Dm, ctx, args, b, args.steps, 1)
+    occ, syms = b.n_occurrences, b.n_symbols
+    ctx.set_option("memo_stats", 1)            # one more pass, untimed, with dict_build's memo counters on
+    try:
+        m = b.run(args.k, args.abundance_min, not args.keep_singletons)
+        memo = b.memo_stats()
+        m.free()
+    finally:
+        ctx.set_option("memo_stats", -1)
+    b.free()
+    return {"workload": "%d x %d bp realistic assemblies (synth.realistic, seed 1234: the headline's strains + 1 indel site per 10 kbp, 20-100 contigs "
+                        "per genome cut at its own places, shuffled, random strands), k=%d, %s" % (
+                            args.genomes, args.genome_len, args.k, "singleton filter" if not args.keep_singletons else "singletons kept"),
+            "ms_per_step": round(1000 * el / args.steps, 3), "kmers_per_s": round(occ * args.steps / el, 1), "bases_per_s": round(syms * args.steps / el, 1),
+            "columns": int(n_cols), "record_memo": memo, "roofline": roofline_of(kernels, occurrences=occ), "kernels": kernels}
+
+
+def c5_leg(D, Dm, ctx, synth, args, orc):
+    """BASELINE configs[4]: 500 genomes, k = 63 (two-word k-mers), singletons kept, gzip-5 .kover"""
+    import copy
+    import tempfile
+    import numpy as np
+    from importlib import import_module
+    kd = import_module("genomic-resistance-mapping-grm-_amd.kover_dataset")
+    a5 = copy.copy(args)
+    a5.k, a5.keep_singletons, a5.abundance_min = 63, True, 1
+    n = min(500, args.genomes)
+    kept = {}
+    b = make_batch(ctx, synth, "P", 0, n, args.genome_len, keep=lambda i, g: kept.__setitem__(i, g) if i == 3 else None)
+    el, n_cols, n_rows, kernels, _ = matrix_leg(D, Dm, ctx, a5, b, args.steps, 1)
+    occ = b.n_occurrences
+    out = {"workload": "%d x %d bp pan-genome (mode P), k=63, singletons kept" % (n, args.genome_len),
+           "ms_per_step": round(1000 * el / args.steps, 3), "kmers_per_s": round(occ * args.steps / el, 1), "columns": int(n_cols),
+           "roofline": roofline_of(kernels, occurrences=occ, words=2), "kernels": kernels}
+    m = b.run(63, 1, False)
+    # one genome's columns against the CPU restatement: with the singletons kept, exactly its own k-mers carry its bit
+    g = 3
+    km, _, _ = orc.count_genome([kept[g].tobytes()], 63, 1)
+    row = m.data()[g // 64]
+    mine = (row >> np.uint64(63 - g % 64)) & np.uint64(1) == 1
+    got = m.kmers()[mine]
+    out["bit_exact_sample"] = bool(got.shape == km.shape and np.array_equal(got, km))
+    out["bit_exact_what"] = "the columns that carry genome %d's bit = the CPU restatement's k-mer set of that genome (%d 63-mers)" % (g, km.shape[0])
+    del row, mine, got
+    d = tempfile.mkdtemp(prefix="grm_c5_")
+    try:
+        path = os.path.join(d, "C5.kover")
+        ids = ["g%05d" % i for i in range(n)]
+        t0 = time.perf_counter()
+        kd.write_header(path, "contigs", "synthetic", None, None, 5, ids, None, None, None, "nothing")
+        m.write_kover_h5(path, 5, 100000)
+        out["kover_gzip5"] = {"seconds": round(time.perf_counter() - t0, 3), "bytes": os.path.getsize(path)}
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    m.free()
+    b.free()
+    return out
+
+
+def _reads_fastq(torch, device, seq_u8, n_reads, read_len, seed):
+    """4-line FASTQ image (numpy uint8) of n_reads reads of read_len from seq_u8 with 0.5 % substitution errors.  Built on the GPU
+    with torch (generating 1 GB per genome with numpy would take longer than every timed leg together); not timed."""
+    import numpy as np
+    seq = torch.from_numpy(np.ascontiguousarray(seq_u8)).to(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    width = 3 + read_len + 3 + read_len + 1
+    rec = torch.empty((n_reads, width), dtype=torch.uint8, device=device)
+    rec[:, 0:3] = torch.tensor(list(b"@r\n"), dtype=torch.uint8, device=device)
+    rec[:, 3 + read_len:6 + read_len] = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device=device)
+    rec[:, 6 + read_len:6 + 2 * read_len] = ord("I")
+    rec[:, -1] = 10
+    ar = torch.arange(read_len, device=device)
+    for a in range(0, n_reads, 1 << 20):
+        b = min(n_reads, a + (1 << 20))
+        st = torch.randint(0, seq.numel() - read_len, (b - a,), generator=gen, device=device)
+        rec[a:b, 3:3 + read_len] = seq[st[:, None] + ar[None, :]]
+    n_err = int(n_reads * read_len * 0.005)
+    r = torch.randint(0, n_reads, (n_err,), generator=gen, device=device)
+    c = torch.randint(0, read_len, (n_err,), generator=gen, device=device)
+    rec[r, 3 + c] = acgt[torch.randint(0, 4, (n_err,), generator=gen, device=device)]
+    out = rec.cpu().numpy().reshape(-1)
+    del rec, seq
+    return out
+
+
+def c4_leg(D, ctx, synth, args, orc):
+    """BASELINE configs[3] at its real depth for a few genomes: paired-end-like 150 bp reads at 100x with errors, FASTQ, k = 21,
+    abundance-min 2 -- the counting stage (parse -> partition -> dedup + count + filter), then one genome's solid set against
+    the CPU restatement (counted chunk-wise on the host threads; also the leg's CPU baseline)"""
+    import copy
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    n_g, cov, rl, k, amin = 8, 100, 150, 21, 2
+    torch = D.torch
+    pg = synth.PanGenome(genome_len=args.genome_len, seed=1234)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    b = ctx.batch(n_g)
+    first = None
+    for g in range(n_g):
+        fa = pg.genome(g)
+        seq = fa[np.isin(fa, acgt)][:args.genome_len]
+        img = _reads_fastq(torch, D.device, seq, args.genome_len * cov // rl, rl, 7700 + g)
+        if g == 0:
+            first = img
+        b.add_array(g, img)
+        del img
+    torch.cuda.empty_cache()
+    b.upload()
+    a4 = copy.copy(args)
+    a4.k, a4.abundance_min = k, amin
+    el, kernels = count_leg(D, ctx, a4, b, max(1, min(args.steps, 2)), 1)
+    occ, syms, in_bytes = b.n_occurrences, b.n_symbols, b.input_bytes
+    steps = max(1, min(args.steps, 2))
+    out = {"workload": "%d genomes x %d bp, %d bp reads at %dx with 0.5 %% substitution errors (%.1f GB of FASTQ resident), k=%d, abundance-min %d: "
+                       "counting stage" % (n_g, args.genome_len, rl, cov, in_bytes / 1e9, k, amin),
+           "ms_per_step": round(1000 * el / steps, 3), "kmers_per_s": round(occ * steps / el, 1), "bases_per_s": round(syms * steps / el, 1),
+           "roofline": roofline_of(kernels), "kernels": kernels}
+    # genome 0: solid k-mers and their counts
+    s0 = b.genome_set(0)
+    gk, gc = s0.kmers()[:, 0], s0.counts().astype(np.int64)
+    s0.free()
+    b.free()
+    # CPU: the FASTQ image cut at record boundaries into one chunk per thread, each counted with abundance-min 1
+    cores = min(os.cpu_count() or 1, 32)
+    rec_bytes = 3 + rl + 3 + rl + 1
+    n_rec = first.size // rec_bytes
+    cuts = [(n_rec * i // cores) * rec_bytes for i in range(cores + 1)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        parts = list(pool.map(lambda i: orc.count_genome([first[cuts[i]:cuts[i + 1]].tobytes()], k, 1), range(cores)))
+    cpu_s = time.perf_counter() - t0
+    total = np.zeros(gk.shape[0], dtype=np.int64)
+    rest, ok, cpu_occ = [], True, 0
+    for km, ct, nocc in parts:
+        cpu_occ += nocc
+        km = km[:, 0]
+        at = np.searchsorted(gk, km)
+        at[at >= gk.shape[0]] = gk.shape[0] - 1 if gk.shape[0] else 0
+        hit = gk[at] == km if gk.shape[0] else np.zeros(km.shape, bool)
+        total += np.bincount(at[hit], weights=ct[hit].astype(np.float64), minlength=gk.shape[0]).astype(np.int64)
+        ok = ok and bool((ct[~hit] == 1).all())              # a k-mer outside the solid set occurs once ...
+        rest.append(km[~hit])
+    rest = np.sort(np.concatenate(rest)) if rest else np.zeros(0, np.uint64)
+    ok = ok and bool((rest[1:] != rest[:-1]).all())          # ... in ONE chunk only
+    ok = ok and bool(np.array_equal(total, gc)) and bool((gc >= amin).all())
+    out["bit_exact_sample"] = ok
+    out["bit_exact_what"] = ("genome 0: every solid k-mer's count = the sum of its counts over %d CPU-counted chunks of the same FASTQ image, "
+                             "and every other k-mer of the image occurs exactly once (%d solid 21-mers)" % (cores, gk.shape[0]))
+    out["cpu_baseline"] = {"value": round(cpu_occ / cpu_s, 1), "unit": "k-mers/s", "cores": cores, "kind": "port",
+                           "sample": "genome 0 of the leg (%.2f GB FASTQ) counted in %d chunks on %d threads by the CPU restatement: %.1f s"
+                                     % (first.size / 1e9, cores, cores, cpu_s)}
+    return out
+
+
+def kover_equals(reader, res, k):
+    """the three datasets the GPU path appended to the .kover, read back, against the CPU restatement's result (dict from
+    oracle_ctypes: "kmers" (U, words) ascending, "matrix" (rows, U)); -> True / False"""
+    import numpy as np
+    want_k, want_m = res["kmers"], res["matrix"]
+    with reader._open() as f:
+        seqs = f.read("kmer_sequences")
+        if len(seqs) != want_k.shape[0]:
+            return False
+        # S<k> letters -> 2-bit words (A=0 C=1 T=2 G=3, first base most significant), most significant word first
+        letters = np.frombuffer(seqs.tobytes(), dtype=np.uint8).reshape(len(seqs), k)
+        words = want_k.shape[1]
+        got = np.zeros((len(seqs), words), dtype=np.uint64)
+        for j in range(k):
+            w = words - 1 - (k - 1 - j) // 32
+            got[:, w] = (got[:, w] << np.uint64(2)) | ((letters[:, j] >> np.uint8(1)) & np.uint8(3)).astype(np.uint64)
+        if not np.array_equal(got, want_k):
+            return False
+        del got, letters, seqs
+        col = f.read("kmer_by_matrix_column")
+        if col.shape[0] != want_k.shape[0] or not np.array_equal(col.astype(np.uint64), np.arange(want_k.shape[0], dtype=np.uint64)):
+            return False
+        m = f.read("kmer_matrix")
+        return m.shape == want_m.shape and m.dtype == np.uint64 and bool(np.array_equal(m, want_m))
+
+
+def host_floors(paths, kover, gzip):
+    """SURVEY 8(d) host-side floors of the end-to-end span, measured on this box: FASTA bytes / disk read bandwidth (page cache
+    dropped per file with POSIX_FADV_DONTNEED), H2D bytes / PCIe bandwidth (pinned buffer), matrix bytes / zlib throughput x cores"""
+    import zlib
+    import numpy as np
+    out = {}
+    try:
+        total = 0
+        for p in paths:
+            fd = os.open(p, os.O_RDONLY)
+            try:
+                os.fsync(fd)
+                os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            finally:
+                os.close(fd)
+        t0 = time.perf_counter()
+        from concurrent.futures import ThreadPoolExecutor
+
+        def rd(p):
+            n = 0
+            with open(p, "rb", buffering=0) as f:
+                while True:
+                    b = f.read(1 << 22)
+                    if not b:
+                        return n
+                    n += len(b)
+        with ThreadPoolExecutor(max_workers=16) as pool:
+            total = sum(pool.map(rd, paths))
+        dt = time.perf_counter() - t0
+        out["disk_read"] = {"bytes": total, "GBps": round(total / dt / 1e9, 2), "floor_s": round(dt, 3),
+                            "how": "all FASTA files read with 16 threads after POSIX_FADV_DONTNEED on each (a tmpfs / overlay may ignore the advice)"}
+    except (OSError, AttributeError) as e:
+        out["disk_read"] = {"error": str(e)}
+    try:
+        import torch
+        nb = 1 << 30
+        hbuf = torch.empty(nb, dtype=torch.uint8).pin_memory()
+        dbuf = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        dbuf.copy_(hbuf, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dbuf.copy_(hbuf, non_blocking=True)
+        torch.cuda.synchronize()
+        gbps = 3 * nb / (time.perf_counter() - t0) / 1e9
+        total = sum(os.path.getsize(p) for p in paths)
+        out["h2d"] = {"GBps": round(gbps, 1), "floor_s": round(total / gbps / 1e9, 3), "how": "1 GiB pinned -> device, 3 copies"}
+        del hbuf, dbuf
+    except Exception as e:          # noqa: BLE001  (a missing torch build detail must not cost the bench line)
+        out["h2d"] = {"error": str(e)}
+    try:
+        raw = os.path.getsize(kover)
+        sample = np.random.default_rng(1).integers(0, 2, size=1 << 22, dtype=np.uint8)      # bits as sparse as a presence row is not: worst case
+        sample = np.packbits(sample).tobytes() * 8
+        t0 = time.perf_counter()
+        z = zlib.compress(sample, gzip)
+        mbps = len(sample) / (time.perf_counter() - t0) / 1e6
+        cores = os.cpu_count() or 1
+        out["deflate"] = {"MBps_per_core_incompressible": round(mbps, 1), "cores": cores, "kover_bytes": raw,
+                          "how": "zlib level %d on 4 MiB of random bits (an upper bound on the work per byte; real rows compress faster)" % gzip}
+        del z
+    except Exception as e:          # noqa: BLE001
+        out["deflate"] = {"error": str(e)}
+    return out
+
+
 def e2e_leg(ctx, synth, args, orc, n_genomes, cpu_genomes):
     """files on disk -> .kover through kover_dataset.from_contigs (the span of dataset/create.py:365-390 plus
     the header), then the CPU restatement over the same span"""
@@ -327,19 +595,29 @@ def e2e_leg(ctx, synth, args, orc, n_genomes, cpu_genomes):
             "span": "FASTA files (page cache) -> label-sorted header -> engine pass -> kmer_sequences / kmer_matrix / "
                     "kmer_by_matrix_column in the .kover (dataset/create.py:311-390), in process",
         })
+        out["floors"] = host_floors(paths, kover, args.gzip)
         cpu_baseline = None
         if cpu_genomes > 0:
             n = min(cpu_genomes, n_genomes)
             cores = min(os.cpu_count() or 1, 64)
+            # the rows of the .kover stand in label order (create.py:334-336): the CPU side takes the genomes in the order the
+            # GPU-written file names them, so that the two matrices can be compared word for word
+            rd = kd.KoverDatasetReader(kover)
+            row_ids = rd.genome_identifiers
+            row_paths = [paths[int(g[1:])] for g in row_ids]
             t0 = time.perf_counter()
-            bufs = [open(p, "rb").read() for p in paths[:n]]
+            bufs = [open(p, "rb").read() for p in row_paths[:n]]
             t_read = time.perf_counter() - t0
             res, count_s, merge_s, occ_cpu = orc.pipeline(bufs, args.k, args.abundance_min, not args.keep_singletons, cores)
             del bufs
+            if n == n_genomes:
+                out["bit_exact"] = kover_equals(rd, res, args.k)
+                out["bit_exact_what"] = ("kmer_sequences, kmer_matrix and kmer_by_matrix_column READ BACK from the GPU-written .kover against the "
+                                         "CPU restatement's dictionary and packed rows for all %d genomes (rows in the file's label order)" % n)
             t1 = time.perf_counter()
             cpu_kover = os.path.join(d, "CPU.kover")
-            ids = ["g%05d" % g for g in range(n)]
-            labels = np.array([g % 2 for g in range(n)], dtype=np.uint8)
+            ids = row_ids[:n]
+            labels = np.array([int(g[1:]) % 2 for g in ids], dtype=np.uint8)
             kd.write_header(cpu_kover, "contigs", data, "synthetic phenotype", md, args.gzip, ids, labels, ["0", "1"], "binary", "singleton")
             hm = eng.HostMatrix(res["kmers"], res["matrix"], n, args.k)
             hm.write_kover_h5(cpu_kover, args.gzip, 100000)
@@ -382,12 +660,16 @@ def main():
         ctx.set_option(name, int(val))
 
     # ---- headline ----
+    if args.only not in (None, "headline"):
+        args.head_genomes = min(args.genomes, 16)      # profiling one of the other legs: the headline shrinks to a token set
+    else:
+        args.head_genomes = args.genomes
     strong = world > 1 and not args.weak_only
     if strong:
-        base, stop = Dm.shard_genomes(args.genomes, world)[rank]
-        n_mine, genomes_total = stop - base, args.genomes
+        base, stop = Dm.shard_genomes(args.head_genomes, world)[rank]
+        n_mine, genomes_total = stop - base, args.head_genomes
     else:
-        base, n_mine, genomes_total = rank * args.genomes, args.genomes, args.genomes * world
+        base, n_mine, genomes_total = rank * args.head_genomes, args.head_genomes, args.head_genomes * world
     batch = make_batch(ctx, synth, args.mode, base, n_mine, args.genome_len)
     setup_s = time.time() - t_setup
     if args.stage == "matrix":
@@ -448,8 +730,21 @@ def main():
             out["weak"] = {"value": round(w_occ * args.steps / w_el, 1), "unit": "k-mers/s", "ms_per_step": round(1000 * w_el / args.steps, 3),
                            "genomes_per_gpu": args.genomes, "genomes_total": args.genomes * world, "columns": int(w_cols)}
 
+    solo = world == 1 and rank == 0 and args.stage == "matrix" and args.mode == "P"
+    # ---- the same strains as real assemblies ----
+    if solo and not args.no_realistic and args.only in (None, "realistic"):
+        out["realistic"] = realistic_leg(D, Dm, ctx, synth, args)
+        out["realistic"]["vs_headline_ms"] = round(out["realistic"]["ms_per_step"] / out["ms_per_step"], 3)
+    # ---- BASELINE configs[4] and configs[3] ----
+    if solo and not args.no_c5 and args.only in (None, "c5") and args.k == 31:
+        from oracle import oracle_ctypes as orc5      # checker only: after the leg's timed region
+        out["c5"] = c5_leg(D, Dm, ctx, synth, args, orc5)
+    if solo and not args.no_c4 and args.only in (None, "c4") and args.k == 31:
+        from oracle import oracle_ctypes as orc4
+        out["c4"] = c4_leg(D, ctx, synth, args, orc4)
+
     # ---- random-ACGT counting stage ----
-    if not args.no_random and not (args.mode == "R" and args.stage == "count"):
+    if not args.no_random and args.only in (None, "random") and not (args.mode == "R" and args.stage == "count"):
         if world > 1:
             rbase, rstop = Dm.shard_genomes(args.genomes, world)[rank]
         else:
@@ -457,18 +752,30 @@ def main():
         rb = make_batch(ctx, synth, "R", rbase, rstop - rbase, args.genome_len)
         r_el, r_kernels = count_leg(D, ctx, args, rb, args.steps, 1)
         r_occ, r_syms = D.sum_i(rb.n_occurrences), D.sum_i(rb.n_symbols)
+        r_ok = None
+        if rank == 0 and args.k <= 32:
+            # two genomes' counted sets against the CPU restatement (after the timed region)
+            from oracle import oracle_ctypes as orcr
+            r_ok = True
+            for g in (0, rstop - rbase - 1):
+                km, ct, nocc = orcr.count_genome([synth.random_genome(rbase + g, genome_len=args.genome_len, seed=1234).tobytes()], args.k, args.abundance_min)
+                sg = rb.genome_set(g)
+                r_ok = r_ok and sg.occurrences == nocc and sg.kmers().shape == km.shape and bool((sg.kmers() == km).all()) and bool((sg.counts() == ct).all())
+                sg.free()
         rb.free()
         if rank == 0:
             out["random_acgt"] = {
                 "workload": "%d independent uniform-ACGT genomes x %d bp (seed 1234+i)%s, k=%d: parse -> partition -> per-genome dedup + count, "
                             "matrix not materialised" % (args.genomes, args.genome_len, ", split over %d ranks" % world if world > 1 else "", args.k),
                 "bases_per_s": round(r_syms * args.steps / r_el, 1), "kmers_per_s": round(r_occ * args.steps / r_el, 1),
-                "ms_per_step": round(1000 * r_el / args.steps, 3), "roofline": roofline_of(r_kernels), "kernels": r_kernels}
+                "ms_per_step": round(1000 * r_el / args.steps, 3), "bit_exact_sample": r_ok,
+                "bit_exact_what": "counted sets (k-mers and counts) of the first and the last genome of rank 0 = the CPU restatement's",
+                "roofline": roofline_of(r_kernels), "kernels": r_kernels}
 
     # ---- end to end + CPU restatement (N = 1) ----
-    if world == 1 and rank == 0 and args.stage == "matrix":
+    if world == 1 and rank == 0 and args.stage == "matrix" and args.only in (None, "headline"):
         cpu_genomes = args.genomes if args.cpu_genomes < 0 else args.cpu_genomes
-        if not args.no_e2e:
+        if not args.no_e2e and args.mode == "P":
             from oracle import oracle_ctypes as orc       # checker / reported baseline only: after every timed GPU region
             e2e, cpu_baseline = e2e_leg(ctx, synth, args, orc, args.genomes, cpu_genomes)
             out["e2e"] = e2e
@@ -482,12 +789,21 @@ def main():
             out["cpu_baseline"] = {"value": round(occ_cpu / (count_s + merge_s), 1), "unit": "k-mers/s", "cores": cores, "kind": "port",
                                    "sample": "%d of the %d genomes (same generator): count %.2fs + merge %.2fs; CPU restatement of DSK+dsk2kover "
                                              "semantics (the reference binaries are absent)" % (len(bufs), args.genomes, count_s, merge_s)}
+    failed = False
     if rank == 0:
         out.setdefault("cpu_baseline", None)
+        # "bit-exact" is part of the metric: any leg that compared its result with the CPU restatement and found a difference fails the run
+        checks = {"e2e": (out.get("e2e") or {}).get("bit_exact"), "c5": (out.get("c5") or {}).get("bit_exact_sample"),
+                  "c4": (out.get("c4") or {}).get("bit_exact_sample"), "random_acgt": (out.get("random_acgt") or {}).get("bit_exact_sample")}
+        out["bit_exact"] = {k: v for k, v in checks.items() if v is not None}
+        failed = any(v is False for v in checks.values())
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         D.dist.destroy_process_group()
+    if failed:
+        sys.stderr.write("bench.py: a leg's result differs from the CPU restatement (see bit_exact)\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

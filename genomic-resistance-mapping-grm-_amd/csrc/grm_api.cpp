@@ -1143,13 +1143,30 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         const uint64_t rstride64 = (uint64_t)(mean_r * 1.02 + 14.0 * std::sqrt(mean_r) + 32.0 + 15.0) / 16 * 16;     // mean + 7.5 sigma
         const uint64_t kstride = (uint64_t)(mean_k + 50.0 * std::sqrt(mean_k) + 256.0 + 15.0) / 16 * 16;
         // genomes of very different sizes would waste most of a layout sized for the largest one
-        // (a segment's record count travels in 16 bits beside the count of its short records: only a forced, tiny bucket count gets near)
+        // (a segment's record count travels in 16 bits beside the count of its short records: only a forced, tiny bucket count gets
+        // near; level 2 raises the overflow flag if one does)
+        const double expected_records = (double)b->total_syms * (2.0 / (w + 1) + 0.005);
         bool rec = n_seg_r < 0xffffffffull && rstride64 < 0xffffffffull && kstride < 0xffffffffull && mean_r / (double)(1u << (bbr - b1r)) < 16000.0 &&
-                   (double)n_regions * (double)kstride <= 3.0 * (double)b->total_syms + 65536.0 * 1024.0;
+                   (double)n_regions * (double)rstride64 <= 4.0 * expected_records + 16.0 * 1024 * 1024;
+        // the fill through the presence bits needs no keys at all: dict_build then decodes the records itself and
+        // level 2 only sorts them by fine bucket; else (probing fill) level 2 expands them to key segments
+        const size_t n_rows_b = ((size_t)G + 63) / 64;
+        // (dict_build's record memo takes LDS: with it the key table has 2^11 slots unless the caller says otherwise, so that
+        // two workgroups still share a CU)
+        b->rec_memo_log2 = c->opt_rec_memo < 0 ? 10 : c->opt_rec_memo == 0 ? 0 : std::min(11, std::max(8, c->opt_rec_memo));
+        const uint32_t cap_r = (b->rec_memo_log2 && c->opt_cap_log2 <= 0) ? 11u : b->cap_log2;
+        bool by_records = c->opt_no_slots <= 0 && c->opt_rec_keys <= 0 && n_rows_b <= 0xffffu &&
+                          ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << cap_r) * 8 <= MATRIX_S_LIMIT;
         if (rec && b->d_recs.ensure((n_regions * rstride64 + 4) * 16) != hipSuccess) {
             (void)hipGetLastError();
             rec = false;
         }
+        if (rec && by_records && b->d_recs2.ensure((n_regions * rstride64 + 4) * 16) != hipSuccess) {
+            (void)hipGetLastError();
+            by_records = false;
+        }
+        // (key segments: a layout of kstride keys per region)
+        if (rec && !by_records && (double)n_regions * (double)kstride > 3.0 * (double)b->total_syms + 65536.0 * 1024.0) rec = false;
         if (rec) {
             const uint32_t rstride = (uint32_t)rstride64;
             KmerLaunch Lr;
@@ -1165,17 +1182,6 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
                 TimeScope t(c, "superkmer_l1", b->total_syms);
                 launch_superkmer_l1(s, Lr, b1r, pbits, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), b->d_cursor1.as<uint32_t>(), b->t_flag.as<int>());
             }
-            // the fill through the presence bits needs no keys at all: dict_build then decodes the records itself and
-            // level 2 only sorts them by fine bucket; else (probing fill) level 2 expands them to key segments
-            const size_t n_rows_b = ((size_t)G + 63) / 64;
-            // (dict_build's record memo takes LDS: with it the key table has 2^11 slots unless the caller says otherwise, so that
-            // two workgroups still share a CU)
-            b->rec_memo_log2 = c->opt_rec_memo < 0 ? 10 : c->opt_rec_memo == 0 ? 0 : std::min(11, std::max(8, c->opt_rec_memo));
-            const uint32_t cap_r = (b->rec_memo_log2 && c->opt_cap_log2 <= 0) ? 11u : b->cap_log2;
-            const bool by_records = c->opt_no_slots <= 0 && c->opt_rec_keys <= 0 && n_rows_b <= 0xffffu &&
-                                    ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << cap_r) * 8 <= MATRIX_S_LIMIT &&
-                                    b->d_recs2.ensure((n_regions * rstride64 + 4) * 16) == hipSuccess;
-            if (!by_records) (void)hipGetLastError();
             b->rec_rstride = rstride; b->rec_kstride = kstride; b->rec_regions = n_regions; b->rec_b1 = b1r;
             int l2_idx = -1;
             if (by_records) {

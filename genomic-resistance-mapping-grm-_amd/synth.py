@@ -92,7 +92,8 @@ class PanGenome:
             seq = np.concatenate(pieces)
         if self.contigs:
             n_contigs = int(rng2.integers(self.contigs[0], self.contigs[1] + 1))
-            cuts = np.sort(rng2.choice(np.arange(1, seq.size), size=n_contigs - 1, replace=False)) if n_contigs > 1 else np.zeros(0, np.int64)
+            cuts = np.unique(rng2.integers(1, seq.size, size=n_contigs - 1)) if n_contigs > 1 else np.zeros(0, np.int64)
+            n_contigs = cuts.size + 1
             bounds = np.concatenate(([0], cuts, [seq.size])).astype(np.int64)
         else:
             n_contigs = self.n_contigs
