@@ -1146,14 +1146,14 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         // (a segment's record count travels in 16 bits beside the count of its short records: only a forced, tiny bucket count gets
         // near; level 2 raises the overflow flag if one does)
         const double expected_records = (double)b->total_syms * (2.0 / (w + 1) + 0.005);
-        bool rec = n_seg_r < 0xffffffffull && rstride64 < 0xffffffffull && kstride < 0xffffffffull && mean_r / (double)(1u << (bbr - b1r)) < 16000.0 &&
+        bool rec = n_seg_r < 0xffffffffull && (rstride64 << b1r) < 0xffffffffull && kstride < 0xffffffffull && mean_r / (double)(1u << (bbr - b1r)) < 16000.0 &&
                    (double)n_regions * (double)rstride64 <= 4.0 * expected_records + 16.0 * 1024 * 1024;
         // the fill through the presence bits needs no keys at all: dict_build then decodes the records itself and
         // level 2 only sorts them by fine bucket; else (probing fill) level 2 expands them to key segments
         const size_t n_rows_b = ((size_t)G + 63) / 64;
         // (dict_build's record memo takes LDS: with it the key table has 2^11 slots unless the caller says otherwise, so that
         // two workgroups still share a CU)
-        b->rec_memo_log2 = c->opt_rec_memo < 0 ? 10 : c->opt_rec_memo == 0 ? 0 : std::min(11, std::max(8, c->opt_rec_memo));
+        b->rec_memo_log2 = c->opt_rec_memo < 0 ? 9 : c->opt_rec_memo == 0 ? 0 : std::min(11, std::max(8, c->opt_rec_memo));
         const uint32_t cap_r = (b->rec_memo_log2 && c->opt_cap_log2 <= 0) ? 11u : b->cap_log2;
         bool by_records = c->opt_no_slots <= 0 && c->opt_rec_keys <= 0 && n_rows_b <= 0xffffu &&
                           ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << cap_r) * 8 <= MATRIX_S_LIMIT;
@@ -1187,7 +1187,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
             if (by_records) {
                 TimeScope t(c, "superkmer_l2", b->total_syms);        // (units: the record count, once it is known)
                 l2_idx = t.idx;
-                launch_superkmer_l2_records(s, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, bbr, b1r, b->d_recs2.p,
+                launch_superkmer_l2_records(s, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, k, bbr, b1r, b->d_recs2.p,
                                             b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->t_flag.as<int>());
             } else {
                 HIPCHK(c, b->d_keys.ensure((n_regions * kstride + 4) * 8));
@@ -1472,7 +1472,7 @@ static int batch_rebucket(grm_batch *b, int new_bb)
     HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 4, s));
     {
         TimeScope t(c, "superkmer_l2_again", 0);
-        launch_superkmer_l2_records(s, b->d_recs.p, b->rec_rstride, b->d_counts1.as<uint32_t>(), b->rec_regions, new_bb, b->rec_b1, b->d_recs2.p,
+        launch_superkmer_l2_records(s, b->d_recs.p, b->rec_rstride, b->d_counts1.as<uint32_t>(), b->rec_regions, b->k, new_bb, b->rec_b1, b->d_recs2.p,
                                     b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->t_flag.as<int>());
     }
     HIPCHK(c, hipGetLastError());
@@ -1533,6 +1533,7 @@ static int run_dict_ladder(grm_batch *b, DictArgs a, uint64_t total_keys, int sb
         HIPCHK(c, hipMemcpyAsync(&h, b->d_ctrl.p, sizeof h, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         if (memo_diag) for (int i = 0; i < 4; i++) b->memo_stats[i] = a.memo_log2 ? h.memo_stats[i] : 0;
+        if (memo_env) fprintf(stderr, "[grm] %s launch %d: 2^%d buckets, 2^%d sub-buckets, overflow %d, need %u (usable %u)\n", tname, attempt, a.bb, sb, h.overflow, h.need, max_fill);
         if (memo_env && a.memo_log2)
             fprintf(stderr, "[grm] %s memo 2^%d: %llu (workgroup, row) ends with the memo on, mean records held %.1f, occurrences asked %llu found %llu; overflow %d\n",
                     tname, a.memo_log2, h.memo_stats[3], h.memo_stats[3] ? (double)h.memo_stats[0] / (double)h.memo_stats[3] : 0.0, h.memo_stats[1],
@@ -1553,7 +1554,11 @@ static int run_dict_ladder(grm_batch *b, DictArgs a, uint64_t total_keys, int sb
         if (a.recs && b->rec_dict && c->opt_sub_bits < 0 && c->opt_bucket_bits < 0) {
             // record form: every sub-bucket workgroup would decode ALL records of its bucket, so more BUCKETS come first
             // (level 2 again, 6 ms) as far as the records' bucket bits and the presence words allow
-            int more = std::min(step, std::min(superkmer_max_bits(), b->rec_b1 + 7) - a.bb);
+            // (a bucket's k-mers follow their minimizers into the finer buckets, a few dozen minimizers of unequal weight per bucket:
+            // the fullest of the new buckets gets more than its even share, so aim at half the usable table, not at 70 %)
+            int step_b = 1;
+            while (step_b < 24 && ((uint64_t)h.need >> step_b) > (uint64_t)max_fill / 2) step_b++;
+            int more = std::min(step_b, std::min(superkmer_max_bits(), b->rec_b1 + 7) - a.bb);
             if (step > std::min(superkmer_max_bits(), b->rec_b1 + 7) - a.bb + 2) more = 0;      // hopeless: straight to the key form
             while (more > 0 && ((size_t)1 << (a.bb + more + sb)) * n_rows * cap * 8 > MATRIX_S_LIMIT) more--;
             if (more > 0) {

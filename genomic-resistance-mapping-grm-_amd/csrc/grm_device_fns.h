@@ -119,7 +119,9 @@ GRM_HD uint32_t hash_slot(uint64_t h, uint32_t cap_mask) { return (uint32_t)h & 
 // only has to look random, and it is evaluated for every symbol: ONE full-rate multiply-add, of which the top 24 bits
 // count (the constant term keeps poly-A, x = 0, from being the smallest m-mer of every genome).
 constexpr int MINIMIZER_ORDER_BITS = 24;
-GRM_HD uint32_t minimizer_hash(uint32_t x) { return mul24(x, 0x9E3779u) + 0x7F4A7C15u; }      // order = result >> 8
+// The multiplier is one of those for which x -> (x * C + K) mod 2^32 >> 8 is INJECTIVE on x < 2^22 (0x9E3779 collides for two thirds
+// of the m-mers: different m-mers with one order value share a bucket, and the buckets get as uneven as with half the minimizers).
+GRM_HD uint32_t minimizer_hash(uint32_t x) { return mul24(x, 0xEC0C71u) + 0x7F4A7C15u; }      // order = result >> 8
 // bucket of a k-mer from the order value (24 bits) of its minimizer.  The minimum of k - 10 values crowds towards 0, so
 // the bucket is NOT its top bits: the value is hashed once more (per run, not per position).
 GRM_HD uint32_t minimizer_bucket(uint32_t order, int bb)
@@ -153,7 +155,7 @@ GRM_HD uint32_t minimizer_bucket_of_kmer(uint64_t key, int k, int bb, int m_len 
 // k-mers (all contain the one m-mer), i.e. at most 2 k - M = 53 bases at k = 32, and travels as ONE 16-byte record
 //     x            bases 0..31 of the run, MSB-first
 //     y[63..22]    bases 32..52; bits behind the run's last base are 0
-//     y[21..12]    0
+//     y[21..12]    0 (bit 12 between level 1 and level 2: "store me on the other strand", run_flip)
 //     y[11..5]     7 bucket bits below the coarse ones
 //     y[4..0]      k-mers in the run (1..22)
 // stored STRAND-CANONICALLY: in the orientation in which the minimizer m-mer is its own canonical form (M is odd: an
@@ -166,53 +168,77 @@ constexpr int RUN_LEN_BITS = 5;
 GRM_HD uint32_t run_len(uint64_t y) { return (uint32_t)y & ((1u << RUN_LEN_BITS) - 1u); }
 GRM_HD uint32_t run_fine(uint64_t y) { return ((uint32_t)y >> RUN_LEN_BITS) & ((1u << RUN_FINE_BITS) - 1u); }
 
-// `len` symbols (len <= 16) from symbol offset `off` of the 64 symbols held MSB-first in the four words d[0..3]; with off and
-// len known at compile time (unrolled callers) this is one bit-field extract, or a funnel shift and a mask
-GRM_HD uint32_t sym_field(const uint32_t (&d)[4], int off, int len)
+// the 16 symbols from symbol offset `off` (0..63) of the 64 symbols held MSB-first in the four words d[0..3], as one word (zeros behind
+// the 64th); with off known at compile time (unrolled callers) this is one v_alignbit_b32, or nothing
+GRM_HD uint32_t sym_window(const uint32_t (&d)[4], int off)
 {
-    const int b = 2 * off, j = b >> 5, sh = b & 31, nb = 2 * len;
-    const uint64_t win = ((uint64_t)d[j] << 32) | (uint64_t)(j + 1 < 4 ? d[j + 1] : 0u);
-    return (uint32_t)(win >> (64 - sh - nb)) & ((1u << nb) - 1u);
+    const int b = 2 * off, j = b >> 5, sh = b & 31;
+    const uint32_t hi = d[j], lo = j + 1 < 4 ? d[j + 1] : 0u;
+    return sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
 }
 GRM_HD uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
 {
     const uint32_t ab = a < b ? a : b;          // (the backend fuses the pair into v_min3_u32)
     return ab < c ? ab : c;
 }
-// Minimizer of the 33 k-mers that start at positions -1 .. 31 of a window: w0 = the packed word of positions 0..31, w1 the
-// next one, prev2 = the 2-bit code of position -1.  val[i + 1], for the k-mer at position i:
-//     bits 31..8   order value of its minimizer
-//     bits  6..1   position of the minimizer occurrence, + 1 (0 .. 31 + W)
-//     bit   0      1 = the reverse complement of that m-mer is the canonical one
-// Equal order values resolve to the leftmost occurrence (the position is part of the compared word).  Hashes of the 32 + W
-// canonical M-mers (fields at fixed offsets of the two words and of their reverse complement: no rolling words), window
-// minimum over W by spans of 3 and 9 (v_min3_u32).  Fully unrolled: everything stays in registers.
-template <int W, int M = 11>
-GRM_HD void run_minimizers(uint64_t w0, uint64_t w1, uint32_t prev2, uint32_t (&val)[RUN_PPT + 1])
+// Minimizer words of a window.  w0 = the packed word of positions 0..31, w1 the next one, prev2 = the 2-bit code of position -1.
+// The word of the M-mer at position q (index q + 1 of h):
+//     bits 31..8   its order value
+//     bits  6..1   q + 1 (0 .. 31 + W)
+//     bit   0      1 = the reverse complement of the m-mer is the canonical one
+// An m-mer and its reverse complement are read as the TOP 22 bits of two 16-symbol words at fixed offsets of (w0 : w1) and of its
+// reverse complement rc(w1) : rc(w0) -- no rolling words; the 10 bits below only break ties that cannot occur (M is odd: an m-mer
+// differs from its reverse complement), so min / compare act on the m-mers themselves.  run_hashes fills h[0 .. n): 8 instructions per
+// m-mer (two v_alignbit, min, compare, shift, multiply-add, and-or, add-with-carry).
+// base + (a < b) / 2 acc + (a != b): a compare and an add-with-carry (the compiler makes three or four instructions of either)
+GRM_HD uint32_t add_is_less(uint32_t base, uint32_t a, uint32_t b)
 {
-    constexpr int NM = RUN_PPT + W;              // m-mers at positions -1 .. 31 + W - 1
-    static_assert(RUN_PPT + W - 1 + M <= 64, "the m-mers of a thread's window lie inside its two words");
-    static_assert(W >= 1 && W <= 27, "window minimum by spans of 1, 3 or 9");
-    uint32_t h[NM];
-    // m-mer q = symbols q .. q + M - 1 of (w0 : w1); its reverse complement = symbols 64 - M - q .. of the reverse complement of
-    // the 64 symbols, rc(w1) : rc(w0)
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t out;
+    __asm__("v_cmp_lt_u32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, 0, %1, vcc" : "=v"(out) : "v"(base), "v"(a), "v"(b) : "vcc");
+    return out;
+#else
+    return base + (uint32_t)(a < b);
+#endif
+}
+GRM_HD uint32_t shift_in_differs(uint32_t acc, uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __asm__("v_cmp_ne_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+    return acc;
+#else
+    return acc + acc + (uint32_t)(a != b);
+#endif
+}
+template <int M = 11>
+GRM_HD uint32_t run_hash_word(uint32_t f32, uint32_t r32, uint32_t pos_field)
+{
+    constexpr uint32_t KEEP = ~0u << (32 - MINIMIZER_ORDER_BITS);
+    const uint32_t m = (f32 < r32 ? f32 : r32) >> (32 - 2 * M);
+    return add_is_less((minimizer_hash(m) & KEEP) | pos_field, r32, f32);
+}
+template <int N, int M = 11>
+GRM_HD void run_hashes(uint64_t w0, uint64_t w1, uint32_t prev2, uint32_t (&h)[N])
+{
+    static_assert(N - 2 + M <= 64, "the m-mers lie inside the two words");
     const uint64_t r1 = revcomp_m(w1, 32), r0 = revcomp_m(w0, 32);
     const uint32_t df[4] = {(uint32_t)(w0 >> 32), (uint32_t)w0, (uint32_t)(w1 >> 32), (uint32_t)w1};
     const uint32_t dr[4] = {(uint32_t)(r1 >> 32), (uint32_t)r1, (uint32_t)(r0 >> 32), (uint32_t)r0};
-    constexpr uint32_t KEEP = ~0u << (32 - MINIMIZER_ORDER_BITS);
-    {
-        // position -1: the symbol before the window, then the first M - 1 of w0
-        const uint32_t f = (prev2 << (2 * (M - 1))) | sym_field(df, 0, M - 1);
-        const uint32_t r = (sym_field(dr, 64 - (M - 1), M - 1) << 2) | (prev2 ^ 2u);
-        h[0] = (minimizer_hash(f < r ? f : r) & KEEP) | (uint32_t)(r < f);
-    }
+    // position -1: the symbol before the window, then the first M - 1 of w0; its reverse complement: rc of those, then rc of the symbol
+    h[0] = run_hash_word<M>((prev2 << 30) | (df[0] >> 2), sym_window(dr, 64 - (M - 1)) | ((prev2 ^ 2u) << (32 - 2 * M)), 0u);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int q = 0; q < NM - 1; q++) {
-        const uint32_t f = sym_field(df, q, M), r = sym_field(dr, 64 - M - q, M);
-        h[q + 1] = (minimizer_hash(f < r ? f : r) & KEEP) | ((uint32_t)(q + 1) << 1) | (uint32_t)(r < f);
-    }
+    for (int q = 0; q < N - 1; q++) h[q + 1] = run_hash_word<M>(sym_window(df, q), sym_window(dr, 64 - M - q), (uint32_t)(q + 1) << 1);
+}
+// val[i + 1] = the smallest word among the W m-mers of the k-mer at position i (-1 .. 31): its minimizer, the LEFTMOST one of equal
+// order (the position is part of the compared word).  h: the words of the m-mers at positions -1 .. 31 + W - 1; window minimum by
+// spans of 3 and 9 (v_min3_u32), in place.
+template <int W>
+GRM_HD void run_window_min(uint32_t (&h)[RUN_PPT + W], uint32_t (&val)[RUN_PPT + 1])
+{
+    constexpr int NM = RUN_PPT + W;
+    static_assert(W >= 1 && W <= 27, "window minimum by spans of 1, 3 or 9");
     constexpr int S = W <= 3 ? 1 : W <= 9 ? 3 : 9;
     if (S >= 3) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -232,6 +258,16 @@ GRM_HD void run_minimizers(uint64_t w0, uint64_t w1, uint32_t prev2, uint32_t (&
 #endif
     for (int i = 0; i <= RUN_PPT; i++) val[i] = min3u(h[i], h[i + MID], h[i + W - S]);     // [i, i + W)
 }
+// all of it by one thread (host emulation; the kernel shares the hashes of neighbouring windows across lanes, grm_superkmer.hip)
+template <int W, int M = 11>
+GRM_HD void run_minimizers(uint64_t w0, uint64_t w1, uint32_t prev2, uint32_t (&val)[RUN_PPT + 1])
+{
+    uint32_t h[RUN_PPT + W];
+    run_hashes<RUN_PPT + W, M>(w0, w1, prev2, h);
+    run_window_min<W>(h, val);
+}
+// a word of the window to the right, seen from this window: the m-mer lies RUN_PPT positions further on
+GRM_HD uint32_t run_hash_from_right(uint32_t h_right) { return h_right + ((uint32_t)RUN_PPT << 1); }
 // first positions of the runs of a window: a valid start whose predecessor is invalid or has another minimizer occurrence.
 // valid: bit i = position i is a valid k-mer start; prev_valid: position -1 is one (of the same genome)
 GRM_HD uint32_t run_heads(uint32_t valid, bool prev_valid, const uint32_t (&val)[RUN_PPT + 1])
@@ -240,7 +276,7 @@ GRM_HD uint32_t run_heads(uint32_t valid, bool prev_valid, const uint32_t (&val)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < RUN_PPT; i++) differs |= (uint32_t)(val[i + 1] != val[i]) << i;
+    for (int i = RUN_PPT - 1; i >= 0; i--) differs = shift_in_differs(differs, val[i + 1], val[i]);
     return valid & (differs | ~((valid << 1) | (uint32_t)prev_valid));
 }
 // positions at the front of a window that continue a run begun before it (0 when position 0 starts a run or is no k-mer start)
@@ -257,32 +293,38 @@ GRM_HD uint32_t run_length(uint32_t heads, uint32_t valid, int i)
     return (uint32_t)__builtin_ctzll(rest) + 1u;
 }
 // The 16-byte record of the run of `len` k-mers that starts at position i of the window (w0, w1, w2: the window's word and
-// the two after it): its len + k - 1 bases, reverse-complemented when `flip`; fine = the 7 bucket bits below the coarse ones
+// the two after it): its len + k - 1 bases as they stand in the stream; fine = the 7 bucket bits below the coarse ones.
+// flip: the run is to be stored on the other strand -- level 1 only SAYS so (bit 12 of y), level 2 turns the record over
+// (run_flip) on its way through: there every lane holds a record, here the lanes with most runs set the pace.
+constexpr uint64_t RUN_FLIP_BIT = 1ull << (RUN_LEN_BITS + RUN_FINE_BITS);
 GRM_HD void run_record(uint64_t w0, uint64_t w1, uint64_t w2, int i, uint32_t len, int k, bool flip, uint32_t fine, uint64_t &x, uint64_t &y)
 {
     const int span = (int)len + k - 1;              // 11 .. 53 bases
-    uint64_t a = i ? ((w0 << (2 * i)) | (w1 >> (64 - 2 * i))) : w0;
-    uint64_t b = i ? ((w1 << (2 * i)) | (w2 >> (64 - 2 * i))) : w1;
-    if (span <= 32) {
-        a &= ~0ull << (64 - 2 * span);
-        b = 0;
+    const uint64_t a = i ? ((w0 << (2 * i)) | (w1 >> (64 - 2 * i))) : w0;
+    const uint64_t b = i ? ((w1 << (2 * i)) | (w2 >> (64 - 2 * i))) : w1;
+    // the first `span` bases: masks of 2 span bits from the top of the 128
+    const int up = 128 - 2 * span;                  // 22 .. 106
+    const uint64_t ma = up >= 64 ? ~0ull << (up - 64) : ~0ull, mb = up >= 64 ? 0ull : ~0ull << up;
+    x = a & ma;
+    y = (b & mb) | (flip ? RUN_FLIP_BIT : 0ull) | ((uint64_t)(fine & ((1u << RUN_FINE_BITS) - 1u)) << RUN_LEN_BITS) | len;
+}
+// a record marked by level 1: reverse complement of its len + k - 1 bases, left-aligned again; the mark goes
+GRM_HD void run_flip(uint64_t &x, uint64_t &y, int k)
+{
+    if (!(y & RUN_FLIP_BIT)) return;
+    const uint64_t low = y & (RUN_FLIP_BIT - 1);
+    const int span = (int)run_len(y) + k - 1;
+    const uint64_t a = x, b = y & ~(2 * RUN_FLIP_BIT - 1);
+    // reverse complement of the 64 bases a : b = rc(b) : rc(a); the run's bases are its LAST `span` ones
+    const uint64_t hi = revcomp_m(b, 32), lo = revcomp_m(a, 32);
+    const int sh = 2 * (64 - span);                  // 22 .. 106
+    if (sh >= 64) {
+        x = lo << (sh - 64);
+        y = low;
     } else {
-        b &= ~0ull << (128 - 2 * span);
+        x = (hi << sh) | (lo >> (64 - sh));
+        y = (lo << sh) | low;
     }
-    if (flip) {
-        // reverse complement of the 64 bases a : b = rc(b) : rc(a); the run's bases are its LAST `span` ones
-        const uint64_t hi = revcomp_m(b, 32), lo = revcomp_m(a, 32);
-        const int sh = 2 * (64 - span);              // 22 .. 106
-        if (sh >= 64) {
-            a = lo << (sh - 64);
-            b = 0;
-        } else {
-            a = (hi << sh) | (lo >> (64 - sh));
-            b = lo << sh;
-        }
-    }
-    x = a;
-    y = b | ((uint64_t)(fine & ((1u << RUN_FINE_BITS) - 1u)) << RUN_LEN_BITS) | len;
 }
 // decoder state of a record: forward / reverse-complement words of the current k-mer, and the bases after it, MSB-aligned
 struct RunDecoder {

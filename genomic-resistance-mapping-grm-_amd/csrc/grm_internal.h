@@ -96,7 +96,7 @@ void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, con
 //   level 2, records only: the region's records sorted by the fine bits, region r again at r * rstride of recs2: segment
 //            vg * 2^bb + bucket = recs2[off[..] .. + len[..]) (in records; dict_build decodes them, DictArgs::recs)
 //            *overflow = 1 when a segment holds more than 65535 records (its count travels in 16 bits)
-void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb, int b1,
+void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb, int b1,
                                  void *recs2, uint64_t *off, uint32_t *len, int *overflow);
 // (bucket << sb) | sub of dictionary keys under minimizer buckets (launch_dict_bucket_ids for the hashed ones)
 void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int k, int bb, int sb, uint32_t *bucket_of, uint32_t *col_of);

@@ -29,9 +29,12 @@ constexpr int SK_FINE_BITS = RUN_FINE_BITS;           // a record carries 7 buck
                                                       // level 2 takes the top bb - b1 of them, so more buckets only need level 2 again
 constexpr int SK_MAX_COARSE = 9;
 constexpr int SK_MAX_BITS = SK_MAX_COARSE + SK_FINE_BITS;         // at most 9 coarse bits (cursors) + the fine field
-// A wave takes 63 consecutive windows per step; its lane 63 works on the window AFTER them (the next wave's, or the next
-// step's, first) only to say how far the run that crosses into it goes on.
-constexpr int SK_WAVE_WINDOWS = 63;
+// A wave takes 62 consecutive windows per step, one per lane.  The W - 1 m-mers a window's last k-mers reach into the next
+// window are hashed by that window's lane and come over with a whole-wave DPP shift (8 instructions per m-mer otherwise: 40 %
+// of them would be hashed twice), and the run that crosses a window's end is finished with what the lane to the right knows.
+// Lane 62 works on the window after the 62 (the next wave's, or the next step's, first) only to say how far the run that crosses
+// into it goes on; lane 63 on the one after that, only to hash.
+constexpr int SK_WAVE_WINDOWS = 62;
 constexpr int SK_STEP_WINDOWS = (SK_THREADS / 64) * SK_WAVE_WINDOWS;
 constexpr size_t SK_L1_LDS = (size_t)SK_PPT * SK_THREADS * 4 + ((size_t)4 << SK_MAX_COARSE) + 128;
 constexpr int SK2_THREADS = 256;
@@ -84,6 +87,8 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     __syncthreads();
     const int lane = lane_id(), wave = wave_id();
     uint32_t *my_val = s_val + threadIdx.x;
+    ulonglong2 *my_recs = recs1 + (uint64_t)vg * B1 * rstride;           // the part's regions: 2^b1 x rstride records (< 2^32 of them: host)
+    const bool narrow = rstride < (1u << 15);                            // (region index x stride as a full-rate 24-bit multiply)
     uint32_t n_valid = 0;
     bool over = false;
     // Related genomes are the same sequence at about the same window numbers: started together, their workgroups would store
@@ -94,12 +99,17 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     for (uint32_t it = 0; it < n_steps; it++) {
         const uint32_t st = it + rot < n_steps ? it + rot : it + rot - n_steps;
         const uint64_t j = j_a + (uint64_t)st * SK_STEP_WINDOWS + (uint32_t)(wave * SK_WAVE_WINDOWS + lane);
+        if (j_a + (uint64_t)st * SK_STEP_WINDOWS + (uint32_t)(wave * SK_WAVE_WINDOWS) >= j_b) continue;        // (the wave as a whole: nothing left)
         uint32_t valid = 0, heads = 0;
-        uint64_t w0 = 0, w1 = 0, w2 = 0;
-        if (j <= j_b) {              // (j_b itself: only for the run that crosses into it; the stream buffers end with slack words)
+        uint64_t w0 = 0, w1 = 0, w2 = 0, vs = 0;
+        uint32_t prev2 = 0;
+        if (j <= j_b + 1) {          // (j_b: only for the run that crosses into it; j_b + 1: only its hashes; the stream buffers end with slack words)
             const uint64_t p0 = j << 5;
+            w0 = a.sym2[j];
+            w1 = a.sym2[j + 1];
+            w2 = a.sym2[j + 2];
+            prev2 = j ? (uint32_t)a.sym2[j - 1] & 3u : 0u;
             // bit t of vs: position p0 - 1 + t starts a k-mer (t = 0 .. 32; k <= 32 keeps all 33 inside the 64 flags read)
-            uint64_t vs;
             if (p0) {
                 const uint64_t q = p0 - 1;
                 vs = valid_starts_at(a.inv[q >> 6], a.inv[(q >> 6) + 1], (int)(q & 63), a.k);
@@ -111,19 +121,27 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
             const uint64_t keep = (t_hi >= 33 ? (1ull << 33) - 1 : (1ull << t_hi) - 1) & ~(t_lo >= 33 ? (1ull << 33) - 1 : (1ull << t_lo) - 1);
             vs &= keep;
             valid = (uint32_t)(vs >> 1);
-            if (valid) {
-                w0 = a.sym2[j];
-                w1 = a.sym2[j + 1];
-                w2 = a.sym2[j + 2];
-                const uint32_t prev2 = j ? (uint32_t)a.sym2[j - 1] & 3u : 0u;
-                uint32_t val[SK_PPT + 1];
-                run_minimizers<W>(w0, w1, prev2, val);
-                heads = run_heads(valid, (vs & 1u) != 0, val);
-                // the minimizer word of a run's first position is the only per-position value the emission needs, and it is
-                // indexed by a run-time position: through LDS (each thread reads back its own column)
+        }
+        {
+            // every lane, whatever it holds (no lane may sit out a DPP move): the words of the m-mers at positions -1 .. 31 of the window,
+            // and of those at 32 .. 31 + W - 1 from the lane to the right
+            uint32_t h[SK_PPT + W];
+            {
+                uint32_t own[SK_PPT + 1];
+                run_hashes<SK_PPT + 1>(w0, w1, prev2, own);
 #pragma unroll
-                for (int i = 0; i < SK_PPT; i++) my_val[i * SK_THREADS] = val[i + 1];
+                for (int i = 0; i <= SK_PPT; i++) h[i] = own[i];
+#pragma unroll
+                for (int t = 0; t + 1 < W; t++)
+                    h[SK_PPT + 1 + t] = run_hash_from_right((uint32_t)__builtin_amdgcn_update_dpp(0, (int)own[1 + t], 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
             }
+            uint32_t val[SK_PPT + 1];
+            run_window_min<W>(h, val);
+            heads = run_heads(valid, (vs & 1u) != 0, val);
+            // the minimizer word of a run's first position is the only per-position value the emission needs, and it is
+            // indexed by a run-time position: through LDS (each thread reads back its own column)
+#pragma unroll
+            for (int i = 0; i < SK_PPT; i++) my_val[i * SK_THREADS] = val[i + 1];
         }
         // how far the run that crosses into the window of the lane to the right goes on there
         const uint32_t lead_next = __shfl_down(run_lead(valid, heads), 1);
@@ -144,7 +162,7 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
             uint64_t rx, ry;
             run_record(w0, w1, w2, i, len, a.k, (v & 1u) != 0, bkt, rx, ry);
             const uint32_t slot = atomicAdd(&cursor[c], 1u);
-            if (slot < rstride) recs1[((uint64_t)vg * B1 + c) * rstride + slot] = make_ulonglong2(rx, ry);
+            if (slot < rstride) my_recs[(narrow ? mul24(c, rstride) : c * rstride) + slot] = make_ulonglong2(rx, ry);
             else over = true;
         }
     }
@@ -276,11 +294,19 @@ __global__ __launch_bounds__(SK2_THREADS) void superkmer_l2_kernel(const ulonglo
 // time and the others eight at a time.
 // Segment vg * 2^bb + bucket = recs2[off[..] .. + (len[..] & 0xffff)) in RECORDS, the first len[..] >> 16 of them short.
 // bin of a record: 2 * fine bucket + (more than 4 k-mers)
+// a record level 1 marked for the other strand is turned over on its way through level 2
+__device__ __forceinline__ void rec_flip(ulonglong2 &r, int k)
+{
+    uint64_t x = r.x, y = r.y;
+    run_flip(x, y, k);
+    r.x = x;
+    r.y = y;
+}
 __device__ __forceinline__ uint32_t rec_bin(uint64_t y, int b2) { return (rec_fine(y, b2) << 1) | (uint32_t)(run_len(y) > 4u); }
 
 template <bool STAGED, int MAXR>
 __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(const ulonglong2 *__restrict__ recs1, uint32_t rstride,
-                                                                            const uint32_t *__restrict__ rcount1, uint64_t n_regions, int bb, int b1,
+                                                                            const uint32_t *__restrict__ rcount1, uint64_t n_regions, int k, int bb, int b1,
                                                                             ulonglong2 *__restrict__ recs2, uint64_t *__restrict__ off,
                                                                             uint32_t *__restrict__ len_out, int *__restrict__ overflow)
 {
@@ -311,6 +337,7 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
             for (int j = 0; j < MAXR; j++) {
                 const uint32_t i = (uint32_t)j * SK2R_THREADS + threadIdx.x;
                 if (i < n) {
+                    rec_flip(in[j], k);
                     srank[i] = (uint16_t)atomicAdd(&hist[rec_bin(in[j].y, b2)], 1u);
                     srec[i] = in[j];
                 }
@@ -356,7 +383,8 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
             for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) out[i] = srec[i];
         } else {
             for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) {
-                const ulonglong2 rec = rr[i];
+                ulonglong2 rec = rr[i];
+                rec_flip(rec, k);
                 const uint32_t f = rec_bin(rec.y, b2);
                 out[start[f] + atomicAdd(&hist[f], 1u)] = rec;
             }
@@ -423,8 +451,8 @@ void launch_superkmer_l2(hipStream_t s, const void *recs1, uint32_t rstride, con
 }
 
 template <int MAXR>
-static void launch_l2r_staged(hipStream_t s, uint32_t grid, const ulonglong2 *r1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb,
-                              int b1, ulonglong2 *r2, uint64_t *off, uint32_t *len, int *overflow)
+static void launch_l2r_staged(hipStream_t s, uint32_t grid, const ulonglong2 *r1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k,
+                              int bb, int b1, ulonglong2 *r2, uint64_t *off, uint32_t *len, int *overflow)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -434,10 +462,10 @@ static void launch_l2r_staged(hipStream_t s, uint32_t grid, const ulonglong2 *r1
     }
     // the records and, beside them, their 16-bit ranks
     hipLaunchKernelGGL((superkmer_l2_records_kernel<true, MAXR>), dim3(grid), dim3(SK2R_THREADS), (size_t)rstride * 18, s, r1, rstride, rcount1,
-                       n_regions, bb, b1, r2, off, len, overflow);
+                       n_regions, k, bb, b1, r2, off, len, overflow);
 }
 
-void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int bb, int b1,
+void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb, int b1,
                                  void *recs2, uint64_t *off, uint32_t *len, int *overflow)
 {
     if (!n_regions) return;
@@ -445,10 +473,10 @@ void launch_superkmer_l2_records(hipStream_t s, const void *recs1, uint32_t rstr
     const ulonglong2 *r1 = reinterpret_cast<const ulonglong2 *>(recs1);
     ulonglong2 *r2 = reinterpret_cast<ulonglong2 *>(recs2);
     // the region in LDS: up to 1536 records (27 KB, five workgroups per CU), 3072 (54 KB, two), 5120 (90 KB, one), else two sweeps
-    if (rstride <= 3u * SK2R_THREADS) launch_l2r_staged<3>(s, grid, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len, overflow);
-    else if (rstride <= 6u * SK2R_THREADS) launch_l2r_staged<6>(s, grid, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len, overflow);
-    else if (rstride <= 10u * SK2R_THREADS) launch_l2r_staged<10>(s, grid, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len, overflow);
-    else hipLaunchKernelGGL((superkmer_l2_records_kernel<false, 0>), dim3(grid), dim3(SK2R_THREADS), 0, s, r1, rstride, rcount1, n_regions, bb, b1, r2, off, len, overflow);
+    if (rstride <= 3u * SK2R_THREADS) launch_l2r_staged<3>(s, grid, r1, rstride, rcount1, n_regions, k, bb, b1, r2, off, len, overflow);
+    else if (rstride <= 6u * SK2R_THREADS) launch_l2r_staged<6>(s, grid, r1, rstride, rcount1, n_regions, k, bb, b1, r2, off, len, overflow);
+    else if (rstride <= 10u * SK2R_THREADS) launch_l2r_staged<10>(s, grid, r1, rstride, rcount1, n_regions, k, bb, b1, r2, off, len, overflow);
+    else hipLaunchKernelGGL((superkmer_l2_records_kernel<false, 0>), dim3(grid), dim3(SK2R_THREADS), 0, s, r1, rstride, rcount1, n_regions, k, bb, b1, r2, off, len, overflow);
 }
 
 void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n, int k, int bb, int sb, uint32_t *bucket_of, uint32_t *col_of)

@@ -7,7 +7,7 @@ i=0
 for OPTS in "$@"; do
   ARGS=""
   for o in $OPTS; do ARGS="$ARGS --opt $o"; done
-  timeout -k 10 200 python3 $R/bench.py --steps 3 --warmup 1 --no-e2e --no-random --cpu-genomes 0 $EXTRA $ARGS > $R/gpurun_out/$TAG/sweep_$i.json 2> $R/gpurun_out/$TAG/sweep_$i.err || echo "run $i failed"
+  timeout -k 10 200 python3 $R/bench.py --steps 3 --warmup 1 --no-e2e --no-random --no-realistic --no-c4 --no-c5 --cpu-genomes 0 $EXTRA $ARGS > $R/gpurun_out/$TAG/sweep_$i.json 2> $R/gpurun_out/$TAG/sweep_$i.err || echo "run $i failed"
   python3 - "$OPTS" $R/gpurun_out/$TAG/sweep_$i.json <<'PY'
 import json, sys
 try:

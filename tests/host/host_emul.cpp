@@ -11,8 +11,23 @@
 
 using namespace grm;
 
+// one thread does it all (run_minimizers) -- and, beside it, the way the kernel's lanes do: every window hashes the 33 m-mers of its
+// own positions, the W - 1 behind them are the first ones of the window to the right, moved over.  false: the two differ
 template <int W>
-static void emul_minimizers(uint64_t w0, uint64_t w1, uint32_t prev2, uint32_t (&val)[RUN_PPT + 1]) { run_minimizers<W>(w0, w1, prev2, val); }
+static bool emul_minimizers(const uint64_t *sym2, uint64_t j, uint32_t (&val)[RUN_PPT + 1])
+{
+    const uint32_t prev2 = j ? (uint32_t)sym2[j - 1] & 3u : 0u;
+    run_minimizers<W>(sym2[j], sym2[j + 1], prev2, val);
+    uint32_t own[RUN_PPT + 1], right[RUN_PPT + 1], h[RUN_PPT + W], val2[RUN_PPT + 1];
+    run_hashes<RUN_PPT + 1>(sym2[j], sym2[j + 1], prev2, own);
+    run_hashes<RUN_PPT + 1>(sym2[j + 1], sym2[j + 2], (uint32_t)sym2[j] & 3u, right);
+    for (int i = 0; i <= RUN_PPT; i++) h[i] = own[i];
+    for (int t = 0; t + 1 < W; t++) h[RUN_PPT + 1 + t] = run_hash_from_right(right[1 + t]);
+    run_window_min<W>(h, val2);
+    for (int i = 0; i <= RUN_PPT; i++)
+        if (val[i] != val2[i]) return false;
+    return true;
+}
 
 extern "C" {
 
@@ -298,9 +313,8 @@ uint64_t emul_runs(const uint64_t *sym2, const uint64_t *inv, uint64_t total_sym
         w.valid = (uint32_t)(vs >> 1);
         w.heads = 0;
         if (w.valid) {
-            const uint32_t prev2 = j ? (uint32_t)sym2[j - 1] & 3u : 0u;
             switch (k - 11 + 1) {
-#define CASE(W) case W: emul_minimizers<W>(sym2[j], sym2[j + 1], prev2, w.val); break;
+#define CASE(W) case W: if (!emul_minimizers<W>(sym2, j, w.val)) return false; break;
                 CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
                 CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22)
 #undef CASE
@@ -335,7 +349,9 @@ uint64_t emul_runs(const uint64_t *sym2, const uint64_t *inv, uint64_t total_sym
             const uint32_t v = cur.val[i + 1];
             const uint32_t bucket = minimizer_bucket(v >> (32 - MINIMIZER_ORDER_BITS), nbits);
             uint64_t x, y;
-            run_record(w0, w1, w2, i, len, k, (v & 1u) != 0, bucket, x, y);
+            run_record(w0, w1, w2, i, len, k, (v & 1u) != 0, bucket, x, y);        // (level 1: the run as it stands, marked)
+            if (((y & RUN_FLIP_BIT) != 0) != ((v & 1u) != 0)) return ~0ull - 7;
+            run_flip(x, y, k);                                                       // (level 2: turned over)
             if (run_len(y) != len || run_fine(y) != (bucket & ((1u << RUN_FINE_BITS) - 1u)) || ((y >> 12) & 0x3ffu)) return ~0ull - 6;
             if (nr < rec_cap) {
                 uint32_t *o = out_rec + 6 * nr;
