@@ -105,14 +105,16 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
         uint32_t prev2 = 0;
         if (j <= j_b + 1) {          // (j_b: only for the run that crosses into it; j_b + 1: only its hashes; the stream buffers end with slack words)
             const uint64_t p0 = j << 5;
-            w0 = a.sym2[j];
-            w1 = a.sym2[j + 1];
-            w2 = a.sym2[j + 2];
-            prev2 = j ? (uint32_t)a.sym2[j - 1] & 3u : 0u;
+            // (streamed once: loads marked non-temporal, so that the packed stream does not push the workgroups' half-filled record
+            // lines out of L2)
+            w0 = __builtin_nontemporal_load(&a.sym2[j]);
+            w1 = __builtin_nontemporal_load(&a.sym2[j + 1]);
+            w2 = __builtin_nontemporal_load(&a.sym2[j + 2]);
+            prev2 = j ? (uint32_t)__builtin_nontemporal_load(&a.sym2[j - 1]) & 3u : 0u;
             // bit t of vs: position p0 - 1 + t starts a k-mer (t = 0 .. 32; k <= 32 keeps all 33 inside the 64 flags read)
             if (p0) {
                 const uint64_t q = p0 - 1;
-                vs = valid_starts_at(a.inv[q >> 6], a.inv[(q >> 6) + 1], (int)(q & 63), a.k);
+                vs = valid_starts_at(__builtin_nontemporal_load(&a.inv[q >> 6]), __builtin_nontemporal_load(&a.inv[(q >> 6) + 1]), (int)(q & 63), a.k);
             } else {
                 vs = valid_starts_at(a.inv[0], a.inv[1], 0, a.k) << 1;
             }
@@ -418,7 +420,10 @@ static void launch_sk1(hipStream_t s, const SkArgs &a, ulonglong2 *recs1, uint32
 }
 
 int superkmer_max_bits() { return SK_MAX_BITS; }
-int superkmer_coarse_bits(int bb) { return bb < SK_MAX_COARSE ? bb : SK_MAX_COARSE; }      // 512 regions per genome part: a region's ~1000 records (5 Mbp) fit LDS
+// 256 regions per genome part: with 512 a workgroup keeps twice the half-filled 128-byte lines open in L2 and writes 1.8x its records to
+// HBM (13.8 GB for 8.0 at 1000 x 5 Mbp; 8.7 with 256), and level 2 still sorts a region's ~2000 records (5 Mbp) inside LDS; with 128 it
+// no longer does (5.6 ms instead of 2.8)
+int superkmer_coarse_bits(int bb) { return bb < 8 ? bb : 8; }
 int superkmer_lmax() { return SK_LMAX; }
 
 void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int b1, int part_bits, void *recs1, uint32_t rstride, uint32_t *rcount1,
