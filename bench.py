@@ -79,6 +79,10 @@ def parse_args():
     ap.add_argument("--no-realistic", action="store_true", help="skip the realistic-assemblies leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the reads leg (BASELINE configs[3])")
     ap.add_argument("--no-c5", action="store_true", help="skip the k=63 leg (BASELINE configs[4])")
+    ap.add_argument("--rank-budget", type=int, default=0, metavar="N",
+                    help="N=1 only: the headline set cut into the N shards of an N-GPU run (BASELINE configs[2]), every rank's pass timed in this "
+                         "one process on this one GPU: partition + local dictionary per shard, the exchange records, the union of the N real "
+                         "payloads, the fill -- what a rank of the N-GPU run spends, without the wire")
     ap.add_argument("--only", default=None, choices=["headline", "realistic", "c4", "c5", "random"],
                     help="run ONE leg (profiling); for any leg but the headline, the headline shrinks to 16 genomes")
     ap.add_argument("--cpu-genomes", type=int, default=-1,
@@ -296,6 +300,94 @@ def count_leg(D, ctx, args, batch, steps, warmup):
 
     elapsed, _ = timed_leg(D, ctx, step, steps, warmup)
     return elapsed, kernel_table(ctx, 0, 0, 0)
+
+
+def rank_budget_leg(ctx, synth, Dm, args, n_ranks, device):
+    """BASELINE configs[2] on one GPU, rank by rank: the 1000 genomes in the word-row blocks of an n_ranks-GPU run; every shard is
+    partitioned and gets its local dictionary, writes its exchange record into ONE payload laid out as the all-gather would leave it,
+    and every rank then builds the global dictionary from that payload and fills its rows.  Times are wall clock around the engine
+    calls (each ends synchronised), best of the timed repetitions; `rank_ms` = what the slowest rank spends between the barrier that
+    starts a pass and its matrix, without the all-gather itself (priced from the payload size at xGMI link speed)."""
+    import torch
+    filt = not args.keep_singletons
+    shards = Dm.shard_genomes(args.genomes, n_ranks)
+    batches = [make_batch(ctx, synth, "P", a, b - a, args.genome_len) for a, b in shards]
+    words = 1 if args.k <= 32 else 2
+    reps = max(2, args.steps)
+    best = {}
+
+    def note(key, r, ms):
+        best.setdefault(key, {})
+        best[key][r] = min(best[key].get(r, 1e30), ms)
+
+    n_cols = 0
+    per_kernel = {}
+    for rep in range(reps + 1):                 # (the first repetition sizes tables and allocates: not kept)
+        keep = rep > 0
+        n_locals, bbs = [], []
+        for r, b in enumerate(batches):
+            if keep and r == 0:
+                ctx.timing(True)
+                ctx.timing_reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            b.partition(args.k, args.abundance_min)
+            t1 = time.perf_counter()
+            n_locals.append(b.local_dict())
+            t2 = time.perf_counter()
+            bbs.append(b.bucket_bits)
+            if keep:
+                note("partition", r, (t1 - t0) * 1e3)
+                note("local_dict", r, (t2 - t1) * 1e3)
+                if r == 0:
+                    for name, ms, _ in ctx.timings():
+                        per_kernel[name] = min(per_kernel.get(name, 1e30), ms)
+                    ctx.timing(False)
+        n_max = max(1, max(n_locals))
+        flags_off, boff_off, stride = batches[0].exchange_layout(n_max, words, max(v & 0xff for v in bbs))
+        payload = torch.empty(n_ranks * stride, dtype=torch.uint8, device=device)
+        for r, b in enumerate(batches):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            b.export_dict_ordered(payload.data_ptr() + r * stride, flags_off, boff_off)
+            torch.cuda.synchronize()
+            if keep:
+                note("export_record", r, (time.perf_counter() - t0) * 1e3)
+        for r, b in enumerate(batches):
+            if keep and r == 0:
+                ctx.timing(True)
+                ctx.timing_reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_cols = b.set_global_dict_gathered(payload.data_ptr(), n_max, n_locals, bbs, filt)
+            t1 = time.perf_counter()
+            m = b.fill()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            m.free()
+            if keep:
+                note("global_dict_from_payload", r, (t1 - t0) * 1e3)
+                note("fill", r, (t2 - t1) * 1e3)
+                if r == 0:
+                    for name, ms, _ in ctx.timings():
+                        per_kernel[name] = min(per_kernel.get(name, 1e30), ms)
+                    ctx.timing(False)
+        del payload
+    for b in batches:
+        b.free()
+    stages = ["partition", "local_dict", "export_record", "global_dict_from_payload", "fill"]
+    per_rank = [round(sum(best[s][r] for s in stages), 3) for r in range(n_ranks)]
+    gather_bytes = n_ranks * stride
+    # every rank receives (n_ranks - 1) records, each over its own xGMI link (all-pairs): one record at ~153 GB/s nominal per link
+    wire_ms = stride / 153e9 * 1e3
+    return {"ranks": n_ranks, "shards": [b - a for a, b in shards], "columns": int(n_cols),
+            "stage_ms_slowest_rank": {s: round(max(best[s].values()), 3) for s in stages},
+            "stage_ms_mean": {s: round(sum(best[s].values()) / n_ranks, 3) for s in stages},
+            "rank_ms": max(per_rank), "rank_ms_all": per_rank,
+            "exchange": {"record_bytes": int(stride), "payload_bytes": int(gather_bytes), "wire_ms_at_153GBps_per_link": round(wire_ms, 3)},
+            "kernels_of_rank0_ms": {k: round(v, 3) for k, v in per_kernel.items()},
+            "what": "host wall clock around the engine's staged calls, one GPU, best of %d repetitions; the all-gather itself is not run "
+                    "(one process): priced from the record size" % reps}
 
 
 def realistic_leg(D, Dm, ctx, synth, args):
@@ -731,6 +823,9 @@ def main():
                            "genomes_per_gpu": args.genomes, "genomes_total": args.genomes * world, "columns": int(w_cols)}
 
     solo = world == 1 and rank == 0 and args.stage == "matrix" and args.mode == "P"
+    if solo and args.rank_budget > 1:
+        out["rank_budget"] = rank_budget_leg(ctx, synth, Dm, args, args.rank_budget, D.device)
+        out["rank_budget"]["speedup_bound_vs_1gpu"] = round(out["ms_per_step"] / (out["rank_budget"]["rank_ms"] + out["rank_budget"]["exchange"]["wire_ms_at_153GBps_per_link"]), 2)
     # ---- the same strains as real assemblies ----
     if solo and not args.no_realistic and args.only in (None, "realistic"):
         out["realistic"] = realistic_leg(D, Dm, ctx, synth, args)

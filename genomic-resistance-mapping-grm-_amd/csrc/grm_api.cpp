@@ -1153,7 +1153,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         const size_t n_rows_b = ((size_t)G + 63) / 64;
         // (dict_build's record memo takes LDS: with it the key table has 2^11 slots unless the caller says otherwise, so that
         // two workgroups still share a CU)
-        b->rec_memo_log2 = c->opt_rec_memo < 0 ? 9 : c->opt_rec_memo == 0 ? 0 : std::min(11, std::max(8, c->opt_rec_memo));
+        b->rec_memo_log2 = c->opt_rec_memo < 0 ? 8 : c->opt_rec_memo == 0 ? 0 : std::min(11, std::max(8, c->opt_rec_memo));
         const uint32_t cap_r = (b->rec_memo_log2 && c->opt_cap_log2 <= 0) ? 11u : b->cap_log2;
         bool by_records = c->opt_no_slots <= 0 && c->opt_rec_keys <= 0 && n_rows_b <= 0xffffu &&
                           ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << cap_r) * 8 <= MATRIX_S_LIMIT;

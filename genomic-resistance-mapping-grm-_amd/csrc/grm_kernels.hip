@@ -2311,19 +2311,20 @@ void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const SegLayout &se
     else GRM_LAUNCH_DW(11, 2)
 #undef GRM_LAUNCH_DW
 }
-static int g_dict_kif = 8, g_table_threads = TABLE_THREADS;
+static int g_dict_kif = 8, g_table_threads = 0;      // 0: every kernel's own default (key form: TABLE_THREADS, record form: 256)
 void set_table_tuning(int kif, int threads)
 {
     g_dict_kif = (kif == 1 || kif == 2 || kif == 4) ? kif : 8;
-    g_table_threads = (threads == 256 || threads == 1024) ? threads : TABLE_THREADS;
+    g_table_threads = (threads == 256 || threads == 512 || threads == 1024) ? threads : 0;
 }
 void launch_dict_build(hipStream_t s, const DictArgs &a)
 {
     const size_t lds = (((size_t)18) << a.cap_log2) + TABLE_SCRATCH_BYTES;
-    const dim3 grid(1u << (a.bb + a.sb)), block(g_table_threads);     // 256 / 512 / 1024 threads: the wave count divides 64
+    const int key_threads = g_table_threads ? g_table_threads : TABLE_THREADS;
+    const dim3 grid(1u << (a.bb + a.sb)), block(key_threads);     // 256 / 512 / 1024 threads: the wave count divides 64
 #define GRM_LAUNCH_DICT(K, T, F, R) hipLaunchKernelGGL((dict_build_kernel<K, T, F, R>), grid, block, lds, s, a)
-    if (a.in_flags) {                   // union over ranks: not a hot kernel, one instance
-        GRM_LAUNCH_DICT(4, 1024, true, false);
+    if (a.in_flags) {                   // union over ranks: one instance; one word-row, i.e. all set-up: 256 threads (0.51 ms against 0.64 with 512)
+        hipLaunchKernelGGL((dict_build_kernel<4, 1024, true, false>), grid, dim3(g_table_threads ? g_table_threads : 256), lds, s, a);
         return;
     }
     if (a.recs) {                       // one record (up to 16 keys) per lane; 8 waves (the instance's launch bound)
@@ -2332,10 +2333,14 @@ void launch_dict_build(hipStream_t s, const DictArgs &a)
         // (a caller-forced table of 2^13 slots leaves no room for the record memo inside the 159 KB a workgroup may allocate: none then)
         if (lds_t + dict_memo_bytes(b.memo_log2, b.cap_log2) > (size_t)159 * 1024) b.memo_log2 = 0;
         const size_t lds_r = lds_t + dict_memo_bytes(b.memo_log2, b.cap_log2);                                              // + the record memo
-        hipLaunchKernelGGL((dict_build_kernel<8, 512, false, true>), grid, dim3(TABLE_THREADS), lds_r, s, b);
+        // 256 threads unless told otherwise: with the 104-record memo (52 KB of LDS) three workgroups share a CU, and what a workgroup
+        // spends outside its word-rows (table set-up, the first bounds -> records round trips, the entries' way out) is latency that
+        // only more workgroups in flight hide -- 1000 x 5 Mbp: 4.0 ms against 4.3 with 512 threads and 208 records; a rank's 128
+        // genomes (two word-rows, nearly all of it set-up): 1.2 against 1.45
+        hipLaunchKernelGGL((dict_build_kernel<8, 512, false, true>), grid, dim3(g_table_threads == 512 || g_table_threads == 1024 ? 512 : 256), lds_r, s, b);
         return;
     }
-    const int kif = (g_table_threads > 512 && g_dict_kif > 4) ? 4 : g_dict_kif;
+    const int kif = (key_threads > 512 && g_dict_kif > 4) ? 4 : g_dict_kif;
     switch (kif) {
     case 1: GRM_LAUNCH_DICT(1, 1024, false, false); break;
     case 2: GRM_LAUNCH_DICT(2, 1024, false, false); break;

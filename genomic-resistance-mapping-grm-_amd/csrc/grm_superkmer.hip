@@ -36,7 +36,14 @@ constexpr int SK_MAX_BITS = SK_MAX_COARSE + SK_FINE_BITS;         // at most 9 c
 // into it goes on; lane 63 on the one after that, only to hash.
 constexpr int SK_WAVE_WINDOWS = 62;
 constexpr int SK_STEP_WINDOWS = (SK_THREADS / 64) * SK_WAVE_WINDOWS;
-constexpr size_t SK_L1_LDS = (size_t)SK_PPT * SK_THREADS * 4 + ((size_t)4 << SK_MAX_COARSE) + 128;
+// runs a wave can hand round among its lanes per step (a wave with more -- every other position a run's first: k = 11, or junk -- takes
+// them lane by lane)
+constexpr int SK_WAVE_RUNS = 320;
+constexpr int SK_WAVES = SK_THREADS / 64;
+constexpr int SK_VAL_PITCH = SK_THREADS + 1;          // minimizer words in LDS: position i of thread t at [i * pitch + t] -- a column per thread when it writes,
+                                                      // and no two positions of one thread in one bank when the lanes of its wave read them back
+constexpr size_t SK_L1_LDS = (size_t)SK_PPT * SK_VAL_PITCH * 4 + ((size_t)4 << SK_MAX_COARSE) + 128 + (size_t)SK_WAVES * (64 * 8 + 64 * 8 + SK_WAVE_RUNS * 2);
+static_assert(SK_L1_LDS <= 159 * 1024, "one 1024-thread workgroup per CU: its LDS");
 constexpr int SK2_THREADS = 256;
 constexpr int SK2R_THREADS = 512;                     // level 2, records only
 constexpr int SK2_TILE_KEYS = SK2_THREADS * SK_LMAX;                // one record per thread: at most 256 x 22 keys = 44 KB of LDS per tile
@@ -67,9 +74,13 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
                                                                    int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    uint32_t *s_val = reinterpret_cast<uint32_t *>(lds_raw);          // [SK_PPT][SK_THREADS]: minimizer word of every position of the step
-    uint32_t *cursor = s_val + SK_PPT * SK_THREADS;                   // records written so far to coarse region c
+    uint32_t *s_val = reinterpret_cast<uint32_t *>(lds_raw);          // [SK_PPT][SK_VAL_PITCH]: minimizer word of every position of the step
+    uint32_t *cursor = s_val + SK_PPT * SK_VAL_PITCH;                 // records written so far to coarse region c
     uint32_t *scratch = cursor + (1u << SK_MAX_COARSE);
+    // per wave, for handing the step's runs round among the lanes: every lane's window word, (run boundaries, lead), and the list of runs
+    uint64_t *w_word = reinterpret_cast<uint64_t *>(scratch + 32) + (threadIdx.x >> 6) * 64;
+    uint2 *w_edge = reinterpret_cast<uint2 *>(reinterpret_cast<uint64_t *>(scratch + 32) + SK_WAVES * 64) + (threadIdx.x >> 6) * 64;
+    uint16_t *w_runs = reinterpret_cast<uint16_t *>(reinterpret_cast<uint64_t *>(scratch + 32) + 2 * SK_WAVES * 64) + (threadIdx.x >> 6) * SK_WAVE_RUNS;
     const int b1 = a.b1;
     const uint32_t B1 = 1u << b1;
     const uint32_t vg = blockIdx.x;
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     for (uint32_t c = threadIdx.x; c < B1; c += SK_THREADS) cursor[c] = 0;
     __syncthreads();
     const int lane = lane_id(), wave = wave_id();
-    uint32_t *my_val = s_val + threadIdx.x;
+    const uint32_t wave_t0 = threadIdx.x & ~63u;
     ulonglong2 *my_recs = recs1 + (uint64_t)vg * B1 * rstride;           // the part's regions: 2^b1 x rstride records (< 2^32 of them: host)
     const bool narrow = rstride < (1u << 15);                            // (region index x stride as a full-rate 24-bit multiply)
     uint32_t n_valid = 0;
@@ -143,29 +154,53 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
             // the minimizer word of a run's first position is the only per-position value the emission needs, and it is
             // indexed by a run-time position: through LDS (each thread reads back its own column)
 #pragma unroll
-            for (int i = 0; i < SK_PPT; i++) my_val[i * SK_THREADS] = val[i + 1];
+            for (int i = 0; i < SK_PPT; i++) s_val[i * SK_VAL_PITCH + threadIdx.x] = val[i + 1];
         }
-        // how far the run that crosses into the window of the lane to the right goes on there
-        const uint32_t lead_next = __shfl_down(run_lead(valid, heads), 1);
         const bool mine = lane < SK_WAVE_WINDOWS && j < j_b;
         if (mine) n_valid += (uint32_t)__popc(valid);
-        // The runs of a lane leave one per round (a lane has ~3.5, at most 32): the slot in the coarse region comes from the
-        // workgroup's LDS cursor of that region, the record goes straight to its place.  A region's lines fill up in
-        // cursor order, 8 records each, and a workgroup keeps 512 of them open: they complete in L2 (mostly).
-        uint32_t hd = mine ? heads : 0u;
-        while (hd) {
-            const int i = __ffs(hd) - 1;
-            hd &= hd - 1;
-            const uint32_t v = my_val[i * SK_THREADS];
-            uint32_t len = run_length(heads, valid, i);
+        // One run = one record: its minimizer word back from LDS, its bucket, its bases out of the window's words, its place from
+        // the LDS cursor of its coarse region.  A lane's window starts ~3.9 runs, the fullest lane of a wave ~8: taken lane by lane
+        // the wave would go round 8 times with half its lanes idle, so the wave's runs are listed (lane, position) and handed round,
+        // 64 at a time, with what a run needs of its window (the words, the run boundaries, the neighbour's lead) read from LDS.
+        const uint32_t lead = run_lead(valid, heads);
+        const uint32_t n_mine = mine ? (uint32_t)__popc(heads) : 0u;
+        const uint32_t upto = wave_scan_incl_dpp(n_mine);
+        const uint32_t n_wave = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
+        auto emit = [&](uint64_t e0, uint64_t e1, uint64_t e2, uint32_t bnd, uint32_t lead_next, uint32_t v, int i) {
+            uint32_t len = (uint32_t)__builtin_ctz((bnd >> 1 >> i) | (0x80000000u >> i)) + 1u;       // run_length(): to the next boundary or the window's end
             if (i + (int)len == SK_PPT) len += lead_next;
             const uint32_t bkt = minimizer_bucket(v >> (32 - MINIMIZER_ORDER_BITS), b1 + SK_FINE_BITS);
             const uint32_t c = bkt >> SK_FINE_BITS;
             uint64_t rx, ry;
-            run_record(w0, w1, w2, i, len, a.k, (v & 1u) != 0, bkt, rx, ry);
+            run_record(e0, e1, e2, i, len, a.k, (v & 1u) != 0, bkt, rx, ry);
             const uint32_t slot = atomicAdd(&cursor[c], 1u);
             if (slot < rstride) my_recs[(narrow ? mul24(c, rstride) : c * rstride) + slot] = make_ulonglong2(rx, ry);
             else over = true;
+        };
+        if (n_wave <= (uint32_t)SK_WAVE_RUNS) {
+            w_word[lane] = w0;
+            w_edge[lane] = make_uint2(heads | ~valid, lead);
+            uint32_t hd = mine ? heads : 0u, at = upto - n_mine;
+            while (hd) {
+                w_runs[at++] = (uint16_t)(((uint32_t)lane << 5) | (uint32_t)(__ffs(hd) - 1));
+                hd &= hd - 1;
+            }
+            for (uint32_t r0 = 0; r0 < n_wave; r0 += 64) {
+                if (r0 + (uint32_t)lane < n_wave) {
+                    const uint32_t e = w_runs[r0 + lane], owner = e >> 5;
+                    const int i = (int)(e & 31u);
+                    emit(w_word[owner], w_word[owner + 1], w_word[owner + 2], w_edge[owner].x, w_edge[owner + 1].y,
+                         s_val[i * SK_VAL_PITCH + wave_t0 + owner], i);
+                }
+            }
+        } else {
+            const uint32_t lead_next = __shfl_down(lead, 1);
+            uint32_t hd = mine ? heads : 0u;
+            while (hd) {
+                const int i = __ffs(hd) - 1;
+                hd &= hd - 1;
+                emit(w0, w1, w2, heads | ~valid, lead_next, s_val[i * SK_VAL_PITCH + threadIdx.x], i);
+            }
         }
     }
     __syncthreads();
