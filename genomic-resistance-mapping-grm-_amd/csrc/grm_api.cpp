@@ -73,6 +73,8 @@ struct grm_ctx {
     int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
     int opt_rec_keys = -1;       // > 0: record form always expands to key segments in level 2 (tests, measurements)
     int opt_rec_coarse = -1;     // record form: coarse bucket bits of level 1 (tests, measurements); < 0 = min(bucket bits, 9)
+    int opt_parse_fused = -1;    // > 0: the single-pass parse kernel (decoupled look-back) instead of summarize / scan / pack -- measured SLOWER
+                                 // (7.1 against 5.0 ms at 1000 x 5 Mbp): kept for tests and measurements
     int opt_memo_stats = -1;     // > 0: dict_build counts what its record memo held / was asked / found (grm_batch_memo_stats)
     int opt_rec_memo = -1;       // record memo of dict_build: log2 of its size base (8..11; 15/32 of 2^that records), 0 = none, < 0 = default (10, with a 2^11 key table)
 };
@@ -293,6 +295,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "rec_keys") c->opt_rec_keys = value;
     else if (n == "rec_memo") c->opt_rec_memo = value;
     else if (n == "memo_stats") c->opt_memo_stats = value;
+    else if (n == "parse_fused") c->opt_parse_fused = value;
     else if (n == "rec_coarse") c->opt_rec_coarse = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
@@ -1079,9 +1082,18 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         HIPCHK(c, b->d_sym2.ensure(max_groups * 16));
         HIPCHK(c, b->d_inv.ensure(max_groups * 8));
         HIPCHK(c, b->d_genome_sym_off.ensure(((size_t)G + 1) * 8));
-        HIPCHK(c, b->d_scan_scratch.ensure(parse_scan_scratch_bytes(b->n_tiles)));
-        HIPCHK(c, b->d_chunk_pre.ensure(parse_chunk_pre_bytes(b->n_tiles)));
     }
+    if (c->opt_parse_fused > 0) {
+        // one pass over the input: a tile learns what runs into it by a look-back over the tiles before it (grm_kernels.hip)
+        HIPCHK(c, b->d_scan_scratch.ensure(parse_fused_desc_bytes(b->n_tiles)));
+        HIPCHK(c, b->d_chunk_pre.ensure(parse_fused_piece_bytes(b->n_tiles)));
+        TimeScope t(c, "parse_fused", b->raw_bytes);
+        HIPCHK(c, launch_parse_fused(s, raw, b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_scan_scratch.as<uint64_t>(), b->d_chunk_pre.as<uint64_t>(),
+                                     b->d_tile_off.as<uint64_t>(), b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>(),
+                                     b->d_genome_tile_off.as<uint32_t>(), G, b->d_genome_sym_off.as<uint64_t>()));
+    } else {
+    HIPCHK(c, b->d_scan_scratch.ensure(parse_scan_scratch_bytes(b->n_tiles)));
+    HIPCHK(c, b->d_chunk_pre.ensure(parse_chunk_pre_bytes(b->n_tiles)));
     // (no memset of the packed stream: parse_pack's companion kernel zeroes the groups that need it)
     {
         TimeScope t(c, "parse_summarize", b->raw_bytes);
@@ -1097,6 +1109,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         TimeScope t(c, "parse_pack", b->raw_bytes);
         launch_parse_pack(s, raw, b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_tile_off.as<uint64_t>(), b->d_tile_state.as<uint8_t>(),
                           b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>(), b->d_sums.as<TileSummary>(), b->d_chunk_pre.as<uint32_t>());
+    }
     }
     HIPCHK(c, hipGetLastError());
     b->h_genome_sym_off.resize(G + 1);

@@ -77,6 +77,13 @@ void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles,
 size_t parse_scan_scratch_bytes(uint32_t n_tiles);
 void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, const uint64_t *tile_off,
                        const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv, const TileSummary *sums, const uint32_t *chunk_pre);
+// single-pass parse (decoupled look-back over the tiles): desc / pieces are scratch of parse_fused_desc_bytes / _piece_bytes; fills
+// tile_off[0 .. n_tiles], sym2, inv, genome_sym_off
+size_t parse_fused_desc_bytes(uint32_t n_tiles);
+size_t parse_fused_piece_bytes(uint32_t n_tiles);
+hipError_t launch_parse_fused(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, uint64_t *desc, uint64_t *pieces,
+                              uint64_t *tile_off, uint64_t *sym2, uint64_t *inv, const uint32_t *genome_tile_off, uint32_t n_genomes,
+                              uint64_t *genome_sym_off);
 void launch_kmer_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);
 int scatter_b1_bits(int bb);
 void launch_kmer_scatter_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *coarse_off,

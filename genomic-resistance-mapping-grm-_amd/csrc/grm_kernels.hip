@@ -10,6 +10,7 @@
 // DESIGN.md ("Kernels").  Wave width is hard-coded to 64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "grm_device_fns.h"
 #include "grm_internal.h"
@@ -305,6 +306,15 @@ __device__ __forceinline__ ScanElem<C> selem_shfl_up(const ScanElem<C> &e, int d
     for (int s = 0; s < 4; s++) r.c[s] = __shfl_up(e.c[s], d);
     return r;
 }
+template <typename C>
+__device__ __forceinline__ ScanElem<C> selem_shfl_down(const ScanElem<C> &e, int d)
+{
+    ScanElem<C> r;
+    r.tbl = __shfl_down(e.tbl, d);
+#pragma unroll
+    for (int s = 0; s < 4; s++) r.c[s] = __shfl_down(e.c[s], d);
+    return r;
+}
 // block-wide scan of elements in thread order.  Returns the exclusive prefix of this thread;
 // *total = combination of all.  lds: >= 16 elements.  Two barriers.
 template <typename C>
@@ -502,6 +512,239 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
             if (a1) atomicOr((unsigned long long *)&sym2[2 * G + 1], (unsigned long long)a1);
             if (bi) atomicOr((unsigned long long *)&inv[G], (unsigned long long)bi);
         }
+    }
+}
+
+// ---- single-pass parse (option "parse_fused"; NOT the default: measured slower, see the end of this comment) ----------
+// parse_summarize + the scan over tile summaries + parse_pack read the 5.6 GB of a 1000-genome batch twice (and 1.4 GB of
+// per-chunk scan prefixes on top).  Here a tile is read ONCE: classified and scanned in registers as before, then the tile
+// learns the parser state and the symbol offset running into it by a decoupled look-back over the tiles before it, and
+// packs what it still holds in registers.  Tile numbers come from a ticket counter, so every tile a workgroup waits for
+// has been started by a workgroup that is resident or done: the wait always ends.
+//   desc[t]   one 64-bit word per tile, written with ONE agent-scope atomic store each time (no flag beside the data):
+//             status (bits 63..62) 0 = nothing yet, 1 = AGGREGATE, 2 = PREFIX
+//             AGGREGATE  what the tile does to the state and how many symbols it emits for every incoming state --
+//                        FASTA: v0 | v1 << 15 | last-line-type << 30 (TileSummary); FASTQ: four 15-bit counts | newlines mod 4 << 60
+//             PREFIX     state running OUT of the tile << 60 | first symbol index AFTER the tile
+// The groups (64 symbols) a tile boundary falls into cannot be stored by either tile alone: both leave their part in
+// pieces[tile][head / tail] and parse_stitch, one thread per tile, puts every such group together with plain stores --
+// no atomics on the stream, nothing to zero beforehand.
+// Measured (1000 x 5 Mbp, 341 000 tiles): 7.1 ms against 2.4 + 2.6 for the two kernels it replaces.  By ablation: load +
+// classify + scan alone 4.1 ms here (2.4 in parse_summarize: that kernel needs 38 VGPRs, this one 101 -- the scan is a chain of
+// cross-lane moves that lives on occupancy), + packing and stores 5.3, + the look-back 7.1-8.3.  The two-pass form is bound by
+// instruction issue and latency, not by the 5.6 GB it reads twice, so reading once buys nothing and the look-back costs.
+constexpr uint64_t PD_AGG = 1ull << 62, PD_PREFIX = 2ull << 62, PD_PAYLOAD = (1ull << 62) - 1;
+__device__ __forceinline__ uint64_t pd_pack(const TileSummary &s)
+{
+    if (s.tag & 4u) return (uint64_t)s.v[0] | ((uint64_t)s.v[1] << 15) | ((uint64_t)s.v[2] << 30) | ((uint64_t)s.v[3] << 45) | ((uint64_t)(s.tag & 3u) << 60);
+    return (uint64_t)s.v[0] | ((uint64_t)s.v[1] << 15) | ((uint64_t)s.tag << 30);
+}
+__device__ __forceinline__ TileSummary pd_unpack(uint64_t d, uint8_t meta)
+{
+    TileSummary s;
+    if (meta & TILE_META_FASTQ) {
+        s.v[0] = (uint32_t)d & 0x7fffu; s.v[1] = (uint32_t)(d >> 15) & 0x7fffu; s.v[2] = (uint32_t)(d >> 30) & 0x7fffu; s.v[3] = (uint32_t)(d >> 45) & 0x7fffu;
+        s.tag = 4u | ((uint32_t)(d >> 60) & 3u);
+    } else {
+        s.v[0] = (uint32_t)d & 0x7fffu; s.v[1] = (uint32_t)(d >> 15) & 0x7fffu; s.v[2] = s.v[3] = 0;
+        s.tag = (uint32_t)(d >> 30) & 3u;
+    }
+    return s;
+}
+// the whole workgroup: state and symbol offset running into `tile` (> 0).  Thread j of a round looks at tile (tile - 1 - base - j): wave
+// by wave the aggregates in front of the nearest known prefix are folded (older tiles first), then the waves' results in turn.
+// A look-back must cover tiles faster than they are started, or every tile ends up walking over all tiles in flight: one every ~10 ns
+// at 1000 x 5 Mbp against ~2 us per round of descriptor loads -- 64 descriptors per round (one wave, the others waiting at the
+// barrier) measured 7.5 ms for the kernel, 256 per round (all of the workgroup) what the table in DESIGN.md says.
+struct LookbackShare {
+    uint32_t tbl[PARSE_THREADS / 64], c[PARSE_THREADS / 64][4], p[PARSE_THREADS / 64], d_lo[PARSE_THREADS / 64], d_hi[PARSE_THREADS / 64];
+};
+__device__ __forceinline__ void parse_lookback(const uint64_t *__restrict__ desc, const uint8_t *__restrict__ tile_meta, uint32_t tile, LookbackShare &sh,
+                                               uint32_t &state_in, uint64_t &off_in)
+{
+    const int lane = lane_id(), wave = wave_id();
+    constexpr int NW = PARSE_THREADS / 64;
+    ScanElem<uint64_t> acc = selem_identity<uint64_t>();          // the tiles between the round looked at and `tile`, as one function
+    for (int64_t idx = (int64_t)tile - 1;; idx -= PARSE_THREADS) {
+        const int64_t mine = idx - (int64_t)threadIdx.x;
+        uint64_t d = PD_PREFIX;                        // before the first tile: state 0, offset 0
+        if (mine >= 0) {
+            do {
+                d = __hip_atomic_load(&desc[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((d >> 62) == 0);
+        }
+        const unsigned long long is_p = __ballot((d >> 62) == 2);
+        const int p = is_p ? (int)__builtin_ctzll(is_p) : 64;        // the nearest tile of this wave's 64 whose prefix is known
+        ScanElem<uint32_t> x = selem_identity<uint32_t>();
+        if (lane < p) x = tile_elem(pd_unpack(d, tile_meta[mine]), tile_meta[mine]);
+        // lane 0 <- (tile of lane p - 1) then ... then (tile of lane 0): older tiles first
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const ScanElem<uint32_t> y = selem_shfl_down(x, dd);
+            if (lane + dd < 64) x = selem_combine(y, x);
+        }
+        const uint32_t p_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d, p & 63), p_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(d >> 32), p & 63);
+        if (lane == 0) {
+            sh.tbl[wave] = x.tbl;
+#pragma unroll
+            for (int q = 0; q < 4; q++) sh.c[wave][q] = x.c[q];
+            sh.p[wave] = (uint32_t)p;
+            sh.d_lo[wave] = p_lo;
+            sh.d_hi[wave] = p_hi;
+        }
+        __syncthreads();
+        bool found = false;
+#pragma unroll
+        for (int w = 0; w < NW && !found; w++) {
+            ScanElem<uint64_t> e;
+            e.tbl = sh.tbl[w];
+#pragma unroll
+            for (int q = 0; q < 4; q++) e.c[q] = sh.c[w][q];
+            acc = selem_combine(e, acc);
+            if (sh.p[w] < 64u) {
+                const uint64_t dp = ((uint64_t)sh.d_hi[w] << 32) | sh.d_lo[w];
+                const uint32_t sp = (uint32_t)(dp >> 60) & 3u;
+                state_in = tbl_apply(acc.tbl, sp);
+                off_in = (dp & ((1ull << 60) - 1)) + (sp == 0 ? acc.c[0] : sp == 1 ? acc.c[1] : sp == 2 ? acc.c[2] : acc.c[3]);
+                found = true;
+            }
+        }
+        __syncthreads();                                // (the shared words are written again in the next round)
+        if (found) return;
+    }
+}
+
+__global__ __launch_bounds__(PARSE_THREADS) void parse_fused_kernel(
+    const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint8_t *__restrict__ tile_meta, uint64_t *__restrict__ desc,
+    uint32_t *__restrict__ ticket, uint64_t *__restrict__ tile_off, uint64_t *__restrict__ sym2, uint64_t *__restrict__ inv,
+    uint64_t *__restrict__ pieces, int ablate)
+{
+    constexpr int MAX_GROUPS = TILE_BYTES / 64 + 2;
+    __shared__ uint64_t partial[ROUNDS_PER_TILE * (PARSE_THREADS / 64)];
+    __shared__ uint64_t w2[2 * MAX_GROUPS];
+    __shared__ uint64_t wi[MAX_GROUPS];
+    __shared__ uint32_t s_tile;
+    __shared__ LookbackShare s_look;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    for (int i = threadIdx.x; i < 2 * MAX_GROUPS; i += PARSE_THREADS) w2[i] = 0;
+    for (int i = threadIdx.x; i < MAX_GROUPS; i += PARSE_THREADS) wi[i] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= n_tiles) return;
+    const uint8_t meta = tile_meta[tile];
+    const bool fastq = (meta & TILE_META_FASTQ) != 0;
+    TileChunks tc;
+    TileChunksFq tq;
+    TileSummary sum;
+    if (fastq) {
+        tile_scan_fq(raw, tile, partial, tq);
+        sum.v[0] = fq_elem_cnt(tq.total, 0); sum.v[1] = fq_elem_cnt(tq.total, 1);
+        sum.v[2] = fq_elem_cnt(tq.total, 2); sum.v[3] = fq_elem_cnt(tq.total, 3);
+        sum.tag = 4u | fq_elem_nl(tq.total);
+    } else {
+        tile_scan(raw, tile, partial, tc);
+        sum.v[0] = pelem32_ch(tc.total);
+        sum.v[1] = pelem32_cs(tc.total) - pelem32_ch(tc.total);
+        sum.v[2] = sum.v[3] = 0;
+        sum.tag = (uint32_t)pelem32_ev(tc.total);
+    }
+    uint32_t st_in = 0;
+    uint64_t off_in = 0;
+    if (ablate) {                 // (timing experiments only: wrong offsets)
+        st_in = 1;
+        off_in = (uint64_t)tile * 16000;
+        if (ablate == 2) return;
+    } else
+    if (tile) {
+        if (threadIdx.x == 0) __hip_atomic_store(&desc[tile], PD_AGG | pd_pack(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        parse_lookback(desc, tile_meta, tile, s_look, st_in, off_in);          // (every thread ends with the same two values)
+    }
+    if (threadIdx.x == 0) {
+        const ScanElem<uint32_t> e = tile_elem(sum, meta);
+        const uint32_t n_mine = st_in == 0 ? e.c[0] : st_in == 1 ? e.c[1] : st_in == 2 ? e.c[2] : e.c[3];
+        __hip_atomic_store(&desc[tile], PD_PREFIX | ((uint64_t)tbl_apply(e.tbl, st_in) << 60) | (off_in + n_mine), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        tile_off[tile] = off_in;
+        if (tile == n_tiles - 1) tile_off[n_tiles] = off_in + n_mine;
+    }
+    const uint64_t sym_base = off_in;
+    const uint32_t lead = (uint32_t)(sym_base & 63ull);
+    const int state = (meta & TILE_META_FIRST) ? 0 : (int)st_in;
+    uint32_t n_tile;
+    auto or_sym = [&](uint32_t i, uint64_t val) { atomicOr((unsigned long long *)&w2[i], (unsigned long long)val); };
+    auto or_inv = [&](uint32_t i, uint64_t val) { atomicOr((unsigned long long *)&wi[i], (unsigned long long)val); };
+    if (fastq) {
+        n_tile = fq_elem_cnt(tq.total, state);
+#pragma unroll
+        for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+            uint32_t m[4], emit, sep, cs, ci;
+            fq_phase_masks(tq.nl[r], m);
+            fq_classify(tq.nl[r], tq.cr[r], tq.ls[r], m, (state + (int)fq_elem_nl(tq.pre[r])) & 3, emit, sep);
+            const int cnt = chunk_pack(tq.w[r], emit, sep, cs, ci);
+            stream_insert(lead + fq_elem_cnt(tq.pre[r], state), cnt, cs, ci, or_sym, or_inv);
+        }
+    } else {
+        const int st = state == T_NONE ? T_SEQ : state;   // only before the first line start of a file
+        n_tile = st == T_SEQ ? pelem32_cs(tc.total) : pelem32_ch(tc.total);
+#pragma unroll
+        for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+            const int ev = pelem32_ev(tc.pre[r]);
+            const int cin = ev ? ev : st;
+            const uint32_t emit = tc.ek[r] | (cin == T_SEQ ? tc.unk[r] : 0u);
+            uint32_t cs, ci;
+            const int cnt = chunk_pack(tc.w[r], emit, tc.sep[r], cs, ci);
+            stream_insert(lead + (st == T_SEQ ? pelem32_cs(tc.pre[r]) : pelem32_ch(tc.pre[r])), cnt, cs, ci, or_sym, or_inv);
+        }
+    }
+    __syncthreads();
+    const uint32_t span = lead + n_tile;
+    const uint32_t n_groups = (span + 63) >> 6;
+    const uint64_t g_base = sym_base >> 6;
+    for (uint32_t g = threadIdx.x; g < n_groups; g += PARSE_THREADS) {
+        const uint64_t a0 = w2[2 * g], a1 = w2[2 * g + 1], bi = wi[g];
+        const uint64_t G = g_base + g;
+        const bool full = (g > 0 || lead == 0) && ((g + 1) * 64 <= span);
+        if (full) {
+            *reinterpret_cast<ulonglong2 *>(&sym2[2 * G]) = make_ulonglong2(a0, a1);
+            inv[G] = bi;
+        } else {
+            // head piece: the group the tile starts inside (its first symbols belong to a tile before it); tail piece: a group the tile
+            // opens but does not fill
+            uint64_t *pc = pieces + ((uint64_t)tile * 2 + ((g == 0 && lead != 0) ? 0 : 1)) * 3;
+            pc[0] = a0; pc[1] = a1; pc[2] = bi;
+        }
+    }
+}
+
+// every group that holds symbols of more than one tile (or ends the stream): the tile with its first symbol ORs the pieces together
+__global__ void parse_stitch_kernel(const uint64_t *__restrict__ tile_off, uint32_t n_tiles, const uint64_t *__restrict__ pieces,
+                                    uint64_t *__restrict__ sym2, uint64_t *__restrict__ inv)
+{
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t <= n_tiles; t += gridDim.x * blockDim.x) {
+        if (t == n_tiles) {
+            // a few groups behind the end of the stream are read by the last k-mer windows: zero
+            const uint64_t G = (tile_off[n_tiles] + 63) >> 6;
+            for (int e = 0; e < 4; e++) { sym2[2 * (G + e)] = 0; sym2[2 * (G + e) + 1] = 0; inv[G + e] = 0; }
+            continue;
+        }
+        const uint64_t off = tile_off[t], end = tile_off[t + 1];
+        if (end == off || !(end & 63ull)) continue;
+        const uint64_t g1 = (end - 1) >> 6;
+        if ((g1 << 6) < off) continue;                  // the group began in an earlier tile: that one's
+        const uint64_t *pc = pieces + ((uint64_t)t * 2 + 1) * 3;
+        uint64_t a0 = pc[0], a1 = pc[1], bi = pc[2];
+        const uint64_t g_end = (g1 + 1) << 6;
+        for (uint32_t u = t + 1; u < n_tiles && tile_off[u] < g_end; u++) {
+            const uint64_t eu = tile_off[u + 1];
+            if (eu > tile_off[u]) {
+                const uint64_t *pu = pieces + (uint64_t)u * 2 * 3;
+                a0 |= pu[0]; a1 |= pu[1]; bi |= pu[2];
+            }
+            if (eu >= g_end) break;
+        }
+        sym2[2 * g1] = a0;
+        sym2[2 * g1 + 1] = a1;
+        inv[g1] = bi;
     }
 }
 
@@ -2208,6 +2451,22 @@ void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, cons
     hipLaunchKernelGGL(parse_prezero_kernel, dim3(((uint64_t)n_tiles + 256) / 256), dim3(256), 0, s, tile_off, n_tiles, sym2, inv);
     hipLaunchKernelGGL(parse_pack_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, tile_off,
                        tile_state, sym2, inv, sums, chunk_pre);
+}
+
+// desc: n_tiles words + the ticket behind them (all zeroed here); pieces: n_tiles x 2 x 3 words
+size_t parse_fused_desc_bytes(uint32_t n_tiles) { return ((size_t)n_tiles + 2) * 8; }
+size_t parse_fused_piece_bytes(uint32_t n_tiles) { return ((size_t)n_tiles + 1) * 48; }
+hipError_t launch_parse_fused(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, uint64_t *desc, uint64_t *pieces,
+                              uint64_t *tile_off, uint64_t *sym2, uint64_t *inv, const uint32_t *genome_tile_off, uint32_t n_genomes,
+                              uint64_t *genome_sym_off)
+{
+    hipError_t e = hipMemsetAsync(desc, 0, parse_fused_desc_bytes(n_tiles), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(parse_fused_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, desc, reinterpret_cast<uint32_t *>(desc + n_tiles),
+                       tile_off, sym2, inv, pieces, getenv("GRM_PARSE_ABLATE") ? atoi(getenv("GRM_PARSE_ABLATE")) : 0);
+    hipLaunchKernelGGL(parse_stitch_kernel, dim3(((uint64_t)n_tiles + 256) / 256), dim3(256), 0, s, tile_off, n_tiles, pieces, sym2, inv);
+    hipLaunchKernelGGL(genome_offsets_kernel, dim3((n_genomes + 256) / 256), dim3(256), 0, s, tile_off, genome_tile_off, n_genomes, genome_sym_off);
+    return hipGetLastError();
 }
 
 static KmerArgs make_args(const KmerLaunch &L)

@@ -264,6 +264,26 @@ def test_record_form_gives_way_to_the_key_form_on_repeats(ctx):
         ctx.timing(False)
 
 
+def test_single_pass_parse_gives_the_same_stream(ctx):
+    """option parse_fused: one kernel reads every tile once and learns the parser state / symbol offset running into it by a
+    decoupled look-back over the tiles before it (FASTA and FASTQ tiles, many files, tiles without symbols); the groups a tile
+    boundary falls into are put together by parse_stitch.  Same matrices and counted sets as the two-pass parse."""
+    rng = np.random.RandomState(5)
+    genomes = _medium_genomes(n=9, length=130_000, seed=12)
+    genomes.append([(">" + "h" * 40_000 + "\n" + cases.rand_seq(rng, 20_000) + "\n>" + "x" * 16_380 + "\n" + cases.rand_seq(rng, 30_000)).encode()])
+    genomes.append([b">empty\n", cases.fasta([("a", cases.rand_seq(rng, 70_001))], width=61, crlf=True).encode()])
+    try:
+        ctx.set_option("parse_fused", 1)
+        _check(ctx, genomes, 31, 1, False)
+        _check(ctx, genomes, 21, 2, True)
+        for name, k, gs in cases.fastq_cases():
+            _check(ctx, gs, k, 1, False)
+        reads = [cases.rand_seq(rng, 150) for _ in range(3000)]
+        _check(ctx, [[cases.fastq(reads).encode()], [cases.fastq(reads[:1700]).encode()]], 21, 2, False)
+    finally:
+        ctx.set_option("parse_fused", -1)
+
+
 def test_parser_stress_layouts(ctx):
     """single-line sequences spanning many 16 KiB tiles, headers longer than a tile, headers that
     straddle tile boundaries, CRLF, blank lines, no trailing newline, lowercase / N runs"""
