@@ -451,6 +451,7 @@ static int build_matrix_mt(const orc_set *sets, int n_genomes, int filter_single
     size_t base = 0;
     for (int t = 0; t < n_threads && !rc; t++) {
         mergeout *o = &jobs[t].out;
+        if (!o->n) continue;                     /* (a slice without k-mers has no arrays: memcpy must not be handed NULL, even for 0 bytes) */
         memcpy(out->kmers + base * words, o->kmers, o->n * words * sizeof(uint64_t));
         memcpy(out->n_genomes_with + base, o->ng, o->n * sizeof(uint32_t));
         for (size_t c = 0; c < o->n; c++)

@@ -25,6 +25,9 @@ class OrcMatrix(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("GRM_ORACLE_SANITIZED") == "1":        # tests/test_sanitizers.py: the AddressSanitizer / UBSan build (oracle/Makefile: asan)
+        subprocess.check_call(["make", "-C", _HERE, "-s", "asan"])
+        return os.path.join(_HERE, "libgrm_oracle_asan.so")
     so = os.path.join(_HERE, "libgrm_oracle.so")
     src = os.path.join(_HERE, "grm_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

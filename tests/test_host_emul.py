@@ -18,10 +18,14 @@ TILE = 16384
 @pytest.fixture(scope="module")
 def emul():
     src = os.path.join(HERE, "host", "host_emul.cpp")
-    so = os.path.join(HERE, "host", "libhost_emul.so")
     hdr = os.path.join(HERE, "..", "genomic-resistance-mapping-grm-_amd", "csrc", "grm_device_fns.h")
+    # tests/test_sanitizers.py runs this module once more in a child process with AddressSanitizer + UBSan preloaded: the per-lane device
+    # code is the one place where an out-of-range shift or index of the kernels can be caught without a GPU
+    sanitized = os.environ.get("GRM_HOST_EMUL_SANITIZED") == "1"
+    so = os.path.join(HERE, "host", "libhost_emul_asan.so" if sanitized else "libhost_emul.so")
+    flags = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"] if sanitized else []
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared"] + flags + ["-o", so, src])
     L = C.CDLL(so)
     L.emul_parse.restype = C.c_uint64
     L.emul_parse.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
