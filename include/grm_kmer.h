@@ -63,9 +63,13 @@ void        grm_destroy(grm_ctx *);
 int         grm_ctx_live_handles(const grm_ctx *);
 const char *grm_last_error(grm_ctx *);
 const char *grm_version(void);
-/* tuning knobs (mainly for tests): name in {"groups_per_thread","bucket_bits","cap_log2",
- * "sub_bits","no_slots","wide_sort","keys_in_flight","table_threads","upload_slab_kb"}; value < 0 restores the
- * automatic choice. */
+/* tuning knobs (tests and measurements; value < 0 restores the automatic choice).  Geometry: "bucket_bits", "cap_log2" (LDS table
+ * slots, log2), "sub_bits", "groups_per_thread", "keys_in_flight", "table_threads" (256 / 512 / 1024).  Paths: "records" (0: never the
+ * minimizer-record form of the partition, 1: from k = 11), "rec_keys" (records always expanded to key segments), "no_slots" (probing
+ * fill), "direct_permute", "dense_layout", "dedup_wg", "dedup_cap_shift", "wide_sort" (k > 32 through the sort-based path), "no_union"
+ * (gathered rank dictionaries sorted as a whole), "parse_fused" (single-pass parse kernel).  Record form: "rec_bucket_shift",
+ * "rec_part_bits", "rec_coarse", "rec_memo" (log2 of dict_build's record memo base, 0 = none), "memo_stats" (1: count memo hits, see
+ * grm_batch_memo_stats).  Host: "upload_slab_kb". */
 int         grm_set_option(grm_ctx *, const char *name, int value);
 /* per-kernel device timings (HIP events on the engine's stream) */
 int         grm_timing_enable(grm_ctx *, int on);
@@ -84,7 +88,7 @@ int  grm_count_genome_buffers(grm_ctx *, const void *const *bufs, const size_t *
  * equal k-mers over the sets and keeps those whose total reaches abundance_min; k <= 32 */
 int  grm_merge_counted_sets(grm_ctx *, grm_kmer_set *const *sets, int n_sets, uint32_t abundance_min, grm_kmer_set **out);
 /* build a set from host arrays (used by dsk2kover when it re-loads multidsk's artefacts); for
- * 33 <= k <= 64 `kmers` holds 2*n words (most significant word of each k-mer first) */
+ * k > 32 `kmers` holds ceil(k/32)*n words (most significant word of each k-mer first) */
 int  grm_kmer_set_from_host(grm_ctx *, const uint64_t *kmers, const uint32_t *counts, size_t n, int k,
                             grm_kmer_set **out);
 size_t          grm_kmer_set_size(const grm_kmer_set *);
@@ -117,7 +121,7 @@ int             grm_matrix_column_counts(grm_matrix *, uint32_t *out);
 int             grm_matrix_sum_rows(grm_matrix *, const uint64_t *row_mask, uint32_t *out);
 /* host-only matrix from caller arrays (copied): rows gathered from several ranks, or tests.
  * Only the accessors and the two writers work on it (no device).  kmers: n_kmers words for
- * k <= 32, 2*n_kmers (most significant word first) for 33 <= k <= 64. */
+ * k <= 32, ceil(k/32)*n_kmers (most significant word first) above. */
 int             grm_matrix_from_host(const uint64_t *kmers, const uint64_t *data, size_t n_kmers, int n_genomes, int k,
                                      grm_matrix **out);
 /* places a host-only matrix (grm_matrix_from_host, e.g. rows read back from a .kover file) in HBM: afterwards the
@@ -152,7 +156,7 @@ int  grm_batch_upload(grm_batch *);
 int  grm_batch_run(grm_batch *, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out);
 /* the same path in stages, so that the host can put ONE collective between them when the
  * genomes are sharded over several GPUs.  Dictionary entries are 8-byte keys for
- * k <= 32 and 16-byte (hi, lo) pairs for 33 <= k <= 64 (abundance-min 1 there); flags are one
+ * k <= 32 and 16-byte (hi, lo) pairs for 33 <= k <= 64 (abundance-min 1 there; the staged calls stop at k = 64, grm_batch_run goes to 128); flags are one
  * byte each (1 = carried by one local genome, 2 = by several); n counts k-mers, not words. */
 int  grm_batch_partition(grm_batch *, int k, uint32_t abundance_min);
 /* same, but keeps per-k-mer occurrence counts so that grm_batch_genome_set can return them
