@@ -1093,11 +1093,14 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
                                      b->d_genome_tile_off.as<uint32_t>(), G, b->d_genome_sym_off.as<uint64_t>()));
     } else {
     HIPCHK(c, b->d_scan_scratch.ensure(parse_scan_scratch_bytes(b->n_tiles)));
-    HIPCHK(c, b->d_chunk_pre.ensure(parse_chunk_pre_bytes(b->n_tiles)));
+    bool any_fastq = false;
+    for (const auto &f : b->files) any_fastq = any_fastq || f.fastq;
+    HIPCHK(c, b->d_chunk_pre.ensure(parse_chunk_pre_bytes(b->n_tiles, any_fastq)));
+    uint64_t *chunk_pre64 = any_fastq ? reinterpret_cast<uint64_t *>(b->d_chunk_pre.as<uint8_t>() + parse_chunk_pre_bytes(b->n_tiles, false)) : nullptr;
     // (no memset of the packed stream: parse_pack's companion kernel zeroes the groups that need it)
     {
         TimeScope t(c, "parse_summarize", b->raw_bytes);
-        launch_parse_summarize(s, raw, b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_sums.as<TileSummary>(), b->d_chunk_pre.as<uint32_t>());
+        launch_parse_summarize(s, raw, b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_sums.as<TileSummary>(), b->d_chunk_pre.as<uint32_t>(), chunk_pre64);
     }
     {
         TimeScope t(c, "parse_scan", b->n_tiles);
@@ -1108,7 +1111,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     {
         TimeScope t(c, "parse_pack", b->raw_bytes);
         launch_parse_pack(s, raw, b->n_tiles, b->d_tile_meta.as<uint8_t>(), b->d_tile_off.as<uint64_t>(), b->d_tile_state.as<uint8_t>(),
-                          b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>(), b->d_sums.as<TileSummary>(), b->d_chunk_pre.as<uint32_t>());
+                          b->d_sym2.as<uint64_t>(), b->d_inv.as<uint64_t>(), b->d_sums.as<TileSummary>(), b->d_chunk_pre.as<uint32_t>(), chunk_pre64);
     }
     }
     HIPCHK(c, hipGetLastError());

@@ -69,14 +69,17 @@ struct KmerLaunch {
 };
 
 // chunk_pre (optional): the exclusive prefix element of every 16-byte chunk of every tile, for parse_pack (parse_chunk_pre_bytes)
-void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, TileSummary *sums, uint32_t *chunk_pre);
-size_t parse_chunk_pre_bytes(uint32_t n_tiles);
+// (chunk_pre64: the same for FASTQ tiles, 8 bytes per chunk; nullptr: parse_pack scans those tiles again)
+void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, TileSummary *sums, uint32_t *chunk_pre,
+                            uint64_t *chunk_pre64);
+size_t parse_chunk_pre_bytes(uint32_t n_tiles, bool with_fastq);
 void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles, const uint8_t *tile_meta, uint64_t *tile_off,
                        uint8_t *tile_state, const uint32_t *genome_tile_off, uint32_t n_genomes,
                        uint64_t *genome_sym_off, void *scratch);
 size_t parse_scan_scratch_bytes(uint32_t n_tiles);
 void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, const uint64_t *tile_off,
-                       const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv, const TileSummary *sums, const uint32_t *chunk_pre);
+                       const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv, const TileSummary *sums, const uint32_t *chunk_pre,
+                       const uint64_t *chunk_pre64);
 // single-pass parse (decoupled look-back over the tiles): desc / pieces are scratch of parse_fused_desc_bytes / _piece_bytes; fills
 // tile_off[0 .. n_tiles], sym2, inv, genome_sym_off
 size_t parse_fused_desc_bytes(uint32_t n_tiles);

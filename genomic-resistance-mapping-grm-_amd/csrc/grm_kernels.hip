@@ -56,11 +56,21 @@ __device__ __forceinline__ void tile_round(const uint4 &v, uint32_t edge, int la
     elem = pelem32_make(chunk_last_event(ls, gt), __popc(ek) + __popc(unk), __popc(ek));
 }
 
+// The scan of a FASTA tile's 1024 chunks (order: round, thread), giving every chunk its exclusive prefix element (ev, cs, ch) and the
+// tile its total.  The element's combine is associative, but a log-step scan of it costs ~14 instructions and a cross-lane move per
+// step and round (138 of parse_summarize's 313 instructions per chunk).  The element has more structure than that:
+//   ev   = type of the nearest line start BEFORE the chunk: inside a wave a ballot and a count-leading-zeros, across the 16
+//          (round, wave) groups two bits per group in one LDS word;
+//   ch   = symbols before the chunk if a header line runs into the tile = sum of known_i = ch_i + (ev_i == SEQ ? extra_i : 0);
+//   cs   = the same if a sequence line does = ch + sum of pend_i = (ev_i == NONE ? extra_i : 0), extra = the chunk's bytes before
+//          its own first line start;
+// i.e. ONE integer prefix sum of the packed pair (known | pend << 16; a tile holds 16384 bytes): six DPP adds per round.
 __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint32_t tile, uint64_t *partial64 /* LDS [16] */,
                                           TileChunks &tc)
 {
-    uint32_t *partial = reinterpret_cast<uint32_t *>(partial64);        // 32-bit elements: one cross-lane move per scan step
+    uint32_t *partial = reinterpret_cast<uint32_t *>(partial64);        // [0..15]: group totals, [16]: last line-start type of every group, 2 bits each
     const int lane = lane_id(), wave = wave_id();
+    static_assert(ROUNDS_PER_TILE == 4 && PARSE_THREADS == 256, "tile_scan assumes 4 rounds x 4 waves");
     uint4 v[ROUNDS_PER_TILE];
     uint32_t edge[ROUNDS_PER_TILE];
 #pragma unroll
@@ -69,43 +79,64 @@ __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint3
         v[r] = *reinterpret_cast<const uint4 *>(raw + base);
         edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;   // lanes > 0 ask their neighbour
     }
-    uint32_t inc[ROUNDS_PER_TILE];
-    tile_round<0>(v[0], edge[0], lane, tc, inc[0]);
-    tile_round<1>(v[1], edge[1], lane, tc, inc[1]);
-    tile_round<2>(v[2], edge[2], lane, tc, inc[2]);
-    tile_round<3>(v[3], edge[3], lane, tc, inc[3]);
+    if (threadIdx.x == 0) partial[16] = 0;
+    uint32_t el[ROUNDS_PER_TILE];
+    tile_round<0>(v[0], edge[0], lane, tc, el[0]);
+    tile_round<1>(v[1], edge[1], lane, tc, el[1]);
+    tile_round<2>(v[2], edge[2], lane, tc, el[2]);
+    tile_round<3>(v[3], edge[3], lane, tc, el[3]);
+    __syncthreads();                                     // (partial[16] zeroed; also orders a caller's LDS writes before its use of them)
+    // nearest line start before the chunk inside its group, and the group's last one
+    uint32_t t_in[ROUNDS_PER_TILE];                      // 0: no line start before the chunk inside its group
+    const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-            const uint32_t o = __shfl_up(inc[r], d);
-            if (lane >= d) inc[r] = pelem32_combine(o, inc[r]);
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        const uint32_t ev = (uint32_t)pelem32_ev(el[r]);
+        const unsigned long long any = __ballot(ev != 0), hdr = __ballot(ev == (uint32_t)T_HDR);
+        const unsigned long long m = any & below;
+        const int src = 63 - (int)__builtin_clzll(m | 1ull);
+        t_in[r] = m ? (((hdr >> src) & 1ull) ? (uint32_t)T_HDR : (uint32_t)T_SEQ) : 0u;
+        if (lane == 0 && any) {
+            const int top = 63 - (int)__builtin_clzll(any);
+            atomicOr(&partial[16], (((hdr >> top) & 1ull) ? (uint32_t)T_HDR : (uint32_t)T_SEQ) << (2 * (r * (PARSE_THREADS / 64) + wave)));
         }
+    }
+    __syncthreads();
+    const uint32_t groups = partial[16];
+    uint32_t inc[ROUNDS_PER_TILE], own[ROUNDS_PER_TILE];
+#pragma unroll
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        const int g = r * (PARSE_THREADS / 64) + wave;
+        const uint32_t lower = groups & ((1u << (2 * g)) - 1u);
+        const uint32_t t_prev = lower ? (groups >> (2 * ((31 - (int)__builtin_clz(lower)) >> 1))) & 3u : 0u;
+        const uint32_t t = t_in[r] ? t_in[r] : t_prev;          // type of the nearest line start before the chunk, 0 = none in this tile
+        const uint32_t ch = pelem32_ch(el[r]), extra = pelem32_cs(el[r]) - ch;
+        own[r] = (ch + (t == (uint32_t)T_SEQ ? extra : 0u)) | ((t == 0u ? extra : 0u) << 16);
+        t_in[r] = t;
+        inc[r] = wave_scan_incl_dpp(own[r]);
     }
     if (lane == 63) {
 #pragma unroll
         for (int r = 0; r < ROUNDS_PER_TILE; r++) partial[r * (PARSE_THREADS / 64) + wave] = inc[r];
     }
     __syncthreads();
-    // prefix of this (round, wave) over the 16 wave partials, kept in scalars (no indexed array)
-    static_assert(ROUNDS_PER_TILE == 4 && PARSE_THREADS == 256, "tile_scan assumes 4 rounds x 4 waves");
-    uint32_t acc = pelem32_make(0, 0, 0);
-    uint32_t wp0 = acc, wp1 = acc, wp2 = acc, wp3 = acc;
+    // prefix of this (round, wave) over the 16 group totals, kept in scalars (no indexed array)
+    uint32_t acc = 0, wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         if (i == wave) wp0 = acc;
         if (i == 4 + wave) wp1 = acc;
         if (i == 8 + wave) wp2 = acc;
         if (i == 12 + wave) wp3 = acc;
-        acc = pelem32_combine(acc, partial[i]);
+        acc += partial[i];
     }
-    tc.total = acc;
-    uint32_t e0 = __shfl_up(inc[0], 1), e1 = __shfl_up(inc[1], 1), e2 = __shfl_up(inc[2], 1), e3 = __shfl_up(inc[3], 1);
-    if (lane == 0) e0 = e1 = e2 = e3 = pelem32_make(0, 0, 0);
-    tc.pre[0] = pelem32_combine(wp0, e0);
-    tc.pre[1] = pelem32_combine(wp1, e1);
-    tc.pre[2] = pelem32_combine(wp2, e2);
-    tc.pre[3] = pelem32_combine(wp3, e3);
+    auto elem = [](uint32_t type, uint32_t packed) { return pelem32_make((int)type, (packed & 0xffffu) + (packed >> 16), packed & 0xffffu); };
+    // the tile's total: its last line start is the last group's with one
+    tc.total = elem(groups ? (groups >> (2 * ((31 - (int)__builtin_clz(groups)) >> 1))) & 3u : 0u, acc);
+    tc.pre[0] = elem(t_in[0], wp0 + inc[0] - own[0]);
+    tc.pre[1] = elem(t_in[1], wp1 + inc[1] - own[1]);
+    tc.pre[2] = elem(t_in[2], wp2 + inc[2] - own[2]);
+    tc.pre[3] = elem(t_in[3], wp3 + inc[3] - own[3]);
 }
 
 // the tile's chunks classified, WITHOUT the scan: the exclusive prefix element of every chunk comes from the caller (parse_pack reads
@@ -158,6 +189,19 @@ __device__ __forceinline__ void tile_round_fq(const uint4 &v, uint32_t edge, int
     elem = fq_elem_make(__popc(nl) & 3u, c);
 }
 
+// FASTQ tiles, the same way: the element (newlines mod 4; symbols for each of the 4 line phases the range may start in) needs no
+// associative scan either.  A chunk that starts p newlines into the tile is in phase (s + p) & 3 when the tile starts in phase s, so
+// with P = the integer prefix sum of the chunks' newline counts the chunk's four counts, ROTATED by P, are what it adds to the four
+// hypotheses -- and those add up as plain integers: one more prefix sum of four packed 16-bit counts (two DPP scans).
+__device__ __forceinline__ uint64_t fq_rotate_counts(uint64_t c16, uint32_t p)      // fields of 16 bits: out[s] = in[(s + p) & 3]
+{
+    const uint32_t sh = 16u * (p & 3u);
+    return sh ? (c16 >> sh) | (c16 << (64u - sh)) : c16;
+}
+__device__ __forceinline__ uint64_t fq_elem_from16(uint32_t nl_mod4, uint64_t c16)    // 16-bit fields -> the element's 15-bit fields
+{
+    return ((uint64_t)(nl_mod4 & 3u) << 60) | (c16 & 0x7fffull) | (((c16 >> 16) & 0x7fffull) << 15) | (((c16 >> 32) & 0x7fffull) << 30) | (((c16 >> 48) & 0x7fffull) << 45);
+}
 __device__ __forceinline__ void tile_scan_fq(const uint8_t *__restrict__ raw, uint32_t tile, uint64_t *partial /* LDS [16] */,
                                              TileChunksFq &tc)
 {
@@ -170,41 +214,88 @@ __device__ __forceinline__ void tile_scan_fq(const uint8_t *__restrict__ raw, ui
         v[r] = *reinterpret_cast<const uint4 *>(raw + base);
         edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;
     }
-    uint64_t inc[ROUNDS_PER_TILE];
-    tile_round_fq<0>(v[0], edge[0], lane, tc, inc[0]);
-    tile_round_fq<1>(v[1], edge[1], lane, tc, inc[1]);
-    tile_round_fq<2>(v[2], edge[2], lane, tc, inc[2]);
-    tile_round_fq<3>(v[3], edge[3], lane, tc, inc[3]);
+    uint64_t el[ROUNDS_PER_TILE];
+    tile_round_fq<0>(v[0], edge[0], lane, tc, el[0]);
+    tile_round_fq<1>(v[1], edge[1], lane, tc, el[1]);
+    tile_round_fq<2>(v[2], edge[2], lane, tc, el[2]);
+    tile_round_fq<3>(v[3], edge[3], lane, tc, el[3]);
+    // newlines before every chunk
+    uint32_t nl_own[ROUNDS_PER_TILE], nl_inc[ROUNDS_PER_TILE];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-            const uint64_t o = __shfl_up(inc[r], d);
-            if (lane >= d) inc[r] = fq_elem_combine(o, inc[r]);
-        }
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        nl_own[r] = (uint32_t)__popc(tc.nl[r]);
+        nl_inc[r] = wave_scan_incl_dpp(nl_own[r]);
     }
+    uint32_t *p32 = reinterpret_cast<uint32_t *>(partial);
+    __syncthreads();                                     // (a caller's LDS writes before this; the words below are free)
+    if (lane == 63) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS_PER_TILE; r++) p32[r * (PARSE_THREADS / 64) + wave] = nl_inc[r];
+    }
+    __syncthreads();
+    uint32_t acc = 0, np0 = 0, np1 = 0, np2 = 0, np3 = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i == wave) np0 = acc;
+        if (i == 4 + wave) np1 = acc;
+        if (i == 8 + wave) np2 = acc;
+        if (i == 12 + wave) np3 = acc;
+        acc += p32[i];
+    }
+    const uint32_t nl_total = acc;
+    const uint32_t nl_pre[ROUNDS_PER_TILE] = {np0 + nl_inc[0] - nl_own[0], np1 + nl_inc[1] - nl_own[1], np2 + nl_inc[2] - nl_own[2], np3 + nl_inc[3] - nl_own[3]};
+    // the chunks' counts, rotated to the tile's phases, summed
+    uint64_t own[ROUNDS_PER_TILE], inc[ROUNDS_PER_TILE];
+#pragma unroll
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        const uint64_t c16 = (uint64_t)fq_elem_cnt(el[r], 0) | ((uint64_t)fq_elem_cnt(el[r], 1) << 16) | ((uint64_t)fq_elem_cnt(el[r], 2) << 32) |
+                             ((uint64_t)fq_elem_cnt(el[r], 3) << 48);
+        own[r] = fq_rotate_counts(c16, nl_pre[r]);
+        inc[r] = (uint64_t)wave_scan_incl_dpp((uint32_t)own[r]) | ((uint64_t)wave_scan_incl_dpp((uint32_t)(own[r] >> 32)) << 32);
+    }
+    __syncthreads();                                     // (everybody has read the newline totals)
     if (lane == 63) {
 #pragma unroll
         for (int r = 0; r < ROUNDS_PER_TILE; r++) partial[r * (PARSE_THREADS / 64) + wave] = inc[r];
     }
     __syncthreads();
-    uint64_t acc = 0;        // identity: nl 0, counts 0
-    uint64_t wp0 = acc, wp1 = acc, wp2 = acc, wp3 = acc;
+    uint64_t acc64 = 0, wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        if (i == wave) wp0 = acc;
-        if (i == 4 + wave) wp1 = acc;
-        if (i == 8 + wave) wp2 = acc;
-        if (i == 12 + wave) wp3 = acc;
-        acc = fq_elem_combine(acc, partial[i]);
+        if (i == wave) wp0 = acc64;
+        if (i == 4 + wave) wp1 = acc64;
+        if (i == 8 + wave) wp2 = acc64;
+        if (i == 12 + wave) wp3 = acc64;
+        acc64 += partial[i];
     }
-    tc.total = acc;
-    uint64_t e0 = __shfl_up(inc[0], 1), e1 = __shfl_up(inc[1], 1), e2 = __shfl_up(inc[2], 1), e3 = __shfl_up(inc[3], 1);
-    if (lane == 0) e0 = e1 = e2 = e3 = 0;
-    tc.pre[0] = fq_elem_combine(wp0, e0);
-    tc.pre[1] = fq_elem_combine(wp1, e1);
-    tc.pre[2] = fq_elem_combine(wp2, e2);
-    tc.pre[3] = fq_elem_combine(wp3, e3);
+    tc.total = fq_elem_from16(nl_total, acc64);
+    tc.pre[0] = fq_elem_from16(nl_pre[0], wp0 + inc[0] - own[0]);
+    tc.pre[1] = fq_elem_from16(nl_pre[1], wp1 + inc[1] - own[1]);
+    tc.pre[2] = fq_elem_from16(nl_pre[2], wp2 + inc[2] - own[2]);
+    tc.pre[3] = fq_elem_from16(nl_pre[3], wp3 + inc[3] - own[3]);
+}
+
+// the FASTQ tile's chunks classified, without the scan (parse_pack: the prefix elements come from parse_summarize's chunk_pre64)
+__device__ __forceinline__ void tile_rounds_fq(const uint8_t *__restrict__ raw, uint32_t tile, TileChunksFq &tc)
+{
+    const int lane = lane_id();
+    uint4 v[ROUNDS_PER_TILE];
+    uint32_t edge[ROUNDS_PER_TILE];
+#pragma unroll
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
+        v[r] = *reinterpret_cast<const uint4 *>(raw + base);
+        edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        tc.w[r][0] = v[r].x; tc.w[r][1] = v[r].y; tc.w[r][2] = v[r].z; tc.w[r][3] = v[r].w;
+        uint32_t nl, gt, cr;
+        chunk_masks(tc.w[r], nl, gt, cr);
+        const uint32_t up = __shfl_up((nl >> 15) & 1u, 1);
+        const uint32_t prev_nl = lane == 0 ? edge[r] : up;
+        tc.nl[r] = nl; tc.cr[r] = cr; tc.ls[r] = ((nl << 1) | prev_nl) & 0xffffu;
+    }
 }
 
 // P1: per tile -> summary.  FASTA: {v0 = symbols emitted whatever runs into the tile, v1 = extra
@@ -212,7 +303,7 @@ __device__ __forceinline__ void tile_scan_fq(const uint8_t *__restrict__ raw, ui
 // FASTQ: {v[s] = symbols when the tile starts in line phase s, tag = 4 | newlines mod 4}.
 __global__ __launch_bounds__(PARSE_THREADS) void parse_summarize_kernel(
     const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint8_t *__restrict__ tile_meta,
-    TileSummary *__restrict__ sums, uint32_t *__restrict__ chunk_pre)
+    TileSummary *__restrict__ sums, uint32_t *__restrict__ chunk_pre, uint64_t *__restrict__ chunk_pre64)
 {
     __shared__ uint64_t partial[ROUNDS_PER_TILE * (PARSE_THREADS / 64)];
     const uint32_t tile = blockIdx.x;
@@ -221,6 +312,10 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_summarize_kernel(
     if (tile_meta[tile] & TILE_META_FASTQ) {
         TileChunksFq tc;
         tile_scan_fq(raw, tile, partial, tc);
+        if (chunk_pre64) {
+#pragma unroll
+            for (int r = 0; r < ROUNDS_PER_TILE; r++) chunk_pre64[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x] = tc.pre[r];
+        }
         s.v[0] = fq_elem_cnt(tc.total, 0); s.v[1] = fq_elem_cnt(tc.total, 1);
         s.v[2] = fq_elem_cnt(tc.total, 2); s.v[3] = fq_elem_cnt(tc.total, 3);
         s.tag = 4u | fq_elem_nl(tc.total);
@@ -443,7 +538,7 @@ __global__ void parse_prezero_kernel(const uint64_t *__restrict__ tile_off, uint
 __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
     const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint8_t *__restrict__ tile_meta,
     const uint64_t *__restrict__ tile_off, const uint8_t *__restrict__ tile_state, uint64_t *__restrict__ sym2,
-    uint64_t *__restrict__ inv, const TileSummary *__restrict__ sums, const uint32_t *__restrict__ chunk_pre)
+    uint64_t *__restrict__ inv, const TileSummary *__restrict__ sums, const uint32_t *__restrict__ chunk_pre, const uint64_t *__restrict__ chunk_pre64)
 {
     constexpr int MAX_GROUPS = TILE_BYTES / 64 + 2;
     __shared__ uint64_t partial[ROUNDS_PER_TILE * (PARSE_THREADS / 64)];
@@ -461,8 +556,16 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
     auto or_inv = [&](uint32_t i, uint64_t val) { atomicOr((unsigned long long *)&wi[i], (unsigned long long)val); };
     if (tile_meta[tile] & TILE_META_FASTQ) {
         TileChunksFq tc;
-        tile_scan_fq(raw, tile, partial, tc);           // its barrier also orders the zeroing above
-        n_tile = fq_elem_cnt(tc.total, state);
+        if (chunk_pre64) {
+            tile_rounds_fq(raw, tile, tc);
+#pragma unroll
+            for (int r = 0; r < ROUNDS_PER_TILE; r++) tc.pre[r] = chunk_pre64[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x];
+            n_tile = sums[tile].v[state];
+            __syncthreads();                              // (orders the zeroing above, as the scan's barriers do)
+        } else {
+            tile_scan_fq(raw, tile, partial, tc);           // its barriers also order the zeroing above
+            n_tile = fq_elem_cnt(tc.total, state);
+        }
 #pragma unroll
         for (int r = 0; r < ROUNDS_PER_TILE; r++) {
             uint32_t m[4], emit, sep, cs, ci;
@@ -2416,11 +2519,13 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap = 256u 
     return (uint32_t)(g > cap ? cap : g);
 }
 
-void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, TileSummary *sums, uint32_t *chunk_pre)
+void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, TileSummary *sums, uint32_t *chunk_pre,
+                            uint64_t *chunk_pre64)
 {
-    hipLaunchKernelGGL(parse_summarize_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, sums, chunk_pre);
+    hipLaunchKernelGGL(parse_summarize_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, sums, chunk_pre, chunk_pre64);
 }
-size_t parse_chunk_pre_bytes(uint32_t n_tiles) { return (size_t)n_tiles * ROUNDS_PER_TILE * PARSE_THREADS * 4; }
+// 4 bytes per 16-byte chunk (FASTA tiles); with FASTQ tiles in the batch 8 more per chunk behind them (chunk_pre64 = chunk_pre + the 4-byte part)
+size_t parse_chunk_pre_bytes(uint32_t n_tiles, bool with_fastq) { return (size_t)n_tiles * ROUNDS_PER_TILE * PARSE_THREADS * (with_fastq ? 12 : 4); }
 // scratch: n_tiles * 20 B (tile prefixes) + n_blocks * (20 + 1 + 8) B + 8 B
 size_t parse_scan_scratch_bytes(uint32_t n_tiles)
 {
@@ -2446,11 +2551,12 @@ void launch_parse_scan(hipStream_t s, const TileSummary *sums, uint32_t n_tiles,
                        genome_sym_off);
 }
 void launch_parse_pack(hipStream_t s, const uint8_t *raw, uint32_t n_tiles, const uint8_t *tile_meta, const uint64_t *tile_off,
-                       const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv, const TileSummary *sums, const uint32_t *chunk_pre)
+                       const uint8_t *tile_state, uint64_t *sym2, uint64_t *inv, const TileSummary *sums, const uint32_t *chunk_pre,
+                       const uint64_t *chunk_pre64)
 {
     hipLaunchKernelGGL(parse_prezero_kernel, dim3(((uint64_t)n_tiles + 256) / 256), dim3(256), 0, s, tile_off, n_tiles, sym2, inv);
     hipLaunchKernelGGL(parse_pack_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, tile_off,
-                       tile_state, sym2, inv, sums, chunk_pre);
+                       tile_state, sym2, inv, sums, chunk_pre, chunk_pre64);
 }
 
 // desc: n_tiles words + the ticket behind them (all zeroed here); pieces: n_tiles x 2 x 3 words
