@@ -73,6 +73,7 @@ struct grm_ctx {
     int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
     int opt_rec_keys = -1;       // > 0: record form always expands to key segments in level 2 (tests, measurements)
     int opt_rec_coarse = -1;     // record form: coarse bucket bits of level 1 (tests, measurements); < 0 = min(bucket bits, 9)
+    int opt_dict_sort_prim = -1; // > 0: the dictionary is sorted by rocPRIM's radix sort instead of the key-range sort of grm_dictsort.hip (tests)
     int opt_parse_fused = -1;    // > 0: the single-pass parse kernel (decoupled look-back) instead of summarize / scan / pack -- measured SLOWER
                                  // (7.1 against 5.0 ms at 1000 x 5 Mbp): kept for tests and measurements
     int opt_memo_stats = -1;     // > 0: dict_build counts what its record memo held / was asked / found (grm_batch_memo_stats)
@@ -296,6 +297,7 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "rec_memo") c->opt_rec_memo = value;
     else if (n == "memo_stats") c->opt_memo_stats = value;
     else if (n == "parse_fused") c->opt_parse_fused = value;
+    else if (n == "dict_sort_prim") c->opt_dict_sort_prim = value;
     else if (n == "rec_coarse") c->opt_rec_coarse = value;
     else if (n == "keys_in_flight") { c->opt_keys_in_flight = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
     else if (n == "table_threads") { c->opt_table_threads = value; set_table_tuning(c->opt_keys_in_flight, c->opt_table_threads); }
@@ -1797,24 +1799,39 @@ static int dict_from_own_entries(grm_batch *b, int filter_singleton)
     HIPCHK(c, d_i0.ensure(n * 4));
     HIPCHK(c, d_i1.ensure(n * 4));
     HIPCHK(c, b->d_entry_col.ensure((n + 1) * 4));
-    {
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // key-range sort (grm_dictsort.hip); the general radix sort when asked for, or when a key range did not fit LDS
+        const bool by_ranges = attempt == 0 && c->opt_dict_sort_prim <= 0;
+        if (attempt == 0 && !by_ranges) continue;
         TimeScope t(c, "dict_sort", n);
-        launch_iota_u32(s, d_i0.as<uint32_t>(), n);
-        size_t tmp_bytes = 0;
-        HIPCHK(c, sort_pairs_u64_u32(s, b->d_local_keys.as<uint64_t>(), d_sk.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, nullptr, tmp_bytes));
-        HIPCHK(c, d_tmp.ensure(tmp_bytes));
-        HIPCHK(c, sort_pairs_u64_u32(s, b->d_local_keys.as<uint64_t>(), d_sk.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, d_tmp.p, tmp_bytes));
+        HIPCHK(c, b->t_flag.ensure(32));
+        HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 4, s));
+        if (by_ranges) {
+            HIPCHK(c, d_tmp.ensure(dict_sort_scratch_bytes(n)));
+            HIPCHK(c, launch_dict_sort(s, b->d_local_keys.as<uint64_t>(), n, 2 * b->k, d_sk.as<uint64_t>(), d_i1.as<uint32_t>(), d_tmp.p, b->t_flag.as<int>()));
+        } else {
+            launch_iota_u32(s, d_i0.as<uint32_t>(), n);
+            size_t tmp_bytes = 0;
+            HIPCHK(c, sort_pairs_u64_u32(s, b->d_local_keys.as<uint64_t>(), d_sk.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, nullptr, tmp_bytes));
+            HIPCHK(c, d_tmp.ensure(tmp_bytes));
+            HIPCHK(c, sort_pairs_u64_u32(s, b->d_local_keys.as<uint64_t>(), d_sk.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, d_tmp.p, tmp_bytes));
+        }
         HIPCHK(c, hipMemsetAsync(d_keep.as<uint32_t>() + n, 0, 4, s));
         launch_dict_mark_idx(s, b->d_local_flags.as<uint8_t>(), d_i1.as<uint32_t>(), n, filter_singleton, d_keep.as<uint32_t>());
         size_t tmp2 = 0;
         HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, nullptr, tmp2));
-        HIPCHK(c, d_tmp.ensure(tmp2));
-        HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, d_tmp.p, tmp2));
+        // (the scan's scratch must not be the sort's: d_tmp may be re-allocated here only after the sort has run -- same stream, in order)
+        HIPCHK(c, b->t_set_tmp.ensure(tmp2));
+        HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, b->t_set_tmp.p, tmp2));
+        int too_big = 0;
         HIPCHK(c, hipMemcpyAsync(&b->n_dict, d_pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&too_big, b->t_flag.p, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        if (by_ranges && too_big) continue;          // (keys crowding under one prefix: a degenerate input)
         HIPCHK(c, b->d_dict.ensure((b->n_dict + 2) * 8));
         launch_dict_select_idx(s, d_sk.as<uint64_t>(), d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), d_i1.as<uint32_t>(), n, b->d_dict.as<uint64_t>(),
                                b->d_entry_col.as<uint32_t>());
+        break;
     }
     HIPCHK(c, hipGetLastError());
     b->entry_cols_ready = true;

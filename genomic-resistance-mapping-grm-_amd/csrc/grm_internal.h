@@ -234,6 +234,10 @@ void launch_runs_emit(hipStream_t s, const uint64_t *keys, const unsigned long l
                       uint64_t n_runs, uint64_t *out_keys, uint32_t *out_counts);
 void launch_split_pairs_u64(hipStream_t s, const uint64_t *pairs, uint64_t n, uint64_t *hi, uint64_t *lo);
 void launch_join_pairs_u64(hipStream_t s, const uint64_t *hi, const uint64_t *lo, uint64_t n, uint64_t *pairs);
+// dictionary sort (grm_dictsort.hip): keys below 2^key_bits -> okeys ascending, oidx = every key's position in `keys`; *too_big (device,
+// zeroed by the caller) = 1: a key range did not fit LDS and the output is NOT sorted (take sort_pairs_u64_u32)
+size_t dict_sort_scratch_bytes(uint64_t n);
+hipError_t launch_dict_sort(hipStream_t s, const uint64_t *keys, uint64_t n, int key_bits, uint64_t *okeys, uint32_t *oidx, void *scratch, int *too_big);
 hipError_t set_max_dynamic_lds();
 void set_table_tuning(int keys_in_flight, int threads);
 

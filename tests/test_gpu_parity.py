@@ -117,6 +117,7 @@ def test_medium_pangenome_all_paths(ctx):
     {"dense_layout": 1}, {"dense_layout": 1, "bucket_bits": 11},      # histogram-sized layout instead of the slack layout
     {"direct_permute": 1},                             # scattered single-step fill
     {"records": 0},                                    # key form of the partition (hashed buckets, levels 1 and 2 on keys)
+    {"dict_sort_prim": 1},                             # dictionary sorted by the general radix sort instead of the key-range sort
     {"rec_keys": 1}, {"rec_keys": 1, "bucket_bits": 10},       # record form, level 2 expanding to key segments
     {"rec_part_bits": 2}, {"rec_part_bits": 3, "rec_keys": 1},  # genomes cut into parts (one workgroup each)
     {"rec_bucket_shift": 1}, {"bucket_bits": 6}, {"bucket_bits": 9, "sub_bits": 1},
@@ -262,6 +263,26 @@ def test_record_form_gives_way_to_the_key_form_on_repeats(ctx):
         assert "superkmer_l1" in names and "kmer_scatter_l1" in names, names        # tried, then redone
     finally:
         ctx.timing(False)
+
+
+def test_dictionary_sort_with_crowded_key_ranges(ctx):
+    """the dictionary's key-range sort (grm_dictsort.hip) splits the k-mers by their top bits and sorts every range inside LDS: 12 000
+    k-mers that all begin with AAAAAA crowd into one range that does not fit -- the flag goes up and the general sort takes over; the
+    same genomes with ordinary k-mers beside them; and the two sorts agree on a pan-genome"""
+    rng = np.random.RandomState(3)
+    crowd = "".join(">r%d\nAAAAAA%s\n" % (i, cases.rand_seq(rng, 25)) for i in range(12_000)).encode()
+    crowd2 = "".join(">r%d\nAAAAAAA%s\n" % (i, cases.rand_seq(rng, 24)) for i in range(9_000)).encode()
+    _check(ctx, [[crowd], [crowd2], [crowd[: len(crowd) // 2]]], 31, 1, False)
+    _check(ctx, [[crowd, (">x\n" + cases.rand_seq(rng, 60_000) + "\n").encode()], [crowd2]], 31, 1, True)
+    genomes = _medium_genomes(n=6, length=150_000, seed=5)
+    for prim in (0, 1):
+        try:
+            ctx.set_option("dict_sort_prim", prim)
+            _check(ctx, genomes, 31, 1, True)
+            _check(ctx, genomes, 19, 1, False)
+            _check(ctx, genomes, 32, 1, False)
+        finally:
+            ctx.set_option("dict_sort_prim", -1)
 
 
 def test_single_pass_parse_gives_the_same_stream(ctx):
