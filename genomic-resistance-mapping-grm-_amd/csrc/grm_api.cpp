@@ -1761,22 +1761,38 @@ static int dict_from_entries(grm_batch *b, const uint64_t *keys, const uint8_t *
     HIPCHK(c, d_sf.ensure(n));
     HIPCHK(c, d_keep.ensure((n + 1) * 4));
     HIPCHK(c, d_pos.ensure((n + 1) * 8));
-    {
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // key-range sort with the entries' indices (the flags follow through them), or the general sort of (key, flag) pairs
+        const bool by_ranges = attempt == 0 && c->opt_dict_sort_prim <= 0;
+        if (attempt == 0 && !by_ranges) continue;
         TimeScope t(c, "dict_sort", n);
-        size_t tmp_bytes = 0;
-        HIPCHK(c, sort_pairs_u64_u8(s, keys, d_sk.as<uint64_t>(), flags, d_sf.as<uint8_t>(), n, nullptr, tmp_bytes));
-        HIPCHK(c, d_tmp.ensure(tmp_bytes));
-        HIPCHK(c, sort_pairs_u64_u8(s, keys, d_sk.as<uint64_t>(), flags, d_sf.as<uint8_t>(), n, d_tmp.p, tmp_bytes));
+        HIPCHK(c, b->t_flag.ensure(32));
+        HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 4, s));
+        if (by_ranges) {
+            HIPCHK(c, b->t_col.ensure(n * 4));
+            HIPCHK(c, d_tmp.ensure(dict_sort_scratch_bytes(n)));
+            HIPCHK(c, launch_dict_sort(s, keys, n, 2 * b->k, d_sk.as<uint64_t>(), b->t_col.as<uint32_t>(), d_tmp.p, b->t_flag.as<int>()));
+            launch_gather_u8(s, flags, b->t_col.as<uint32_t>(), n, d_sf.as<uint8_t>());
+        } else {
+            size_t tmp_bytes = 0;
+            HIPCHK(c, sort_pairs_u64_u8(s, keys, d_sk.as<uint64_t>(), flags, d_sf.as<uint8_t>(), n, nullptr, tmp_bytes));
+            HIPCHK(c, d_tmp.ensure(tmp_bytes));
+            HIPCHK(c, sort_pairs_u64_u8(s, keys, d_sk.as<uint64_t>(), flags, d_sf.as<uint8_t>(), n, d_tmp.p, tmp_bytes));
+        }
         HIPCHK(c, hipMemsetAsync(d_keep.as<uint32_t>() + n, 0, 4, s));
         launch_dict_mark(s, d_sk.as<uint64_t>(), d_sf.as<uint8_t>(), n, filter_singleton, d_keep.as<uint32_t>());
         size_t tmp2 = 0;
         HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, nullptr, tmp2));
-        HIPCHK(c, d_tmp.ensure(tmp2));
-        HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, d_tmp.p, tmp2));
+        HIPCHK(c, b->t_set_tmp.ensure(tmp2));
+        HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, b->t_set_tmp.p, tmp2));
+        int too_big = 0;
         HIPCHK(c, hipMemcpyAsync(&b->n_dict, d_pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&too_big, b->t_flag.p, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        if (by_ranges && too_big) continue;
         HIPCHK(c, b->d_dict.ensure((b->n_dict + 2) * 8));
         launch_dict_select(s, d_sk.as<uint64_t>(), d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n, b->d_dict.as<uint64_t>());
+        break;
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));

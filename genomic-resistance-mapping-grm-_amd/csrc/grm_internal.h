@@ -215,6 +215,7 @@ void launch_segments_compact(hipStream_t s, const uint64_t *src, const uint32_t 
                              uint32_t *dst_cnt);
 void launch_segment_starts(hipStream_t s, const uint32_t *ids, uint64_t n, uint32_t n_ids, uint64_t *start);
 void launch_gather_u64(hipStream_t s, const uint64_t *src, const uint32_t *index, uint64_t n, uint64_t *dst);
+void launch_gather_u8(hipStream_t s, const uint8_t *src, const uint32_t *index, uint64_t n, uint8_t *dst);
 void launch_matrix_fill(hipStream_t s, const uint64_t *keys, const SegLayout &seg,
                         uint32_t n_genomes, int bb, int sb, uint32_t cap_log2, const uint64_t *dkeys,
                         const uint32_t *dcol, const uint64_t *seg_start, uint64_t *matrix, uint64_t n_cols,

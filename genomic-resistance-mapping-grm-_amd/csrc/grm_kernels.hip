@@ -2773,6 +2773,15 @@ void launch_dict_select(hipStream_t s, const uint64_t *skeys, const uint32_t *ke
     if (!n) return;
     hipLaunchKernelGGL(dict_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, skeys, keep, pos, n, dict);
 }
+__global__ void gather_u8_kernel(const uint8_t *__restrict__ src, const uint32_t *__restrict__ index, uint64_t n, uint8_t *__restrict__ dst)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[index[i]];
+}
+void launch_gather_u8(hipStream_t s, const uint8_t *src, const uint32_t *index, uint64_t n, uint8_t *dst)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(gather_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, index, n, dst);
+}
 void launch_dict_mark_idx(hipStream_t s, const uint8_t *flags, const uint32_t *sidx, uint64_t n, int filter_singleton, uint32_t *keep)
 {
     if (!n) return;
