@@ -1865,7 +1865,7 @@ static int dict_attach(grm_batch *b, uint64_t *n_kmers)
         HIPCHK(c, b->d_entry_col.ensure((b->n_local + 1) * 4));
         if (!b->entry_cols_ready) {
             TimeScope t(c, "dict_entry_cols", b->n_local);
-            HIPCHK(c, b->d_prefix.ensure(((size_t)1 << 20) * 4 + 16));
+            HIPCHK(c, b->d_prefix.ensure(((size_t)1 << 22) * 4 + 16));
             launch_dict_entry_cols(s, b->d_dict.as<uint64_t>(), b->n_dict, b->d_local_keys.as<uint64_t>(), b->n_local, b->k,
                                    b->d_prefix.as<uint32_t>(), b->d_entry_col.as<uint32_t>());
         }

@@ -193,7 +193,7 @@ struct RankShifts { uint8_t d[64]; };
 void launch_union_segments(hipStream_t s, const uint8_t *payload, uint32_t n_ranks, uint64_t stride, uint64_t flags_off, uint64_t boff_off,
                            uint32_t n_buckets, const RankShifts &shifts, uint64_t *off, uint32_t *len, uint64_t *flag_off);
 // column of every local entry: position of its key in the sorted global dictionary, 0xffffffff if filtered / absent
-// (prefix_first: scratch of 2^20 + 2 uint32)
+// (prefix_first: scratch of 2^22 + 2 uint32)
 void launch_dict_entry_cols(hipStream_t s, const uint64_t *dict, uint64_t n_dict, const uint64_t *entry_keys, uint64_t n_entries, int k,
                             uint32_t *prefix_first, uint32_t *entry_col);
 // matrix[r][entry_col[e]] = presence word of entry e in row r.  entry_major: scratch of n_cols * n_rows words for

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
 // classify + scan alone 4.1 ms here (2.4 in parse_summarize: that kernel needs 38 VGPRs, this one 101 -- the scan is a chain of
 // cross-lane moves that lives on occupancy), + packing and stores 5.3, + the look-back 7.1-8.3.  The two-pass form is bound by
 // instruction issue and latency, not by the 5.6 GB it reads twice, so reading once buys nothing and the look-back costs.
-constexpr uint64_t PD_AGG = 1ull << 62, PD_PREFIX = 2ull << 62, PD_PAYLOAD = (1ull << 62) - 1;
+constexpr uint64_t PD_AGG = 1ull << 62, PD_PREFIX = 2ull << 62;
 __device__ __forceinline__ uint64_t pd_pack(const TileSummary &s)
 {
     if (s.tag & 4u) return (uint64_t)s.v[0] | ((uint64_t)s.v[1] << 15) | ((uint64_t)s.v[2] << 30) | ((uint64_t)s.v[3] << 45) | ((uint64_t)(s.tag & 3u) << 60);
@@ -2148,22 +2148,17 @@ __global__ void union_segments_kernel(const uint8_t *__restrict__ payload, uint3
     }
 }
 
-// column of every local entry = rank of its key in the sorted global dictionary.  A table of the first
-// dictionary position of every PB-bit key prefix (4 MiB, L2-resident) narrows the search to a handful of entries.
+// column of every local entry = rank of its key in the sorted global dictionary.  A table of the first dictionary position of every
+// PB-bit key prefix (2^22 prefixes: ~2.5 entries each at 10 M columns) narrows the search to one or two steps.  The table is filled from
+// one sweep of the sorted dictionary (entry i opens every prefix between its predecessor's and its own) -- a binary search per prefix, as
+// before, was 2^20 x 23 dependent loads: most of the 0.53 ms this step took.
 __global__ void dict_prefix_index_kernel(const uint64_t *__restrict__ dict, uint64_t n_dict, int shift, uint32_t n_prefix,
                                          uint32_t *__restrict__ first)
 {
-    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p <= n_prefix; p += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t lo = 0, hi = n_dict;
-        if (p == n_prefix) lo = n_dict;
-        else {
-            const uint64_t want = p << shift;
-            while (lo < hi) {
-                const uint64_t m = (lo + hi) >> 1;
-                if (dict[m] < want) lo = m + 1; else hi = m;
-            }
-        }
-        first[p] = (uint32_t)lo;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_dict; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t lo = i ? (dict[i - 1] >> shift) + 1 : 0;                    // prefixes after the predecessor's ...
+        const uint64_t hi = i < n_dict ? (dict[i] >> shift) : (uint64_t)n_prefix;  // ... up to this entry's (the end: all that are left, and n_prefix itself)
+        for (uint64_t p = lo; p <= hi && p <= n_prefix; p++) first[p] = (uint32_t)i;
     }
 }
 __global__ void dict_entry_cols_kernel(const uint64_t *__restrict__ dict, uint64_t n_dict, const uint64_t *__restrict__ entry_keys,
@@ -2733,13 +2728,13 @@ void launch_union_segments(hipStream_t s, const uint8_t *payload, uint32_t n_ran
                        flags_off, boff_off, n_buckets, shifts, off, len, flag_off);
 }
 void launch_dict_entry_cols(hipStream_t s, const uint64_t *dict, uint64_t n_dict, const uint64_t *entry_keys, uint64_t n_entries, int k,
-                            uint32_t *prefix_first /* 2^20 + 2 entries */, uint32_t *entry_col)
+                            uint32_t *prefix_first /* 2^22 + 2 entries */, uint32_t *entry_col)
 {
     if (!n_entries) return;
-    const int pb = 2 * k < 20 ? 2 * k : 20;
+    const int pb = 2 * k < 22 ? 2 * k : 22;
     const int shift = 2 * k - pb;
     const uint32_t n_prefix = 1u << pb;
-    hipLaunchKernelGGL(dict_prefix_index_kernel, dim3(grid_for((uint64_t)n_prefix + 1, 256)), dim3(256), 0, s, dict, n_dict, shift, n_prefix,
+    hipLaunchKernelGGL(dict_prefix_index_kernel, dim3(grid_for(n_dict + 1, 256, 256u * 32u)), dim3(256), 0, s, dict, n_dict, shift, n_prefix,
                        prefix_first);
     hipLaunchKernelGGL(dict_entry_cols_kernel, dim3(grid_for(n_entries, 256, 256u * 32u)), dim3(256), 0, s, dict, n_dict, entry_keys,
                        n_entries, shift, n_prefix, prefix_first, entry_col);
