@@ -183,6 +183,8 @@ def kernel_table(ctx, n_cols, n_rows, n_local):
             byts = 0.375 * d["units"] / d["launches"] + 16.0 * n_records           # read the packed stream, write the records
         elif name == "dict_build" and n_records is not None:
             byts = 16.0 * n_records + 8.0 * n_local * n_rows + 9.0 * n_local        # read the records; presence words + (key, flag) per entry
+        elif name == "record_dedup" and n_records is not None:
+            byts = 16.0 * n_records + 12.0 * d["units"] / d["launches"]             # read the records; write <= a key + a 4-byte count per k-mer
         elif ALGO_BYTES.get(name) is not None:
             byts = ALGO_BYTES[name] * d["units"] / d["launches"]
             if name == "dict_build":

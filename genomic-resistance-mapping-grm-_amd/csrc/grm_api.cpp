@@ -72,6 +72,8 @@ struct grm_ctx {
     int opt_rec_bucket_shift = -1; // record form: bucket bits on top of the key form's choice (default 1)
     int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
     int opt_rec_keys = -1;       // > 0: record form always expands to key segments in level 2 (tests, measurements)
+    int opt_rec_count = -1;      // 0: counting partitions never take the record form
+    int opt_rec_count_cap = -1;  // counting over records: log2 slots of a wave's table (8..10; tests of the shared-table path)
     int opt_rec_coarse = -1;     // record form: coarse bucket bits of level 1 (tests, measurements); < 0 = min(bucket bits, 9)
     int opt_dict_sort_prim = -1; // > 0: the dictionary is sorted by rocPRIM's radix sort instead of the key-range sort of grm_dictsort.hip (tests)
     int opt_parse_fused = -1;    // > 0: the single-pass parse kernel (decoupled look-back) instead of summarize / scan / pack -- measured SLOWER
@@ -294,6 +296,8 @@ extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
     else if (n == "rec_bucket_shift") c->opt_rec_bucket_shift = value;
     else if (n == "rec_part_bits") c->opt_rec_part_bits = value;
     else if (n == "rec_keys") c->opt_rec_keys = value;
+    else if (n == "rec_count") c->opt_rec_count = value;
+    else if (n == "rec_count_cap") c->opt_rec_count_cap = value;
     else if (n == "rec_memo") c->opt_rec_memo = value;
     else if (n == "memo_stats") c->opt_memo_stats = value;
     else if (n == "parse_fused") c->opt_parse_fused = value;
@@ -721,7 +725,7 @@ struct grm_batch {
     int k = 0, bb = 0;
     uint32_t abundance_min = 1;
     uint64_t total_keys = 0;       // k-mer occurrences
-    DevBuf d_counts, d_off, d_cursor, d_cursor1, d_counts1, d_off1, d_keys, d_keys1, d_len, d_kcnt;
+    DevBuf d_counts, d_off, d_cursor, d_cursor1, d_counts1, d_off1, d_keys, d_keys1, d_len, d_kcnt, d_koff, d_klen;
     bool deduped = false;
     uint64_t seg_stride = 0;       // 0: dense layout (d_off); else slack layout: segment i at i * seg_stride, length d_len[i]
     // record form of the partition (grm_superkmer.hip): minimizer buckets; d_recs holds the level-1 records, the key
@@ -1138,10 +1142,17 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     // segment sizes inside a region.
     // (k < 19: a k-mer holds fewer than 9 m-mers and runs get short: measured at 300 x 5 Mbp, the record form takes 16.2 ms against
     // 18.0 for the key form at k = 21, but 19.8 against 17.9 at k = 15 and 28.7 against 16.8 at k = 12 -- unless asked for)
-    if (k >= (c->opt_records > 0 ? SK_M : SK_M + 8) && abundance_min == 1 && !want_counts && c->opt_records != 0 && !b->rec_failed &&
+    // A counting partition (counts wanted, or an abundance filter) takes the records too when every genome is one part: level 2 sorts the
+    // records by bucket and record_dedup (grm_kernels.hip) counts the k-mers of a (genome, bucket) segment straight from its records --
+    // 1.45 B per k-mer moved twice instead of 8 B moved twice and read a third time.  (Few large genomes -- reads -- are cut into
+    // parts, whose counts would have to be added up per genome: they stay on the key form.)
+    const bool counting = abundance_min > 1 || want_counts;
+    if (k >= (c->opt_records > 0 ? SK_M : SK_M + 8) && (!counting || (G >= 128 && c->opt_rec_count != 0)) && c->opt_records != 0 && !b->rec_failed &&
         c->opt_dense_layout <= 0) {
         int bbr = c->opt_bucket_bits >= 0 ? b->bb : b->bb + (c->opt_rec_bucket_shift >= 0 ? c->opt_rec_bucket_shift : 1);
         if (c->opt_bucket_bits < 0 && b->rec_bb_hint > bbr && b->rec_bb_hint_k == k) bbr = b->rec_bb_hint;
+        // (counting: a wave's table of 512 slots per segment -- segments of ~150 k-mers, minimizer buckets being uneven)
+        if (counting && c->opt_bucket_bits < 0) while (bbr < superkmer_coarse_bits(bbr + 1) + 7 && (max_g >> bbr) > 192) bbr++;
         bbr = std::min(bbr, superkmer_max_bits());
         const int b1r = c->opt_rec_coarse > 0 ? std::max(bbr - 7, std::min(c->opt_rec_coarse, superkmer_coarse_bits(bbr))) : superkmer_coarse_bits(bbr);
         // one workgroup per genome part owns the part's regions: enough parts to fill the device when genomes are few
@@ -1150,6 +1161,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         // parts per genome -- level 1 gains, level 2 and dict_build pay for the smaller segments)
         while (((uint64_t)G << pbits) < 256 && pbits < 6 && (max_g >> (pbits + 1)) >= 65536) pbits++;
         if (c->opt_rec_part_bits >= 0) pbits = std::min(c->opt_rec_part_bits, 6);
+        if (counting) pbits = 0;
         const uint64_t n_parts = (uint64_t)G << pbits;
         const uint64_t n_regions = n_parts << b1r, n_seg_r = n_parts << bbr;
         // records per region: a run ends where the minimizer occurrence changes -- 2 / (w + 1) per position for the w m-mers
@@ -1173,18 +1185,29 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         // two workgroups still share a CU)
         b->rec_memo_log2 = c->opt_rec_memo < 0 ? 8 : c->opt_rec_memo == 0 ? 0 : std::min(11, std::max(8, c->opt_rec_memo));
         const uint32_t cap_r = (b->rec_memo_log2 && c->opt_cap_log2 <= 0) ? 11u : b->cap_log2;
-        bool by_records = c->opt_no_slots <= 0 && c->opt_rec_keys <= 0 && n_rows_b <= 0xffffu &&
+        bool by_records = !counting && c->opt_no_slots <= 0 && c->opt_rec_keys <= 0 && n_rows_b <= 0xffffu &&
                           ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << cap_r) * 8 <= MATRIX_S_LIMIT;
+        // counting: segments of more than 448 k-mers take the second, workgroup-wide launch, and more than 1792 distinct ones fit no table
+        if (counting && (max_g >> bbr) > 600) rec = false;
+        const bool l2_records = by_records || counting;
         if (rec && b->d_recs.ensure((n_regions * rstride64 + 4) * 16) != hipSuccess) {
             (void)hipGetLastError();
             rec = false;
         }
-        if (rec && by_records && b->d_recs2.ensure((n_regions * rstride64 + 4) * 16) != hipSuccess) {
+        if (rec && l2_records && b->d_recs2.ensure((n_regions * rstride64 + 4) * 16) != hipSuccess) {
             (void)hipGetLastError();
+            if (counting) rec = false;
             by_records = false;
         }
         // (key segments: a layout of kstride keys per region)
         if (rec && !by_records && (double)n_regions * (double)kstride > 3.0 * (double)b->total_syms + 65536.0 * 1024.0) rec = false;
+        if (rec && counting) {
+            hipError_t e = b->d_keys.ensure((n_regions * kstride + 4) * 8);
+            if (e == hipSuccess && want_counts) e = b->d_kcnt.ensure((n_regions * kstride + 4) * 4);
+            if (e == hipSuccess) e = b->d_koff.ensure((n_seg_r + 1) * 8);
+            if (e == hipSuccess) e = b->d_klen.ensure((n_seg_r + 1) * 4);
+            if (e != hipSuccess) { (void)hipGetLastError(); rec = false; }
+        }
         if (rec) {
             const uint32_t rstride = (uint32_t)rstride64;
             KmerLaunch Lr;
@@ -1202,7 +1225,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
             }
             b->rec_rstride = rstride; b->rec_kstride = kstride; b->rec_regions = n_regions; b->rec_b1 = b1r;
             int l2_idx = -1;
-            if (by_records) {
+            if (l2_records) {
                 TimeScope t(c, "superkmer_l2", b->total_syms);        // (units: the record count, once it is known)
                 l2_idx = t.idx;
                 launch_superkmer_l2_records(s, b->d_recs.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, k, bbr, b1r, b->d_recs2.p,
@@ -1220,6 +1243,39 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
             HIPCHK(c, hipMemcpyAsync(&h, b->t_flag.p, 32, hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
             if (l2_idx >= 0 && l2_idx < (int)c->recs.size()) c->recs[l2_idx].units = h.records;
+            if (!h.over && counting) {
+                // distinct k-mers (+ counts, abundance filter) of every (genome, bucket) segment, from its records
+                const int cap_w = c->opt_rec_count_cap == 8 ? 8 : 9;
+                HIPCHK(c, b->d_marks.ensure(n_regions + 16));
+                HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 8, s));
+                {
+                    TimeScope t(c, "record_dedup", h.total);
+                    launch_record_count(s, b->d_recs2.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, k, bbr, b1r, kstride, cap_w, abundance_min,
+                                        b->d_keys.as<uint64_t>(), want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, b->d_koff.as<uint64_t>(),
+                                        b->d_klen.as<uint32_t>(), b->t_flag.as<int>(), b->d_marks.as<uint8_t>(), b->t_flag.as<int>() + 1);
+                }
+                HIPCHK(c, hipGetLastError());
+                int fl[2] = {0, 0};
+                HIPCHK(c, hipMemcpyAsync(fl, b->t_flag.p, 8, hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipStreamSynchronize(s));
+                if (!fl[0] && fl[1]) {
+                    // segments with more k-mers or records than a wave takes: the workgroup form over the regions that hold one
+                    TimeScope t(c, "record_dedup_rest", h.total);
+                    launch_record_dedup_rest(s, b->d_recs2.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, k, bbr, b1r, kstride, cap_w, abundance_min,
+                                             b->d_keys.as<uint64_t>(), want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, b->d_koff.as<uint64_t>(),
+                                             b->d_klen.as<uint32_t>(), b->t_flag.as<int>(), b->d_marks.as<uint8_t>());
+                    HIPCHK(c, hipGetLastError());
+                    HIPCHK(c, hipMemcpyAsync(fl, b->t_flag.p, 4, hipMemcpyDeviceToHost, s));
+                    HIPCHK(c, hipStreamSynchronize(s));
+                }
+                h.over = fl[0];
+                if (!h.over) {
+                    // the key segments take the place of the record segments
+                    std::swap(b->d_off.p, b->d_koff.p); std::swap(b->d_off.bytes, b->d_koff.bytes);
+                    std::swap(b->d_len.p, b->d_klen.p); std::swap(b->d_len.bytes, b->d_klen.bytes);
+                    b->deduped = true;
+                }
+            }
             if (!h.over) {
                 b->bb = bbr;
                 b->total_keys = h.total;
@@ -3146,6 +3202,14 @@ static int genome_set_impl(grm_batch *b, int g, bool have_counts, grm_kmer_set *
         for (uint64_t i = 0; i <= B; i++) off[i] = ((uint64_t)g * B + i) * b->seg_stride;
         HIPCHK(c, hipMemcpy(len.data(), b->d_len.as<uint32_t>() + (uint64_t)g * B, B * 4, hipMemcpyDeviceToHost));
         set->occurrences = 0;        // filled below when the batch kept the pre-dedup counts
+    } else if (b->rec_mode) {
+        // key segments expanded from records: regions leave gaps (lengths from level 2 or the dedup); one part per genome
+        if (b->rec_part_bits != 0 || !b->deduped) return fail(c, GRM_ERR_STATE, "internal: a genome's set from record segments needs one part per genome and a dedup");
+        HIPCHK(c, hipMemcpy(off.data(), b->d_off.as<uint64_t>() + (uint64_t)g * B, B * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(len.data(), b->d_len.as<uint32_t>() + (uint64_t)g * B, B * 4, hipMemcpyDeviceToHost));
+        uint32_t occ = 0;
+        HIPCHK(c, hipMemcpy(&occ, b->d_cursor1.as<uint32_t>() + g, 4, hipMemcpyDeviceToHost));        // level 1: k-mers of the part
+        set->occurrences = occ;
     } else {
         HIPCHK(c, hipMemcpy(off.data(), b->d_off.as<uint64_t>() + (uint64_t)g * B, (B + 1) * 8, hipMemcpyDeviceToHost));
         set->occurrences = off[B] - off[0];

@@ -347,6 +347,15 @@ GRM_HD void run_next(RunDecoder &d, uint64_t kmask, int rcshift)
     d.fwd = ((d.fwd << 2) | sy) & kmask;
     d.rc = (d.rc >> 2) | ((sy ^ 2ull) << rcshift);
 }
+// canonical k-mer number t of a record without rolling up to it: bases t .. t + k - 1 of the run (x: bases 0..31, y's top bits: the
+// bases from 32 on; t <= RUN_LMAX - 1 = 21 and t + k <= 53, so y's low fields are never reached)
+GRM_HD uint64_t run_kmer_at(uint64_t x, uint64_t y, int k, uint32_t t)
+{
+    const uint64_t hi = t ? ((x << (2 * t)) | (y >> (64 - 2 * t))) : x;
+    const uint64_t fwd = hi >> (64 - 2 * k);
+    const uint64_t rc = revcomp_m(fwd, k);
+    return fwd < rc ? fwd : rc;
+}
 
 // ---- FASTA byte classification -------------------------------------------------------
 // 4-bit mask of the bytes of x that equal c (SWAR exact zero-byte test, then bit gather)

@@ -133,6 +133,12 @@ struct SegLayout {
 };
 void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const SegLayout &seg, uint64_t n_segments, uint32_t cap_log2,
                          uint32_t abundance_min, uint32_t *len_out, const uint32_t *marks, uint32_t *counts_out, int *overflow);
+void launch_record_count(hipStream_t s, const void *recs, uint32_t rstride, const uint32_t *rcount, uint64_t n_regions, int k, int bb, int b1,
+                         uint64_t kstride, int cap_log2, uint32_t abundance_min, uint64_t *keys, uint32_t *counts_out, uint64_t *koff,
+                         uint32_t *klen, int *overflow, uint8_t *region_big, int *any_big);
+void launch_record_dedup_rest(hipStream_t s, const void *recs, uint32_t rstride, const uint32_t *rcount, uint64_t n_regions, int k, int bb, int b1,
+                              uint64_t kstride, int cap_log2, uint32_t abundance_min, uint64_t *keys, uint32_t *counts_out, uint64_t *koff,
+                              uint32_t *klen, int *overflow, const uint8_t *region_big);
 void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const SegLayout &seg, uint64_t n_segments, int wave_cap_log2,
                               uint32_t abundance_min, uint32_t *len_out, uint32_t *marks, uint32_t *counts_out, int *overflow);
 // dict_build: per-(bucket, sub-bucket) union over all genomes in an LDS table + the presence bits of

@@ -1432,6 +1432,446 @@ __global__ __launch_bounds__(WAVES * 64) void bucket_dedup_wave_kernel(
     }
 }
 
+// K4 from the record form (counting stage; one part per genome): the (genome, minimizer bucket) segments are runs of level-2
+// RECORDS -- 16 bytes for ~11 k-mers -- and the distinct k-mers of a segment with their counts leave as key segments in the
+// region's key space (region * kstride; a segment gets room for all its k-mers, koff / klen say where the distinct ones stand).
+// Two launches: record_count_kernel (below) takes every segment a wave can hold, record_dedup_kernel what that leaves -- segments
+// of more than 7/8 x 512 k-mers or more than 64 records; minimizer buckets are uneven, a few per thousand hold three times the mean.
+// Common to both: one workgroup per region at a time.  Pass A adds up the records and k-mers per fine bucket (level 2 left the
+// region's records sorted by fine bucket) and lays the key segments out.  A chunk of 64 records goes to LDS with the prefix sum of
+// the run lengths and a bitmap of the positions where a record's k-mers start, so that a LANE takes a K-MER (lanes that rolled
+// through records of 1..21 k-mers would idle two thirds of the time): its record is the popcount of the bitmap below its
+// position, the k-mer is cut out of the record's words directly.
+// record_dedup_kernel: the workgroup's waves share ONE table of 64-bit keys and counts; the slots a segment claims are listed as
+// they are claimed, and the pass that writes the segment out walks that list and leaves every slot empty again (nothing is
+// proportional to the table).  Only a segment whose DISTINCT k-mers exceed that table raises *overflow.
+__device__ __forceinline__ uint32_t record_slot_hash(uint64_t key)
+{
+    // three 24-bit multiplies (full rate) instead of mix64's 64-bit ones; the table index is taken from the top
+    const uint32_t a = (uint32_t)key & 0xffffffu, b = (uint32_t)(key >> 24) & 0xffffffu, c = (uint32_t)(key >> 48);
+    return __umul24(a, 0xC2B2AFu) + __umul24(b, 0x85EBCBu) + (__umul24(c, 0x9E3779u) << 7);
+}
+// records of a chunk -> LDS; returns the k-mers they hold
+__device__ __forceinline__ uint32_t record_chunk_stage(ulonglong2 rec, uint32_t n_chunk, ulonglong2 *srec, uint16_t *sstart, uint64_t *starts,
+                                                       uint8_t *firstrec)
+{
+    const int lane = lane_id();
+    const uint32_t ln = (uint32_t)lane < n_chunk ? run_len(rec.y) : 0u;
+    const uint32_t incl = wave_scan_incl_dpp(ln), st = incl - ln;
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    srec[lane] = rec;
+    sstart[lane] = (uint16_t)st;
+    // (a block of 64 positions in which no record starts -- the chunk's last -- belongs to the last record: first record "n_chunk")
+    if (lane < (int)((64u * RUN_LMAX + 63) / 64)) { starts[lane] = 0; firstrec[lane] = (uint8_t)n_chunk; }
+    wave_lds_fence();
+    const uint32_t w = st >> 6;
+    const uint32_t w_prev = __shfl_up(w, 1);
+    if (ln) {
+        atomicOr((unsigned long long *)&starts[w], 1ull << (st & 63u));
+        if (lane == 0 || w_prev != w) firstrec[w] = (uint8_t)lane;
+    }
+    wave_lds_fence();
+    return tot;
+}
+// canonical k-mer number q of the staged chunk
+__device__ __forceinline__ uint64_t record_chunk_kmer(uint32_t q, int k, const ulonglong2 *srec, const uint16_t *sstart, const uint64_t *starts,
+                                                      const uint8_t *firstrec)
+{
+    const uint32_t w = q >> 6;
+    const uint64_t word = starts[w];
+    const uint32_t o = (uint32_t)firstrec[w] + (uint32_t)__popcll(word & ((2ull << (q & 63u)) - 1ull)) - 1u;
+    const ulonglong2 r = srec[o];
+    return run_kmer_at(r.x, r.y, k, q - sstart[o]);
+}
+// up to four keys per lane (EMPTY_KEY = none) into the table, counted; slots claimed are appended to the list dl.
+// As dedup_insert4: the first-probe reads, then the claims of empty home slots, are in flight together; only a key that finds
+// someone else's key at home walks the probe sequence.  (Probing the four keys side by side until the last lane's last key has a
+// slot was tried: every round costs the whole wave four keys' worth of instructions, 4.5 against 3.5 wave instructions per k-mer.)
+// SHARED: several waves work on the table (the list's end is an LDS counter).  Returns false when the table is full.
+// nj: how many of the four hold keys in ANY lane (uniform): the others are skipped.
+template <uint32_t CAP_LOG2, bool SHARED>
+__device__ __forceinline__ bool record_insert4(uint64_t *tk, uint32_t *tc, uint16_t *dl, uint32_t *nd_shared, const uint64_t kv[4], uint32_t nj, uint32_t &nd)
+{
+    constexpr uint32_t MASK = (1u << CAP_LOG2) - 1;
+    uint32_t sl[4];
+    uint64_t cur[4];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if ((uint32_t)j >= nj) break;
+        sl[j] = record_slot_hash(kv[j]) >> (32 - CAP_LOG2);
+        cur[j] = lds_peek(&tk[sl[j]]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if ((uint32_t)j >= nj) break;
+        if (kv[j] != EMPTY_KEY && cur[j] == EMPTY_KEY)
+            cur[j] = atomicCAS((unsigned long long *)&tk[sl[j]], (unsigned long long)EMPTY_KEY, (unsigned long long)kv[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if ((uint32_t)j >= nj) break;
+        bool ins = false;
+        uint32_t slot = sl[j];
+        if (kv[j] != EMPTY_KEY) {
+            if (cur[j] == EMPTY_KEY) ins = true;                       // the CAS claimed the home slot
+            else if (cur[j] != kv[j]) {                                // someone else's key there: probe on
+                slot = 0xffffffffu;
+                uint32_t at = (sl[j] + 1) & MASK;
+                for (uint32_t probe = 0; probe < MASK; probe++, at = (at + 1) & MASK) {
+                    uint64_t c2 = lds_peek(&tk[at]);
+                    if (c2 == EMPTY_KEY)
+                        c2 = atomicCAS((unsigned long long *)&tk[at], (unsigned long long)EMPTY_KEY, (unsigned long long)kv[j]);
+                    if (c2 == EMPTY_KEY) { ins = true; slot = at; break; }
+                    if (c2 == kv[j]) { slot = at; break; }
+                }
+            }
+            if (slot != 0xffffffffu) atomicAdd(&tc[slot], 1u);
+            else ok = false;
+        }
+        const uint64_t m = __ballot(ins);
+        if (m) {                                            // uniform
+            uint32_t base = nd;
+            if (SHARED) {
+                uint32_t got = 0;
+                if (lane_id() == 0) got = atomicAdd(nd_shared, (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            }
+            if (ins) dl[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)slot;
+            nd += (uint32_t)__popcll(m);
+        }
+    }
+    return !__any(!ok);
+}
+
+template <int CAP_LOG2, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void record_dedup_kernel(
+    const ulonglong2 *__restrict__ recs, uint32_t rstride, const uint32_t *__restrict__ rcount, uint64_t n_regions, int k, int b2,
+    uint64_t kstride, uint32_t abundance_min,
+    uint64_t *__restrict__ keys, uint32_t *__restrict__ counts_out, uint64_t *__restrict__ koff, uint32_t *__restrict__ klen,
+    int *__restrict__ overflow, const uint8_t *__restrict__ region_big)
+{
+    // (CAP: the slots of a wave's table in record_count_kernel<CAP_LOG2>, whose leavings these are)
+    constexpr uint32_t CAP = 1u << CAP_LOG2, MAX_FILL = CAP - CAP / 8;
+    constexpr uint32_t BIG = CAP * WAVES;
+    constexpr int BIG_LOG2 = CAP_LOG2 + (WAVES == 4 ? 2 : WAVES == 2 ? 1 : 3);
+    static_assert((1u << BIG_LOG2) == BIG, "WAVES is 2, 4 or 8");
+    constexpr int NF = 1 << RUN_FINE_BITS;
+    constexpr uint32_t CH = 64, CH_WORDS = (CH * RUN_LMAX + 63) / 64;
+    constexpr uint32_t THREADS = WAVES * 64;
+    __shared__ uint64_t tk_all[BIG];                    // the waves' tables; ONE table of the workgroup for a segment too large for a wave's
+    __shared__ uint32_t tc_all[BIG];
+    __shared__ uint16_t dl_all[BIG];                    // slots claimed, in the order of their claims
+    __shared__ ulonglong2 srec_all[WAVES][CH];
+    __shared__ uint16_t sstart_all[WAVES][CH];
+    __shared__ uint64_t starts_all[WAVES][CH_WORDS];
+    __shared__ uint8_t firstrec_all[WAVES][CH_WORDS + 2];
+    __shared__ uint32_t kcount[NF], kstart[NF], rcnt[NF], rstart[NF];       // k-mers / records per fine bucket, and where they start
+    __shared__ uint16_t small_list[NF], big_list[NF];
+    __shared__ uint32_t scratch[32];
+    __shared__ uint64_t scratch64[32];
+    __shared__ uint32_t big_fail, big_nd;
+    const int lane = lane_id(), wave = wave_id();
+    const uint32_t B2 = 1u << b2;
+    ulonglong2 *srec = srec_all[wave];
+    uint16_t *sstart = sstart_all[wave];
+    uint64_t *starts = starts_all[wave];
+    uint8_t *firstrec = firstrec_all[wave];
+    // the tables start empty and every segment leaves them so
+    for (uint32_t i = threadIdx.x; i < BIG; i += THREADS) { tk_all[i] = EMPTY_KEY; tc_all[i] = 0; }
+    __syncthreads();
+    for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
+        if (!region_big[region]) continue;                      // only what record_count_kernel left
+        const uint32_t n = min(rcount[region], rstride);
+        const ulonglong2 *rr = recs + region * rstride;
+        const uint64_t seg0 = region << b2;
+        // ---- pass A: records and k-mers per fine bucket -> record segments, key segments ----
+        if (threadIdx.x < NF) { kcount[threadIdx.x] = 0; rcnt[threadIdx.x] = 0; }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+            const uint64_t y = rr[i].y;
+            const uint32_t f = run_fine(y) >> (RUN_FINE_BITS - b2);
+            atomicAdd(&kcount[f], run_len(y));
+            atomicAdd(&rcnt[f], 1u);
+        }
+        __syncthreads();
+        const uint32_t cnt = threadIdx.x < B2 ? kcount[threadIdx.x] : 0u;
+        const uint32_t rc = threadIdx.x < B2 ? rcnt[threadIdx.x] : 0u;
+        uint64_t both_total;
+        const uint64_t both = block_scan_sum64(((uint64_t)rc << 32) | cnt, scratch64, &both_total);
+        const uint32_t pre = (uint32_t)both, region_keys = (uint32_t)both_total;
+        const bool fits = region_keys <= kstride;                 // uniform
+        // ("small" is what record_count_kernel<CAP_LOG2> took -- up to MAX_FILL k-mers in up to 64 records)
+        const bool is_small = threadIdx.x < B2 && cnt <= MAX_FILL && rc <= 64u;
+        const bool is_big = threadIdx.x < B2 && !is_small;
+        uint32_t n_small, n_big;
+        const uint32_t ps = block_scan_sum(is_small ? 1u : 0u, scratch, &n_small);
+        const uint32_t pb = block_scan_sum(is_big ? 1u : 0u, scratch, &n_big);
+        if (threadIdx.x < B2) {
+            kstart[threadIdx.x] = pre;
+            rstart[threadIdx.x] = (uint32_t)(both >> 32);
+            koff[seg0 + threadIdx.x] = region * kstride + pre;
+            if (!fits) klen[seg0 + threadIdx.x] = 0;
+            if (is_small) small_list[ps] = (uint16_t)threadIdx.x;
+            if (is_big) big_list[pb] = (uint16_t)threadIdx.x;
+        }
+        if (threadIdx.x == 0) { big_fail = 0; big_nd = 0; }
+        __syncthreads();
+        if (!fits) {
+            if (threadIdx.x == 0) atomicExch(overflow, 1);
+            continue;
+        }
+        // ---- segments too large for a wave's table: the workgroup's waves share one table ----
+        for (uint32_t bi = 0; bi < n_big; bi++) {
+            const uint32_t f = big_list[bi];
+            const uint32_t nr = rcnt[f], r0 = rstart[f];
+            uint32_t nd = 0;
+            bool ok = true;
+            for (uint32_t c0 = (uint32_t)wave * CH; c0 < nr; c0 += WAVES * CH) {
+                const uint32_t nc = min(CH, nr - c0);
+                const ulonglong2 rec = (uint32_t)lane < nc ? rr[r0 + c0 + lane] : make_ulonglong2(0, 0);
+                const uint32_t tot = record_chunk_stage(rec, nc, srec, sstart, starts, firstrec);
+                for (uint32_t q0 = 0; q0 < tot; q0 += 256) {
+                    uint64_t kv[4];
+                    const uint32_t nj = min(4u, (tot - q0 + 63u) >> 6);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if ((uint32_t)j >= nj) break;
+                        const uint32_t q = q0 + 64u * j + lane;
+                        kv[j] = q < tot ? record_chunk_kmer(q, k, srec, sstart, starts, firstrec) : EMPTY_KEY;
+                    }
+                    ok &= record_insert4<BIG_LOG2, true>(tk_all, tc_all, dl_all, &big_nd, kv, nj, nd);
+                }
+                wave_lds_fence();
+            }
+            if (!ok && lane == 0) atomicExch(&big_fail, 1u);
+            __syncthreads();
+            const bool failed = big_fail != 0;                  // uniform
+            const uint32_t nd_all = min(big_nd, BIG);
+            const uint64_t dst = region * kstride + kstart[f];
+            uint32_t base = 0;
+            for (uint32_t p0 = 0; p0 < nd_all; p0 += THREADS) {
+                const uint32_t p = p0 + threadIdx.x;
+                const uint32_t slot = p < nd_all ? dl_all[p] : 0u;
+                const uint64_t key = tk_all[slot];
+                const uint32_t c = tc_all[slot];
+                const bool keep = !failed && p < nd_all && c >= abundance_min;
+                uint32_t sweep_total;
+                const uint32_t pos = sweep_compact(keep, scratch, &sweep_total);
+                if (keep) {
+                    keys[dst + base + pos] = key;
+                    if (counts_out) counts_out[dst + base + pos] = c;
+                }
+                base += sweep_total;
+            }
+            __syncthreads();
+            for (uint32_t p = threadIdx.x; p < nd_all; p += THREADS) {
+                const uint32_t slot = dl_all[p];
+                tk_all[slot] = EMPTY_KEY;
+                tc_all[slot] = 0;
+            }
+            if (threadIdx.x == 0) {
+                klen[seg0 + f] = base;
+                if (failed) atomicExch(overflow, 1);
+                big_fail = 0;
+                big_nd = 0;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// The counting stage's main launch over the record form: as record_dedup_kernel (which now takes what this one leaves), with the
+// table cut down to ONE 32-bit word per slot.  The insert chain of the 64-bit table -- read the key, claim it, walk on, count,
+// list the slot, read key and count back -- ran at 33 of record_dedup's 50 ms with neither the VALU (56 %) nor the LDS (40 %)
+// busy: 16 waves per CU (37 KB of LDS per workgroup) waiting for one another's LDS round trips.  Here a wave's table is 2 KB:
+//   slot = count << 20 | fingerprint << 9 | (number of the k-mer inside its segment + 1)          0 = empty
+// A k-mer claims its home slot with ONE 32-bit compare-and-swap; a slot held by another k-mer with another fingerprint (11 more
+// bits of the hash) is passed by, one with the same fingerprint names its k-mer, which is cut out of the staged records again and
+// compared (a true repeat, or one in 2048 of the others).  The keys stay in registers (up to 7 per lane: a wave's segments have up
+// to 448 k-mers in up to 64 records), so the pass that writes the segment out reads one word per claimed slot and zeroes it.
+// Segments beyond that -- and counts from 4094 on -- are left to record_dedup_kernel (region_big / *overflow).
+template <int NW>
+__device__ __forceinline__ uint32_t record_stage_small(ulonglong2 rec, uint32_t nr, ulonglong2 *srec, uint16_t *sstart, uint64_t *starts, uint8_t *firstrec)
+{
+    const int lane = lane_id();
+    const uint32_t ln = (uint32_t)lane < nr ? run_len(rec.y) : 0u;
+    const uint32_t incl = wave_scan_incl_dpp(ln), st = incl - ln;
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    srec[lane] = rec;
+    sstart[lane] = (uint16_t)st;
+    if (lane < NW) { starts[lane] = 0; firstrec[lane] = (uint8_t)nr; }
+    wave_lds_fence();
+    const uint32_t w = st >> 6;
+    const uint32_t w_prev = __shfl_up(w, 1);
+    if (ln) {
+        atomicOr((unsigned long long *)&starts[w], 1ull << (st & 63u));
+        if (lane == 0 || w_prev != w) firstrec[w] = (uint8_t)lane;
+    }
+    wave_lds_fence();
+    return tot;
+}
+
+template <int CAP_LOG2, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 5) void record_count_kernel(
+    const ulonglong2 *__restrict__ recs, uint32_t rstride, const uint32_t *__restrict__ rcount, uint64_t n_regions, int k, int b2,
+    uint64_t kstride, uint32_t abundance_min,
+    uint64_t *__restrict__ keys, uint32_t *__restrict__ counts_out, uint64_t *__restrict__ koff, uint32_t *__restrict__ klen,
+    int *__restrict__ overflow, uint8_t *__restrict__ region_big, int *__restrict__ any_big)
+{
+    constexpr uint32_t CAP = 1u << CAP_LOG2, MASK = CAP - 1, MAX_FILL = CAP - CAP / 8;
+    constexpr int KJ = (int)((MAX_FILL + 63) / 64);                 // keys a lane holds
+    constexpr int NW = KJ + 1;                                      // bitmap words of a segment's k-mer positions
+    constexpr uint32_t ID_BITS = 9, FP_BITS = 11, FP_MASK = ((1u << FP_BITS) - 1) << ID_BITS, ONE = 1u << (ID_BITS + FP_BITS);
+    static_assert(MAX_FILL + 1 <= (1u << ID_BITS), "a k-mer's number inside its segment fits the slot word");
+    constexpr int NF = 1 << RUN_FINE_BITS;
+    constexpr uint32_t THREADS = WAVES * 64;
+    __shared__ uint32_t tab_all[WAVES][CAP];
+    __shared__ ulonglong2 srec_all[WAVES][64];
+    __shared__ uint16_t sstart_all[WAVES][64];
+    __shared__ uint64_t starts_all[WAVES][NW];
+    __shared__ uint8_t firstrec_all[WAVES][NW + (8 - NW % 8)];
+    __shared__ uint32_t kcount[NF], kstart[NF], rcnt[NF], rstart[NF];
+    __shared__ uint16_t small_list[NF];
+    __shared__ uint32_t scratch[32];
+    __shared__ uint64_t scratch64[32];
+    const int lane = lane_id(), wave = wave_id();
+    const uint32_t B2 = 1u << b2;
+    uint32_t *tab = tab_all[wave];
+    ulonglong2 *srec = srec_all[wave];
+    uint16_t *sstart = sstart_all[wave];
+    uint64_t *starts = starts_all[wave];
+    uint8_t *firstrec = firstrec_all[wave];
+    for (uint32_t i = threadIdx.x; i < WAVES * CAP; i += THREADS) (&tab_all[0][0])[i] = 0;
+    bool saturated = false;
+    __syncthreads();
+    for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
+        const uint32_t n = min(rcount[region], rstride);
+        const ulonglong2 *rr = recs + region * rstride;
+        const uint64_t seg0 = region << b2;
+        // ---- pass A: records and k-mers per fine bucket -> record segments, key segments ----
+        if (threadIdx.x < NF) { kcount[threadIdx.x] = 0; rcnt[threadIdx.x] = 0; }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+            const uint64_t y = rr[i].y;
+            const uint32_t f = run_fine(y) >> (RUN_FINE_BITS - b2);
+            atomicAdd(&kcount[f], run_len(y));
+            atomicAdd(&rcnt[f], 1u);
+        }
+        __syncthreads();
+        const uint32_t cnt = threadIdx.x < B2 ? kcount[threadIdx.x] : 0u;
+        const uint32_t rc = threadIdx.x < B2 ? rcnt[threadIdx.x] : 0u;
+        uint64_t both_total;
+        const uint64_t both = block_scan_sum64(((uint64_t)rc << 32) | cnt, scratch64, &both_total);
+        const uint32_t pre = (uint32_t)both, region_keys = (uint32_t)both_total;
+        const bool fits = region_keys <= kstride;                 // uniform
+        const bool is_small = threadIdx.x < B2 && cnt <= MAX_FILL && rc <= 64u;
+        uint32_t n_small;
+        const uint32_t ps = block_scan_sum(is_small ? 1u : 0u, scratch, &n_small);
+        if (threadIdx.x < B2) {
+            kstart[threadIdx.x] = pre;
+            rstart[threadIdx.x] = (uint32_t)(both >> 32);
+            koff[seg0 + threadIdx.x] = region * kstride + pre;
+            if (!fits || !is_small) klen[seg0 + threadIdx.x] = 0;
+            if (is_small) small_list[ps] = (uint16_t)threadIdx.x;
+        }
+        if (threadIdx.x == 0) {
+            const bool big = fits && n_small < B2;
+            region_big[region] = big ? 1 : 0;
+            if (big) atomicExch(any_big, 1);
+            if (!fits) atomicExch(overflow, 1);
+        }
+        __syncthreads();
+        if (fits) {
+            // (a segment's records are asked for two segments ahead)
+            uint32_t idx = (uint32_t)wave;
+            uint32_t f = idx < n_small ? small_list[idx] : 0u;
+            uint32_t nr = idx < n_small ? rcnt[f] : 0u;
+            ulonglong2 first = (uint32_t)lane < nr ? rr[rstart[f] + lane] : make_ulonglong2(0, 0);
+            uint32_t f_n = idx + WAVES < n_small ? small_list[idx + WAVES] : 0u;
+            uint32_t nr_n = idx + WAVES < n_small ? rcnt[f_n] : 0u;
+            ulonglong2 second = (uint32_t)lane < nr_n ? rr[rstart[f_n] + lane] : make_ulonglong2(0, 0);
+            while (idx < n_small) {
+                const uint32_t tot = record_stage_small<NW>(first, nr, srec, sstart, starts, firstrec);
+                const uint32_t nj = (tot + 63u) >> 6;
+                const uint32_t idx_2 = idx + 2 * WAVES;
+                const uint32_t f_2 = idx_2 < n_small ? small_list[idx_2] : 0u;
+                const uint32_t nr_2 = idx_2 < n_small ? rcnt[f_2] : 0u;
+                first = second;
+                second = (uint32_t)lane < nr_2 ? rr[rstart[f_2] + lane] : make_ulonglong2(0, 0);
+                uint64_t kv[KJ];
+                uint32_t sl[KJ], old[KJ];
+                uint32_t fresh = 0;
+                // the claims of the home slots: all in flight together
+#pragma unroll
+                for (int j = 0; j < KJ; j++) {
+                    if ((uint32_t)j >= nj) break;
+                    const uint32_t q = 64u * j + lane;
+                    kv[j] = q < tot ? record_chunk_kmer(q, k, srec, sstart, starts, firstrec) : EMPTY_KEY;
+                    const uint32_t h = record_slot_hash(kv[j]);
+                    sl[j] = h >> (32 - CAP_LOG2);
+                    const uint32_t nw = ONE | ((h >> (32 - CAP_LOG2 - FP_BITS)) << ID_BITS & FP_MASK) | (q + 1u);
+                    old[j] = q < tot ? atomicCAS(&tab[sl[j]], 0u, nw) : 0xffffffffu;
+                }
+#pragma unroll
+                for (int j = 0; j < KJ; j++) {
+                    if ((uint32_t)j >= nj) break;
+                    if (old[j] != 0xffffffffu) {
+                        uint32_t o = old[j], at = sl[j];
+                        bool mine = true;
+                        // (the slot word again -- only a k-mer that found its home slot taken comes here)
+                        const uint32_t nw = o == 0u ? 0u
+                                                    : ONE | ((record_slot_hash(kv[j]) >> (32 - CAP_LOG2 - FP_BITS)) << ID_BITS & FP_MASK) | (64u * j + lane + 1u);
+                        while (o != 0u) {
+                            if (((o ^ nw) & FP_MASK) == 0u) {             // the same fingerprint: the same k-mer?
+                                const uint64_t other = record_chunk_kmer((o & ((1u << ID_BITS) - 1u)) - 1u, k, srec, sstart, starts, firstrec);
+                                if (other == kv[j]) {
+                                    const uint32_t was = atomicAdd(&tab[at], ONE);
+                                    if ((was >> (ID_BITS + FP_BITS)) >= 4094u) saturated = true;
+                                    mine = false;
+                                    break;
+                                }
+                            }
+                            at = (at + 1) & MASK;
+                            o = atomicCAS(&tab[at], 0u, nw);
+                        }
+                        if (mine) { fresh |= 1u << j; sl[j] = at; }
+                    }
+                }
+                wave_lds_fence();
+                // the segment leaves: claimed slots in the order of the k-mers, each left empty
+                const uint64_t dst = region * kstride + kstart[f];
+                uint32_t base = 0;
+#pragma unroll
+                for (int j = 0; j < KJ; j++) {
+                    if ((uint32_t)j >= nj) break;
+                    const bool fr = (fresh >> j) & 1u;
+                    uint32_t c = 0;
+                    if (fr) {
+                        c = tab[sl[j]] >> (ID_BITS + FP_BITS);
+                        tab[sl[j]] = 0;
+                    }
+                    const bool keep = fr && c >= abundance_min;
+                    const uint64_t m = __ballot(keep);
+                    if (keep) {
+                        const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        keys[dst + pos] = kv[j];
+                        if (counts_out) counts_out[dst + pos] = c;
+                    }
+                    base += (uint32_t)__popcll(m);
+                }
+                if (lane == 0) klen[seg0 + f] = base;
+                wave_lds_fence();
+                idx += WAVES;
+                f = f_n; nr = nr_n;
+                f_n = f_2; nr_n = nr_2;
+            }
+        }
+        __syncthreads();
+    }
+    if (__any(saturated) && lane == 0) atomicExch(overflow, 1);
+}
+
 // ------------------------------------------------------------------------------------
 // Stage 3a (K5): per-bucket dictionary AND presence bits.  One workgroup per (bucket, sub-bucket)
 // unions the bucket's segment of EVERY genome in an LDS table; a wave takes one genome at a time,
@@ -2670,6 +3110,38 @@ void launch_bucket_dedup_wave(hipStream_t s, uint64_t *keys, const SegLayout &se
     else if (wave_cap_log2 == 10) GRM_LAUNCH_DW(10, 4)
     else GRM_LAUNCH_DW(11, 2)
 #undef GRM_LAUNCH_DW
+}
+// counting stage over the record form: the wave-table launch (2^cap_log2 one-word slots per wave; 8: tests), then -- when it left
+// segments behind (too many k-mers or records for a wave; *any_big, read back by the caller) -- launch_record_dedup_rest
+void launch_record_count(hipStream_t s, const void *recs, uint32_t rstride, const uint32_t *rcount, uint64_t n_regions, int k, int bb, int b1,
+                         uint64_t kstride, int cap_log2, uint32_t abundance_min, uint64_t *keys, uint32_t *counts_out, uint64_t *koff,
+                         uint32_t *klen, int *overflow, uint8_t *region_big, int *any_big)
+{
+    if (!n_regions) return;
+    const ulonglong2 *r = reinterpret_cast<const ulonglong2 *>(recs);
+    const int b2 = bb - b1;
+    const uint32_t grid = (uint32_t)(n_regions < 256u * 32u ? n_regions : 256u * 32u);
+    if (cap_log2 <= 8)
+        hipLaunchKernelGGL((record_count_kernel<8, 4>), dim3(grid), dim3(256), 0, s, r, rstride, rcount, n_regions, k, b2, kstride, abundance_min, keys,
+                           counts_out, koff, klen, overflow, region_big, any_big);
+    else
+        hipLaunchKernelGGL((record_count_kernel<9, 4>), dim3(grid), dim3(256), 0, s, r, rstride, rcount, n_regions, k, b2, kstride, abundance_min, keys,
+                           counts_out, koff, klen, overflow, region_big, any_big);
+}
+void launch_record_dedup_rest(hipStream_t s, const void *recs, uint32_t rstride, const uint32_t *rcount, uint64_t n_regions, int k, int bb, int b1,
+                              uint64_t kstride, int cap_log2, uint32_t abundance_min, uint64_t *keys, uint32_t *counts_out, uint64_t *koff,
+                              uint32_t *klen, int *overflow, const uint8_t *region_big)
+{
+    if (!n_regions) return;
+    const ulonglong2 *r = reinterpret_cast<const ulonglong2 *>(recs);
+    const int b2 = bb - b1;
+    const uint32_t grid = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
+    if (cap_log2 <= 8)
+        hipLaunchKernelGGL((record_dedup_kernel<8, 4>), dim3(grid), dim3(256), 0, s, r, rstride, rcount, n_regions, k, b2, kstride, abundance_min, keys,
+                           counts_out, koff, klen, overflow, region_big);
+    else
+        hipLaunchKernelGGL((record_dedup_kernel<9, 4>), dim3(grid), dim3(256), 0, s, r, rstride, rcount, n_regions, k, b2, kstride, abundance_min, keys,
+                           counts_out, koff, klen, overflow, region_big);
 }
 static int g_dict_kif = 8, g_table_threads = 0;      // 0: every kernel's own default (key form: TABLE_THREADS, record form: 256)
 void set_table_tuning(int kif, int threads)

@@ -69,7 +69,8 @@ const char *grm_version(void);
  * fill), "direct_permute", "dense_layout", "dedup_wg", "dedup_cap_shift", "wide_sort" (k > 32 through the sort-based path), "no_union"
  * (gathered rank dictionaries sorted as a whole), "parse_fused" (single-pass parse kernel).  Record form: "rec_bucket_shift",
  * "rec_part_bits", "rec_coarse", "rec_memo" (log2 of dict_build's record memo base, 0 = none), "memo_stats" (1: count memo hits, see
- * grm_batch_memo_stats).  Host: "upload_slab_kb". */
+ * grm_batch_memo_stats), "rec_count" (0: a counting partition never takes the record form), "rec_count_cap" (8: its wave tables hold
+ * 256 slots instead of 512).  Host: "upload_slab_kb". */
 int         grm_set_option(grm_ctx *, const char *name, int value);
 /* per-kernel device timings (HIP events on the engine's stream) */
 int         grm_timing_enable(grm_ctx *, int on);

@@ -360,6 +360,8 @@ uint64_t emul_runs(const uint64_t *sym2, const uint64_t *inv, uint64_t total_sym
             nr++;
             RunDecoder d = run_open(x, y, k);
             for (uint32_t t = 0; t < len; t++) {
+                // (the counting stage cuts k-mer number t out of the record's words directly: the same k-mer)
+                if (run_kmer_at(x, y, k, t) != run_canonical(d)) return ~0ull - 8;
                 if (n < cap) { out_keys[n] = run_canonical(d); out_bucket[n] = bucket; }
                 n++;
                 run_next(d, kmask, rcshift);

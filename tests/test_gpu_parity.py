@@ -977,6 +977,45 @@ def test_counting_stage_on_random_genomes(ctx):
     b.free()
 
 
+@pytest.mark.parametrize("k,opts,by_records", [(31, {}, True), (21, {}, True), (32, {}, True), (31, {"rec_count": 0}, False), (25, {"bucket_bits": 6}, True),
+                                               (31, {"rec_count_cap": 8}, True), (31, {"bucket_bits": 5, "rec_count_cap": 8}, False),
+                                               (31, {"bucket_bits": 4}, False)])
+def test_counting_stage_through_the_record_form(ctx, k, opts, by_records):
+    """from 128 genomes on a counting partition moves records (level 1), expands them to key segments by minimizer bucket (level 2)
+    and counts there: counted sets with a repeated stretch and contigs on either strand equal the oracle's, with and without the
+    abundance filter; "rec_count" 0 is the key form on the same input; the matrix of the filtered sets too.  "rec_count_cap" 8: wave
+    tables of 256 slots, so that segments of more than 224 k-mers take the workgroup's shared table (1024 slots) -- and with 2^5 buckets
+    (~1000 distinct k-mers per segment) overflow it, which sends the batch to the key form; 2^4 buckets: segments too large to try"""
+    n = 130
+    pg = synth.realistic(genome_len=30_000, seed=17, contigs=(1, 4), indel_sites=10, n_snps=300, n_accessory=3, accessory_len=500)
+    genomes = []
+    for i in range(n):
+        g = pg.genome(i).tobytes()
+        genomes.append(g + g[: 4000 + 37 * i])                  # a repeated stretch (cut inside a line): counts above 1
+    check = (0, 1, 63, 64, 127, n - 1)
+    try:
+        for name, v in opts.items():
+            ctx.set_option(name, v)
+        for amin in (1, 2):
+            b = ctx.batch(n)
+            for g, f in enumerate(genomes):
+                b.add(g, f)
+            b.upload()
+            b.partition_counts(k, amin)
+            assert (b.bucket_bits & 0x100 != 0) == by_records
+            for g in check:
+                km, ct, nocc = orc.count_genome([genomes[g]], k, amin)
+                s = b.genome_set(g)
+                assert s.occurrences == nocc
+                assert s.kmers().shape == km.shape and (s.kmers() == km).all() and (s.counts() == ct).all()
+                s.free()
+            b.free()
+        _check(ctx, [[g] for g in genomes], k, 2, True)
+    finally:
+        for name in opts:
+            ctx.set_option(name, -1)
+
+
 # ---- the reference-held fixture through the HIP path -------------------------------------------
 def test_reference_31mers_through_the_engine(ctx, golden_dir):
     """the 196 canonical 31-mers the reference ships (page/results/**, output of the real DSK pipeline) as
