@@ -2702,14 +2702,14 @@ static int build_matrix_multi(grm_ctx *c, grm_kmer_set *const *sets, int n_genom
 // Three stages, as for one-word k-mers: local (partition + per-bucket dictionary of this batch's
 // genomes), global (sort / merge / filter of the k-mers of every rank), fill.
 struct WideHash {
-    DevBuf counts, off, cursor1, keys, keys1, len;
+    DevBuf counts, off, cursor1, keys, keys1, len, recs, recs2;
     DevBuf stage_lo, stage_hi, stage_flags, stage_cnt, stage_off, matrix_s, birth, entry_col, entry_major, flag;
     DevBuf loc_lo, loc_hi, loc_flags, idx0, idx1, idx2, t_a, t_b, keep, pos, tmp, g_hi, g_lo;
     int sb = 0, sb_hint = -1, sb_hint_k = 0, sb_hint_bb = -1;
     uint32_t cap_log2 = 0, n_wg = 0, U = 0;
     uint64_t n_local = 0, n_sorted = 0;
     uint64_t seg_stride = 0;       // 0: dense layout (off); else slack layout (segment i at i * seg_stride, length len[i])
-    bool slack_failed = false, have_bits = false, own_dict = false;
+    bool slack_failed = false, have_bits = false, own_dict = false, rec_failed = false;
     bool have_local = false, have_global = false;
 };
 static void wide_hash_free(WideHash *w) { delete w; }
@@ -2747,10 +2747,68 @@ static int wide_hash_local(grm_batch *b, int k, bool *fallback)
     L.sym2 = b->d_sym2.as<uint64_t>(); L.inv = b->d_inv.as<uint64_t>(); L.total_syms = b->total_syms;
     L.genome_sym_off = b->d_genome_sym_off.as<uint64_t>(); L.n_genomes = G; L.k = k; L.bb = bb; L.groups_per_thread = 1;
 
-    HIPCHK(c, W.cursor1.ensure(n_coarse * 4)); HIPCHK(c, W.flag.ensure(16));
+    HIPCHK(c, W.cursor1.ensure(std::max<uint64_t>(n_coarse, G) * 4)); HIPCHK(c, W.flag.ensure(32));
+    // ---- record form (grm_superkmer.hip): from 128 genomes on (one part per genome) the k-mers travel as 24-byte run records --
+    // runs of up to 22 k-mers that share the minimizer among the m-mers in the middle of the k-mer: 2.1 B per k-mer through level 1
+    // and level 2 instead of 16 B through wh_scatter_l1 / l2, and wh_dict_build cuts the k-mers out of the records ----
+    bool by_recs = false;
+    if (c->opt_records != 0 && c->opt_dense_layout <= 0 && !W.rec_failed && G >= 128 && k <= 64) {
+        int bbr = c->opt_bucket_bits >= 0 ? bb : bb + 1;           // (minimizer buckets are less even than hashed k-mers: one more bit)
+        bbr = std::min(bbr, superkmer_coarse_bits(bbr) + 7);
+        const int b1r = superkmer_coarse_bits(bbr);
+        const uint64_t n_regions = (uint64_t)G << b1r, n_seg_r = (uint64_t)G << bbr;
+        const int w = superkmer_wide_window(k);
+        const double mean_k = (double)(max_g >> b1r) + 1.0;
+        const double mean_r = mean_k * (2.0 / (w + 1) + 0.005);
+        const uint64_t rstride64 = (uint64_t)(mean_r * 1.02 + 14.0 * std::sqrt(mean_r) + 32.0 + 15.0) / 16 * 16;
+        const double expected_records = (double)b->total_syms * (2.0 / (w + 1) + 0.005);
+        bool rec = n_seg_r < 0xffffffffull && (rstride64 << b1r) < 0xffffffffull && mean_r / (double)(1u << (bbr - b1r)) < 16000.0 &&
+                   (double)n_regions * (double)rstride64 <= 4.0 * expected_records + 16.0 * 1024 * 1024 &&
+                   ((size_t)1 << bbr) * (((size_t)G + 63) / 64) * cap * 8 <= MATRIX_S_LIMIT;
+        if (rec) {
+            hipError_t e = W.recs.ensure((n_regions * rstride64 + 4) * 24);
+            if (e == hipSuccess) e = W.recs2.ensure((n_regions * rstride64 + 4) * 24);
+            if (e == hipSuccess) e = W.off.ensure((n_seg_r + 1) * 8);
+            if (e == hipSuccess) e = W.len.ensure((n_seg_r + 1) * 4);
+            if (e == hipSuccess) e = W.counts.ensure((n_regions + 1) * 4);
+            if (e != hipSuccess) { (void)hipGetLastError(); rec = false; }
+        }
+        if (rec) {
+            const uint32_t rstride = (uint32_t)rstride64;
+            KmerLaunch Lr = L;
+            Lr.bb = bbr;
+            HIPCHK(c, hipMemsetAsync(W.flag.p, 0, 32, s));
+            {
+                TimeScope t(c, "superkmer_l1", b->total_syms);
+                launch_superkmer_l1(s, Lr, b1r, 0, W.recs.p, rstride, W.counts.as<uint32_t>(), W.cursor1.as<uint32_t>(), W.flag.as<int>());
+            }
+            int l2_idx = -1;
+            {
+                TimeScope t(c, "superkmer_l2", b->total_syms);
+                l2_idx = t.idx;
+                launch_superkmer_l2_wide(s, W.recs.p, rstride, W.counts.as<uint32_t>(), n_regions, k, bbr, b1r, W.recs2.p, W.off.as<uint64_t>(),
+                                         W.len.as<uint32_t>(), W.flag.as<int>());
+            }
+            launch_sum_u32(s, W.cursor1.as<uint32_t>(), G, reinterpret_cast<uint64_t *>(W.flag.as<uint8_t>() + 8));
+            launch_sum_u32(s, W.counts.as<uint32_t>(), n_regions, reinterpret_cast<uint64_t *>(W.flag.as<uint8_t>() + 16));
+            HIPCHK(c, hipGetLastError());
+            struct { int over; int pad; uint64_t total; uint64_t records; uint64_t pad2; } h;
+            HIPCHK(c, hipMemcpyAsync(&h, W.flag.p, 32, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (l2_idx >= 0 && l2_idx < (int)c->recs.size()) c->recs[l2_idx].units = h.records;
+            if (!h.over) {
+                by_recs = true;
+                bb = bbr;
+                b->bb = bbr;
+                b->total_keys = h.total;
+            } else {
+                W.rec_failed = true;         // repeat-rich input: the key form from now on
+            }
+        }
+    }
     // ---- partition: slack layout (no histogram pass; see batch_partition_impl), dense layout as the fallback ----
     W.seg_stride = 0;
-    bool slack = c->opt_dense_layout <= 0 && !W.slack_failed;
+    bool slack = !by_recs && c->opt_dense_layout <= 0 && !W.slack_failed;
     uint32_t fine_cap = 0;
     uint64_t region_stride = 0;
     if (slack) {
@@ -2784,7 +2842,7 @@ static int wide_hash_local(grm_batch *b, int k, bool *fallback)
         if (h.over) { W.slack_failed = true; slack = false; }
         else { b->total_keys = h.total; W.seg_stride = fine_cap; }
     }
-    if (!slack) {
+    if (!slack && !by_recs) {
         HIPCHK(c, W.counts.ensure((n_seg + 1) * 4)); HIPCHK(c, W.off.ensure((n_seg + 1) * 8));
         HIPCHK(c, hipMemsetAsync(W.counts.p, 0, (n_seg + 1) * 4, s));
         HIPCHK(c, hipMemsetAsync(W.cursor1.p, 0, n_coarse * 4, s));
@@ -2816,7 +2874,8 @@ static int wide_hash_local(grm_batch *b, int k, bool *fallback)
     }
     const uint64_t NK = b->total_keys;
     SegLayout seg;
-    if (W.seg_stride) { seg.off = nullptr; seg.len = W.len.as<uint32_t>(); seg.stride = W.seg_stride; }
+    if (by_recs) { seg.off = W.off.as<uint64_t>(); seg.len = W.len.as<uint32_t>(); seg.stride = 0; }         // (in records)
+    else if (W.seg_stride) { seg.off = nullptr; seg.len = W.len.as<uint32_t>(); seg.stride = W.seg_stride; }
     else { seg.off = W.off.as<uint64_t>(); seg.len = nullptr; seg.stride = 0; }
 
     // ---- per-bucket dictionary + presence bits; the sub-bucket count jumps to what a failed launch asked for ----
@@ -2841,9 +2900,9 @@ static int wide_hash_local(grm_batch *b, int k, bool *fallback)
         HIPCHK(c, hipMemsetAsync(W.flag.p, 0, 16, s));
         {
             TimeScope t(c, "wh_dict_build", NK);
-            launch_wh_dict_build(s, W.keys.p, seg, G, bb, sb, cap_log2, W.stage_lo.as<uint64_t>(), W.stage_hi.as<uint64_t>(),
+            launch_wh_dict_build(s, by_recs ? W.recs2.p : W.keys.p, seg, G, bb, sb, cap_log2, W.stage_lo.as<uint64_t>(), W.stage_hi.as<uint64_t>(),
                                  W.stage_flags.as<uint8_t>(), W.stage_cnt.as<uint32_t>(), W.matrix_s.as<uint64_t>(), W.birth.as<uint16_t>(),
-                                 W.flag.as<int>(), W.flag.as<uint32_t>() + 1);
+                                 W.flag.as<int>(), W.flag.as<uint32_t>() + 1, by_recs ? k : 0);
         }
         HIPCHK(c, hipGetLastError());
         struct { int over; uint32_t need; } h;

@@ -747,4 +747,101 @@ GRM_HD void for_each_kmer_wide(uint64_t w0, uint64_t w1, uint64_t w2, int off, u
     }
 }
 
+
+// ---- run records of two-word k-mers (33 <= k <= 64) -----------------------------------------------------------------
+// The minimizer of such a k-mer is taken among the RUNW_W(k) <= 22 m-mers in the MIDDLE of its k - 10: the window minimum,
+// the run heads and the 7 + 5 + 1 field bits are then exactly those of one-word k-mers, computed on the stream moved on by
+// runw_offset(k) positions.  (The window has the parity of k - 10, so that it is centred: a k-mer and its reverse complement
+// look at the same m-mers and land in the same bucket.)  A run of up to 22 k-mers is up to 85 bases: THREE words,
+//     r[0], r[1]        bases 0..63
+//     r[2][63..22]      bases 64..84          r[2][12..0] as y[12..0] of the 16-byte record (flip mark, fine bucket, length)
+// stored strand-canonically as the 16-byte records are (level 1 marks, level 2 turns over).
+GRM_HD int runw_window(int k) { return ((k - 10) & 1) ? 21 : 22; }
+GRM_HD int runw_offset(int k) { return (k - 10 - runw_window(k)) / 2; }
+struct RunW {
+    uint64_t r[3];
+};
+// 192-bit shift to the left by 0 <= sh < 192 bits
+GRM_HD void shl192(uint64_t &a, uint64_t &b, uint64_t &c, int sh)
+{
+    if (sh >= 128) { a = c; b = 0; c = 0; sh -= 128; }
+    else if (sh >= 64) { a = b; b = c; c = 0; sh -= 64; }
+    if (sh) {
+        a = (a << sh) | (b >> (64 - sh));
+        b = (b << sh) | (c >> (64 - sh));
+        c <<= sh;
+    }
+}
+// the record of the run of `len` k-mers that starts at position i (0..31) of the window whose words are e0..e3
+GRM_HD RunW runw_record(uint64_t e0, uint64_t e1, uint64_t e2, uint64_t e3, int i, uint32_t len, int k, bool flip, uint32_t fine)
+{
+    const int span = (int)len + k - 1;               // 33 .. 85 bases
+    uint64_t a = e0, b = e1, c = e2;
+    if (i) {
+        a = (e0 << (2 * i)) | (e1 >> (64 - 2 * i));
+        b = (e1 << (2 * i)) | (e2 >> (64 - 2 * i));
+        c = (e2 << (2 * i)) | (e3 >> (64 - 2 * i));
+    }
+    // the first `span` bases: 2 span bits from the top of the 192
+    const uint64_t mb = span >= 64 ? ~0ull : ~0ull << (128 - 2 * span);
+    const uint64_t mc = span > 64 ? ~0ull << (192 - 2 * span) : 0ull;
+    RunW o;
+    o.r[0] = a;
+    o.r[1] = b & mb;
+    o.r[2] = (c & mc) | (flip ? RUN_FLIP_BIT : 0ull) | ((uint64_t)(fine & ((1u << RUN_FINE_BITS) - 1u)) << RUN_LEN_BITS) | len;
+    return o;
+}
+// a record marked by level 1: reverse complement of its bases, left-aligned again; the mark goes
+GRM_HD void runw_flip(RunW &o, int k)
+{
+    if (!(o.r[2] & RUN_FLIP_BIT)) return;
+    const uint64_t low = o.r[2] & (RUN_FLIP_BIT - 1);
+    const int span = (int)run_len(o.r[2]) + k - 1;
+    // reverse complement of the 96 bases r0 : r1 : r2 = rc(r2) : rc(r1) : rc(r0); the run's bases are its LAST `span` ones
+    uint64_t a = revcomp_m(o.r[2] & ~(2 * RUN_FLIP_BIT - 1), 32), b = revcomp_m(o.r[1], 32), c = revcomp_m(o.r[0], 32);
+    shl192(a, b, c, 2 * (96 - span));
+    o.r[0] = a;
+    o.r[1] = b;
+    o.r[2] = c | low;
+}
+// canonical k-mer number t (0 .. 21) of a record
+GRM_HD K128 runw_kmer_at(const RunW &o, int k, uint32_t t)
+{
+    uint64_t a = o.r[0], b = o.r[1], c = o.r[2] & ~(2 * RUN_FLIP_BIT - 1);
+    if (t) {
+        a = (a << (2 * t)) | (b >> (64 - 2 * t));
+        b = (b << (2 * t)) | (c >> (64 - 2 * t));
+    }
+    // the k-mer = the top 2k bits of a : b, right-aligned in hi : lo
+    const int sh = 128 - 2 * k;                      // 0 .. 62
+    K128 f, r;
+    f.hi = sh ? a >> sh : a;
+    f.lo = sh ? (a << (64 - sh)) | (b >> sh) : b;
+    // reverse complement: the groups of the left-aligned k-mer reversed = right-aligned, complemented
+    // (the 128-bit frame a : b with the k-mer at its top, reversed group by group, has the k-mer's groups at its bottom)
+    const uint64_t m_hi = k == 64 ? ~0ull : ((1ull << (2 * k - 64)) - 1);
+    r.hi = (rev_groups64(b) ^ 0xAAAAAAAAAAAAAAAAull) & m_hi;
+    r.lo = rev_groups64(a) ^ 0xAAAAAAAAAAAAAAAAull;
+    return k128_less(r, f) ? r : f;
+}
+// valid k-mer starts for k up to 64: bit i <=> position o + i (o = 0..63 inside the group of i0) starts k symbols without an invalid
+// one; i0, i1, i2: three consecutive words of inv bits; meaningful for i + k - 1 <= 127 - o ... the callers use i <= 32
+GRM_HD uint64_t valid_starts_wide(uint64_t i0, uint64_t i1, uint64_t i2, int o, int k)
+{
+    // inv bits of symbols o .. o + 127 in (lo, hi)
+    uint64_t lo = o ? ((i0 >> o) | (i1 << (64 - o))) : i0;
+    uint64_t hi = o ? ((i1 >> o) | (i2 << (64 - o))) : i1;
+    // OR of the k bits from every position on: doubling
+    int covered = 1;
+    while (covered * 2 <= k) {
+        const uint64_t nlo = covered >= 64 ? hi : (lo >> covered) | (hi << (64 - covered));
+        const uint64_t nhi = covered >= 64 ? 0ull : hi >> covered;
+        lo |= nlo; hi |= nhi;
+        covered *= 2;
+    }
+    const int r = k - covered;
+    if (r) lo |= (lo >> r) | (hi << (64 - r));
+    return ~lo;
+}
+
 }  // namespace grm

@@ -113,6 +113,7 @@ void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n
 int superkmer_max_bits();
 int superkmer_coarse_bits(int bb);      // b1 of a partition with 2^bb buckets
 int superkmer_lmax();
+int superkmer_wide_window(int k);            // m-mers a two-word k-mer takes its minimizer from (21 or 22, in its middle)
 void launch_region_hist(hipStream_t s, const uint64_t *keys1, const uint64_t *coarse_off, uint64_t n_regions, int bb,
                         uint32_t *counts);
 void launch_kmer_scatter_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const uint64_t *keys1,
@@ -133,6 +134,8 @@ struct SegLayout {
 };
 void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const SegLayout &seg, uint64_t n_segments, uint32_t cap_log2,
                          uint32_t abundance_min, uint32_t *len_out, const uint32_t *marks, uint32_t *counts_out, int *overflow);
+void launch_superkmer_l2_wide(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb, int b1,
+                              void *recs2, uint64_t *off, uint32_t *len_out, int *overflow);
 void launch_record_count(hipStream_t s, const void *recs, uint32_t rstride, const uint32_t *rcount, uint64_t n_regions, int k, int bb, int b1,
                          uint64_t kstride, int cap_log2, uint32_t abundance_min, uint64_t *keys, uint32_t *counts_out, uint64_t *koff,
                          uint32_t *klen, int *overflow, uint8_t *region_big, int *any_big);
@@ -301,7 +304,7 @@ void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const
 // entries leave staged at wg * cap in entry-id order; presence words at matrix_s[wg][row][entry id] (nullptr: no bits)
 void launch_wh_dict_build(hipStream_t s, const void *keys, const SegLayout &seg, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
                           uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint64_t *matrix_s,
-                          uint16_t *birth, int *overflow, uint32_t *need);
+                          uint16_t *birth, int *overflow, uint32_t *need, int recs_k = 0);
 void launch_wh_dict_gather(hipStream_t s, const uint64_t *stage_lo, const uint64_t *stage_hi, const uint8_t *stage_flags,
                            const uint64_t *stage_off, uint32_t n_wg, uint32_t cap, uint64_t *out_lo, uint64_t *out_hi, uint8_t *out_flags);
 void launch_wh_mark(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint8_t *flags, const uint32_t *order, uint64_t n,

@@ -42,7 +42,8 @@ constexpr int SK_WAVE_RUNS = 320;
 constexpr int SK_WAVES = SK_THREADS / 64;
 constexpr int SK_VAL_PITCH = SK_THREADS + 1;          // minimizer words in LDS: position i of thread t at [i * pitch + t] -- a column per thread when it writes,
                                                       // and no two positions of one thread in one bank when the lanes of its wave read them back
-constexpr size_t SK_L1_LDS = (size_t)SK_PPT * SK_VAL_PITCH * 4 + ((size_t)4 << SK_MAX_COARSE) + 128 + (size_t)SK_WAVES * (64 * 8 + 64 * 8 + SK_WAVE_RUNS * 2);
+constexpr int SK_WORD_PITCH = 66;                     // window words a wave keeps for handing runs round: its 64 lanes' + the two behind them (two-word k-mers)
+constexpr size_t SK_L1_LDS = (size_t)SK_PPT * SK_VAL_PITCH * 4 + ((size_t)4 << SK_MAX_COARSE) + 128 + (size_t)SK_WAVES * (SK_WORD_PITCH * 8 + 64 * 8 + SK_WAVE_RUNS * 2);
 static_assert(SK_L1_LDS <= 159 * 1024, "one 1024-thread workgroup per CU: its LDS");
 constexpr int SK2_THREADS = 256;
 constexpr int SK2R_THREADS = 512;                     // level 2, records only
@@ -68,7 +69,10 @@ struct SkArgs {
 // belongs to the window it STARTS in; the one that crosses the window's end goes on for as many positions as the next
 // window's thread (the lane to the right) finds in front of its first head.  Each run leaves as one record, stored at the
 // LDS cursor of its coarse region.
-template <int W>
+// WIDE (two-word k-mers, 33 <= k <= 64): W = runw_window(k) m-mers in the middle of the k-mer -- the same minimizers, heads and leads
+// computed on the stream moved on by runw_offset(k) positions; validity over k <= 64 symbols; records of 24 bytes (recs1 counts in
+// 8-byte words then: three per record).
+template <int W, bool WIDE>
 __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulonglong2 *__restrict__ recs1, uint32_t rstride,
                                                                    uint32_t *__restrict__ rcount1, uint32_t *__restrict__ part_kmers,
                                                                    int *__restrict__ overflow)
@@ -78,9 +82,9 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     uint32_t *cursor = s_val + SK_PPT * SK_VAL_PITCH;                 // records written so far to coarse region c
     uint32_t *scratch = cursor + (1u << SK_MAX_COARSE);
     // per wave, for handing the step's runs round among the lanes: every lane's window word, (run boundaries, lead), and the list of runs
-    uint64_t *w_word = reinterpret_cast<uint64_t *>(scratch + 32) + (threadIdx.x >> 6) * 64;
-    uint2 *w_edge = reinterpret_cast<uint2 *>(reinterpret_cast<uint64_t *>(scratch + 32) + SK_WAVES * 64) + (threadIdx.x >> 6) * 64;
-    uint16_t *w_runs = reinterpret_cast<uint16_t *>(reinterpret_cast<uint64_t *>(scratch + 32) + 2 * SK_WAVES * 64) + (threadIdx.x >> 6) * SK_WAVE_RUNS;
+    uint64_t *w_word = reinterpret_cast<uint64_t *>(scratch + 32) + (threadIdx.x >> 6) * SK_WORD_PITCH;
+    uint2 *w_edge = reinterpret_cast<uint2 *>(reinterpret_cast<uint64_t *>(scratch + 32) + SK_WAVES * SK_WORD_PITCH) + (threadIdx.x >> 6) * 64;
+    uint16_t *w_runs = reinterpret_cast<uint16_t *>(reinterpret_cast<uint64_t *>(scratch + 32) + SK_WAVES * (SK_WORD_PITCH + 64)) + (threadIdx.x >> 6) * SK_WAVE_RUNS;
     const int b1 = a.b1;
     const uint32_t B1 = 1u << b1;
     const uint32_t vg = blockIdx.x;
@@ -99,6 +103,8 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     const int lane = lane_id(), wave = wave_id();
     const uint32_t wave_t0 = threadIdx.x & ~63u;
     ulonglong2 *my_recs = recs1 + (uint64_t)vg * B1 * rstride;           // the part's regions: 2^b1 x rstride records (< 2^32 of them: host)
+    uint64_t *my_recs_w = reinterpret_cast<uint64_t *>(recs1) + (uint64_t)vg * B1 * rstride * 3;      // (WIDE: 24-byte records)
+    const int woff = WIDE ? runw_offset(a.k) : 0;
     const bool narrow = rstride < (1u << 15);                            // (region index x stride as a full-rate 24-bit multiply)
     uint32_t n_valid = 0;
     bool over = false;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
         const uint64_t j = j_a + (uint64_t)st * SK_STEP_WINDOWS + (uint32_t)(wave * SK_WAVE_WINDOWS + lane);
         if (j_a + (uint64_t)st * SK_STEP_WINDOWS + (uint32_t)(wave * SK_WAVE_WINDOWS) >= j_b) continue;        // (the wave as a whole: nothing left)
         uint32_t valid = 0, heads = 0;
-        uint64_t w0 = 0, w1 = 0, w2 = 0, vs = 0;
+        uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, vs = 0;
         uint32_t prev2 = 0;
         if (j <= j_b + 1) {          // (j_b: only for the run that crosses into it; j_b + 1: only its hashes; the stream buffers end with slack words)
             const uint64_t p0 = j << 5;
@@ -121,9 +127,18 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
             w0 = __builtin_nontemporal_load(&a.sym2[j]);
             w1 = __builtin_nontemporal_load(&a.sym2[j + 1]);
             w2 = __builtin_nontemporal_load(&a.sym2[j + 2]);
+            if (WIDE) w3 = __builtin_nontemporal_load(&a.sym2[j + 3]);
             prev2 = j ? (uint32_t)__builtin_nontemporal_load(&a.sym2[j - 1]) & 3u : 0u;
             // bit t of vs: position p0 - 1 + t starts a k-mer (t = 0 .. 32; k <= 32 keeps all 33 inside the 64 flags read)
-            if (p0) {
+            if (WIDE) {
+                if (p0) {
+                    const uint64_t q = p0 - 1;
+                    vs = valid_starts_wide(__builtin_nontemporal_load(&a.inv[q >> 6]), __builtin_nontemporal_load(&a.inv[(q >> 6) + 1]),
+                                           __builtin_nontemporal_load(&a.inv[(q >> 6) + 2]), (int)(q & 63), a.k);
+                } else {
+                    vs = valid_starts_wide(a.inv[0], a.inv[1], a.inv[2], 0, a.k) << 1;
+                }
+            } else if (p0) {
                 const uint64_t q = p0 - 1;
                 vs = valid_starts_at(__builtin_nontemporal_load(&a.inv[q >> 6]), __builtin_nontemporal_load(&a.inv[(q >> 6) + 1]), (int)(q & 63), a.k);
             } else {
@@ -141,7 +156,13 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
             uint32_t h[SK_PPT + W];
             {
                 uint32_t own[SK_PPT + 1];
-                run_hashes<SK_PPT + 1>(w0, w1, prev2, own);
+                if (WIDE && woff) {
+                    // the m-mers the k-mers of this window look at start woff positions further on
+                    run_hashes<SK_PPT + 1>((w0 << (2 * woff)) | (w1 >> (64 - 2 * woff)), (w1 << (2 * woff)) | (w2 >> (64 - 2 * woff)),
+                                           (uint32_t)(w0 >> (64 - 2 * woff)) & 3u, own);
+                } else {
+                    run_hashes<SK_PPT + 1>(w0, w1, prev2, own);
+                }
 #pragma unroll
                 for (int i = 0; i <= SK_PPT; i++) h[i] = own[i];
 #pragma unroll
@@ -166,19 +187,28 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
         const uint32_t n_mine = mine ? (uint32_t)__popc(heads) : 0u;
         const uint32_t upto = wave_scan_incl_dpp(n_mine);
         const uint32_t n_wave = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
-        auto emit = [&](uint64_t e0, uint64_t e1, uint64_t e2, uint32_t bnd, uint32_t lead_next, uint32_t v, int i) {
+        auto emit = [&](uint64_t e0, uint64_t e1, uint64_t e2, uint64_t e3, uint32_t bnd, uint32_t lead_next, uint32_t v, int i) {
             uint32_t len = (uint32_t)__builtin_ctz((bnd >> 1 >> i) | (0x80000000u >> i)) + 1u;       // run_length(): to the next boundary or the window's end
             if (i + (int)len == SK_PPT) len += lead_next;
             const uint32_t bkt = minimizer_bucket(v >> (32 - MINIMIZER_ORDER_BITS), b1 + SK_FINE_BITS);
             const uint32_t c = bkt >> SK_FINE_BITS;
-            uint64_t rx, ry;
-            run_record(e0, e1, e2, i, len, a.k, (v & 1u) != 0, bkt, rx, ry);
             const uint32_t slot = atomicAdd(&cursor[c], 1u);
-            if (slot < rstride) my_recs[(narrow ? mul24(c, rstride) : c * rstride) + slot] = make_ulonglong2(rx, ry);
-            else over = true;
+            if (WIDE) {
+                const RunW rw = runw_record(e0, e1, e2, e3, i, len, a.k, (v & 1u) != 0, bkt);
+                if (slot < rstride) {
+                    uint64_t *o = my_recs_w + 3ull * ((narrow ? mul24(c, rstride) : c * rstride) + slot);
+                    o[0] = rw.r[0]; o[1] = rw.r[1]; o[2] = rw.r[2];
+                } else over = true;
+            } else {
+                uint64_t rx, ry;
+                run_record(e0, e1, e2, i, len, a.k, (v & 1u) != 0, bkt, rx, ry);
+                if (slot < rstride) my_recs[(narrow ? mul24(c, rstride) : c * rstride) + slot] = make_ulonglong2(rx, ry);
+                else over = true;
+            }
         };
         if (n_wave <= (uint32_t)SK_WAVE_RUNS) {
             w_word[lane] = w0;
+            if (WIDE && lane == 63) { w_word[64] = w1; w_word[65] = w2; }
             w_edge[lane] = make_uint2(heads | ~valid, lead);
             uint32_t hd = mine ? heads : 0u, at = upto - n_mine;
             while (hd) {
@@ -189,7 +219,7 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
                 if (r0 + (uint32_t)lane < n_wave) {
                     const uint32_t e = w_runs[r0 + lane], owner = e >> 5;
                     const int i = (int)(e & 31u);
-                    emit(w_word[owner], w_word[owner + 1], w_word[owner + 2], w_edge[owner].x, w_edge[owner + 1].y,
+                    emit(w_word[owner], w_word[owner + 1], w_word[owner + 2], WIDE ? w_word[owner + 3] : 0ull, w_edge[owner].x, w_edge[owner + 1].y,
                          s_val[i * SK_VAL_PITCH + wave_t0 + owner], i);
                 }
             }
@@ -199,7 +229,7 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
             while (hd) {
                 const int i = __ffs(hd) - 1;
                 hd &= hd - 1;
-                emit(w0, w1, w2, heads | ~valid, lead_next, s_val[i * SK_VAL_PITCH + threadIdx.x], i);
+                emit(w0, w1, w2, w3, heads | ~valid, lead_next, s_val[i * SK_VAL_PITCH + threadIdx.x], i);
             }
         }
     }
@@ -430,6 +460,90 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
     }
 }
 
+// Level 2 for the 24-byte records of two-word k-mers: a region's records sorted by fine bucket (and turned over where level 1
+// marked them), as superkmer_l2_records_kernel does for 16-byte ones.  A thread keeps its <= SKW_MAXR records in registers
+// between the counting and the placing; the sorted region is put together in LDS and leaves with full-line stores.  Regions
+// of more records than that are swept twice (count, then place straight into global memory).
+// Segment vg * 2^bb + bucket = recs2[off[..] .. + len[..]) in RECORDS.
+constexpr int SKW_THREADS = 512, SKW_MAXR = 8;
+__global__ __launch_bounds__(SKW_THREADS) void superkmer_l2_wide_kernel(const uint64_t *__restrict__ recs1, uint32_t rstride,
+                                                                        const uint32_t *__restrict__ rcount1, uint64_t n_regions, int k, int bb, int b1,
+                                                                        uint64_t *__restrict__ recs2, uint64_t *__restrict__ off,
+                                                                        uint32_t *__restrict__ len_out, int *__restrict__ overflow)
+{
+    constexpr int NF = 1 << SK_FINE_BITS;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint64_t *sout = reinterpret_cast<uint64_t *>(lds_raw);              // [3 * min(rstride, SKW_THREADS * SKW_MAXR)]
+    __shared__ uint32_t hist[NF], start[NF];
+    __shared__ uint32_t scratch[32];
+    const int b2 = bb - b1;
+    const uint32_t B2 = 1u << b2;
+    for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
+        const uint32_t n = min(rcount1[region], rstride);
+        const uint64_t *rr = recs1 + region * rstride * 3;
+        uint64_t *out = recs2 + region * rstride * 3;
+        const uint64_t seg0 = region << b2;
+        const bool staged = n <= (uint32_t)(SKW_THREADS * SKW_MAXR);       // uniform
+        if (threadIdx.x < NF) hist[threadIdx.x] = 0;
+        __syncthreads();
+        RunW in[SKW_MAXR];
+        uint32_t rank[SKW_MAXR];
+        if (staged) {
+#pragma unroll
+            for (int j = 0; j < SKW_MAXR; j++) {
+                const uint32_t i = (uint32_t)j * SKW_THREADS + threadIdx.x;
+                if (i < n) { in[j].r[0] = rr[3 * i]; in[j].r[1] = rr[3 * i + 1]; in[j].r[2] = rr[3 * i + 2]; }
+                else { in[j].r[0] = in[j].r[1] = in[j].r[2] = 0; }
+            }
+#pragma unroll
+            for (int j = 0; j < SKW_MAXR; j++) {
+                const uint32_t i = (uint32_t)j * SKW_THREADS + threadIdx.x;
+                rank[j] = 0;
+                if (i < n) {
+                    runw_flip(in[j], k);
+                    rank[j] = atomicAdd(&hist[rec_fine(in[j].r[2], b2)], 1u);
+                }
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < n; i += SKW_THREADS) atomicAdd(&hist[rec_fine(rr[3 * i + 2], b2)], 1u);
+        }
+        __syncthreads();
+        const uint32_t cnt = threadIdx.x < B2 ? hist[threadIdx.x] : 0u;
+        uint32_t total;
+        const uint32_t pre = block_scan_sum(cnt, scratch, &total);
+        if (threadIdx.x < B2) {
+            start[threadIdx.x] = pre;
+            hist[threadIdx.x] = 0;
+            off[seg0 + threadIdx.x] = region * rstride + pre;
+            len_out[seg0 + threadIdx.x] = cnt;
+            if (cnt > 0xffffu) atomicExch(overflow, 1);
+        }
+        __syncthreads();
+        if (staged) {
+#pragma unroll
+            for (int j = 0; j < SKW_MAXR; j++) {
+                const uint32_t i = (uint32_t)j * SKW_THREADS + threadIdx.x;
+                if (i < n) {
+                    const uint32_t at = 3u * (start[rec_fine(in[j].r[2], b2)] + rank[j]);
+                    sout[at] = in[j].r[0]; sout[at + 1] = in[j].r[1]; sout[at + 2] = in[j].r[2];
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < 3u * n; i += SKW_THREADS) out[i] = sout[i];
+        } else {
+            for (uint32_t i = threadIdx.x; i < n; i += SKW_THREADS) {
+                RunW r;
+                r.r[0] = rr[3 * i]; r.r[1] = rr[3 * i + 1]; r.r[2] = rr[3 * i + 2];
+                runw_flip(r, k);
+                const uint32_t f = rec_fine(r.r[2], b2);
+                const uint64_t at = 3ull * (start[f] + atomicAdd(&hist[f], 1u));
+                out[at] = r.r[0]; out[at + 1] = r.r[1]; out[at + 2] = r.r[2];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // bucket ((bucket << sb) | sub) of dictionary keys under minimizer buckets (the probing form of the fill builds its
 // per-bucket tables from the dictionary): the minimizer is re-derived from the k-mer itself
 __global__ void minimizer_bucket_ids_kernel(const uint64_t *__restrict__ dict, uint64_t n, int k, int bb, int sb,
@@ -442,15 +556,15 @@ __global__ void minimizer_bucket_ids_kernel(const uint64_t *__restrict__ dict, u
     }
 }
 
-template <int W>
+template <int W, bool WIDE = false>
 static void launch_sk1(hipStream_t s, const SkArgs &a, ulonglong2 *recs1, uint32_t rstride, uint32_t *rcount1, uint32_t *part_kmers, int *overflow)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(superkmer_l1_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_L1_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(superkmer_l1_kernel<W, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_L1_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(superkmer_l1_kernel<W>, dim3(a.n_genomes << a.part_bits), dim3(SK_THREADS), SK_L1_LDS, s, a, recs1, rstride, rcount1,
+    hipLaunchKernelGGL((superkmer_l1_kernel<W, WIDE>), dim3(a.n_genomes << a.part_bits), dim3(SK_THREADS), SK_L1_LDS, s, a, recs1, rstride, rcount1,
                        part_kmers, overflow);
 }
 
@@ -460,6 +574,7 @@ int superkmer_max_bits() { return SK_MAX_BITS; }
 // no longer does (5.6 ms instead of 2.8)
 int superkmer_coarse_bits(int bb) { return bb < 8 ? bb : 8; }
 int superkmer_lmax() { return SK_LMAX; }
+int superkmer_wide_window(int k) { return runw_window(k); }
 
 void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int b1, int part_bits, void *recs1, uint32_t rstride, uint32_t *rcount1,
                          uint32_t *part_kmers, int *overflow)
@@ -471,13 +586,18 @@ void launch_superkmer_l1(hipStream_t s, const KmerLaunch &L, int b1, int part_bi
     a.b1 = b1;
     a.part_bits = part_bits;
     ulonglong2 *r = reinterpret_cast<ulonglong2 *>(recs1);
+    if (L.k > 32) {         // two-word k-mers: 24-byte records, the window in the middle of the k-mer
+        if (runw_window(L.k) == 21) launch_sk1<21, true>(s, a, r, rstride, rcount1, part_kmers, overflow);
+        else launch_sk1<22, true>(s, a, r, rstride, rcount1, part_kmers, overflow);
+        return;
+    }
     switch (L.k - SK_M + 1) {
 #define GRM_SK_CASE(W) case W: launch_sk1<W>(s, a, r, rstride, rcount1, part_kmers, overflow); break;
         GRM_SK_CASE(1) GRM_SK_CASE(2) GRM_SK_CASE(3) GRM_SK_CASE(4) GRM_SK_CASE(5) GRM_SK_CASE(6) GRM_SK_CASE(7) GRM_SK_CASE(8)
         GRM_SK_CASE(9) GRM_SK_CASE(10) GRM_SK_CASE(11) GRM_SK_CASE(12) GRM_SK_CASE(13) GRM_SK_CASE(14) GRM_SK_CASE(15)
         GRM_SK_CASE(16) GRM_SK_CASE(17) GRM_SK_CASE(18) GRM_SK_CASE(19) GRM_SK_CASE(20) GRM_SK_CASE(21) GRM_SK_CASE(22)
 #undef GRM_SK_CASE
-        default: break;     // the host only asks for 11 <= k <= 32
+        default: break;     // the host only asks for 11 <= k <= 32 here
     }
 }
 
@@ -524,6 +644,22 @@ void launch_minimizer_bucket_ids(hipStream_t s, const uint64_t *dict, uint64_t n
     if (!n) return;
     const uint64_t g = (n + 255) / 256;
     hipLaunchKernelGGL(minimizer_bucket_ids_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, dict, n, k, bb, sb, bucket_of, col_of);
+}
+
+void launch_superkmer_l2_wide(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb, int b1,
+                              void *recs2, uint64_t *off, uint32_t *len_out, int *overflow)
+{
+    if (!n_regions) return;
+    const uint32_t cap = rstride < (uint32_t)(SKW_THREADS * SKW_MAXR) ? rstride : (uint32_t)(SKW_THREADS * SKW_MAXR);
+    const size_t lds = (size_t)cap * 24;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(superkmer_l2_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SKW_THREADS * SKW_MAXR * 24);
+        attr_set = true;
+    }
+    const uint32_t grid = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
+    hipLaunchKernelGGL(superkmer_l2_wide_kernel, dim3(grid), dim3(SKW_THREADS), lds, s, reinterpret_cast<const uint64_t *>(recs1), rstride, rcount1,
+                       n_regions, k, bb, b1, reinterpret_cast<uint64_t *>(recs2), off, len_out, overflow);
 }
 
 }  // namespace grm

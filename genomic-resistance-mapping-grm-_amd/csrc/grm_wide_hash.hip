@@ -290,9 +290,56 @@ __device__ __forceinline__ uint32_t wide_find_or_insert(ulonglong2 *tkey, uint32
 // (64 genomes) between two barriers; words[slot] collects the bits of the current row, meta[slot] = entry id | SEEN |
 // MULTI.  Entries leave in entry-id order at wg * cap (staged; the host gathers them densely in workgroup order, which
 // is also the order of the exchange records), the words at matrix_s[wg][row][entry id].
+// RECS (record form of the partition, grm_superkmer.hip): `keys` are the 24-byte run records level 2 left sorted by minimizer
+// bucket, a segment = seg.off / seg.len in records.  A wave puts a chunk of 64 records into LDS with the prefix sum of their
+// lengths and the bitmap of the positions where a record's k-mers start; a lane then takes a K-MER (its record = the popcount
+// of the bitmap below its position), cut out of the record's three words (runw_kmer_at) -- as the counting stage does for
+// one-word k-mers (record_count_kernel, grm_kernels.hip).
 constexpr uint32_t WMETA_ID = 0x1fffu, WMETA_SEEN = 0x4000u, WMETA_MULTI = 0x8000u;
+constexpr uint32_t WREC_WORDS = (64 * RUN_LMAX + 63) / 64;                  // bitmap words of a chunk's k-mer positions
+constexpr uint32_t WREC_WAVE_BYTES = 64 * 24 + 64 * 2 + WREC_WORDS * 8 + 32;  // records, starts, bitmap, first record of every bitmap word
+struct WideRecStage {
+    uint64_t *srec;         // [64][3]
+    uint16_t *sstart;       // [64]
+    uint64_t *starts;       // [WREC_WORDS]
+    uint8_t *firstrec;      // [WREC_WORDS]
+};
+__device__ __forceinline__ uint32_t wide_rec_stage(const uint64_t *__restrict__ src, uint32_t nc, const WideRecStage &st)
+{
+    const int lane = lane_id();
+    uint64_t r0 = 0, r1 = 0, r2 = 0;
+    if ((uint32_t)lane < nc) { r0 = src[3 * lane]; r1 = src[3 * lane + 1]; r2 = src[3 * lane + 2]; }
+    const uint32_t ln = (uint32_t)lane < nc ? run_len(r2) : 0u;
+    const uint32_t incl = wave_scan_incl_dpp(ln), s0 = incl - ln;
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    st.srec[3 * lane] = r0; st.srec[3 * lane + 1] = r1; st.srec[3 * lane + 2] = r2;
+    st.sstart[lane] = (uint16_t)s0;
+    if (lane < (int)WREC_WORDS) { st.starts[lane] = 0; st.firstrec[lane] = (uint8_t)nc; }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __asm__ volatile("" ::: "memory");
+    const uint32_t w = s0 >> 6;
+    const uint32_t w_prev = __shfl_up(w, 1);
+    if (ln) {
+        atomicOr((unsigned long long *)&st.starts[w], 1ull << (s0 & 63u));
+        if (lane == 0 || w_prev != w) st.firstrec[w] = (uint8_t)lane;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __asm__ volatile("" ::: "memory");
+    return tot;
+}
+__device__ __forceinline__ ulonglong2 wide_rec_kmer(uint32_t q, int k, const WideRecStage &st)       // (lo, hi) as the key segments hold them
+{
+    const uint32_t w = q >> 6;
+    const uint64_t word = st.starts[w];
+    const uint32_t o = (uint32_t)st.firstrec[w] + (uint32_t)__popcll(word & ((2ull << (q & 63u)) - 1ull)) - 1u;
+    RunW r;
+    r.r[0] = st.srec[3 * o]; r.r[1] = st.srec[3 * o + 1]; r.r[2] = st.srec[3 * o + 2];
+    const K128 key = runw_kmer_at(r, k, q - st.sstart[o]);
+    return make_ulonglong2(key.lo, key.hi);
+}
+template <bool RECS>
 __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
-    const ulonglong2 *__restrict__ keys, const SegLayout seg, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
+    const ulonglong2 *__restrict__ keys, const SegLayout seg, int k, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
     uint64_t *__restrict__ stage_lo, uint64_t *__restrict__ stage_hi, uint8_t *__restrict__ stage_flags,
     uint32_t *__restrict__ stage_cnt, uint64_t *__restrict__ matrix_s, uint16_t *__restrict__ birth, int *__restrict__ overflow,
     uint32_t *__restrict__ need)
@@ -303,6 +350,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
     unsigned long long *words = reinterpret_cast<unsigned long long *>(lds_raw + (size_t)cap * 16);
     uint16_t *meta = reinterpret_cast<uint16_t *>(lds_raw + (size_t)cap * 24);
     uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_raw + (size_t)cap * 26);
+    uint8_t *stage_raw = lds_raw + (size_t)cap * 26 + TABLE_SCRATCH_BYTES;             // RECS: WREC_WAVE_BYTES per wave
     int *const full_p = reinterpret_cast<int *>(scratch + 16);        // (read with lds_peek: a volatile int would go through the flat path)
     auto is_full = [&]() { return lds_peek(full_p) != 0; };
     uint32_t &n_distinct = scratch[17];
@@ -318,9 +366,19 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
     const uint32_t per_row = 64u / (uint32_t)nw;
     auto seg_of = [&](uint32_t gg, uint64_t &s0, uint64_t &n) {
         const uint64_t idx = (uint64_t)gg * B + b;
-        if (seg.off) { s0 = seg.off[idx]; n = seg.len ? (uint64_t)seg.len[idx] : seg.off[idx + 1] - s0; }
+        if (RECS) { s0 = seg.off[idx]; n = seg.len[idx] & 0xffffu; }
+        else if (seg.off) { s0 = seg.off[idx]; n = seg.len ? (uint64_t)seg.len[idx] : seg.off[idx + 1] - s0; }
         else { s0 = idx * seg.stride; n = seg.len[idx]; }
     };
+    WideRecStage st;
+    {
+        uint8_t *mine = stage_raw + (size_t)wave_id() * WREC_WAVE_BYTES;
+        st.srec = reinterpret_cast<uint64_t *>(mine);
+        st.sstart = reinterpret_cast<uint16_t *>(mine + 64 * 24);
+        st.starts = reinterpret_cast<uint64_t *>(mine + 64 * 24 + 64 * 2);
+        st.firstrec = mine + 64 * 24 + 64 * 2 + WREC_WORDS * 8;
+    }
+    const uint64_t *recs = reinterpret_cast<const uint64_t *>(keys);
     // bounds of the next genome's segment are requested while the current one is processed
     uint32_t g = (uint32_t)wave;
     uint64_t s0 = 0, n = 0;
@@ -335,14 +393,19 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                 // read, a key found there ORs its bit in under a predicate; only a key that is in neither slot goes round
                 // the insertion loop (a bit mask of the lane's keys still to do, no per-key branches)
                 constexpr int KJ = 2;                    // keys per lane in flight (segments hold ~300 keys)
-                for (uint64_t i0 = lane; i0 < n && !is_full(); i0 += 64 * KJ) {
+                // RECS: chunk after chunk of 64 records (n_keys k-mers each); else one "chunk" = the segment's keys
+                for (uint64_t c0 = 0; c0 < (RECS ? n : 1u) && !is_full(); c0 += 64) {
+                uint64_t n_keys = n;
+                if (RECS) n_keys = wide_rec_stage(recs + 3 * (s0 + c0), (uint32_t)min((uint64_t)64, n - c0), st);
+                for (uint64_t i0 = lane; i0 < n_keys + (uint64_t)lane && !is_full(); i0 += 64 * KJ) {        // (uniform trip count)
                     ulonglong2 kv[KJ];
                     uint64_t hv[KJ];
                     uint32_t sl[KJ];
 #pragma unroll
                     for (int j = 0; j < KJ; j++) {
                         const uint64_t i = i0 + 64u * j;
-                        kv[j] = i < n ? keys[s0 + i] : make_ulonglong2(WH_EMPTY, WH_EMPTY);
+                        if (RECS) kv[j] = i < n_keys ? wide_rec_kmer((uint32_t)i, k, st) : make_ulonglong2(WH_EMPTY, WH_EMPTY);
+                        else kv[j] = i < n_keys ? keys[s0 + i] : make_ulonglong2(WH_EMPTY, WH_EMPTY);
                     }
 #pragma unroll
                     for (int j = 0; j < KJ; j++) {
@@ -391,6 +454,8 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                         }
                     }
                 }
+                if (RECS) { __builtin_amdgcn_s_waitcnt(0xC07F); __asm__ volatile("" ::: "memory"); }      // the staging arrays are free again
+                }
             }
             s0 = s0_next;
             n = n_next;
@@ -423,6 +488,18 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
             uint64_t sv = 0, nv = 0;
             seg_of(gg, sv, nv);
             for (uint64_t i = lane; i < nv; i += 64) {
+                if (RECS) {                 // (a lane rolls through its record: this is the rare way out)
+                    RunW rw;
+                    rw.r[0] = recs[3 * (sv + i)]; rw.r[1] = recs[3 * (sv + i) + 1]; rw.r[2] = recs[3 * (sv + i) + 2];
+                    for (uint32_t t = 0; t < run_len(rw.r[2]); t++) {
+                        const K128 key = runw_kmer_at(rw, k, t);
+                        const uint64_t h = mix128(key.hi, key.lo);
+                        if (sb && hash_sub(h, bb, sb) != sub) continue;
+                        const uint32_t lo = (uint32_t)h;
+                        atomicMax(&hll[lo & (HLL_M - 1)], (uint32_t)__clz((lo >> 12) | 1u) - 11u);
+                    }
+                    continue;
+                }
                 const ulonglong2 key = keys[sv + i];
                 const uint64_t h = mix128(key.y, key.x);
                 if (sb && hash_sub(h, bb, sb) != sub) continue;
@@ -561,13 +638,18 @@ void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const
     hipLaunchKernelGGL(wide_l2_kernel, dim3(grid), dim3(WH_THREADS), WH_LDS_BYTES, s, reinterpret_cast<const ulonglong2 *>(keys1),
                        reinterpret_cast<ulonglong2 *>(keys), off, n_regions, L.bb, b1, region_stride, fine_cap, cursor1, len_out, overflow);
 }
+// recs_k: 0 = `keys` are 16-byte keys; else k, and `keys` are 24-byte run records (seg.off / seg.len in records)
 void launch_wh_dict_build(hipStream_t s, const void *keys, const SegLayout &seg, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
                           uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint64_t *matrix_s,
-                          uint16_t *birth, int *overflow, uint32_t *need)
+                          uint16_t *birth, int *overflow, uint32_t *need, int recs_k)
 {
-    const size_t lds = (((size_t)26) << cap_log2) + TABLE_SCRATCH_BYTES;
-    hipLaunchKernelGGL(wide_dict_build_kernel, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, reinterpret_cast<const ulonglong2 *>(keys),
-                       seg, n_genomes, bb, sb, cap_log2, stage_lo, stage_hi, stage_flags, stage_cnt, matrix_s, birth, overflow, need);
+    const size_t lds = (((size_t)26) << cap_log2) + TABLE_SCRATCH_BYTES + (recs_k ? (size_t)(TABLE_THREADS / 64) * WREC_WAVE_BYTES : 0);
+    if (recs_k)
+        hipLaunchKernelGGL(wide_dict_build_kernel<true>, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, reinterpret_cast<const ulonglong2 *>(keys),
+                           seg, recs_k, n_genomes, bb, sb, cap_log2, stage_lo, stage_hi, stage_flags, stage_cnt, matrix_s, birth, overflow, need);
+    else
+        hipLaunchKernelGGL(wide_dict_build_kernel<false>, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, reinterpret_cast<const ulonglong2 *>(keys),
+                           seg, 0, n_genomes, bb, sb, cap_log2, stage_lo, stage_hi, stage_flags, stage_cnt, matrix_s, birth, overflow, need);
 }
 void launch_wh_dict_gather(hipStream_t s, const uint64_t *stage_lo, const uint64_t *stage_hi, const uint8_t *stage_flags,
                            const uint64_t *stage_off, uint32_t n_wg, uint32_t cap, uint64_t *out_lo, uint64_t *out_hi, uint8_t *out_flags)
@@ -612,7 +694,9 @@ hipError_t wh_set_max_dynamic_lds()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(wide_l2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(wide_dict_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(wide_dict_build_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(wide_dict_build_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
 }
 
 }  // namespace grm

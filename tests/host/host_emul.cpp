@@ -29,6 +29,25 @@ static bool emul_minimizers(const uint64_t *sym2, uint64_t j, uint32_t (&val)[RU
     return true;
 }
 
+// (two-word k-mers through the record form: see emul_runs_wide)
+static uint64_t shifted_word(const uint64_t *sym2, uint64_t j, int c) { return c ? (sym2[j] << (2 * c)) | (sym2[j + 1] >> (64 - 2 * c)) : sym2[j]; }
+template <int W>
+static bool emul_minimizers_wide(const uint64_t *sym2, uint64_t j, int c, uint32_t (&val)[RUN_PPT + 1])
+{
+    const uint64_t w0 = shifted_word(sym2, j, c), w1 = shifted_word(sym2, j + 1, c), w2 = shifted_word(sym2, j + 2, c);
+    const uint32_t prev2 = c ? (uint32_t)(sym2[j] >> (64 - 2 * c)) & 3u : (j ? (uint32_t)sym2[j - 1] & 3u : 0u);
+    run_minimizers<W>(w0, w1, prev2, val);
+    uint32_t own[RUN_PPT + 1], right[RUN_PPT + 1], h[RUN_PPT + W], val2[RUN_PPT + 1];
+    run_hashes<RUN_PPT + 1>(w0, w1, prev2, own);
+    run_hashes<RUN_PPT + 1>(w1, w2, (uint32_t)w0 & 3u, right);
+    for (int i = 0; i <= RUN_PPT; i++) h[i] = own[i];
+    for (int t = 0; t + 1 < W; t++) h[RUN_PPT + 1 + t] = run_hash_from_right(right[1 + t]);
+    run_window_min<W>(h, val2);
+    for (int i = 0; i <= RUN_PPT; i++)
+        if (val[i] != val2[i]) return false;
+    return true;
+}
+
 extern "C" {
 
 // raw: tile-aligned image (multiple of 16 bytes), raw[-1] must be '\n' conceptually: the
@@ -365,6 +384,71 @@ uint64_t emul_runs(const uint64_t *sym2, const uint64_t *inv, uint64_t total_sym
                 if (n < cap) { out_keys[n] = run_canonical(d); out_bucket[n] = bucket; }
                 n++;
                 run_next(d, kmask, rcshift);
+            }
+        }
+        cur = nxt;
+    }
+    *n_records = nr;
+    return n;
+}
+
+// The same for two-word k-mers (33 <= k <= 64; grm_device_fns.h "run records of two-word k-mers"): the minimizer among the
+// runw_window(k) m-mers in the middle of the k-mer = the one-word machinery on the stream moved on by runw_offset(k) positions,
+// 24-byte records (runw_record / runw_flip), every k-mer cut out of its record (runw_kmer_at).  out_keys: (hi, lo) per decoded
+// k-mer; out_rec: {length, flipped} per record.
+uint64_t emul_runs_wide(const uint64_t *sym2, const uint64_t *inv, uint64_t total_syms, uint64_t lo, uint64_t hi, int k, int coarse_bits,
+                        uint64_t *out_keys, uint32_t *out_bucket, uint64_t cap, uint32_t *out_rec, uint64_t rec_cap, uint64_t *n_records)
+{
+    uint64_t n = 0, nr = 0;
+    const int nbits = coarse_bits + RUN_FINE_BITS;
+    const int W = runw_window(k), c = runw_offset(k);
+    const uint64_t last = total_syms >= (uint64_t)k ? total_syms - k + 1 : 0;
+    const uint64_t p_end = hi < last ? hi : last;
+    const uint64_t jw_lo = lo >> 5, jw_hi = hi > lo ? (hi + 31) >> 5 : jw_lo;
+    struct Win { uint32_t valid, heads, lead; uint32_t val[RUN_PPT + 1]; };
+    auto window = [&](uint64_t j, Win &w) -> bool {
+        const uint64_t p0 = j << 5;
+        uint64_t vs;
+        if (p0) {
+            const uint64_t q = p0 - 1;
+            vs = valid_starts_wide(inv[q >> 6], inv[(q >> 6) + 1], inv[(q >> 6) + 2], (int)(q & 63), k);
+        } else {
+            vs = valid_starts_wide(inv[0], inv[1], inv[2], 0, k) << 1;
+        }
+        const uint64_t t_lo = lo + 1 > p0 ? lo + 1 - p0 : 0, t_hi = p_end + 1 > p0 ? p_end + 1 - p0 : 0;
+        const uint64_t keep = (t_hi >= 33 ? (1ull << 33) - 1 : (1ull << t_hi) - 1) & ~(t_lo >= 33 ? (1ull << 33) - 1 : (1ull << t_lo) - 1);
+        vs &= keep;
+        w.valid = (uint32_t)(vs >> 1);
+        w.heads = 0;
+        if (w.valid) {
+            if (W == 21) { if (!emul_minimizers_wide<21>(sym2, j, c, w.val)) return false; }
+            else if (!emul_minimizers_wide<22>(sym2, j, c, w.val)) return false;
+            w.heads = run_heads(w.valid, (vs & 1u) != 0, w.val);
+        }
+        w.lead = run_lead(w.valid, w.heads);
+        return true;
+    };
+    Win cur, nxt;
+    if (jw_hi > jw_lo && !window(jw_lo, cur)) return ~0ull;
+    for (uint64_t j = jw_lo; j < jw_hi; j++) {
+        if (!window(j + 1, nxt)) return ~0ull;
+        for (int i = 0; i < RUN_PPT; i++) {
+            if (!((cur.heads >> i) & 1u)) continue;
+            uint32_t len = run_length(cur.heads, cur.valid, i);
+            if (i + (int)len == RUN_PPT) len += nxt.lead;
+            if (len > (uint32_t)W) return ~0ull - 5;
+            const uint32_t v = cur.val[i + 1];
+            const uint32_t bucket = minimizer_bucket(v >> (32 - MINIMIZER_ORDER_BITS), nbits);
+            RunW r = runw_record(sym2[j], sym2[j + 1], sym2[j + 2], sym2[j + 3], i, len, k, (v & 1u) != 0, bucket);
+            if (((r.r[2] & RUN_FLIP_BIT) != 0) != ((v & 1u) != 0)) return ~0ull - 7;
+            runw_flip(r, k);
+            if (run_len(r.r[2]) != len || run_fine(r.r[2]) != (bucket & ((1u << RUN_FINE_BITS) - 1u)) || ((r.r[2] >> 12) & 0x3ffu)) return ~0ull - 6;
+            if (nr < rec_cap) { out_rec[2 * nr] = len; out_rec[2 * nr + 1] = v & 1u; }
+            nr++;
+            for (uint32_t t = 0; t < len; t++) {
+                const K128 key = runw_kmer_at(r, k, t);
+                if (n < cap) { out_keys[2 * n] = key.hi; out_keys[2 * n + 1] = key.lo; out_bucket[n] = bucket; }
+                n++;
             }
         }
         cur = nxt;

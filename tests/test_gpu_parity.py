@@ -621,6 +621,43 @@ def test_two_word_kmers(ctx, k, tmp_path):
         m.free(); b.free()
 
 
+@pytest.mark.parametrize("k,opts", [(33, {}), (34, {}), (47, {}), (63, {}), (64, {}), (63, {"bucket_bits": 3, "cap_log2": 9}), (63, {"bucket_bits": 9})])
+def test_two_word_kmers_through_the_record_form(ctx, k, opts):
+    """from 128 genomes on two-word k-mers travel as 24-byte run records (the minimizer among the 21 / 22 m-mers in the middle of the
+    k-mer): assemblies with their own contigs on either strand, indels, a repeated stretch and runs of N, against the oracle, with and
+    without singletons; small tables (sub-buckets: every workgroup cuts the k-mers out of all its bucket's records) and many buckets;
+    "records" 0 is the key form on the same input"""
+    n = 131
+    pg = synth.realistic(genome_len=20_000, seed=23 + k, contigs=(1, 5), indel_sites=8, n_snps=200, n_accessory=2, accessory_len=400)
+    genomes = []
+    for i in range(n):
+        g = pg.genome(i).tobytes()
+        if i % 7 == 0:
+            g = g[:1000] + b"N" * (1 + i % 5) + g[1000:]        # (inside a line: bases that are none)
+        genomes.append([g + g[: 1500 + 11 * i]])
+    genomes[5] = [b""]
+    genomes[9] = [b">tiny\n" + b"ACGT" * 10 + b"\n"]              # shorter than k
+    want_names = {"superkmer_l1", "superkmer_l2", "wh_dict_build"}
+    try:
+        for name, v in opts.items():
+            ctx.set_option(name, v)
+        ctx.timing(True)
+        ctx.timing_reset()
+        _check(ctx, genomes, k, 1, False)
+        names = {t[0] for t in ctx.timings()}
+        assert want_names <= names and "wh_scatter_l1" not in names, names
+        _check(ctx, genomes, k, 1, True)
+        ctx.set_option("records", 0)
+        ctx.timing_reset()
+        _check(ctx, genomes, k, 1, True)
+        assert "wh_scatter_l1" in {t[0] for t in ctx.timings()}
+    finally:
+        ctx.timing(False)
+        ctx.set_option("records", -1)
+        for name in opts:
+            ctx.set_option(name, -1)
+
+
 @pytest.mark.parametrize("k", [33, 63])
 def test_two_word_sets_merge(ctx, k):
     """dsk2kover's job at k > 32: per-genome counted sets (abundance-min 2 applied per genome) ->
@@ -977,7 +1014,7 @@ def test_counting_stage_on_random_genomes(ctx):
     b.free()
 
 
-@pytest.mark.parametrize("k,opts,by_records", [(31, {}, True), (21, {}, True), (32, {}, True), (31, {"rec_count": 0}, False), (25, {"bucket_bits": 6}, True),
+@pytest.mark.parametrize("k,opts,by_records", [(31, {}, True), (21, {}, True), (32, {}, True), (31, {"rec_count": 0}, False), (25, {"bucket_bits": 7}, True),
                                                (31, {"rec_count_cap": 8}, True), (31, {"bucket_bits": 5, "rec_count_cap": 8}, False),
                                                (31, {"bucket_bits": 4}, False)])
 def test_counting_stage_through_the_record_form(ctx, k, opts, by_records):

@@ -48,6 +48,9 @@ def emul():
     L.emul_revcomp.argtypes = [C.c_uint64, C.c_int]
     L.emul_mix64.restype = C.c_uint64
     L.emul_mix64.argtypes = [C.c_uint64]
+    L.emul_runs_wide.restype = C.c_uint64
+    L.emul_runs_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64,
+                                 C.c_void_p, C.c_uint64, C.c_void_p]
     L.emul_runs.restype = C.c_uint64
     L.emul_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64,
                             C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -298,6 +301,48 @@ def test_run_records_decode_to_the_oracles_kmers(emul, k):
         assert emul.emul_minimizer_bucket_of_kmer(int(keys[i]), k, nbits - 5) == int(buckets[i]) >> 5
     if k >= 19:
         assert 0.8 * 2 / (k - 9) < len(recs) / n < 1.3 * 2 / (k - 9)      # ~2 / (W + 1) runs per k-mer (low-complexity stretches: more)
+
+
+@pytest.mark.parametrize("k", [33, 34, 47, 63, 64])
+def test_wide_run_records_decode_to_the_oracles_kmers(emul, k):
+    """two-word k-mers through the record form (24-byte records; the minimizer among the 21 / 22 m-mers in the middle of the k-mer):
+    record after record the k-mers of the stream in order, or in reverse where the record is stored on the other strand; together
+    exactly the oracle's counted k-mers; a k-mer and its reverse complement get the same bucket"""
+    rng = np.random.RandomState(200 + k)
+    a = cases.rand_seq(rng, 6000)
+    files = [cases.fasta([("a", a), ("b", "ACGT" * 100 + "A" * 150 + cases.rand_seq(rng, 2000) + "N" * 3 + "GATTACA" * 60), ("short", a[:k - 1])], width=70).encode(),
+             (">c\n" + cases.revcomp(a)[100:4000].lower() + "\n").encode()]
+    sym2, inv, nsym = _parse(emul, files)
+    cap = max(1, nsym)
+    direct = np.zeros(2 * cap, dtype=np.uint64)
+    nd = emul.emul_kmers_wide(sym2.ctypes.data, inv.ctypes.data, nsym, k, direct.ctypes.data, cap)
+    direct = direct[:2 * nd].reshape(nd, 2)
+    keys = np.zeros(2 * cap, dtype=np.uint64)
+    buckets = np.zeros(cap, dtype=np.uint32)
+    recs = np.zeros((cap, 2), dtype=np.uint32)
+    n_rec = C.c_uint64(0)
+    n = emul.emul_runs_wide(sym2.ctypes.data, inv.ctypes.data, nsym, 0, nsym, k, 9, keys.ctypes.data, buckets.ctypes.data, cap,
+                            recs.ctypes.data, cap, C.byref(n_rec))
+    assert n <= cap, "emul_runs_wide found an inconsistency: code %d" % ((1 << 64) - 1 - n)
+    assert n == nd
+    keys = keys[:2 * n].reshape(n, 2)
+    recs = recs[:n_rec.value]
+    lens, flipped = recs[:, 0].astype(np.int64), recs[:, 1]
+    w = 21 if (k - 10) % 2 else 22
+    assert lens.sum() == n and lens.min() >= 1 and lens.max() == w
+    at = 0
+    for ln, fl in zip(lens, flipped):
+        want = direct[at:at + ln]
+        assert (keys[at:at + ln] == (want[::-1] if fl else want)).all()
+        at += ln
+    assert 0.25 < flipped.mean() < 0.75
+    km, ct, nocc = orc.count_genome(files, k)
+    uniq, counts = np.unique(keys, axis=0, return_counts=True)
+    assert nocc == n and uniq.shape == km.shape and (uniq == km).all() and (counts == ct).all()
+    # one bucket per k-mer, whatever the strand it was read on (the reverse-complemented copy of `a`)
+    seen = {}
+    for (h, l), b in zip(keys.tolist(), buckets[:n].tolist()):
+        assert seen.setdefault((h, l), b) == b
 
 
 def _record_multiset(recs):
