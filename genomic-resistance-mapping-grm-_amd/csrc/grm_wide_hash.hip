@@ -297,44 +297,122 @@ __device__ __forceinline__ uint32_t wide_find_or_insert(ulonglong2 *tkey, uint32
 // one-word k-mers (record_count_kernel, grm_kernels.hip).
 constexpr uint32_t WMETA_ID = 0x1fffu, WMETA_SEEN = 0x4000u, WMETA_MULTI = 0x8000u;
 constexpr uint32_t WREC_WORDS = (64 * RUN_LMAX + 63) / 64;                  // bitmap words of a chunk's k-mer positions
-constexpr uint32_t WREC_WAVE_BYTES = 64 * 24 + 64 * 2 + WREC_WORDS * 8 + 32;  // records, starts, bitmap, first record of every bitmap word
+// per wave: records, their memo ids, starts, bitmap, first record of every bitmap word
+constexpr uint32_t WREC_WAVE_BYTES = 64 * 24 + 64 * 2 + 64 * 2 + WREC_WORDS * 8 + WREC_WORDS * 4 + 8;
 struct WideRecStage {
     uint64_t *srec;         // [64][3]
+    uint16_t *smid;         // [64] memo id of the record when this wave entered it (its k-mers' slots are noted), else 0xffff
     uint16_t *sstart;       // [64]
     uint64_t *starts;       // [WREC_WORDS]
-    uint8_t *firstrec;      // [WREC_WORDS]
+    uint32_t *firstrec;     // [WREC_WORDS]
 };
-__device__ __forceinline__ uint32_t wide_rec_stage(const uint64_t *__restrict__ src, uint32_t nc, const WideRecStage &st)
+// The RECORD MEMO, as dict_build's (grm_kernels.hip): genomes of a pan-genome hold the same runs, so the bucket's records are kept
+// in a small LDS table with the table slots of their k-mers.  A record that is held costs ONE atomic OR into the record's own presence
+// word -- no k-mer is cut out, hashed or looked up; at the end of a word-row the word of every held record goes to its k-mers'
+// words.  The first occurrence of a record goes the direct way and notes the slots.  A record the memo has no room for (or whose
+// bucket is being written) goes the direct way too: an accelerator, never a point of failure.
+constexpr uint32_t WMEMO_ENT = 96, WMEMO_BUCKETS = 64, WMEMO_KS = 24, WMEMO_NONE = 0xffffu, WMEMO_LOCK = 0x0000ffffu;
+constexpr uint32_t WMEMO_BYTES = WMEMO_BUCKETS * 16 + WMEMO_ENT * 24 + WMEMO_ENT * 8 + WMEMO_ENT * WMEMO_KS * 2 + 16;
+struct WideMemo {
+    uint32_t *slot;                 // buckets of 4: 0 = empty, WMEMO_LOCK = being written, else tag << 16 | id + 1
+    uint64_t *rec;                  // [3 * WMEMO_ENT]
+    unsigned long long *words;      // [WMEMO_ENT] presence word of the current word-row
+    uint16_t *kslot;                // [WMEMO_KS * WMEMO_ENT] table slot of the record's k-mer t, 0xffff = none (not this sub-bucket's)
+    uint32_t *ctl;                  // [0] records held
+};
+__device__ __forceinline__ uint32_t wmemo_hash(uint64_t r0, uint64_t r1, uint64_t r2)
+{
+    const uint32_t h = __umul24((uint32_t)r0, 0x9E3779u) + __umul24((uint32_t)(r0 >> 24), 0x85EBCBu) + __umul24((uint32_t)(r0 >> 48), 0xC2B2AFu) +
+                       __umul24((uint32_t)r1, 0xD6E8FFu) + __umul24((uint32_t)(r1 >> 24), 0xA54FF5u) + __umul24((uint32_t)(r1 >> 48), 0x3C6EF3u) +
+                       __umul24((uint32_t)(r2 >> 40), 0x7F4A7Du) + __umul24((uint32_t)(r2 >> 16), 0x94D049u) + __umul24((uint32_t)r2 & 0xffffu, 0xBF5847u);
+    return h ^ (h >> 13);
+}
+// 0: the record is held and `bit` went into its word; 1: this lane entered it (*id: its k-mers' slots are to be noted); 2: not held
+__device__ __forceinline__ int wmemo_take(const WideMemo &M, uint64_t r0, uint64_t r1, uint64_t r2, unsigned long long bit, uint32_t *id_out)
+{
+    const uint32_t h = wmemo_hash(r0, r1, r2);
+    const uint32_t tag = (h >> 16) | 1u;          // (never 0: an entry word is never 0 or the lock)
+    uint32_t *bucket = &M.slot[(h & (WMEMO_BUCKETS - 1)) << 2];
+    for (int round = 0; round < 4; round++) {
+        bool again = false;
+        for (int q = 0; q < 4; q++) {
+            uint32_t v = lds_peek(&bucket[q]);
+            if (v == 0) {
+                if (lds_peek(&M.ctl[0]) >= WMEMO_ENT) return 2;
+                v = atomicCAS(&bucket[q], 0u, WMEMO_LOCK);
+                if (v == 0) {
+                    const uint32_t id = atomicAdd(&M.ctl[0], 1u);
+                    if (id >= WMEMO_ENT) return 2;                 // (the slot stays locked: whoever reaches it goes the direct way)
+                    M.rec[3 * id] = r0; M.rec[3 * id + 1] = r1; M.rec[3 * id + 2] = r2;
+                    for (uint32_t t = 0; t < WMEMO_KS; t += 4) *reinterpret_cast<uint64_t *>(&M.kslot[id * WMEMO_KS + t]) = ~0ull;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                    __hip_atomic_store(&bucket[q], (tag << 16) | (id + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    *id_out = id;
+                    return 1;
+                }
+            }
+            if (v == WMEMO_LOCK) { again = true; continue; }       // being written (or abandoned): look again, then give up
+            if ((v >> 16) == tag) {
+                const uint32_t id = (v & 0xffffu) - 1u;
+                if (M.rec[3 * id] == r0 && M.rec[3 * id + 1] == r1 && M.rec[3 * id + 2] == r2) {
+                    atomicOr(&M.words[id], bit);
+                    return 0;
+                }
+            }
+        }
+        if (!again) return 2;                                       // a full bucket without the record
+    }
+    return 2;
+}
+// A chunk of up to 64 records: those the memo holds are done with here; the others are put into LDS (in their order) for the lanes
+// to take their k-mers.  Returns the k-mers staged.
+__device__ __forceinline__ uint32_t wide_rec_stage(const uint64_t *__restrict__ src, uint32_t nc, const WideRecStage &st, const WideMemo &M,
+                                                   unsigned long long bit)
 {
     const int lane = lane_id();
     uint64_t r0 = 0, r1 = 0, r2 = 0;
-    if ((uint32_t)lane < nc) { r0 = src[3 * lane]; r1 = src[3 * lane + 1]; r2 = src[3 * lane + 2]; }
-    const uint32_t ln = (uint32_t)lane < nc ? run_len(r2) : 0u;
+    const bool have = (uint32_t)lane < nc;
+    if (have) { r0 = src[3 * lane]; r1 = src[3 * lane + 1]; r2 = src[3 * lane + 2]; }
+    uint32_t mid = WMEMO_NONE;
+    bool direct = have;
+    if (have) {
+        uint32_t id = 0;
+        const int how = wmemo_take(M, r0, r1, r2, bit, &id);
+        direct = how != 0;
+        if (how == 1) mid = id;
+    }
+    const uint64_t dm = __ballot(direct);
+    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+    const uint32_t n_direct = (uint32_t)__popcll(dm);
+    const uint32_t ln = direct ? run_len(r2) : 0u;
     const uint32_t incl = wave_scan_incl_dpp(ln), s0 = incl - ln;
     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    st.srec[3 * lane] = r0; st.srec[3 * lane + 1] = r1; st.srec[3 * lane + 2] = r2;
-    st.sstart[lane] = (uint16_t)s0;
-    if (lane < (int)WREC_WORDS) { st.starts[lane] = 0; st.firstrec[lane] = (uint8_t)nc; }
+    if (lane < (int)WREC_WORDS) { st.starts[lane] = 0; st.firstrec[lane] = n_direct; }
+    if (direct) {
+        st.srec[3 * pos] = r0; st.srec[3 * pos + 1] = r1; st.srec[3 * pos + 2] = r2;
+        st.sstart[pos] = (uint16_t)s0;
+        st.smid[pos] = (uint16_t)mid;
+    }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __asm__ volatile("" ::: "memory");
-    const uint32_t w = s0 >> 6;
-    const uint32_t w_prev = __shfl_up(w, 1);
-    if (ln) {
-        atomicOr((unsigned long long *)&st.starts[w], 1ull << (s0 & 63u));
-        if (lane == 0 || w_prev != w) st.firstrec[w] = (uint8_t)lane;
+    if (direct) {
+        atomicOr((unsigned long long *)&st.starts[s0 >> 6], 1ull << (s0 & 63u));
+        atomicMin(&st.firstrec[s0 >> 6], pos);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __asm__ volatile("" ::: "memory");
     return tot;
 }
-__device__ __forceinline__ ulonglong2 wide_rec_kmer(uint32_t q, int k, const WideRecStage &st)       // (lo, hi) as the key segments hold them
+// k-mer q of the staged records: (lo, hi) as the key segments hold them; o / t: its record among the staged ones, its number inside it
+__device__ __forceinline__ ulonglong2 wide_rec_kmer(uint32_t q, int k, const WideRecStage &st, uint32_t &o, uint32_t &t)
 {
     const uint32_t w = q >> 6;
     const uint64_t word = st.starts[w];
-    const uint32_t o = (uint32_t)st.firstrec[w] + (uint32_t)__popcll(word & ((2ull << (q & 63u)) - 1ull)) - 1u;
+    o = st.firstrec[w] + (uint32_t)__popcll(word & ((2ull << (q & 63u)) - 1ull)) - 1u;
+    t = q - st.sstart[o];
     RunW r;
     r.r[0] = st.srec[3 * o]; r.r[1] = st.srec[3 * o + 1]; r.r[2] = st.srec[3 * o + 2];
-    const K128 key = runw_kmer_at(r, k, q - st.sstart[o]);
+    const K128 key = runw_kmer_at(r, k, t);
     return make_ulonglong2(key.lo, key.hi);
 }
 template <bool RECS>
@@ -371,12 +449,26 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
         else { s0 = idx * seg.stride; n = seg.len[idx]; }
     };
     WideRecStage st;
+    WideMemo M;
     {
         uint8_t *mine = stage_raw + (size_t)wave_id() * WREC_WAVE_BYTES;
         st.srec = reinterpret_cast<uint64_t *>(mine);
-        st.sstart = reinterpret_cast<uint16_t *>(mine + 64 * 24);
-        st.starts = reinterpret_cast<uint64_t *>(mine + 64 * 24 + 64 * 2);
-        st.firstrec = mine + 64 * 24 + 64 * 2 + WREC_WORDS * 8;
+        st.starts = reinterpret_cast<uint64_t *>(mine + 64 * 24);
+        st.firstrec = reinterpret_cast<uint32_t *>(mine + 64 * 24 + WREC_WORDS * 8);
+        st.sstart = reinterpret_cast<uint16_t *>(mine + 64 * 24 + WREC_WORDS * 12);
+        st.smid = reinterpret_cast<uint16_t *>(mine + 64 * 24 + WREC_WORDS * 12 + 64 * 2);
+        uint8_t *mraw = stage_raw + (size_t)(blockDim.x >> 6) * WREC_WAVE_BYTES;
+        M.slot = reinterpret_cast<uint32_t *>(mraw);
+        M.rec = reinterpret_cast<uint64_t *>(mraw + WMEMO_BUCKETS * 16);
+        M.words = reinterpret_cast<unsigned long long *>(mraw + WMEMO_BUCKETS * 16 + WMEMO_ENT * 24);
+        M.kslot = reinterpret_cast<uint16_t *>(mraw + WMEMO_BUCKETS * 16 + WMEMO_ENT * 32);
+        M.ctl = reinterpret_cast<uint32_t *>(mraw + WMEMO_BUCKETS * 16 + WMEMO_ENT * 32 + WMEMO_ENT * WMEMO_KS * 2);
+        if (RECS) {
+            for (uint32_t i = threadIdx.x; i < WMEMO_BUCKETS * 4; i += blockDim.x) M.slot[i] = 0;
+            for (uint32_t i = threadIdx.x; i < WMEMO_ENT; i += blockDim.x) M.words[i] = 0;
+            if (threadIdx.x == 0) M.ctl[0] = 0;
+            __syncthreads();
+        }
     }
     const uint64_t *recs = reinterpret_cast<const uint64_t *>(keys);
     // bounds of the next genome's segment are requested while the current one is processed
@@ -396,16 +488,25 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                 // RECS: chunk after chunk of 64 records (n_keys k-mers each); else one "chunk" = the segment's keys
                 for (uint64_t c0 = 0; c0 < (RECS ? n : 1u) && !is_full(); c0 += 64) {
                 uint64_t n_keys = n;
-                if (RECS) n_keys = wide_rec_stage(recs + 3 * (s0 + c0), (uint32_t)min((uint64_t)64, n - c0), st);
+                if (RECS) n_keys = wide_rec_stage(recs + 3 * (s0 + c0), (uint32_t)min((uint64_t)64, n - c0), st, M, bit);
                 for (uint64_t i0 = lane; i0 < n_keys + (uint64_t)lane && !is_full(); i0 += 64 * KJ) {        // (uniform trip count)
                     ulonglong2 kv[KJ];
                     uint64_t hv[KJ];
                     uint32_t sl[KJ];
+                    uint32_t note[KJ];                   // RECS: where in the memo the k-mer's slot is noted (its record entered by this wave), else ~0
 #pragma unroll
                     for (int j = 0; j < KJ; j++) {
                         const uint64_t i = i0 + 64u * j;
-                        if (RECS) kv[j] = i < n_keys ? wide_rec_kmer((uint32_t)i, k, st) : make_ulonglong2(WH_EMPTY, WH_EMPTY);
-                        else kv[j] = i < n_keys ? keys[s0 + i] : make_ulonglong2(WH_EMPTY, WH_EMPTY);
+                        note[j] = ~0u;
+                        if (RECS) {
+                            kv[j] = make_ulonglong2(WH_EMPTY, WH_EMPTY);
+                            if (i < n_keys) {
+                                uint32_t o, t;
+                                kv[j] = wide_rec_kmer((uint32_t)i, k, st, o, t);
+                                const uint32_t mid = st.smid[o];
+                                if (mid != WMEMO_NONE) note[j] = mid * WMEMO_KS + t;
+                            }
+                        } else kv[j] = i < n_keys ? keys[s0 + i] : make_ulonglong2(WH_EMPTY, WH_EMPTY);
                     }
 #pragma unroll
                     for (int j = 0; j < KJ; j++) {
@@ -425,7 +526,10 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                         const bool hit0 = c0[j].x == kv[j].x && c0[j].y == kv[j].y;
                         const bool hit1 = c1[j].x == kv[j].x && c1[j].y == kv[j].y;
                         const uint32_t at = hit1 ? ((sl[j] + 1) & cap_mask) : sl[j];
-                        if (active && (hit0 | hit1)) __hip_atomic_fetch_or(&words[at], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (active && (hit0 | hit1)) {
+                            __hip_atomic_fetch_or(&words[at], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (RECS && note[j] != ~0u) M.kslot[note[j]] = (uint16_t)at;
+                        }
                         todo |= (uint32_t)(active && !(hit0 | hit1)) << j;
                     }
                     while (todo) {
@@ -434,8 +538,9 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                         todo &= todo - 1;
                         ulonglong2 key = kv[0];
                         uint64_t h = hv[0];
+                        uint32_t nt = note[0];
 #pragma unroll
-                        for (int q = 1; q < KJ; q++) { if (j == q) { key = kv[q]; h = hv[q]; } }
+                        for (int q = 1; q < KJ; q++) { if (j == q) { key = kv[q]; h = hv[q]; nt = note[q]; } }
                         bool ins;
                         const uint32_t slot = wide_find_or_insert(tkey, cap_mask, key.y, key.x, h, &ins);
                         bool over = slot == 0xffffffffu;
@@ -447,6 +552,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                                 over = id >= max_fill;
                             }
                             __hip_atomic_fetch_or(&words[slot], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (RECS && nt != ~0u) M.kslot[nt] = (uint16_t)slot;
                         }
                         if (over) {
                             __hip_atomic_store(full_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // (what it would have needed is counted after the word-row loop)
@@ -462,6 +568,18 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
         }
         __syncthreads();
         if (is_full()) break;    // read between two barriers: uniform
+        if (RECS) {
+            // the words of the held records go to their k-mers' words
+            const uint32_t held = min(M.ctl[0], WMEMO_ENT);
+            for (uint32_t e = threadIdx.x; e < held * WMEMO_KS; e += blockDim.x) {
+                const uint32_t id = e / WMEMO_KS;
+                const unsigned long long w = M.words[id];
+                const uint32_t ks = M.kslot[e];
+                if (w && ks != 0xffffu) __hip_atomic_fetch_or(&words[ks], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __syncthreads();
+            for (uint32_t id = threadIdx.x; id < held; id += blockDim.x) M.words[id] = 0;
+        }
         for (uint32_t slot = threadIdx.x; slot < cap; slot += blockDim.x) {
             if (tkey[slot].x == WH_EMPTY) continue;
             const unsigned long long wd = words[slot];
@@ -643,7 +761,7 @@ void launch_wh_dict_build(hipStream_t s, const void *keys, const SegLayout &seg,
                           uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint64_t *matrix_s,
                           uint16_t *birth, int *overflow, uint32_t *need, int recs_k)
 {
-    const size_t lds = (((size_t)26) << cap_log2) + TABLE_SCRATCH_BYTES + (recs_k ? (size_t)(TABLE_THREADS / 64) * WREC_WAVE_BYTES : 0);
+    const size_t lds = (((size_t)26) << cap_log2) + TABLE_SCRATCH_BYTES + (recs_k ? (size_t)(TABLE_THREADS / 64) * WREC_WAVE_BYTES + WMEMO_BYTES : 0);
     if (recs_k)
         hipLaunchKernelGGL(wide_dict_build_kernel<true>, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, reinterpret_cast<const ulonglong2 *>(keys),
                            seg, recs_k, n_genomes, bb, sb, cap_log2, stage_lo, stage_hi, stage_flags, stage_cnt, matrix_s, birth, overflow, need);
