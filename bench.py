@@ -173,16 +173,22 @@ def kernel_table(ctx, n_cols, n_rows, n_local):
         d["launches"] += 1
         d["units"] += units
     kernels = {}
-    # record form of the partition: the run records (16 B) level 1 wrote = the units of "superkmer_l2"
+    # record form of the partition: the run records level 1 wrote = the units of "superkmer_l2" (16 bytes each; 24 for two-word k-mers,
+    # whose dictionary kernel is wh_dict_build)
     n_records = per["superkmer_l2"]["units"] / per["superkmer_l2"]["launches"] if "superkmer_l2" in per else None
+    rec_bytes = 24.0 if "wh_dict_build" in per else 16.0
     for name, d in per.items():
         avg_ms = d["ms"] / d["launches"]
         e = {"avg_ms": round(avg_ms, 4), "launches": d["launches"]}
         byts = None
         if name == "superkmer_l1" and n_records is not None:
-            byts = 0.375 * d["units"] / d["launches"] + 16.0 * n_records           # read the packed stream, write the records
+            byts = 0.375 * d["units"] / d["launches"] + rec_bytes * n_records      # read the packed stream, write the records
         elif name == "dict_build" and n_records is not None:
             byts = 16.0 * n_records + 8.0 * n_local * n_rows + 9.0 * n_local        # read the records; presence words + (key, flag) per entry
+        elif name == "wh_dict_build" and n_records is not None:
+            byts = 24.0 * n_records + 8.0 * n_local * n_rows + 17.0 * n_local       # the same for two-word k-mers
+        elif name == "superkmer_l2" and n_records is not None:
+            byts = 2.0 * rec_bytes * n_records                                      # read and write every record
         elif name == "record_dedup" and n_records is not None:
             byts = 16.0 * n_records + 12.0 * d["units"] / d["launches"]             # read the records; write <= a key + a 4-byte count per k-mer
         elif ALGO_BYTES.get(name) is not None:

@@ -458,14 +458,15 @@ def _rank_worker(rank, world, port, n_genomes, k, genome_len, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,genome_len", [(31, 60_000), (47, 60_000), (31, 1_500_000), (63, 1_500_000)])
-def test_two_ranks_real_engine_one_gpu(ctx, k, genome_len):
+@pytest.mark.parametrize("k,genome_len,n_genomes", [(31, 60_000, 100), (47, 60_000, 100), (31, 1_500_000, 100), (63, 1_500_000, 100),
+                                                     (47, 30_000, 400), (63, 30_000, 300)])
+def test_two_ranks_real_engine_one_gpu(ctx, k, genome_len, n_genomes):
     """N>1 path end to end with the HIP engine: 2 processes, genomes sharded 64 + 36, dictionary
     all-gather, identical global dictionary, rows stacked == single-process oracle matrix
-    (1.5 Mbp genomes: millions of dictionary entries per rank)"""
+    (1.5 Mbp genomes: millions of dictionary entries per rank; 400 / 300 genomes at k > 32: shards of 256 + 144 genomes, both through
+    the 24-byte record form, and of 192 + 108, the second through the key form)"""
     import socket
     import torch.multiprocessing as mp
-    n_genomes = 100
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
