@@ -2747,18 +2747,24 @@ static int wide_hash_local(grm_batch *b, int k, bool *fallback)
     L.sym2 = b->d_sym2.as<uint64_t>(); L.inv = b->d_inv.as<uint64_t>(); L.total_syms = b->total_syms;
     L.genome_sym_off = b->d_genome_sym_off.as<uint64_t>(); L.n_genomes = G; L.k = k; L.bb = bb; L.groups_per_thread = 1;
 
-    HIPCHK(c, W.cursor1.ensure(std::max<uint64_t>(n_coarse, G) * 4)); HIPCHK(c, W.flag.ensure(32));
-    // ---- record form (grm_superkmer.hip): from 128 genomes on (one part per genome) the k-mers travel as 24-byte run records --
+    HIPCHK(c, W.cursor1.ensure(std::max<uint64_t>(n_coarse, (uint64_t)G << 6) * 4)); HIPCHK(c, W.flag.ensure(32));
+    // ---- record form (grm_superkmer.hip): the k-mers travel as 24-byte run records --
     // runs of up to 22 k-mers that share the minimizer among the m-mers in the middle of the k-mer: 2.1 B per k-mer through level 1
     // and level 2 instead of 16 B through wh_scatter_l1 / l2, and wh_dict_build cuts the k-mers out of the records ----
     bool by_recs = false;
-    if (c->opt_records != 0 && c->opt_dense_layout <= 0 && !W.rec_failed && G >= 128 && k <= 64) {
+    int rec_pbits = 0;
+    if (c->opt_records != 0 && c->opt_dense_layout <= 0 && !W.rec_failed && k <= 64) {
         int bbr = c->opt_bucket_bits >= 0 ? bb : bb + 1;           // (minimizer buckets are less even than hashed k-mers: one more bit)
         bbr = std::min(bbr, superkmer_coarse_bits(bbr) + 7);
         const int b1r = superkmer_coarse_bits(bbr);
-        const uint64_t n_regions = (uint64_t)G << b1r, n_seg_r = (uint64_t)G << bbr;
+        // one workgroup of level 1 per genome part: enough parts to fill the device when genomes are few (as batch_partition_impl)
+        int pbits = 0;
+        while (((uint64_t)G << pbits) < 256 && pbits < 6 && (max_g >> (pbits + 1)) >= 65536) pbits++;
+        if (c->opt_rec_part_bits >= 0) pbits = std::min(c->opt_rec_part_bits, 6);
+        const uint64_t n_parts = (uint64_t)G << pbits;
+        const uint64_t n_regions = n_parts << b1r, n_seg_r = n_parts << bbr;
         const int w = superkmer_wide_window(k);
-        const double mean_k = (double)(max_g >> b1r) + 1.0;
+        const double mean_k = (double)((max_g >> pbits) >> b1r) + 1.0;
         const double mean_r = mean_k * (2.0 / (w + 1) + 0.005);
         const uint64_t rstride64 = (uint64_t)(mean_r * 1.02 + 14.0 * std::sqrt(mean_r) + 32.0 + 15.0) / 16 * 16;
         const double expected_records = (double)b->total_syms * (2.0 / (w + 1) + 0.005);
@@ -2780,7 +2786,7 @@ static int wide_hash_local(grm_batch *b, int k, bool *fallback)
             HIPCHK(c, hipMemsetAsync(W.flag.p, 0, 32, s));
             {
                 TimeScope t(c, "superkmer_l1", b->total_syms);
-                launch_superkmer_l1(s, Lr, b1r, 0, W.recs.p, rstride, W.counts.as<uint32_t>(), W.cursor1.as<uint32_t>(), W.flag.as<int>());
+                launch_superkmer_l1(s, Lr, b1r, pbits, W.recs.p, rstride, W.counts.as<uint32_t>(), W.cursor1.as<uint32_t>(), W.flag.as<int>());
             }
             int l2_idx = -1;
             {
@@ -2789,7 +2795,7 @@ static int wide_hash_local(grm_batch *b, int k, bool *fallback)
                 launch_superkmer_l2_wide(s, W.recs.p, rstride, W.counts.as<uint32_t>(), n_regions, k, bbr, b1r, W.recs2.p, W.off.as<uint64_t>(),
                                          W.len.as<uint32_t>(), W.flag.as<int>());
             }
-            launch_sum_u32(s, W.cursor1.as<uint32_t>(), G, reinterpret_cast<uint64_t *>(W.flag.as<uint8_t>() + 8));
+            launch_sum_u32(s, W.cursor1.as<uint32_t>(), n_parts, reinterpret_cast<uint64_t *>(W.flag.as<uint8_t>() + 8));
             launch_sum_u32(s, W.counts.as<uint32_t>(), n_regions, reinterpret_cast<uint64_t *>(W.flag.as<uint8_t>() + 16));
             HIPCHK(c, hipGetLastError());
             struct { int over; int pad; uint64_t total; uint64_t records; uint64_t pad2; } h;
@@ -2798,6 +2804,7 @@ static int wide_hash_local(grm_batch *b, int k, bool *fallback)
             if (l2_idx >= 0 && l2_idx < (int)c->recs.size()) c->recs[l2_idx].units = h.records;
             if (!h.over) {
                 by_recs = true;
+                rec_pbits = pbits;
                 bb = bbr;
                 b->bb = bbr;
                 b->total_keys = h.total;
@@ -2902,7 +2909,7 @@ static int wide_hash_local(grm_batch *b, int k, bool *fallback)
             TimeScope t(c, "wh_dict_build", NK);
             launch_wh_dict_build(s, by_recs ? W.recs2.p : W.keys.p, seg, G, bb, sb, cap_log2, W.stage_lo.as<uint64_t>(), W.stage_hi.as<uint64_t>(),
                                  W.stage_flags.as<uint8_t>(), W.stage_cnt.as<uint32_t>(), W.matrix_s.as<uint64_t>(), W.birth.as<uint16_t>(),
-                                 W.flag.as<int>(), W.flag.as<uint32_t>() + 1, by_recs ? k : 0);
+                                 W.flag.as<int>(), W.flag.as<uint32_t>() + 1, by_recs ? k : 0, rec_pbits);
         }
         HIPCHK(c, hipGetLastError());
         struct { int over; uint32_t need; } h;

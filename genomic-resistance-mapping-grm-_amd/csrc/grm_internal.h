@@ -304,7 +304,7 @@ void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const
 // entries leave staged at wg * cap in entry-id order; presence words at matrix_s[wg][row][entry id] (nullptr: no bits)
 void launch_wh_dict_build(hipStream_t s, const void *keys, const SegLayout &seg, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
                           uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint64_t *matrix_s,
-                          uint16_t *birth, int *overflow, uint32_t *need, int recs_k = 0);
+                          uint16_t *birth, int *overflow, uint32_t *need, int recs_k = 0, int part_bits = 0);
 void launch_wh_dict_gather(hipStream_t s, const uint64_t *stage_lo, const uint64_t *stage_hi, const uint8_t *stage_flags,
                            const uint64_t *stage_off, uint32_t n_wg, uint32_t cap, uint64_t *out_lo, uint64_t *out_hi, uint8_t *out_flags);
 void launch_wh_mark(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint8_t *flags, const uint32_t *order, uint64_t n,

@@ -120,7 +120,9 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
         uint32_t valid = 0, heads = 0;
         uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, vs = 0;
         uint32_t prev2 = 0;
-        if (j <= j_b + 1) {          // (j_b: only for the run that crosses into it; j_b + 1: only its hashes; the stream buffers end with slack words)
+        // (j_b: only for the run that crosses into it; j_b + 1: only its hashes; WIDE: j_b + 2 for its word -- a run of 85 bases that starts late in
+        // the part's last window reaches the fourth word; the stream buffers end with slack words)
+        if (j <= j_b + (WIDE ? 2 : 1)) {
             const uint64_t p0 = j << 5;
             // (streamed once: loads marked non-temporal, so that the packed stream does not push the workgroups' half-filled record
             // lines out of L2)

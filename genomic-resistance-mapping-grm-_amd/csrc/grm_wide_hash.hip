@@ -417,7 +417,7 @@ __device__ __forceinline__ ulonglong2 wide_rec_kmer(uint32_t q, int k, const Wid
 }
 template <bool RECS>
 __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
-    const ulonglong2 *__restrict__ keys, const SegLayout seg, int k, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
+    const ulonglong2 *__restrict__ keys, const SegLayout seg, int k, int part_bits, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
     uint64_t *__restrict__ stage_lo, uint64_t *__restrict__ stage_hi, uint8_t *__restrict__ stage_flags,
     uint32_t *__restrict__ stage_cnt, uint64_t *__restrict__ matrix_s, uint16_t *__restrict__ birth, int *__restrict__ overflow,
     uint32_t *__restrict__ need)
@@ -442,6 +442,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
     const int lane = lane_id(), wave = wave_id(), nw = blockDim.x >> 6;        // nw = 8: divides 64
     const uint32_t max_fill = cap - (cap >> 3);
     const uint32_t per_row = 64u / (uint32_t)nw;
+    // (RECS: a genome may be cut into 2^part_bits parts, each with segments of its own: gg counts parts then)
     auto seg_of = [&](uint32_t gg, uint64_t &s0, uint64_t &n) {
         const uint64_t idx = (uint64_t)gg * B + b;
         if (RECS) { s0 = seg.off[idx]; n = seg.len[idx] & 0xffffu; }
@@ -472,13 +473,17 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
     }
     const uint64_t *recs = reinterpret_cast<const uint64_t *>(keys);
     // bounds of the next genome's segment are requested while the current one is processed
+    const uint32_t n_parts = RECS ? 1u << part_bits : 1u;
     uint32_t g = (uint32_t)wave;
     uint64_t s0 = 0, n = 0;
-    if (g < G) seg_of(g, s0, n);
+    if (g < G) seg_of(g << (RECS ? part_bits : 0), s0, n);
     for (uint32_t r = 0; r < n_rows; r++) {
         for (uint32_t jr = 0; jr < per_row; jr++, g += nw) {
+          for (uint32_t part = 0; part < n_parts; part++) {
+            // (the next segment: the genome's next part, or the first part of the wave's next genome)
             uint64_t s0_next = 0, n_next = 0;
-            if (g + nw < G) seg_of(g + nw, s0_next, n_next);
+            if (part + 1 < n_parts) { if (g < G) seg_of((g << part_bits) + part + 1, s0_next, n_next); }
+            else if (g + nw < G) seg_of((g + nw) << (RECS ? part_bits : 0), s0_next, n_next);
             if (g < G && !is_full()) {
                 const unsigned long long bit = 1ull << (63 - (g & 63));
                 // straight-line and predicated, as dict_build's probe (grm_kernels.hip): both probe slots of every key are
@@ -565,6 +570,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
             }
             s0 = s0_next;
             n = n_next;
+          }
         }
         __syncthreads();
         if (is_full()) break;    // read between two barriers: uniform
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
         uint64_t *scr64 = reinterpret_cast<uint64_t *>(lds_raw + (size_t)HLL_M * 4);
         for (uint32_t i = threadIdx.x; i < HLL_M; i += blockDim.x) hll[i] = 0;
         __syncthreads();
-        for (uint32_t gg = (uint32_t)wave; gg < G; gg += (uint32_t)nw) {
+        for (uint32_t gg = (uint32_t)wave; gg < G * n_parts; gg += (uint32_t)nw) {
             uint64_t sv = 0, nv = 0;
             seg_of(gg, sv, nv);
             for (uint64_t i = lane; i < nv; i += 64) {
@@ -759,15 +765,15 @@ void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const
 // recs_k: 0 = `keys` are 16-byte keys; else k, and `keys` are 24-byte run records (seg.off / seg.len in records)
 void launch_wh_dict_build(hipStream_t s, const void *keys, const SegLayout &seg, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
                           uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint64_t *matrix_s,
-                          uint16_t *birth, int *overflow, uint32_t *need, int recs_k)
+                          uint16_t *birth, int *overflow, uint32_t *need, int recs_k, int part_bits)
 {
     const size_t lds = (((size_t)26) << cap_log2) + TABLE_SCRATCH_BYTES + (recs_k ? (size_t)(TABLE_THREADS / 64) * WREC_WAVE_BYTES + WMEMO_BYTES : 0);
     if (recs_k)
         hipLaunchKernelGGL(wide_dict_build_kernel<true>, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, reinterpret_cast<const ulonglong2 *>(keys),
-                           seg, recs_k, n_genomes, bb, sb, cap_log2, stage_lo, stage_hi, stage_flags, stage_cnt, matrix_s, birth, overflow, need);
+                           seg, recs_k, part_bits, n_genomes, bb, sb, cap_log2, stage_lo, stage_hi, stage_flags, stage_cnt, matrix_s, birth, overflow, need);
     else
         hipLaunchKernelGGL(wide_dict_build_kernel<false>, dim3(1u << (bb + sb)), dim3(TABLE_THREADS), lds, s, reinterpret_cast<const ulonglong2 *>(keys),
-                           seg, 0, n_genomes, bb, sb, cap_log2, stage_lo, stage_hi, stage_flags, stage_cnt, matrix_s, birth, overflow, need);
+                           seg, 0, 0, n_genomes, bb, sb, cap_log2, stage_lo, stage_hi, stage_flags, stage_cnt, matrix_s, birth, overflow, need);
 }
 void launch_wh_dict_gather(hipStream_t s, const uint64_t *stage_lo, const uint64_t *stage_hi, const uint8_t *stage_flags,
                            const uint64_t *stage_off, uint32_t n_wg, uint32_t cap, uint64_t *out_lo, uint64_t *out_hi, uint8_t *out_flags)

@@ -622,9 +622,29 @@ def test_two_word_kmers(ctx, k, tmp_path):
         m.free(); b.free()
 
 
+def test_two_word_kmers_of_few_large_genomes_in_parts(ctx):
+    """few genomes: level 1 cuts each into parts (one workgroup per part), the dictionary workgroups go through a genome's parts; runs that
+    cross a part boundary, forced part counts, a genome shorter than the others"""
+    gs = [synth.random_genome(i, genome_len=300_000 if i else 90_000, seed=5, n_contigs=2).tobytes() for i in range(3)]
+    genomes = [[gs[0]], [gs[1]], [gs[2][:200_000] + gs[1][1000:150_000]]]
+    for k in (47, 63, 64):
+        for opts in ({}, {"rec_part_bits": 3}, {"rec_part_bits": 6}):
+            try:
+                for name, v in opts.items():
+                    ctx.set_option(name, v)
+                ctx.timing(True)
+                ctx.timing_reset()
+                _check(ctx, genomes, k, 1, False)
+                assert "superkmer_l1" in {t[0] for t in ctx.timings()}
+            finally:
+                ctx.timing(False)
+                for name in opts:
+                    ctx.set_option(name, -1)
+
+
 @pytest.mark.parametrize("k,opts", [(33, {}), (34, {}), (47, {}), (63, {}), (64, {}), (63, {"bucket_bits": 3, "cap_log2": 9}), (63, {"bucket_bits": 9})])
 def test_two_word_kmers_through_the_record_form(ctx, k, opts):
-    """from 128 genomes on two-word k-mers travel as 24-byte run records (the minimizer among the 21 / 22 m-mers in the middle of the
+    """two-word k-mers travel as 24-byte run records (the minimizer among the 21 / 22 m-mers in the middle of the
     k-mer): assemblies with their own contigs on either strand, indels, a repeated stretch and runs of N, against the oracle, with and
     without singletons; small tables (sub-buckets: every workgroup cuts the k-mers out of all its bucket's records) and many buckets;
     "records" 0 is the key form on the same input"""
