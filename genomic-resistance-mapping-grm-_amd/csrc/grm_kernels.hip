@@ -1690,7 +1690,7 @@ __global__ __launch_bounds__(WAVES * 64) void record_dedup_kernel(
 // bits of the hash) is passed by, one with the same fingerprint names its k-mer, which is cut out of the staged records again and
 // compared (a true repeat, or one in 2048 of the others).  The keys stay in registers (up to 7 per lane: a wave's segments have up
 // to 448 k-mers in up to 64 records), so the pass that writes the segment out reads one word per claimed slot and zeroes it.
-// Segments beyond that -- and counts from 4094 on -- are left to record_dedup_kernel (region_big / *overflow).
+// Segments beyond that are left to record_dedup_kernel (region_big).
 template <int NW>
 __device__ __forceinline__ uint32_t record_stage_small(ulonglong2 rec, uint32_t nr, ulonglong2 *srec, uint16_t *sstart, uint64_t *starts, uint8_t *firstrec)
 {
@@ -1743,7 +1743,6 @@ __global__ __launch_bounds__(WAVES * 64, 5) void record_count_kernel(
     uint64_t *starts = starts_all[wave];
     uint8_t *firstrec = firstrec_all[wave];
     for (uint32_t i = threadIdx.x; i < WAVES * CAP; i += THREADS) (&tab_all[0][0])[i] = 0;
-    bool saturated = false;
     __syncthreads();
     for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
         const uint32_t n = min(rcount[region], rstride);
@@ -1826,8 +1825,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void record_count_kernel(
                             if (((o ^ nw) & FP_MASK) == 0u) {             // the same fingerprint: the same k-mer?
                                 const uint64_t other = record_chunk_kmer((o & ((1u << ID_BITS) - 1u)) - 1u, k, srec, sstart, starts, firstrec);
                                 if (other == kv[j]) {
-                                    const uint32_t was = atomicAdd(&tab[at], ONE);
-                                    if ((was >> (ID_BITS + FP_BITS)) >= 4094u) saturated = true;
+                                    atomicAdd(&tab[at], ONE);       // (a count stays below the segment's <= 448 k-mers: 12 bits hold it)
                                     mine = false;
                                     break;
                                 }
@@ -1869,7 +1867,6 @@ __global__ __launch_bounds__(WAVES * 64, 5) void record_count_kernel(
         }
         __syncthreads();
     }
-    if (__any(saturated) && lane == 0) atomicExch(overflow, 1);
 }
 
 // ------------------------------------------------------------------------------------

@@ -298,13 +298,20 @@ __device__ __forceinline__ uint32_t wide_find_or_insert(ulonglong2 *tkey, uint32
 constexpr uint32_t WMETA_ID = 0x1fffu, WMETA_SEEN = 0x4000u, WMETA_MULTI = 0x8000u;
 constexpr uint32_t WREC_WORDS = (64 * RUN_LMAX + 63) / 64;                  // bitmap words of a chunk's k-mer positions
 // per wave: records, their memo ids, starts, bitmap, first record of every bitmap word
-constexpr uint32_t WREC_WAVE_BYTES = 64 * 24 + 64 * 2 + 64 * 2 + WREC_WORDS * 8 + WREC_WORDS * 4 + 8;
+constexpr uint32_t WREC_SEGS = 16;                                           // segments a wave packs its chunks from at a time
+constexpr uint32_t WREC_WAVE_BYTES = 64 * 24 + 64 * 2 + 64 * 2 + WREC_WORDS * 8 + WREC_WORDS * 4 + 8 + 64 + WREC_SEGS * 13 + 8;
 struct WideRecStage {
     uint64_t *srec;         // [64][3]
     uint16_t *smid;         // [64] memo id of the record when this wave entered it (its k-mers' slots are noted), else 0xffff
     uint16_t *sstart;       // [64]
     uint64_t *starts;       // [WREC_WORDS]
     uint32_t *firstrec;     // [WREC_WORDS]
+    uint8_t *sgb;           // [64] the record's genome inside the word-row (bit 63 - sgb)
+    // the group of segments the chunks are packed from: records before the end of segment i (running), where record f of the group
+    // stands (seg_base[i] + f), the segment's genome inside the word-row
+    uint64_t *seg_base;     // [WREC_SEGS]
+    uint32_t *seg_end;      // [WREC_SEGS]
+    uint8_t *seg_gb;        // [WREC_SEGS]
 };
 // The RECORD MEMO, as dict_build's (grm_kernels.hip): genomes of a pan-genome hold the same runs, so the bucket's records are kept
 // in a small LDS table with the table slots of their k-mers.  A record that is held costs ONE atomic OR into the record's own presence
@@ -327,10 +334,27 @@ __device__ __forceinline__ uint32_t wmemo_hash(uint64_t r0, uint64_t r1, uint64_
                        __umul24((uint32_t)(r2 >> 40), 0x7F4A7Du) + __umul24((uint32_t)(r2 >> 16), 0x94D049u) + __umul24((uint32_t)r2 & 0xffffu, 0xBF5847u);
     return h ^ (h >> 13);
 }
-// 0: the record is held and `bit` went into its word; 1: this lane entered it (*id: its k-mers' slots are to be noted); 2: not held
-__device__ __forceinline__ int wmemo_take(const WideMemo &M, uint64_t r0, uint64_t r1, uint64_t r2, unsigned long long bit, uint32_t *id_out)
+// The common case, straight-line: the record's bucket holds it (the first slot with its tag).  ORs `bit` into its word and returns true then.
+__device__ __forceinline__ bool wmemo_hit(const WideMemo &M, uint64_t r0, uint64_t r1, uint64_t r2, unsigned long long bit, uint32_t h)
 {
-    const uint32_t h = wmemo_hash(r0, r1, r2);
+    const uint32_t tag = (h >> 16) | 1u;
+    const uint4 v = *reinterpret_cast<const uint4 *>(&M.slot[(h & (WMEMO_BUCKETS - 1)) << 2]);
+    uint32_t e = 0;
+    e = (v.w >> 16) == tag ? v.w : e;
+    e = (v.z >> 16) == tag ? v.z : e;
+    e = (v.y >> 16) == tag ? v.y : e;
+    e = (v.x >> 16) == tag ? v.x : e;
+    const uint32_t idp = e & 0xffffu;                   // id + 1 (0: no slot with the tag; a slot being written has tag 0)
+    bool ok = idp != 0u;
+    const uint32_t id = ok ? idp - 1u : 0u;
+    ok = ok && M.rec[3 * id] == r0 && M.rec[3 * id + 1] == r1 && M.rec[3 * id + 2] == r2;
+    if (ok) atomicOr(&M.words[id], bit);
+    return ok;
+}
+// The rest (first occurrence of a record, a slot being written, a second slot with the same tag).
+// 0: the record is held and `bit` went into its word; 1: this lane entered it (*id: its k-mers' slots are to be noted); 2: not held
+__device__ __forceinline__ int wmemo_take(const WideMemo &M, uint64_t r0, uint64_t r1, uint64_t r2, unsigned long long bit, uint32_t h, uint32_t *id_out)
+{
     const uint32_t tag = (h >> 16) | 1u;          // (never 0: an entry word is never 0 or the lock)
     uint32_t *bucket = &M.slot[(h & (WMEMO_BUCKETS - 1)) << 2];
     for (int round = 0; round < 4; round++) {
@@ -364,26 +388,28 @@ __device__ __forceinline__ int wmemo_take(const WideMemo &M, uint64_t r0, uint64
     }
     return 2;
 }
-// A chunk of up to 64 records: those the memo holds are done with here; the others are put into LDS (in their order) for the lanes
-// to take their k-mers.  Returns the k-mers staged.
-__device__ __forceinline__ uint32_t wide_rec_stage(const uint64_t *__restrict__ src, uint32_t nc, const WideRecStage &st, const WideMemo &M,
-                                                   unsigned long long bit)
+// A chunk of up to 64 records (one per lane, `have`; gb: the record's genome inside the word-row): those the memo holds are done
+// with here; the others are put into LDS (in their order) for the lanes to take their k-mers.  Returns the k-mers staged.
+__device__ __forceinline__ uint32_t wide_rec_stage(bool have, uint64_t r0, uint64_t r1, uint64_t r2, uint32_t gb, const WideRecStage &st,
+                                                   const WideMemo &M)
 {
     const int lane = lane_id();
-    uint64_t r0 = 0, r1 = 0, r2 = 0;
-    const bool have = (uint32_t)lane < nc;
-    if (have) { r0 = src[3 * lane]; r1 = src[3 * lane + 1]; r2 = src[3 * lane + 2]; }
+    const unsigned long long bit = 1ull << (63u - gb);
     uint32_t mid = WMEMO_NONE;
     bool direct = have;
-    if (have) {
+    const uint32_t h = wmemo_hash(r0, r1, r2);
+    if (have && !wmemo_hit(M, r0, r1, r2, bit, h)) {
         uint32_t id = 0;
-        const int how = wmemo_take(M, r0, r1, r2, bit, &id);
+        const int how = wmemo_take(M, r0, r1, r2, bit, h, &id);
         direct = how != 0;
         if (how == 1) mid = id;
+    } else {
+        direct = false;
     }
     const uint64_t dm = __ballot(direct);
     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
     const uint32_t n_direct = (uint32_t)__popcll(dm);
+    if (!n_direct) return 0;                            // (uniform) the common case in a pan-genome: every record held
     const uint32_t ln = direct ? run_len(r2) : 0u;
     const uint32_t incl = wave_scan_incl_dpp(ln), s0 = incl - ln;
     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -392,6 +418,7 @@ __device__ __forceinline__ uint32_t wide_rec_stage(const uint64_t *__restrict__ 
         st.srec[3 * pos] = r0; st.srec[3 * pos + 1] = r1; st.srec[3 * pos + 2] = r2;
         st.sstart[pos] = (uint16_t)s0;
         st.smid[pos] = (uint16_t)mid;
+        st.sgb[pos] = (uint8_t)gb;
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __asm__ volatile("" ::: "memory");
@@ -458,6 +485,13 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
         st.firstrec = reinterpret_cast<uint32_t *>(mine + 64 * 24 + WREC_WORDS * 8);
         st.sstart = reinterpret_cast<uint16_t *>(mine + 64 * 24 + WREC_WORDS * 12);
         st.smid = reinterpret_cast<uint16_t *>(mine + 64 * 24 + WREC_WORDS * 12 + 64 * 2);
+        {
+            uint8_t *more = mine + ((64 * 24 + WREC_WORDS * 12 + 64 * 4 + 7) & ~7u);
+            st.seg_base = reinterpret_cast<uint64_t *>(more);
+            st.seg_end = reinterpret_cast<uint32_t *>(more + WREC_SEGS * 8);
+            st.seg_gb = more + WREC_SEGS * 12;
+            st.sgb = more + WREC_SEGS * 13;
+        }
         uint8_t *mraw = stage_raw + (size_t)(blockDim.x >> 6) * WREC_WAVE_BYTES;
         M.slot = reinterpret_cast<uint32_t *>(mraw);
         M.rec = reinterpret_cast<uint64_t *>(mraw + WMEMO_BUCKETS * 16);
@@ -473,45 +507,154 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
     }
     const uint64_t *recs = reinterpret_cast<const uint64_t *>(keys);
     // bounds of the next genome's segment are requested while the current one is processed
-    const uint32_t n_parts = RECS ? 1u << part_bits : 1u;
-    uint32_t g = (uint32_t)wave;
-    uint64_t s0 = 0, n = 0;
-    if (g < G) seg_of(g << (RECS ? part_bits : 0), s0, n);
+    const int pb = RECS ? part_bits : 0;
+    const uint32_t n_parts = 1u << pb;
+    // key form: the bounds of the wave's next segments (genome wave + i * nw) are asked for two steps ahead
+    auto seg_step = [&](uint32_t i, uint64_t &a, uint64_t &c) {
+        const uint32_t gq = (uint32_t)wave + i * (uint32_t)nw;
+        a = 0; c = 0;
+        if (!RECS && gq < G) seg_of(gq, a, c);
+    };
+    uint32_t g = (uint32_t)wave, step = 0;
+    uint64_t s0, n, s1, n1;
+    seg_step(0, s0, n);
+    seg_step(1, s1, n1);
     for (uint32_t r = 0; r < n_rows; r++) {
-        for (uint32_t jr = 0; jr < per_row; jr++, g += nw) {
-          for (uint32_t part = 0; part < n_parts; part++) {
-            // (the next segment: the genome's next part, or the first part of the wave's next genome)
-            uint64_t s0_next = 0, n_next = 0;
-            if (part + 1 < n_parts) { if (g < G) seg_of((g << part_bits) + part + 1, s0_next, n_next); }
-            else if (g + nw < G) seg_of((g + nw) << (RECS ? part_bits : 0), s0_next, n_next);
-            if (g < G && !is_full()) {
-                const unsigned long long bit = 1ull << (63 - (g & 63));
-                // straight-line and predicated, as dict_build's probe (grm_kernels.hip): both probe slots of every key are
-                // read, a key found there ORs its bit in under a predicate; only a key that is in neither slot goes round
-                // the insertion loop (a bit mask of the lane's keys still to do, no per-key branches)
-                constexpr int KJ = 2;                    // keys per lane in flight (segments hold ~300 keys)
-                // RECS: chunk after chunk of 64 records (n_keys k-mers each); else one "chunk" = the segment's keys
-                for (uint64_t c0 = 0; c0 < (RECS ? n : 1u) && !is_full(); c0 += 64) {
-                uint64_t n_keys = n;
-                if (RECS) n_keys = wide_rec_stage(recs + 3 * (s0 + c0), (uint32_t)min((uint64_t)64, n - c0), st, M, bit);
-                for (uint64_t i0 = lane; i0 < n_keys + (uint64_t)lane && !is_full(); i0 += 64 * KJ) {        // (uniform trip count)
-                    ulonglong2 kv[KJ];
-                    uint64_t hv[KJ];
-                    uint32_t sl[KJ];
-                    uint32_t note[KJ];                   // RECS: where in the memo the k-mer's slot is noted (its record entered by this wave), else ~0
+        if constexpr (RECS) {
+            // The wave's segments of this word-row -- part p of genome r * 64 + wave + j * nw: t = j << pb | p -- in groups of WREC_SEGS:
+            // their records are taken 64 at a time ACROSS the segments (a segment holds ~30 records: taken one segment at a time, half the
+            // lanes of every chunk idled and the dictionary was bound by the instructions of its ~8 million chunks).  A lane finds the
+            // segment of its record by a search over the group's running record counts.
+            const uint32_t T = per_row << pb;
+            for (uint32_t t0 = 0; t0 < T && !is_full(); t0 += WREC_SEGS) {
+                {
+                    const uint32_t t = t0 + (uint32_t)lane;
+                    const uint32_t gq = r * 64u + (uint32_t)wave + (t >> pb) * (uint32_t)nw;
+                    uint64_t a = 0, c = 0;
+                    if ((uint32_t)lane < WREC_SEGS && t < T && gq < G) seg_of((gq << pb) + (t & (n_parts - 1)), a, c);
+                    const uint32_t incl = wave_scan_incl_dpp((uint32_t)c);
+                    if ((uint32_t)lane < WREC_SEGS) {
+                        st.seg_end[lane] = incl;
+                        st.seg_base[lane] = a - (uint64_t)(incl - (uint32_t)c);
+                        st.seg_gb[lane] = (uint8_t)(gq & 63u);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __asm__ volatile("" ::: "memory");
+                }
+                const uint32_t total = st.seg_end[WREC_SEGS - 1];
+                for (uint32_t f0 = 0; f0 < total && !is_full(); f0 += 64) {
+                    const uint32_t f = f0 + (uint32_t)lane;
+                    const bool have = f < total;
+                    uint32_t lo = 0, hi = WREC_SEGS - 1;            // first segment whose running count exceeds f
 #pragma unroll
-                    for (int j = 0; j < KJ; j++) {
-                        const uint64_t i = i0 + 64u * j;
-                        note[j] = ~0u;
-                        if (RECS) {
+                    for (int it = 0; it < 4; it++) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        const bool below = st.seg_end[mid] > f;
+                        hi = below ? mid : hi;
+                        lo = below ? lo : min(mid + 1, WREC_SEGS - 1);
+                    }
+                    const uint64_t at = st.seg_base[lo] + f;
+                    const uint32_t gb = st.seg_gb[lo];
+                    uint64_t r0 = 0, r1 = 0, r2 = 0;
+                    if (have) { r0 = recs[3 * at]; r1 = recs[3 * at + 1]; r2 = recs[3 * at + 2]; }
+                    const uint64_t n_keys = wide_rec_stage(have, r0, r1, r2, gb, st, M);
+                    constexpr int KJ = 2;
+                    for (uint64_t i0 = lane; i0 < n_keys + (uint64_t)lane && !is_full(); i0 += 64 * KJ) {        // (uniform trip count)
+                        ulonglong2 kv[KJ];
+                        uint64_t hv[KJ];
+                        uint32_t sl[KJ];
+                        uint32_t note[KJ];               // where in the memo the k-mer's slot is noted (its record entered by this wave), else ~0
+                        unsigned long long kbit[KJ];
+#pragma unroll
+                        for (int j = 0; j < KJ; j++) {
+                            const uint64_t i = i0 + 64u * j;
+                            note[j] = ~0u;
+                            kbit[j] = 0;
                             kv[j] = make_ulonglong2(WH_EMPTY, WH_EMPTY);
                             if (i < n_keys) {
                                 uint32_t o, t;
                                 kv[j] = wide_rec_kmer((uint32_t)i, k, st, o, t);
                                 const uint32_t mid = st.smid[o];
                                 if (mid != WMEMO_NONE) note[j] = mid * WMEMO_KS + t;
+                                kbit[j] = 1ull << (63u - st.sgb[o]);
                             }
-                        } else kv[j] = i < n_keys ? keys[s0 + i] : make_ulonglong2(WH_EMPTY, WH_EMPTY);
+                        }
+#pragma unroll
+                        for (int j = 0; j < KJ; j++) {
+                            hv[j] = mix128(kv[j].y, kv[j].x);
+                            sl[j] = hash_slot(hv[j], cap_mask);
+                        }
+                        ulonglong2 c0[KJ], c1[KJ];
+#pragma unroll
+                        for (int j = 0; j < KJ; j++) {
+                            c0[j] = tkey[sl[j]];
+                            c1[j] = tkey[(sl[j] + 1) & cap_mask];
+                        }
+                        uint32_t todo = 0;
+#pragma unroll
+                        for (int j = 0; j < KJ; j++) {
+                            const bool active = !(kv[j].x == WH_EMPTY && kv[j].y == WH_EMPTY) && (!sb || hash_sub(hv[j], bb, sb) == sub);
+                            const bool hit0 = c0[j].x == kv[j].x && c0[j].y == kv[j].y;
+                            const bool hit1 = c1[j].x == kv[j].x && c1[j].y == kv[j].y;
+                            const uint32_t at2 = hit1 ? ((sl[j] + 1) & cap_mask) : sl[j];
+                            if (active && (hit0 | hit1)) {
+                                __hip_atomic_fetch_or(&words[at2], kbit[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (note[j] != ~0u) M.kslot[note[j]] = (uint16_t)at2;
+                            }
+                            todo |= (uint32_t)(active && !(hit0 | hit1)) << j;
+                        }
+                        while (todo) {
+                            if (is_full()) break;
+                            const int j = __ffs(todo) - 1;
+                            todo &= todo - 1;
+                            ulonglong2 key = kv[0];
+                            uint64_t h = hv[0];
+                            uint32_t nt = note[0];
+                            unsigned long long kb = kbit[0];
+#pragma unroll
+                            for (int q = 1; q < KJ; q++) { if (j == q) { key = kv[q]; h = hv[q]; nt = note[q]; kb = kbit[q]; } }
+                            bool ins;
+                            const uint32_t slot = wide_find_or_insert(tkey, cap_mask, key.y, key.x, h, &ins);
+                            bool over = slot == 0xffffffffu;
+                            if (!over) {
+                                if (ins) {
+                                    const uint32_t id = atomicAdd(&n_distinct, 1u);
+                                    meta[slot] = (uint16_t)(id & WMETA_ID);
+                                    if (birth && id < cap) birth[((uint64_t)wg << cap_log2) + id] = (uint16_t)r;
+                                    over = id >= max_fill;
+                                }
+                                __hip_atomic_fetch_or(&words[slot], kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (nt != ~0u) M.kslot[nt] = (uint16_t)slot;
+                            }
+                            if (over) {
+                                __hip_atomic_store(full_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                break;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);      // the staging arrays are free again
+                    __asm__ volatile("" ::: "memory");
+                }
+            }
+        } else {
+        for (uint32_t jr = 0; jr < per_row; jr++, g += nw) {
+            uint64_t s0_next = s1, n_next = n1;
+            seg_step(step + 2, s1, n1);
+            step++;
+            if (g < G && !is_full()) {
+                const unsigned long long bit = 1ull << (63 - (g & 63));
+                // straight-line and predicated, as dict_build's probe (grm_kernels.hip): both probe slots of every key are
+                // read, a key found there ORs its bit in under a predicate; only a key that is in neither slot goes round
+                // the insertion loop (a bit mask of the lane's keys still to do, no per-key branches)
+                constexpr int KJ = 2;                    // keys per lane in flight (segments hold ~300 keys)
+                for (uint64_t i0 = lane; i0 < n && !is_full(); i0 += 64 * KJ) {
+                    ulonglong2 kv[KJ];
+                    uint64_t hv[KJ];
+                    uint32_t sl[KJ];
+#pragma unroll
+                    for (int j = 0; j < KJ; j++) {
+                        const uint64_t i = i0 + 64u * j;
+                        kv[j] = i < n ? keys[s0 + i] : make_ulonglong2(WH_EMPTY, WH_EMPTY);
                     }
 #pragma unroll
                     for (int j = 0; j < KJ; j++) {
@@ -531,10 +674,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                         const bool hit0 = c0[j].x == kv[j].x && c0[j].y == kv[j].y;
                         const bool hit1 = c1[j].x == kv[j].x && c1[j].y == kv[j].y;
                         const uint32_t at = hit1 ? ((sl[j] + 1) & cap_mask) : sl[j];
-                        if (active && (hit0 | hit1)) {
-                            __hip_atomic_fetch_or(&words[at], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (RECS && note[j] != ~0u) M.kslot[note[j]] = (uint16_t)at;
-                        }
+                        if (active && (hit0 | hit1)) __hip_atomic_fetch_or(&words[at], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         todo |= (uint32_t)(active && !(hit0 | hit1)) << j;
                     }
                     while (todo) {
@@ -543,9 +683,8 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                         todo &= todo - 1;
                         ulonglong2 key = kv[0];
                         uint64_t h = hv[0];
-                        uint32_t nt = note[0];
 #pragma unroll
-                        for (int q = 1; q < KJ; q++) { if (j == q) { key = kv[q]; h = hv[q]; nt = note[q]; } }
+                        for (int q = 1; q < KJ; q++) { if (j == q) { key = kv[q]; h = hv[q]; } }
                         bool ins;
                         const uint32_t slot = wide_find_or_insert(tkey, cap_mask, key.y, key.x, h, &ins);
                         bool over = slot == 0xffffffffu;
@@ -557,7 +696,6 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                                 over = id >= max_fill;
                             }
                             __hip_atomic_fetch_or(&words[slot], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (RECS && nt != ~0u) M.kslot[nt] = (uint16_t)slot;
                         }
                         if (over) {
                             __hip_atomic_store(full_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // (what it would have needed is counted after the word-row loop)
@@ -565,12 +703,10 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                         }
                     }
                 }
-                if (RECS) { __builtin_amdgcn_s_waitcnt(0xC07F); __asm__ volatile("" ::: "memory"); }      // the staging arrays are free again
-                }
             }
             s0 = s0_next;
             n = n_next;
-          }
+        }
         }
         __syncthreads();
         if (is_full()) break;    // read between two barriers: uniform

@@ -1074,6 +1074,37 @@ def test_counting_stage_through_the_record_form(ctx, k, opts, by_records):
             ctx.set_option(name, -1)
 
 
+def test_counting_stage_with_heavily_repeated_kmers(ctx):
+    """a k-mer that one genome holds 6000 times (a homopolymer, a short tandem repeat): its segment is far beyond what a wave's one-word
+    table slots take (448 k-mers, counts of 12 bits), so it is counted in the workgroup's 64-bit table -- or its region overflows and the
+    batch goes to the key form; either way the counted sets equal the oracle's, count for count"""
+    n, k = 130, 31
+    rng = np.random.RandomState(3)
+    genomes = []
+    for i in range(n):
+        body = cases.rand_seq(rng, 3000 if i % 2 else 400_000)
+        if i == 0:
+            body = "A" * 6030 + body + "ACGT" * 1600                 # A^31 6000 times; the four rotations of (ACGT)^n ~1590 times each
+        if i == 77:
+            body = body + "N" + "TG" * 5000                          # (TG)^n / (GT)^n: ~4985 times each, canonical forms of two k-mers
+        genomes.append((">g%d\n%s\n" % (i, body)).encode())
+    for amin in (1, 3):
+        b = ctx.batch(n)
+        for g, f in enumerate(genomes):
+            b.add(g, f)
+        b.upload()
+        b.partition_counts(k, amin)
+        for g in (0, 1, 77, n - 1):
+            km, ct, nocc = orc.count_genome([genomes[g]], k, amin)
+            s_ = b.genome_set(g)
+            assert s_.occurrences == nocc
+            assert s_.kmers().shape == km.shape and (s_.kmers() == km).all() and (s_.counts() == ct).all()
+            if g == 0 and amin == 1:
+                assert ct.max() >= 6000
+            s_.free()
+        b.free()
+
+
 # ---- the reference-held fixture through the HIP path -------------------------------------------
 def test_reference_31mers_through_the_engine(ctx, golden_dir):
     """the 196 canonical 31-mers the reference ships (page/results/**, output of the real DSK pipeline) as
