@@ -735,6 +735,7 @@ struct grm_batch {
     // are expanded from d_recs only if a later stage asks for them (batch_expand_keys).
     DevBuf d_recs, d_recs2;
     bool rec_mode = false, rec_failed = false, rec_dict = false;
+    int rec_count_pbits = 0;           // counting over records: parts per genome (log2) level 1 cut -- their k-mer counts add up to the genome's
     uint32_t rec_rstride = 0;
     uint64_t rec_kstride = 0, rec_regions = 0;
     int rec_b1 = 0;                // coarse bits of the record regions
@@ -1142,18 +1143,20 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
     // segment sizes inside a region.
     // (k < 19: a k-mer holds fewer than 9 m-mers and runs get short: measured at 300 x 5 Mbp, the record form takes 16.2 ms against
     // 18.0 for the key form at k = 21, but 19.8 against 17.9 at k = 15 and 28.7 against 16.8 at k = 12 -- unless asked for)
-    // A counting partition (counts wanted, or an abundance filter) takes the records too when every genome is one part: level 2 sorts the
-    // records by bucket and record_dedup (grm_kernels.hip) counts the k-mers of a (genome, bucket) segment straight from its records --
-    // 1.45 B per k-mer moved twice instead of 8 B moved twice and read a third time.  (Few large genomes -- reads -- are cut into
-    // parts, whose counts would have to be added up per genome: they stay on the key form.)
+    // A counting partition (counts wanted, or an abundance filter) takes the records too: level 2 sorts the records by bucket and
+    // record_count / record_dedup (grm_kernels.hip) count the k-mers of a (genome, bucket) segment straight from its records --
+    // 1.45 B per k-mer moved twice instead of 8 B moved twice and read a third time.  Few large genomes (read sets) are cut into
+    // parts for level 1: record_merge then counts a genome's bucket over its parts' segments in one workgroup-wide table.
     const bool counting = abundance_min > 1 || want_counts;
-    if (k >= (c->opt_records > 0 ? SK_M : SK_M + 8) && (!counting || (G >= 128 && c->opt_rec_count != 0)) && c->opt_records != 0 && !b->rec_failed &&
+    if (k >= (c->opt_records > 0 ? SK_M : SK_M + 8) && (!counting || c->opt_rec_count != 0) && c->opt_records != 0 && !b->rec_failed &&
         c->opt_dense_layout <= 0) {
         int bbr = c->opt_bucket_bits >= 0 ? b->bb : b->bb + (c->opt_rec_bucket_shift >= 0 ? c->opt_rec_bucket_shift : 1);
         if (c->opt_bucket_bits < 0 && b->rec_bb_hint > bbr && b->rec_bb_hint_k == k) bbr = b->rec_bb_hint;
         // (counting: a wave's table of 512 slots per segment -- segments of ~150 k-mers, minimizer buckets being uneven)
         if (counting && c->opt_bucket_bits < 0) while (bbr < superkmer_coarse_bits(bbr + 1) + 7 && (max_g >> bbr) > 192) bbr++;
         bbr = std::min(bbr, superkmer_max_bits());
+        // (a record carries 7 bucket bits below the coarse ones)
+        if (c->opt_rec_coarse <= 0) bbr = std::min(bbr, superkmer_coarse_bits(bbr) + 7);
         const int b1r = c->opt_rec_coarse > 0 ? std::max(bbr - 7, std::min(c->opt_rec_coarse, superkmer_coarse_bits(bbr))) : superkmer_coarse_bits(bbr);
         // one workgroup per genome part owns the part's regions: enough parts to fill the device when genomes are few
         int pbits = 0;
@@ -1161,7 +1164,8 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         // parts per genome -- level 1 gains, level 2 and dict_build pay for the smaller segments)
         while (((uint64_t)G << pbits) < 256 && pbits < 6 && (max_g >> (pbits + 1)) >= 65536) pbits++;
         if (c->opt_rec_part_bits >= 0) pbits = std::min(c->opt_rec_part_bits, 6);
-        if (counting) pbits = 0;
+        // (counting a read set with more, smaller parts -- so that level 2 still sorts a region inside LDS: 3.8 instead of 7.1 ms for C4's
+        // 7e8 records -- costs record_merge more than that: 27.1 against 20.2 ms with 128 instead of 32 parts per genome)
         const uint64_t n_parts = (uint64_t)G << pbits;
         const uint64_t n_regions = n_parts << b1r, n_seg_r = n_parts << bbr;
         // records per region: a run ends where the minimizer occurrence changes -- 2 / (w + 1) per position for the w m-mers
@@ -1187,8 +1191,10 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
         const uint32_t cap_r = (b->rec_memo_log2 && c->opt_cap_log2 <= 0) ? 11u : b->cap_log2;
         bool by_records = !counting && c->opt_no_slots <= 0 && c->opt_rec_keys <= 0 && n_rows_b <= 0xffffu &&
                           ((size_t)1 << bbr) * n_rows_b * ((size_t)1 << cap_r) * 8 <= MATRIX_S_LIMIT;
-        // counting: segments of more than 448 k-mers take the second, workgroup-wide launch, and more than 1792 distinct ones fit no table
-        if (counting && (max_g >> bbr) > 600) rec = false;
+        // counting, one part per genome: segments of more than 448 k-mers take the second, workgroup-wide launch, and more than 1792 distinct
+        // ones fit no table; level 1 runs one workgroup per part: fewer than 128 of them leave the device idle (the key form then)
+        if (counting && pbits == 0 && (max_g >> bbr) > 600) rec = false;
+        if (counting && n_parts < (pbits ? 32u : 128u)) rec = false;
         const bool l2_records = by_records || counting;
         if (rec && b->d_recs.ensure((n_regions * rstride64 + 4) * 16) != hipSuccess) {
             (void)hipGetLastError();
@@ -1243,7 +1249,36 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
             HIPCHK(c, hipMemcpyAsync(&h, b->t_flag.p, 32, hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
             if (l2_idx >= 0 && l2_idx < (int)c->recs.size()) c->recs[l2_idx].units = h.records;
-            if (!h.over && counting) {
+            bool merged_parts = false;
+            if (!h.over && counting && pbits > 0) {
+                // genomes in parts: a genome's bucket is counted over its parts' record segments (the table must hold its DISTINCT k-mers:
+                // 2^12 slots first, 2^13 if those overflow, the key form after that)
+                const uint64_t n_seg_g = (uint64_t)G << bbr;
+                HIPCHK(c, b->d_koff.ensure((n_seg_g + 1) * 8));
+                HIPCHK(c, b->d_klen.ensure((n_seg_g + 1) * 4));
+                int fl = 0;
+                for (int big = c->opt_rec_count_cap >= 12 ? std::min(13, c->opt_rec_count_cap) : 12; big <= 13; big++) {
+                    HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 8, s));
+                    {
+                        TimeScope t(c, "record_merge", h.total);
+                        HIPCHK(c, launch_record_merge(s, b->d_recs2.p, rstride, b->d_counts1.as<uint32_t>(), b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), G, pbits,
+                                                      k, bbr, b1r, kstride << pbits, big, abundance_min, b->d_keys.as<uint64_t>(),
+                                                      want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, b->d_koff.as<uint64_t>(), b->d_klen.as<uint32_t>(),
+                                                      b->t_flag.as<int>()));
+                    }
+                    HIPCHK(c, hipGetLastError());
+                    HIPCHK(c, hipMemcpyAsync(&fl, b->t_flag.p, 4, hipMemcpyDeviceToHost, s));
+                    HIPCHK(c, hipStreamSynchronize(s));
+                    if (!fl) break;
+                }
+                h.over = fl;
+                if (!h.over) {
+                    std::swap(b->d_off.p, b->d_koff.p); std::swap(b->d_off.bytes, b->d_koff.bytes);
+                    std::swap(b->d_len.p, b->d_klen.p); std::swap(b->d_len.bytes, b->d_klen.bytes);
+                    b->deduped = true;
+                    merged_parts = true;
+                }
+            } else if (!h.over && counting) {
                 // distinct k-mers (+ counts, abundance filter) of every (genome, bucket) segment, from its records
                 const int cap_w = c->opt_rec_count_cap == 8 ? 8 : 9;
                 HIPCHK(c, b->d_marks.ensure(n_regions + 16));
@@ -1280,7 +1315,8 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
                 b->bb = bbr;
                 b->total_keys = h.total;
                 b->seg_stride = 0;
-                b->rec_part_bits = pbits;
+                b->rec_part_bits = merged_parts ? 0 : pbits;         // (merged: the segments are the genomes' again)
+                b->rec_count_pbits = counting ? pbits : 0;
                 b->rec_mode = true;
                 b->rec_dict = by_records;
                 if (by_records) b->cap_log2 = cap_r;
@@ -3273,9 +3309,10 @@ static int genome_set_impl(grm_batch *b, int g, bool have_counts, grm_kmer_set *
         if (b->rec_part_bits != 0 || !b->deduped) return fail(c, GRM_ERR_STATE, "internal: a genome's set from record segments needs one part per genome and a dedup");
         HIPCHK(c, hipMemcpy(off.data(), b->d_off.as<uint64_t>() + (uint64_t)g * B, B * 8, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(len.data(), b->d_len.as<uint32_t>() + (uint64_t)g * B, B * 4, hipMemcpyDeviceToHost));
-        uint32_t occ = 0;
-        HIPCHK(c, hipMemcpy(&occ, b->d_cursor1.as<uint32_t>() + g, 4, hipMemcpyDeviceToHost));        // level 1: k-mers of the part
-        set->occurrences = occ;
+        std::vector<uint32_t> occ((size_t)1 << b->rec_count_pbits);
+        HIPCHK(c, hipMemcpy(occ.data(), b->d_cursor1.as<uint32_t>() + ((size_t)g << b->rec_count_pbits), occ.size() * 4, hipMemcpyDeviceToHost));   // level 1: k-mers of the parts
+        set->occurrences = 0;
+        for (uint32_t v : occ) set->occurrences += v;
     } else {
         HIPCHK(c, hipMemcpy(off.data(), b->d_off.as<uint64_t>() + (uint64_t)g * B, (B + 1) * 8, hipMemcpyDeviceToHost));
         set->occurrences = off[B] - off[0];

@@ -136,6 +136,9 @@ void launch_bucket_dedup(hipStream_t s, uint64_t *keys, const SegLayout &seg, ui
                          uint32_t abundance_min, uint32_t *len_out, const uint32_t *marks, uint32_t *counts_out, int *overflow);
 void launch_superkmer_l2_wide(hipStream_t s, const void *recs1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k, int bb, int b1,
                               void *recs2, uint64_t *off, uint32_t *len_out, int *overflow);
+hipError_t launch_record_merge(hipStream_t s, const void *recs, uint32_t rstride, const uint32_t *rcount, const uint64_t *roff, const uint32_t *rlen,
+                               uint32_t n_genomes, int part_bits, int k, int bb, int b1, uint64_t kstride, int big_log2, uint32_t abundance_min,
+                               uint64_t *keys, uint32_t *counts_out, uint64_t *koff, uint32_t *klen, int *overflow);
 void launch_record_count(hipStream_t s, const void *recs, uint32_t rstride, const uint32_t *rcount, uint64_t n_regions, int k, int bb, int b1,
                          uint64_t kstride, int cap_log2, uint32_t abundance_min, uint64_t *keys, uint32_t *counts_out, uint64_t *koff,
                          uint32_t *klen, int *overflow, uint8_t *region_big, int *any_big);

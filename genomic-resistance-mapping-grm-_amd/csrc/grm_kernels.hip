@@ -1681,6 +1681,150 @@ __global__ __launch_bounds__(WAVES * 64) void record_dedup_kernel(
     }
 }
 
+// K4 from the record form when genomes are cut into PARTS (few large genomes, read sets): level 1 / level 2 left every part its own
+// regions, a genome's k-mer counts are sums over its parts.  One workgroup of 8 waves per (genome, coarse bucket) at a time: pass A
+// adds up the k-mers per fine bucket over the parts' regions and lays the GENOME's key segments out; then, fine bucket by fine
+// bucket, the waves go through the parts' record segments (level 2's off / len) chunk by chunk -- lane = k-mer as above -- into ONE
+// table of 2^BIG_LOG2 64-bit keys and counts; the claimed slots leave in the order of their claims and are emptied again.  A read
+// set at 100x is mostly repeats of k-mers already in the table (read, compare, count); the table must hold the bucket's DISTINCT
+// k-mers (solid + erroneous): *overflow otherwise, and the host tries the larger table, then the key form.
+template <int BIG_LOG2>
+__global__ __launch_bounds__(512) void record_merge_kernel(
+    const ulonglong2 *__restrict__ recs, uint32_t rstride, const uint32_t *__restrict__ rcount, const uint64_t *__restrict__ roff,
+    const uint32_t *__restrict__ rlen, uint32_t n_genomes, int part_bits, int k, int b1, int b2, uint64_t kstride, uint32_t abundance_min,
+    uint64_t *__restrict__ keys, uint32_t *__restrict__ counts_out, uint64_t *__restrict__ koff, uint32_t *__restrict__ klen,
+    int *__restrict__ overflow)
+{
+    constexpr uint32_t BIG = 1u << BIG_LOG2, WAVES = 8, THREADS = 512;
+    constexpr int NF = 1 << RUN_FINE_BITS;
+    constexpr uint32_t CH = 64, CH_WORDS = (CH * RUN_LMAX + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint64_t *tk_all = reinterpret_cast<uint64_t *>(lds_raw);
+    uint32_t *tc_all = reinterpret_cast<uint32_t *>(lds_raw + (size_t)BIG * 8);
+    uint16_t *dl_all = reinterpret_cast<uint16_t *>(lds_raw + (size_t)BIG * 12);
+    uint8_t *wave_raw = lds_raw + (size_t)BIG * 14;                     // per wave: records 1024, starts bitmap 176, first record 24, run starts 128
+    __shared__ uint32_t kcount[NF], kstart[NF];
+    __shared__ uint32_t scratch[32];
+    __shared__ uint32_t big_fail, big_nd;
+    const int lane = lane_id(), wave = wave_id();
+    const uint32_t B1 = 1u << b1, B2 = 1u << b2, P = 1u << part_bits;
+    const int bb = b1 + b2;
+    ulonglong2 *srec = reinterpret_cast<ulonglong2 *>(wave_raw + (size_t)wave * 1360);
+    uint64_t *starts = reinterpret_cast<uint64_t *>(wave_raw + (size_t)wave * 1360 + 1024);
+    uint8_t *firstrec = wave_raw + (size_t)wave * 1360 + 1024 + 176;
+    uint16_t *sstart = reinterpret_cast<uint16_t *>(wave_raw + (size_t)wave * 1360 + 1024 + 176 + 32);
+    static_assert(CH_WORDS * 8 <= 176 && CH_WORDS <= 32, "staging layout");
+    for (uint32_t i = threadIdx.x; i < BIG; i += THREADS) { tk_all[i] = EMPTY_KEY; tc_all[i] = 0; }
+    if (threadIdx.x == 0) { big_fail = 0; big_nd = 0; }
+    __syncthreads();
+    const uint64_t n_regions = (uint64_t)n_genomes << b1;
+    for (uint64_t region = blockIdx.x; region < n_regions; region += gridDim.x) {
+        const uint32_t g = (uint32_t)(region >> b1), c = (uint32_t)region & (B1 - 1);
+        const uint64_t seg0 = region << b2;                             // the genome's segments of this coarse bucket
+        // ---- pass A: k-mers per fine bucket over the parts -> key segments ----
+        if (threadIdx.x < NF) kcount[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t p = 0; p < P; p++) {
+            const uint64_t rp = ((((uint64_t)g << part_bits) + p) << b1) + c;
+            const uint32_t n = min(rcount[rp], rstride);
+            const ulonglong2 *rr = recs + rp * rstride;
+            for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+                const uint64_t y = rr[i].y;
+                atomicAdd(&kcount[run_fine(y) >> (RUN_FINE_BITS - b2)], run_len(y));
+            }
+        }
+        __syncthreads();
+        const uint32_t cnt = threadIdx.x < B2 ? kcount[threadIdx.x] : 0u;
+        uint32_t region_keys;
+        const uint32_t pre = block_scan_sum(cnt, scratch, &region_keys);
+        const bool fits = region_keys <= kstride;                 // uniform
+        if (threadIdx.x < B2) {
+            kstart[threadIdx.x] = pre;
+            koff[seg0 + threadIdx.x] = region * kstride + pre;
+            if (!fits || !cnt) klen[seg0 + threadIdx.x] = 0;
+        }
+        __syncthreads();
+        if (!fits) {
+            if (threadIdx.x == 0) atomicExch(overflow, 1);
+            continue;
+        }
+        for (uint32_t f = 0; f < B2; f++) {
+            if (!kcount[f]) continue;                              // uniform
+            uint32_t nd = 0;
+            bool ok = true;
+            // a wave takes whole parts: their record segments (level 2's bounds; the next part's are asked for ahead)
+            uint32_t p = (uint32_t)wave;
+            uint64_t r0 = 0;
+            uint32_t nr = 0;
+            if (p < P) {
+                const uint64_t sp = ((((uint64_t)g << part_bits) + p) << bb) + ((uint64_t)c << b2) + f;
+                r0 = roff[sp];
+                nr = rlen[sp] & 0xffffu;
+            }
+            while (p < P) {
+                uint64_t r0_n = 0;
+                uint32_t nr_n = 0;
+                if (p + WAVES < P) {
+                    const uint64_t sp = ((((uint64_t)g << part_bits) + p + WAVES) << bb) + ((uint64_t)c << b2) + f;
+                    r0_n = roff[sp];
+                    nr_n = rlen[sp] & 0xffffu;
+                }
+                for (uint32_t c0 = 0; c0 < nr; c0 += CH) {
+                    const uint32_t nc = min(CH, nr - c0);
+                    const ulonglong2 rec = (uint32_t)lane < nc ? recs[r0 + c0 + lane] : make_ulonglong2(0, 0);
+                    const uint32_t tot = record_chunk_stage(rec, nc, srec, sstart, starts, firstrec);
+                    for (uint32_t q0 = 0; q0 < tot; q0 += 256) {
+                        uint64_t kv[4];
+                        const uint32_t nj = min(4u, (tot - q0 + 63u) >> 6);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if ((uint32_t)j >= nj) break;
+                            const uint32_t q = q0 + 64u * j + lane;
+                            kv[j] = q < tot ? record_chunk_kmer(q, k, srec, sstart, starts, firstrec) : EMPTY_KEY;
+                        }
+                        ok &= record_insert4<BIG_LOG2, true>(tk_all, tc_all, dl_all, &big_nd, kv, nj, nd);
+                    }
+                    wave_lds_fence();
+                }
+                p += WAVES; r0 = r0_n; nr = nr_n;
+            }
+            if (!ok && lane == 0) atomicExch(&big_fail, 1u);
+            __syncthreads();
+            const bool failed = big_fail != 0;                  // uniform
+            const uint32_t nd_all = min(big_nd, BIG);
+            const uint64_t dst = region * kstride + kstart[f];
+            uint32_t base = 0;
+            for (uint32_t p0 = 0; p0 < nd_all; p0 += THREADS) {
+                const uint32_t pp = p0 + threadIdx.x;
+                const uint32_t slot = pp < nd_all ? dl_all[pp] : 0u;
+                const uint64_t key = tk_all[slot];
+                const uint32_t cn = tc_all[slot];
+                const bool keep = !failed && pp < nd_all && cn >= abundance_min;
+                uint32_t sweep_total;
+                const uint32_t pos = sweep_compact(keep, scratch, &sweep_total);
+                if (keep) {
+                    keys[dst + base + pos] = key;
+                    if (counts_out) counts_out[dst + base + pos] = cn;
+                }
+                base += sweep_total;
+            }
+            __syncthreads();
+            for (uint32_t pp = threadIdx.x; pp < nd_all; pp += THREADS) {
+                const uint32_t slot = dl_all[pp];
+                tk_all[slot] = EMPTY_KEY;
+                tc_all[slot] = 0;
+            }
+            if (threadIdx.x == 0) {
+                klen[seg0 + f] = base;
+                if (failed) atomicExch(overflow, 1);
+                big_fail = 0;
+                big_nd = 0;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // The counting stage's main launch over the record form: as record_dedup_kernel (which now takes what this one leaves), with the
 // table cut down to ONE 32-bit word per slot.  The insert chain of the 64-bit table -- read the key, claim it, walk on, count,
 // list the slot, read key and count back -- ran at 33 of record_dedup's 50 ms with neither the VALU (56 %) nor the LDS (40 %)
@@ -3139,6 +3283,32 @@ void launch_record_dedup_rest(hipStream_t s, const void *recs, uint32_t rstride,
     else
         hipLaunchKernelGGL((record_dedup_kernel<9, 4>), dim3(grid), dim3(256), 0, s, r, rstride, rcount, n_regions, k, b2, kstride, abundance_min, keys,
                            counts_out, koff, klen, overflow, region_big);
+}
+// counting stage over the record form, genomes in parts: big_log2 in {12, 13} slots of the workgroup's table
+hipError_t launch_record_merge(hipStream_t s, const void *recs, uint32_t rstride, const uint32_t *rcount, const uint64_t *roff, const uint32_t *rlen,
+                               uint32_t n_genomes, int part_bits, int k, int bb, int b1, uint64_t kstride, int big_log2, uint32_t abundance_min,
+                               uint64_t *keys, uint32_t *counts_out, uint64_t *koff, uint32_t *klen, int *overflow)
+{
+    const uint64_t n_regions = (uint64_t)n_genomes << b1;
+    if (!n_regions) return hipSuccess;
+    const ulonglong2 *r = reinterpret_cast<const ulonglong2 *>(recs);
+    const int b2 = bb - b1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(record_merge_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(record_merge_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const size_t lds = ((size_t)14 << (big_log2 >= 13 ? 13 : 12)) + 8 * 1360;
+    const uint32_t grid = (uint32_t)(n_regions < 256u * 8u ? n_regions : 256u * 8u);
+    if (big_log2 >= 13)
+        hipLaunchKernelGGL(record_merge_kernel<13>, dim3(grid), dim3(512), lds, s, r, rstride, rcount, roff, rlen, n_genomes, part_bits, k, b1, b2, kstride,
+                           abundance_min, keys, counts_out, koff, klen, overflow);
+    else
+        hipLaunchKernelGGL(record_merge_kernel<12>, dim3(grid), dim3(512), lds, s, r, rstride, rcount, roff, rlen, n_genomes, part_bits, k, b1, b2, kstride,
+                           abundance_min, keys, counts_out, koff, klen, overflow);
+    return hipSuccess;
 }
 static int g_dict_kif = 8, g_table_threads = 0;      // 0: every kernel's own default (key form: TABLE_THREADS, record form: 256)
 void set_table_tuning(int kif, int threads)

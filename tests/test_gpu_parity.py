@@ -384,19 +384,41 @@ def test_deep_read_set_counts(ctx):
         r = "".join(r)
         reads.append(cases.revcomp(r) if rng.rand() < 0.5 else r)
     fq = cases.fastq(reads).encode()
-    for opts in ({}, {"bucket_bits": 15}):
+    # (default: the read set is cut into 64 parts for level 1 and counted over its parts' record segments, record_merge;
+    # "rec_count" 0: the key form; a table of 2^13 slots from the start; fewer parts: the key form again)
+    for opts in ({}, {"bucket_bits": 15}, {"rec_count": 0}, {"rec_count_cap": 13}, {"rec_part_bits": 5}, {"rec_part_bits": 2}):
         try:
             for name, v in opts.items():
                 ctx.set_option(name, v)
             for amin in (1, 2):
                 km, ct, nocc = orc.count_genome([fq], 21, amin)
+                ctx.timing(True)
+                ctx.timing_reset()
                 s = ctx.count_genome([fq], 21, amin)
+                names = {t[0] for t in ctx.timings()}
+                assert ("record_merge" in names) == (opts.get("rec_count", -1) != 0 and opts.get("rec_part_bits", 6) >= 5), names
                 assert s.occurrences == nocc
                 assert s.kmers().shape == km.shape and (s.kmers() == km).all() and (s.counts() == ct).all()
                 s.free()
         finally:
+            ctx.timing(False)
             for name in opts:
                 ctx.set_option(name, -1)
+    # three read sets in one batch (the parts of a genome are merged, not those of its neighbours), one of them tiny
+    fqs = [fq, cases.fastq(reads[:9000]).encode(), cases.fastq(reads[100:130]).encode()]
+    for amin in (1, 3):
+        b = ctx.batch(3)
+        for g, f in enumerate(fqs):
+            b.add(g, f)
+        b.upload()
+        b.partition_counts(21, amin)
+        for g, f in enumerate(fqs):
+            km, ct, nocc = orc.count_genome([f], 21, amin)
+            s = b.genome_set(g)
+            assert s.occurrences == nocc
+            assert s.kmers().shape == km.shape and (s.kmers() == km).all() and (s.counts() == ct).all()
+            s.free()
+        b.free()
 
 
 @pytest.mark.parametrize("k", [31, 63])
