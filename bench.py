@@ -191,6 +191,8 @@ def kernel_table(ctx, n_cols, n_rows, n_local):
             byts = 2.0 * rec_bytes * n_records                                      # read and write every record
         elif name == "record_dedup" and n_records is not None:
             byts = 16.0 * n_records + 12.0 * d["units"] / d["launches"]             # read the records; write <= a key + a 4-byte count per k-mer
+        elif name == "record_merge" and n_records is not None:
+            byts = 16.0 * n_records                                                 # read the records (what it writes: the distinct k-mers, few at 100x)
         elif ALGO_BYTES.get(name) is not None:
             byts = ALGO_BYTES[name] * d["units"] / d["launches"]
             if name == "dict_build":
