@@ -419,6 +419,14 @@ def test_deep_read_set_counts(ctx):
             assert s.kmers().shape == km.shape and (s.kmers() == km).all() and (s.counts() == ct).all()
             s.free()
         b.free()
+    # ... and the matrix of the solid k-mers of the three (abundance-min 2: the dictionary is built from the merged, filtered segments)
+    ctx.timing(True)
+    ctx.timing_reset()
+    try:
+        _check(ctx, [[f] for f in fqs], 21, 2, False)
+        assert "record_merge" in {t[0] for t in ctx.timings()}
+    finally:
+        ctx.timing(False)
 
 
 @pytest.mark.parametrize("k", [31, 63])
