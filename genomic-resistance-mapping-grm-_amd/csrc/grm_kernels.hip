@@ -1567,7 +1567,7 @@ __global__ __launch_bounds__(WAVES * 64) void record_dedup_kernel(
     __shared__ uint64_t starts_all[WAVES][CH_WORDS];
     __shared__ uint8_t firstrec_all[WAVES][CH_WORDS + 2];
     __shared__ uint32_t kcount[NF], kstart[NF], rcnt[NF], rstart[NF];       // k-mers / records per fine bucket, and where they start
-    __shared__ uint16_t small_list[NF], big_list[NF];
+    __shared__ uint16_t big_list[NF];
     __shared__ uint32_t scratch[32];
     __shared__ uint64_t scratch64[32];
     __shared__ uint32_t big_fail, big_nd;
@@ -1604,15 +1604,13 @@ __global__ __launch_bounds__(WAVES * 64) void record_dedup_kernel(
         // ("small" is what record_count_kernel<CAP_LOG2> took -- up to MAX_FILL k-mers in up to 64 records)
         const bool is_small = threadIdx.x < B2 && cnt <= MAX_FILL && rc <= 64u;
         const bool is_big = threadIdx.x < B2 && !is_small;
-        uint32_t n_small, n_big;
-        const uint32_t ps = block_scan_sum(is_small ? 1u : 0u, scratch, &n_small);
+        uint32_t n_big;
         const uint32_t pb = block_scan_sum(is_big ? 1u : 0u, scratch, &n_big);
         if (threadIdx.x < B2) {
             kstart[threadIdx.x] = pre;
             rstart[threadIdx.x] = (uint32_t)(both >> 32);
             koff[seg0 + threadIdx.x] = region * kstride + pre;
             if (!fits) klen[seg0 + threadIdx.x] = 0;
-            if (is_small) small_list[ps] = (uint16_t)threadIdx.x;
             if (is_big) big_list[pb] = (uint16_t)threadIdx.x;
         }
         if (threadIdx.x == 0) { big_fail = 0; big_nd = 0; }

@@ -113,39 +113,55 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
     // part's steps somewhere else.
     const uint32_t n_steps = (uint32_t)((j_b - j_a + SK_STEP_WINDOWS - 1) / SK_STEP_WINDOWS);
     const uint32_t rot = n_steps ? (uint32_t)((vg * 0x9E3779B1u) >> 8) % n_steps : 0u;
+    // The words of a step are asked for one step ahead (a wave that waited for them at the top of every step left its SIMD to three others,
+    // which wait for theirs: 55 % of the wave cycles were waits): the raw words of the stream and of the flags, used a step later.
+    struct StepWords {
+        uint64_t w0, w1, w2, w3, pw, i0, i1, i2;
+    };
+    auto step_window = [&](uint32_t it) -> uint64_t {
+        const uint32_t st = it + rot < n_steps ? it + rot : it + rot - n_steps;
+        return j_a + (uint64_t)st * SK_STEP_WINDOWS + (uint32_t)(wave * SK_WAVE_WINDOWS + lane);
+    };
+    auto fetch = [&](uint32_t it, StepWords &f) {
+        f.w0 = f.w1 = f.w2 = f.w3 = f.pw = f.i0 = f.i1 = f.i2 = 0;
+        if (it >= n_steps) return;
+        const uint64_t j = step_window(it);
+        // (j_b: only for the run that crosses into it; j_b + 1: only its hashes; WIDE: j_b + 2 for its word -- a run of 85 bases that starts late
+        // in the part's last window reaches the fourth word; the stream buffers end with slack words)
+        if (j <= j_b + (WIDE ? 2 : 1)) {
+            // (streamed once: loads marked non-temporal, so that the packed stream does not push the workgroups' half-filled record
+            // lines out of L2)
+            f.w0 = __builtin_nontemporal_load(&a.sym2[j]);
+            f.w1 = __builtin_nontemporal_load(&a.sym2[j + 1]);
+            f.w2 = __builtin_nontemporal_load(&a.sym2[j + 2]);
+            if (WIDE) f.w3 = __builtin_nontemporal_load(&a.sym2[j + 3]);
+            f.pw = j ? __builtin_nontemporal_load(&a.sym2[j - 1]) : 0ull;
+            const uint64_t q = j ? (j << 5) - 1 : 0;
+            f.i0 = __builtin_nontemporal_load(&a.inv[q >> 6]);
+            f.i1 = __builtin_nontemporal_load(&a.inv[(q >> 6) + 1]);
+            if (WIDE) f.i2 = __builtin_nontemporal_load(&a.inv[(q >> 6) + 2]);
+        }
+    };
+    StepWords nxt;
+    fetch(0, nxt);
     for (uint32_t it = 0; it < n_steps; it++) {
         const uint32_t st = it + rot < n_steps ? it + rot : it + rot - n_steps;
-        const uint64_t j = j_a + (uint64_t)st * SK_STEP_WINDOWS + (uint32_t)(wave * SK_WAVE_WINDOWS + lane);
+        const uint64_t j = step_window(it);
+        const StepWords cur = nxt;
+        fetch(it + 1, nxt);
         if (j_a + (uint64_t)st * SK_STEP_WINDOWS + (uint32_t)(wave * SK_WAVE_WINDOWS) >= j_b) continue;        // (the wave as a whole: nothing left)
         uint32_t valid = 0, heads = 0;
         uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, vs = 0;
         uint32_t prev2 = 0;
-        // (j_b: only for the run that crosses into it; j_b + 1: only its hashes; WIDE: j_b + 2 for its word -- a run of 85 bases that starts late in
-        // the part's last window reaches the fourth word; the stream buffers end with slack words)
         if (j <= j_b + (WIDE ? 2 : 1)) {
             const uint64_t p0 = j << 5;
-            // (streamed once: loads marked non-temporal, so that the packed stream does not push the workgroups' half-filled record
-            // lines out of L2)
-            w0 = __builtin_nontemporal_load(&a.sym2[j]);
-            w1 = __builtin_nontemporal_load(&a.sym2[j + 1]);
-            w2 = __builtin_nontemporal_load(&a.sym2[j + 2]);
-            if (WIDE) w3 = __builtin_nontemporal_load(&a.sym2[j + 3]);
-            prev2 = j ? (uint32_t)__builtin_nontemporal_load(&a.sym2[j - 1]) & 3u : 0u;
+            w0 = cur.w0; w1 = cur.w1; w2 = cur.w2; w3 = cur.w3;
+            prev2 = (uint32_t)cur.pw & 3u;
             // bit t of vs: position p0 - 1 + t starts a k-mer (t = 0 .. 32; k <= 32 keeps all 33 inside the 64 flags read)
-            if (WIDE) {
-                if (p0) {
-                    const uint64_t q = p0 - 1;
-                    vs = valid_starts_wide(__builtin_nontemporal_load(&a.inv[q >> 6]), __builtin_nontemporal_load(&a.inv[(q >> 6) + 1]),
-                                           __builtin_nontemporal_load(&a.inv[(q >> 6) + 2]), (int)(q & 63), a.k);
-                } else {
-                    vs = valid_starts_wide(a.inv[0], a.inv[1], a.inv[2], 0, a.k) << 1;
-                }
-            } else if (p0) {
-                const uint64_t q = p0 - 1;
-                vs = valid_starts_at(__builtin_nontemporal_load(&a.inv[q >> 6]), __builtin_nontemporal_load(&a.inv[(q >> 6) + 1]), (int)(q & 63), a.k);
-            } else {
-                vs = valid_starts_at(a.inv[0], a.inv[1], 0, a.k) << 1;
-            }
+            const int qo = p0 ? (int)((p0 - 1) & 63) : 0;
+            if (WIDE) vs = valid_starts_wide(cur.i0, cur.i1, cur.i2, qo, a.k);
+            else vs = valid_starts_at(cur.i0, cur.i1, qo, a.k);
+            if (!p0) vs <<= 1;
             // ... of THIS genome: lo <= p0 - 1 + t < p_end
             const uint64_t t_lo = lo + 1 > p0 ? lo + 1 - p0 : 0, t_hi = p_end + 1 > p0 ? p_end + 1 - p0 : 0;
             const uint64_t keep = (t_hi >= 33 ? (1ull << 33) - 1 : (1ull << t_hi) - 1) & ~(t_lo >= 33 ? (1ull << 33) - 1 : (1ull << t_lo) - 1);
