@@ -142,13 +142,15 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
             if (WIDE) f.i2 = __builtin_nontemporal_load(&a.inv[(q >> 6) + 2]);
         }
     };
-    StepWords nxt;
+    StepWords nxt, nxt2;
     fetch(0, nxt);
+    fetch(1, nxt2);
     for (uint32_t it = 0; it < n_steps; it++) {
         const uint32_t st = it + rot < n_steps ? it + rot : it + rot - n_steps;
         const uint64_t j = step_window(it);
         const StepWords cur = nxt;
-        fetch(it + 1, nxt);
+        nxt = nxt2;
+        fetch(it + 2, nxt2);
         if (j_a + (uint64_t)st * SK_STEP_WINDOWS + (uint32_t)(wave * SK_WAVE_WINDOWS) >= j_b) continue;        // (the wave as a whole: nothing left)
         uint32_t valid = 0, heads = 0;
         uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, vs = 0;
