@@ -366,11 +366,30 @@ GRM_HD uint32_t byte_eq_mask4(uint32_t x, uint32_t c)
     return (((z >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xfu;
 }
 // masks over one 16-byte chunk: bit j <=> byte j
-GRM_HD void chunk_masks(const uint32_t w[4], uint32_t &nl, uint32_t &gt, uint32_t &cr)
+// nonzero iff a byte of x equals c (the classic zero-byte test: exact as a yes / no, four instructions)
+GRM_HD uint32_t byte_eq_any4(uint32_t x, uint32_t c)
+{
+    const uint32_t y = x ^ (c * 0x01010101u);
+    return (y - 0x01010101u) & ~y & 0x80808080u;
+}
+// (need_gt false: FASTQ -- '>' is a common quality value there and no line type depends on it)
+GRM_HD void chunk_masks(const uint32_t w[4], uint32_t &nl, uint32_t &gt, uint32_t &cr, bool need_gt = true)
 {
     const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
     nl = byte_eq_mask4(w0, '\n') | (byte_eq_mask4(w1, '\n') << 4) | (byte_eq_mask4(w2, '\n') << 8) | (byte_eq_mask4(w3, '\n') << 12);
-    gt = byte_eq_mask4(w0, '>') | (byte_eq_mask4(w1, '>') << 4) | (byte_eq_mask4(w2, '>') << 8) | (byte_eq_mask4(w3, '>') << 12);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // '>' and CR are rare (a header per contig; no CR at all in most files): a wave whose 1 KiB holds neither -- nearly every wave --
+    // skips their masks (2 x 36 of the ~125 instructions of this function; the parse kernels are bound by instruction issue).
+    // Called with every lane active (tile_round / tile_round_fq / tile_rounds_fq).
+    uint32_t rare = byte_eq_any4(w0, '\r') | byte_eq_any4(w1, '\r') | byte_eq_any4(w2, '\r') | byte_eq_any4(w3, '\r');
+    if (need_gt) rare |= byte_eq_any4(w0, '>') | byte_eq_any4(w1, '>') | byte_eq_any4(w2, '>') | byte_eq_any4(w3, '>');
+    if (!__any(rare != 0u)) {
+        gt = 0;
+        cr = 0;
+        return;
+    }
+#endif
+    gt = need_gt ? byte_eq_mask4(w0, '>') | (byte_eq_mask4(w1, '>') << 4) | (byte_eq_mask4(w2, '>') << 8) | (byte_eq_mask4(w3, '>') << 12) : 0u;
     cr = byte_eq_mask4(w0, '\r') | (byte_eq_mask4(w1, '\r') << 4) | (byte_eq_mask4(w2, '\r') << 8) | (byte_eq_mask4(w3, '\r') << 12);
 }
 

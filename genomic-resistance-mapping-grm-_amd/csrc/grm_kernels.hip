@@ -173,7 +173,7 @@ __device__ __forceinline__ void tile_round_fq(const uint4 &v, uint32_t edge, int
 {
     tc.w[R][0] = v.x; tc.w[R][1] = v.y; tc.w[R][2] = v.z; tc.w[R][3] = v.w;
     uint32_t nl, gt, cr;
-    chunk_masks(tc.w[R], nl, gt, cr);
+    chunk_masks(tc.w[R], nl, gt, cr, false);
     const uint32_t up = __shfl_up((nl >> 15) & 1u, 1);
     const uint32_t prev_nl = lane == 0 ? edge : up;
     const uint32_t ls = ((nl << 1) | prev_nl) & 0xffffu;
@@ -291,7 +291,7 @@ __device__ __forceinline__ void tile_rounds_fq(const uint8_t *__restrict__ raw, 
     for (int r = 0; r < ROUNDS_PER_TILE; r++) {
         tc.w[r][0] = v[r].x; tc.w[r][1] = v[r].y; tc.w[r][2] = v[r].z; tc.w[r][3] = v[r].w;
         uint32_t nl, gt, cr;
-        chunk_masks(tc.w[r], nl, gt, cr);
+        chunk_masks(tc.w[r], nl, gt, cr, false);
         const uint32_t up = __shfl_up((nl >> 15) & 1u, 1);
         const uint32_t prev_nl = lane == 0 ? edge[r] : up;
         tc.nl[r] = nl; tc.cr[r] = cr; tc.ls[r] = ((nl << 1) | prev_nl) & 0xffffu;
