@@ -2996,6 +2996,28 @@ static int wide_hash_global(grm_batch *b, const uint64_t *hi, const uint64_t *lo
         need(W.idx0, n * 4); need(W.idx1, n * 4); need(W.idx2, n * 4); need(W.t_a, n * 8); need(W.t_b, n * 8);
         need(W.keep, (n + 1) * 4); need(W.pos, (n + 1) * 4);
         if (e != hipSuccess) return fail(c, GRM_ERR_OOM, "dictionary buffers: %s", hipGetErrorString(e));
+        // by key ranges of the top 64 bits, ties by the low word (grm_wide_hash.hip); the two-pass radix sort below when a range is too
+        // crowded for its LDS sort (or asked for: "dict_sort_prim")
+        bool sorted = false;
+        if (c->opt_dict_sort_prim <= 0) {
+            need(W.tmp, dict_sort_scratch_bytes(n));
+            need(W.flag, 32);
+            if (e != hipSuccess) return fail(c, GRM_ERR_OOM, "dictionary buffers: %s", hipGetErrorString(e));
+            HIPCHK(c, hipMemsetAsync(W.flag.p, 0, 4, s));
+            launch_wh_top64(s, hi, lo, n, b->k, W.t_a.as<uint64_t>());
+            HIPCHK(c, launch_dict_sort(s, W.t_a.as<uint64_t>(), n, 64, W.t_b.as<uint64_t>(), W.idx2.as<uint32_t>(), W.tmp.p, W.flag.as<int>()));
+            int too_big = 0;
+            HIPCHK(c, hipMemcpyAsync(&too_big, W.flag.p, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (!too_big) {
+                launch_wh_ties(s, W.t_b.as<uint64_t>(), W.idx2.as<uint32_t>(), lo, n);
+                launch_gather_u64(s, hi, W.idx2.as<uint32_t>(), n, W.t_b.as<uint64_t>());
+                launch_gather_u64(s, lo, W.idx2.as<uint32_t>(), n, W.t_a.as<uint64_t>());     // sorted: hi = t_b, lo = t_a
+                HIPCHK(c, hipGetLastError());
+                sorted = true;
+            }
+        }
+        if (!sorted) {
         launch_iota_u32(s, W.idx0.as<uint32_t>(), n);
         size_t tb = 0;
         // stable LSD sort by (hi, lo): by lo, then by hi
@@ -3009,6 +3031,7 @@ static int wide_hash_global(grm_batch *b, const uint64_t *hi, const uint64_t *lo
         if (e == hipSuccess) e = sort_pairs_u64_u32(s, W.t_a.as<uint64_t>(), W.t_b.as<uint64_t>(), W.idx1.as<uint32_t>(), W.idx2.as<uint32_t>(), n, W.tmp.p, tb);
         launch_gather_u64(s, lo, W.idx2.as<uint32_t>(), n, W.t_a.as<uint64_t>());     // sorted: hi = t_b, lo = t_a
         if (e != hipSuccess) return fail(c, GRM_ERR_HIP, "dictionary sort: %s", hipGetErrorString(e));
+        }
         HIPCHK(c, hipMemsetAsync(W.keep.as<uint32_t>() + n, 0, 4, s));
         // a k-mer held by several ranks shows up as a run of equal keys: one column, carried by >= 2 genomes
         launch_wh_mark(s, W.t_b.as<uint64_t>(), W.t_a.as<uint64_t>(), flags, W.idx2.as<uint32_t>(), n, filter_singleton, W.keep.as<uint32_t>());

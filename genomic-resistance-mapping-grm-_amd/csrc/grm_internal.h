@@ -305,6 +305,8 @@ void launch_wh_l1(hipStream_t s, const KmerLaunch &L, const uint64_t *off, uint3
 void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const void *keys1, void *keys, uint64_t region_stride,
                   uint32_t fine_cap, const uint32_t *cursor1, uint32_t *len_out, int *overflow);
 // entries leave staged at wg * cap in entry-id order; presence words at matrix_s[wg][row][entry id] (nullptr: no bits)
+void launch_wh_top64(hipStream_t s, const uint64_t *hi, const uint64_t *lo, uint64_t n, int k, uint64_t *top);
+void launch_wh_ties(hipStream_t s, const uint64_t *top_sorted, uint32_t *order, const uint64_t *lo, uint64_t n);
 void launch_wh_dict_build(hipStream_t s, const void *keys, const SegLayout &seg, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
                           uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint64_t *matrix_s,
                           uint16_t *birth, int *overflow, uint32_t *need, int recs_k = 0, int part_bits = 0);

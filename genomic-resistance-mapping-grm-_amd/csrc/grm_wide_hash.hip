@@ -917,6 +917,43 @@ void launch_wh_dict_gather(hipStream_t s, const uint64_t *stage_lo, const uint64
     hipLaunchKernelGGL(wide_dict_gather_kernel, dim3(n_wg), dim3(256), 0, s, stage_lo, stage_hi, stage_flags, stage_off, cap, out_lo, out_hi,
                        out_flags);
 }
+// The dictionary of two-word k-mers through the key-range sort of one-word ones (grm_dictsort.hip): sorted by the TOP 64 bits of the
+// 2k (the first 32 bases) with the entries' indices; entries that agree there -- the two alleles of a SNP in the k-mer's second half --
+// stand together then, and a thread per such group puts its indices in the order of the low words.
+__global__ void wide_top64_kernel(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n, int k, uint64_t *__restrict__ top)
+{
+    const int up = 128 - 2 * k;              // 0 .. 62
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        top[i] = up ? (hi[i] << up) | (lo[i] >> (64 - up)) : hi[i];
+}
+__global__ void wide_ties_kernel(const uint64_t *__restrict__ top_sorted, uint32_t *__restrict__ order, const uint64_t *__restrict__ lo, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t t = top_sorted[i];
+        if ((i && top_sorted[i - 1] == t) || i + 1 >= n || top_sorted[i + 1] != t) continue;       // not the first of a group of two or more
+        uint64_t e = i + 2;
+        while (e < n && top_sorted[e] == t) e++;
+        for (uint64_t a = i + 1; a < e; a++) {           // insertion sort of the group's indices by the low word
+            const uint32_t ia = order[a];
+            const uint64_t la = lo[ia];
+            uint64_t b = a;
+            while (b > i && lo[order[b - 1]] > la) { order[b] = order[b - 1]; b--; }
+            order[b] = ia;
+        }
+    }
+}
+void launch_wh_top64(hipStream_t s, const uint64_t *hi, const uint64_t *lo, uint64_t n, int k, uint64_t *top)
+{
+    if (!n) return;
+    const uint64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(wide_top64_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, hi, lo, n, k, top);
+}
+void launch_wh_ties(hipStream_t s, const uint64_t *top_sorted, uint32_t *order, const uint64_t *lo, uint64_t n)
+{
+    if (!n) return;
+    const uint64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(wide_ties_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, top_sorted, order, lo, n);
+}
 void launch_wh_mark(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint8_t *flags, const uint32_t *order, uint64_t n,
                     int filter_singleton, uint32_t *keep)
 {

@@ -672,7 +672,8 @@ def test_two_word_kmers_of_few_large_genomes_in_parts(ctx):
                     ctx.set_option(name, -1)
 
 
-@pytest.mark.parametrize("k,opts", [(33, {}), (34, {}), (47, {}), (63, {}), (64, {}), (63, {"bucket_bits": 3, "cap_log2": 9}), (63, {"bucket_bits": 9})])
+@pytest.mark.parametrize("k,opts", [(33, {}), (34, {}), (47, {}), (63, {}), (64, {}), (63, {"bucket_bits": 3, "cap_log2": 9}), (63, {"bucket_bits": 9}),
+                                    (47, {"dict_sort_prim": 1})])
 def test_two_word_kmers_through_the_record_form(ctx, k, opts):
     """two-word k-mers travel as 24-byte run records (the minimizer among the 21 / 22 m-mers in the middle of the
     k-mer): assemblies with their own contigs on either strand, indels, a repeated stretch and runs of N, against the oracle, with and
