@@ -73,7 +73,7 @@ struct grm_ctx {
     int opt_rec_part_bits = -1;  // record form: parts per genome, log2 (tests)
     int opt_rec_keys = -1;       // > 0: record form always expands to key segments in level 2 (tests, measurements)
     int opt_rec_count = -1;      // 0: counting partitions never take the record form
-    int opt_rec_count_cap = -1;  // counting over records: log2 slots of a wave's table (8..10; tests of the shared-table path)
+    int opt_rec_count_cap = -1;  // counting over records: log2 slots of a wave's table (8 / 9; tests of the shared-table path), or of record_merge's table (12 / 13)
     int opt_rec_coarse = -1;     // record form: coarse bucket bits of level 1 (tests, measurements); < 0 = min(bucket bits, 9)
     int opt_dict_sort_prim = -1; // > 0: the dictionary is sorted by rocPRIM's radix sort instead of the key-range sort of grm_dictsort.hip (tests)
     int opt_parse_fused = -1;    // > 0: the single-pass parse kernel (decoupled look-back) instead of summarize / scan / pack -- measured SLOWER

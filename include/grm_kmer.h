@@ -70,7 +70,7 @@ const char *grm_version(void);
  * (gathered rank dictionaries sorted as a whole), "parse_fused" (single-pass parse kernel).  Record form: "rec_bucket_shift",
  * "rec_part_bits", "rec_coarse", "rec_memo" (log2 of dict_build's record memo base, 0 = none), "memo_stats" (1: count memo hits, see
  * grm_batch_memo_stats), "rec_count" (0: a counting partition never takes the record form), "rec_count_cap" (8: its wave tables hold
- * 256 slots instead of 512).  Host: "upload_slab_kb". */
+ * 256 slots instead of 512; 12 / 13: log2 slots of the workgroup's table when genomes are counted over their parts).  Host: "upload_slab_kb". */
 int         grm_set_option(grm_ctx *, const char *name, int value);
 /* per-kernel device timings (HIP events on the engine's stream) */
 int         grm_timing_enable(grm_ctx *, int on);
