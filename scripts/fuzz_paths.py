@@ -1,0 +1,82 @@
+"""Randomised differential check on the GPU box: random k, genome counts and sizes, assembly shapes, abundance filters and engine knobs;
+every matrix and every counted set against the CPU oracle.  python scripts/fuzz_paths.py [seconds] [seed]"""
+import os
+import sys
+import time
+from importlib import import_module
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import grm_amd                                          # noqa: E402
+from oracle import oracle_ctypes as orc                 # noqa: E402
+
+synth = import_module("genomic-resistance-mapping-grm-_amd.synth")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.RandomState(seed)
+t0 = time.time()
+n_cases = 0
+with grm_amd.Context(0) as ctx:
+    while time.time() - t0 < budget:
+        k = int(rng.choice([19, 21, 25, 31, 32, 33, 34, 47, 63, 64]))
+        n = int(rng.choice([1, 2, 3, 7, 40, 70, 129, 150]))
+        L = int(rng.choice([2_000, 20_000, 150_000])) if n <= 7 else int(rng.choice([1_500, 8_000, 25_000]))
+        pg = synth.realistic(genome_len=L, seed=int(rng.randint(1 << 30)), contigs=(1, 6), indel_sites=max(1, L // 3000), n_snps=max(1, L // 80),
+                             n_accessory=2, accessory_len=min(600, L // 3))
+        genomes = []
+        for i in range(n):
+            g = pg.genome(i).tobytes()
+            if rng.rand() < 0.3:
+                g = g + g[: int(rng.randint(0, len(g)))]                # a repeated stretch
+            if rng.rand() < 0.1:
+                g = b""
+            genomes.append([g])
+        amin = int(rng.choice([1, 1, 2]))
+        filt = bool(rng.rand() < 0.5)
+        opts = {}
+        if rng.rand() < 0.3:
+            opts["rec_part_bits"] = int(rng.randint(0, 7))
+        if rng.rand() < 0.3:              # (forced bucket counts: not so few that a bucket's k-mers fit no LDS table -- that is a loud error by design)
+            lo_bits = max(3, int(np.ceil(np.log2(max(2.0, 2.2 * L / 1500.0)))))
+            opts["bucket_bits"] = int(rng.randint(lo_bits, max(lo_bits + 1, 12)))
+        if rng.rand() < 0.15:
+            opts["records"] = 0
+        if rng.rand() < 0.15:
+            opts["cap_log2"] = int(rng.randint(8, 12))
+        desc = "k=%d n=%d L=%d amin=%d filt=%d opts=%s" % (k, n, L, amin, filt, opts)
+        try:
+            for name, v in opts.items():
+                ctx.set_option(name, v)
+            want = orc.build_matrix(genomes, k, amin, filt)
+            b = ctx.batch(n)
+            for gi, files in enumerate(genomes):
+                for f in files:
+                    b.add(gi, f)
+            b.upload()
+            m = b.run(k, amin, filt)
+            ok = (m.kmers().shape == want["kmers"].shape and (m.kmers() == want["kmers"]).all() and (m.data() == want["matrix"]).all()
+                  and b.n_occurrences == want["n_occurrences"])
+            m.free()
+            if ok and k <= 32:
+                b.partition_counts(k, amin)
+                for gi in sorted(set([0, n // 2, n - 1])):
+                    km, ct, nocc = orc.count_genome(genomes[gi], k, amin)
+                    s = b.genome_set(gi)
+                    ok = ok and s.occurrences == nocc and s.kmers().shape == km.shape and (s.kmers() == km).all() and (s.counts() == ct).all()
+                    s.free()
+            b.free()
+            if not ok:
+                print("MISMATCH", desc, flush=True)
+                sys.exit(1)
+        except Exception:
+            print("ERROR in case", desc, flush=True)
+            raise
+        finally:
+            for name in opts:
+                ctx.set_option(name, -1)
+        n_cases += 1
+        if n_cases % 10 == 0:
+            print("%d cases ok (%.0f s) last: %s" % (n_cases, time.time() - t0, desc), flush=True)
+print("fuzz ok: %d cases in %.0f s (seed %d)" % (n_cases, time.time() - t0, seed))
