@@ -599,6 +599,95 @@ extern "C" int grm_matrix_risk_index(grm_matrix *m, const uint32_t *lut_presence
     return GRM_OK;
 }
 
+// The HDF5 chunks of kmer_matrix (what = 0: chunk_elems columns of one word-row each, row-major) or of kmer_sequences
+// (what = 1: chunk_elems strings each) as zlib streams made on the device (grm_deflate.hip).  Host result (malloc): the
+// streams at starts[i] (multiples of 16), lens[i] bytes each.  The chunks go through the device in slabs of a few GB.
+static int matrix_deflate_device(grm_matrix *m, int what, uint64_t chunk_elems, unsigned char **streams, uint64_t **starts_out, uint32_t **lens_out,
+                                 uint64_t *n_chunks_out)
+{
+    grm_ctx *c = m->ctx;
+    if (!c) return GRM_ERR_NO_DEVICE;
+    if (chunk_elems == 0 || chunk_elems > 0x7fffffffu) return fail(c, GRM_ERR_ARG, "deflate: chunk of %llu elements", (unsigned long long)chunk_elems);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint64_t U = m->n_kmers, R = m->n_rows;
+    const uint64_t per_row = (U + chunk_elems - 1) / chunk_elems;
+    const uint64_t n_chunks = what == 0 ? per_row * R : per_row;
+    const uint64_t raw = chunk_elems * (what == 0 ? 8ull : (uint64_t)m->k);
+    if (raw >= ((uint64_t)1 << 32) - 4096) return fail(c, GRM_ERR_ARG, "deflate: a chunk of %llu bytes is beyond the encoder's 4 GiB", (unsigned long long)raw);
+    *streams = nullptr; *starts_out = nullptr; *lens_out = nullptr; *n_chunks_out = n_chunks;
+    if (!n_chunks) return GRM_OK;
+    const uint64_t cap = deflate_chunk_cap(raw);
+    const uint64_t per_chunk = cap + (what == 0 ? 2 * chunk_elems : 0);
+    const uint64_t slab = std::max<uint64_t>(1, std::min<uint64_t>(n_chunks, ((uint64_t)4 << 30) / per_chunk));
+    DevBuf d_out, d_tok, d_sizes, d_off, d_packed;
+    HIPCHK(c, d_out.alloc(slab * cap));
+    if (what == 0) HIPCHK(c, d_tok.alloc(slab * chunk_elems * 2));
+    HIPCHK(c, d_sizes.alloc(slab * 4));
+    HIPCHK(c, d_off.alloc((slab + 1) * 8));
+    uint64_t *starts = static_cast<uint64_t *>(malloc(n_chunks * 8));
+    uint32_t *lens = static_cast<uint32_t *>(malloc(n_chunks * 4));
+    unsigned char *host = nullptr;
+    uint64_t host_used = 0, host_cap = 0;
+    auto bail = [&](int rc) { free(starts); free(lens); free(host); return rc; };
+    if (!starts || !lens) return bail(fail(c, GRM_ERR_OOM, "deflate: host allocation failed"));
+    std::vector<uint64_t> off(slab + 1);
+    for (uint64_t c0 = 0; c0 < n_chunks; c0 += slab) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(slab, n_chunks - c0);
+        hipError_t e;
+        {
+            TimeScope t(c, what == 0 ? "deflate_rows" : "deflate_kmer_strings", (uint64_t)n * raw);
+            e = what == 0 ? launch_deflate_rows(s, m->d_data.as<uint64_t>(), U, (uint32_t)chunk_elems, (uint32_t)per_row, c0, n, d_tok.as<uint16_t>(),
+                                                d_out.as<uint8_t>(), cap, d_sizes.as<uint32_t>())
+                          : launch_deflate_kmer_strings(s, m->d_kmers.as<uint64_t>(), U, m->words, m->k, (uint32_t)chunk_elems, c0, n, d_out.as<uint8_t>(), cap,
+                                                        d_sizes.as<uint32_t>());
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(lens + c0, d_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "deflate on the device: %s", hipGetErrorString(e)));
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            if (lens[c0 + i] == 0 || lens[c0 + i] > cap) return bail(fail(c, GRM_ERR_STATE, "deflate: chunk %llu came back with %u bytes", (unsigned long long)(c0 + i), lens[c0 + i]));
+            off[i] = total;
+            total += ((uint64_t)lens[c0 + i] + 15) & ~15ull;
+        }
+        if (host_used + total > host_cap) {
+            // first slab: the whole result at this slab's ratio; later: what is missing
+            host_cap = host_used + std::max<uint64_t>(total, c0 == 0 ? total * ((n_chunks + n - 1) / n) + (total >> 4) : total * 2);
+            unsigned char *p = static_cast<unsigned char *>(realloc(host, host_cap));
+            if (!p) return bail(fail(c, GRM_ERR_OOM, "deflate: host allocation of %llu bytes failed", (unsigned long long)host_cap));
+            host = p;
+        }
+        if ((e = d_packed.ensure(total)) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "deflate: %s", hipGetErrorString(e)));
+        e = hipMemcpyAsync(d_off.p, off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = launch_deflate_compact(s, d_out.as<uint8_t>(), cap, d_sizes.as<uint32_t>(), n, d_off.as<uint64_t>(), d_packed.as<uint8_t>());
+        if (e == hipSuccess) e = hipMemcpyAsync(host + host_used, d_packed.p, total, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "deflate: gathering the streams: %s", hipGetErrorString(e)));
+        for (uint32_t i = 0; i < n; i++) starts[c0 + i] = host_used + off[i];
+        host_used += total;
+    }
+    *streams = host; *starts_out = starts; *lens_out = lens;
+    return GRM_OK;
+}
+extern "C" int grm_matrix_deflate_rows(grm_matrix *m, int chunk_cols, unsigned char **streams, uint64_t **starts, uint32_t **lens, uint64_t *n_chunks)
+{
+    if (!m || !streams || !starts || !lens || !n_chunks || chunk_cols <= 0) return GRM_ERR_ARG;
+    if (!m->ctx || !m->d_data.p) return m->ctx ? fail(m->ctx, GRM_ERR_STATE, "grm_matrix_deflate_rows: the matrix is not on the device") : GRM_ERR_NO_DEVICE;
+    // chunk dimensions as the writer lays them out: (1, min(n_kmers, chunk_cols)) (dataset/create.py:160,230)
+    const uint64_t cw = m->n_kmers ? std::min<uint64_t>(m->n_kmers, (uint64_t)chunk_cols) : 1;
+    return matrix_deflate_device(m, 0, cw, streams, starts, lens, n_chunks);
+}
+extern "C" int grm_matrix_deflate_kmer_strings(grm_matrix *m, int chunk_elems, unsigned char **streams, uint64_t **starts, uint32_t **lens, uint64_t *n_chunks)
+{
+    if (!m || !streams || !starts || !lens || !n_chunks || chunk_elems <= 0) return GRM_ERR_ARG;
+    if (!m->ctx || !m->d_kmers.p) return m->ctx ? fail(m->ctx, GRM_ERR_STATE, "grm_matrix_deflate_kmer_strings: the dictionary is not on the device") : GRM_ERR_NO_DEVICE;
+    const uint64_t ce = m->n_kmers ? std::min<uint64_t>(m->n_kmers, (uint64_t)chunk_elems) : 1;
+    return matrix_deflate_device(m, 1, ce, streams, starts, lens, n_chunks);
+}
+extern "C" void grm_host_free(void *p) { free(p); }
+extern "C" int grm_internal_matrix_on_device(const grm_matrix *m) { return m && m->ctx && m->d_data.p && m->d_kmers.p; }
+
 extern "C" void grm_matrix_free(grm_matrix *m)
 {
     if (!m) return;

@@ -10,10 +10,17 @@
 //     kmer_by_matrix_column  min-uint[U]           gzip G   (identity here: column c <-> k-mer c)
 //
 // libhdf5 is dlopen()ed at run time (h5py is not a dependency; the C library may live in a
-// conda prefix).  The matrix is the heavy part: its chunks are deflated on all host cores with
-// zlib and handed to H5Dwrite_chunk, because single-threaded deflate inside H5Dwrite is the
-// end-to-end bottleneck (hard part 4).
+// conda prefix).  The chunks reach the file as finished zlib streams through H5Dwrite_chunk:
+//   * a matrix that lives on the device is deflated THERE (grm_deflate.hip: one wave per chunk; kmer_matrix and
+//     kmer_sequences), only the compressed bytes cross PCIe -- deflating 1 GB of presence words on the host's CPU share
+//     (16 cores on the measured box) was 0.8 s of a 1.4 s end-to-end run with the device idle;
+//   * a host-only matrix (rows gathered from other ranks, tests without a GPU), GRM_DEFLATE=host, or a libhdf5 without
+//     H5Dwrite_chunk: chunks deflated on the host threads (libdeflate when it can be dlopen()ed, else zlib), the rows of a
+//     device matrix arriving while earlier ones are deflated.
+// A failed append never leaves a plausible file: whatever of the three datasets exists is unlinked before the file is
+// closed (kmer_pack.py:28 ignores the tool's return code; unwritten chunks would read back as "absent everywhere").
 #include <dlfcn.h>
+#include <sched.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -124,13 +131,36 @@ hid_t make_dcpl(H5 &H, int rank, const hsize_t *chunk, int gzip)
     return p;
 }
 
-// body(i0, i1) over [0, n) split across the host cores
+// Threads for the host-side work: GRM_WRITER_THREADS, else what this process may actually use -- its CPU affinity, cut down to
+// the cgroup's CPU quota when there is one (a 256-thread box may hand a job 16 CPUs: more threads than that only take turns).
+unsigned host_threads()
+{
+    if (const char *e = getenv("GRM_WRITER_THREADS")) {
+        const int v = atoi(e);
+        if (v > 0) return (unsigned)v;
+    }
+    unsigned nt = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) nt = (unsigned)CPU_COUNT(&set);
+    if (nt == 0) nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {            // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[64];
+        long long period = 0;
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && strcmp(q, "max") != 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) nt = std::min<unsigned>(nt, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+        }
+        fclose(f);
+    }
+    return nt;
+}
+
+// body(i0, i1) over [0, n) split across the host threads
 template <typename Body>
 void parallel_for(size_t n, Body &&body)
 {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 4;
-    if (nt > 64) nt = 64;
+    unsigned nt = host_threads();
     if (n < (size_t)1 << 16) nt = 1;
     const size_t per = (n + nt - 1) / nt;
     std::vector<std::thread> th;
@@ -142,39 +172,102 @@ void parallel_for(size_t n, Body &&body)
     for (auto &t : th) t.join();
 }
 
-// deflate `n_chunks` equally sized raw chunks on the host cores; get_chunk(i, buf) must leave the
+// libdeflate, when the box has it: the same zlib container from a faster encoder (any valid stream satisfies HDF5's filter)
+struct LibDeflate {
+    void *h = nullptr;
+    bool tried = false;
+    void *(*alloc)(int) = nullptr;
+    size_t (*zlib_compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+    size_t (*zlib_bound)(void *, size_t) = nullptr;
+    void (*free_compressor)(void *) = nullptr;
+    bool load()
+    {
+        if (tried) return h != nullptr;
+        tried = true;
+        if (const char *e = getenv("GRM_DEFLATE_LIB"))
+            if (!strcmp(e, "zlib")) return false;
+        for (const char *n : {"libdeflate.so.0", "libdeflate.so", "/opt/conda/lib/libdeflate.so"}) {
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) return false;
+        alloc = reinterpret_cast<decltype(alloc)>(dlsym(h, "libdeflate_alloc_compressor"));
+        zlib_compress = reinterpret_cast<decltype(zlib_compress)>(dlsym(h, "libdeflate_zlib_compress"));
+        zlib_bound = reinterpret_cast<decltype(zlib_bound)>(dlsym(h, "libdeflate_zlib_compress_bound"));
+        free_compressor = reinterpret_cast<decltype(free_compressor)>(dlsym(h, "libdeflate_free_compressor"));
+        if (!alloc || !zlib_compress || !zlib_bound || !free_compressor) { dlclose(h); h = nullptr; }
+        return h != nullptr;
+    }
+};
+LibDeflate g_ld;
+
+// the finished streams of a dataset's chunks, wherever they were made
+struct Streams {
+    std::vector<std::vector<unsigned char>> z;      // host-made: one vector per chunk
+    unsigned char *buf = nullptr;                   // device-made (grm_matrix_deflate_*): malloc'ed block + starts + lens
+    uint64_t *starts = nullptr;
+    uint32_t *lens = nullptr;
+    uint64_t n = 0;
+    Streams() = default;
+    Streams(const Streams &) = delete;
+    Streams &operator=(const Streams &) = delete;
+    ~Streams() { grm_host_free(buf); grm_host_free(starts); grm_host_free(lens); }
+    const unsigned char *at(size_t i) const { return buf ? buf + starts[i] : z[i].data(); }
+    size_t len(size_t i) const { return buf ? lens[i] : z[i].size(); }
+};
+
+// deflate `n_chunks` equally sized raw chunks on the host threads; get_chunk(i, buf) must leave the
 // (padded) chunk bytes in buf and return a pointer to them
 template <typename GetChunk>
-bool deflate_chunks(size_t n_chunks, size_t chunk_bytes, int gzip, GetChunk &&get_chunk, std::vector<std::vector<unsigned char>> &z)
+bool deflate_chunks(size_t n_chunks, size_t chunk_bytes, int gzip, GetChunk &&get_chunk, Streams &out)
 {
-    z.assign(n_chunks, {});
+    out.z.assign(n_chunks, {});
+    out.n = n_chunks;
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 4;
-    if (nt > 64) nt = 64;
+    unsigned nt = host_threads();
     if (nt > n_chunks) nt = (unsigned)n_chunks;
+    const bool use_ld = g_ld.load();
     auto work = [&]() {
         std::vector<unsigned char> raw(chunk_bytes);
+        void *comp = use_ld ? g_ld.alloc(gzip) : nullptr;
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= n_chunks) break;
             const unsigned char *src = get_chunk(i, raw.data());
-            uLongf zl = compressBound(chunk_bytes);
-            z[i].resize(zl);
-            if (compress2(z[i].data(), &zl, src, chunk_bytes, gzip) != Z_OK) bad = 1;
-            z[i].resize(zl);
+            auto &z = out.z[i];
+            if (comp) {
+                z.resize(g_ld.zlib_bound(comp, chunk_bytes));
+                const size_t zl = g_ld.zlib_compress(comp, src, chunk_bytes, z.data(), z.size());
+                if (!zl) bad = 1;
+                z.resize(zl);
+            } else {
+                uLongf zl = compressBound(chunk_bytes);
+                z.resize(zl);
+                if (compress2(z.data(), &zl, src, chunk_bytes, gzip) != Z_OK) bad = 1;
+                z.resize(zl);
+            }
         }
+        if (comp) g_ld.free_compressor(comp);
     };
     std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++) th.emplace_back(work);
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
     for (auto &t : th) t.join();
     return !bad;
 }
 
-// 1-D dataset.  With gzip and H5Dwrite_chunk available the chunks are deflated in parallel
-// (single-threaded deflate inside H5Dwrite runs at ~60 MB/s: 10 s for the k-mer strings alone).
-int write_1d(H5 &H, hid_t file, const char *name, hid_t type, size_t elem_bytes, const void *data, hsize_t n, int gzip, std::string &err)
+// GRM_FAULT_H5_CHUNK=<i> (tests): the i-th chunk handed to HDF5 in this call fails, as a full disk would make it
+struct Fault {
+    long at = -1, seen = 0;
+    Fault() { if (const char *e = getenv("GRM_FAULT_H5_CHUNK")) at = atol(e); }
+    bool hit() { return at >= 0 && seen++ == at; }
+};
+
+// 1-D dataset with `ce` elements per chunk.  streams != nullptr: its finished chunks; else raw `data` (deflated here when gzip > 0
+// and H5Dwrite_chunk exists, plain H5Dwrite otherwise)
+int write_1d(H5 &H, hid_t file, const char *name, hid_t type, size_t elem_bytes, const void *data, hsize_t n, int gzip, const Streams *streams,
+             Fault &fault, std::string &err)
 {
     if (H.Lexists(file, name, 0) > 0) H.Ldelete(file, name, 0);
     hsize_t dims[1] = {n};
@@ -192,21 +285,24 @@ int write_1d(H5 &H, hid_t file, const char *name, hid_t type, size_t elem_bytes,
     else {
         if (n > 0 && gzip > 0 && H.Dwrite_chunk) {
             const size_t n_chunks = (size_t)((n + ce - 1) / ce), cb = (size_t)ce * elem_bytes;
-            std::vector<std::vector<unsigned char>> z;
-            const unsigned char *base = static_cast<const unsigned char *>(data);
-            const bool ok = deflate_chunks(n_chunks, cb, gzip, [&](size_t i, unsigned char *buf) -> const unsigned char * {
-                const size_t e0 = i * (size_t)ce, ne = (size_t)std::min<hsize_t>(ce, n - e0);
-                if (ne == (size_t)ce) return base + e0 * elem_bytes;
-                memcpy(buf, base + e0 * elem_bytes, ne * elem_bytes);            // edge chunk: pad with the fill value 0
-                memset(buf + ne * elem_bytes, 0, cb - ne * elem_bytes);
-                return buf;
-            }, z);
-            if (!ok) { err = "zlib compress2 failed"; rc = -1; }
+            Streams own;
+            if (!streams) {
+                const unsigned char *base = static_cast<const unsigned char *>(data);
+                const bool ok = deflate_chunks(n_chunks, cb, gzip, [&](size_t i, unsigned char *buf) -> const unsigned char * {
+                    const size_t e0 = i * (size_t)ce, ne = (size_t)std::min<hsize_t>(ce, n - e0);
+                    if (ne == (size_t)ce) return base + e0 * elem_bytes;
+                    memcpy(buf, base + e0 * elem_bytes, ne * elem_bytes);            // edge chunk: pad with the fill value 0
+                    memset(buf + ne * elem_bytes, 0, cb - ne * elem_bytes);
+                    return buf;
+                }, own);
+                if (!ok) { err = "deflate failed"; rc = -1; }
+                streams = &own;
+            } else if (streams->n != n_chunks) { err = std::string(name) + ": chunk count of the prepared streams"; rc = -1; }
             for (size_t i = 0; i < n_chunks && !rc; i++) {
                 hsize_t off[1] = {i * ce};
-                if (H.Dwrite_chunk(ds, 0, 0, off, z[i].size(), z[i].data()) < 0) { err = std::string("H5Dwrite_chunk ") + name; rc = -1; }
+                if (fault.hit() || H.Dwrite_chunk(ds, 0, 0, off, streams->len(i), streams->at(i)) < 0) { err = std::string("H5Dwrite_chunk ") + name; rc = -1; }
             }
-        } else if (n > 0 && H.Dwrite(ds, type, 0, 0, 0, data) < 0) { err = std::string("H5Dwrite ") + name; rc = -1; }
+        } else if (n > 0 && (fault.hit() || H.Dwrite(ds, type, 0, 0, 0, data) < 0)) { err = std::string("H5Dwrite ") + name; rc = -1; }
         H.Dclose(ds);
     }
     if (dcpl > 0) H.Pclose(dcpl);
@@ -221,14 +317,23 @@ extern "C" int grm_internal_fail(grm_matrix *m, int code, const char *msg);
 extern "C" uint64_t *grm_internal_matrix_download_begin(grm_matrix *m, int *already);
 extern "C" int grm_internal_matrix_download_rows(grm_matrix *m, size_t r0, size_t r1);
 extern "C" void grm_internal_matrix_download_end(grm_matrix *m);
+extern "C" int grm_internal_matrix_on_device(const grm_matrix *m);
 
-extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, int gzip_level, int chunk_cols)
+// The append itself.  parts == nullptr: kmer_matrix holds m's own rows.  Otherwise kmer_matrix has n_rows_total word-rows whose
+// chunks come finished from n_parts producers (ranks of a multi-GPU run, each having deflated the rows it filled): part p covers
+// rows [row0[p], row0[p] + rows[p]) with its chunks row-major at streams[p] + starts[p][i], lens[p][i] bytes; m gives the
+// dictionary (kmer_sequences, kmer_by_matrix_column) and must hold the same columns on every producer.
+static int write_kover(grm_matrix *m, const char *existing_h5_path, int gzip_level, int chunk_cols, uint64_t n_rows_total, int n_parts,
+                       const unsigned char *const *p_streams, const uint64_t *const *p_starts, const uint32_t *const *p_lens, const uint64_t *p_row0,
+                       const uint64_t *p_rows)
 {
     if (!m || !existing_h5_path) return GRM_ERR_ARG;
     if (gzip_level < 0 || gzip_level > 9) return grm_internal_fail(m, GRM_ERR_ARG, "gzip level must be 0..9");
     if (chunk_cols <= 0) chunk_cols = 100000;                        // BLOCK_SIZE, dataset/create.py:41
     H5 &H = g_h5;
     if (!H.load()) return grm_internal_fail(m, GRM_ERR_HDF5, H.err.c_str());
+    const bool parts = n_parts > 0;
+    if (parts && (gzip_level == 0 || !H.Dwrite_chunk)) return grm_internal_fail(m, GRM_ERR_ARG, "prepared chunks need gzip > 0 and H5Dwrite_chunk (HDF5 >= 1.10.3)");
     // GRM_TRACE=1: phase timings on stderr
     const bool trace = getenv("GRM_TRACE") && atoi(getenv("GRM_TRACE")) > 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -236,67 +341,114 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
     auto lap = [&](const char *what) {
         if (!trace) return;
         const double t = now();
-        fprintf(stderr, "[grm_write_kover_h5] %-28s %8.1f ms\n", what, (t - t_last) * 1e3);
+        fprintf(stderr, "[grm_write_kover_h5] %-36s %8.1f ms\n", what, (t - t_last) * 1e3);
         t_last = t;
     };
-    const size_t U = grm_matrix_n_kmers(m), R = grm_matrix_n_rows(m);
+    const size_t U = grm_matrix_n_kmers(m), R = parts ? (size_t)n_rows_total : grm_matrix_n_rows(m);
     const int k = grm_matrix_k(m);
-    // The dictionary comes down first (small); the matrix then follows row by row on a thread of its own
-    // while this one writes the k-mer strings, and the chunk deflaters below start on a row as soon as
-    // it has arrived.
-    const uint64_t *kmers = grm_matrix_kmers(m);
-    if (!kmers) return GRM_ERR_HIP;
-    int already = 0;
-    const uint64_t *data = grm_internal_matrix_download_begin(m, &already);
-    if (!data) return GRM_ERR_HIP;
-    std::atomic<size_t> rows_ready(already ? R : 0);
-    std::atomic<int> copy_failed(0);
-    std::thread copier([&]() {
-        if (already) return;
-        for (size_t r = 0; r < R; r++) {
-            if (grm_internal_matrix_download_rows(m, r, r + 1) != GRM_OK) { copy_failed = 1; rows_ready = R; return; }
-            rows_ready = r + 1;
+    const hsize_t cw = U ? (U < (size_t)chunk_cols ? U : (hsize_t)chunk_cols) : 1;       // chunks (1, min(U, chunk_cols)) as from_tsv does (create.py:160,230)
+    const size_t chunks_per_row = (U + cw - 1) / cw;
+    if (parts) {
+        uint64_t covered = 0;
+        for (int p = 0; p < n_parts; p++) {
+            if (!p_streams[p] && p_rows[p]) return grm_internal_fail(m, GRM_ERR_ARG, "prepared chunks: a part without streams");
+            if (p_row0[p] != covered) return grm_internal_fail(m, GRM_ERR_ARG, "prepared chunks: the parts must cover the rows in order, without gaps");
+            covered += p_rows[p];
         }
-        grm_internal_matrix_download_end(m);
-    });
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{copier};
-    lap("k-mers device -> host");
+        if (covered != n_rows_total) return grm_internal_fail(m, GRM_ERR_ARG, "prepared chunks: the parts do not add up to the matrix's rows");
+    }
+    const char *mode = getenv("GRM_DEFLATE");
+    const bool on_device = grm_internal_matrix_on_device(m) && gzip_level > 0 && H.Dwrite_chunk && !(mode && !strcmp(mode, "host"));
+
+    // ---- the producers of the two large datasets start first: they run beside the HDF5 calls of this thread ----
+    Streams seq_streams, mat_streams;
+    std::atomic<int> dev_rc(GRM_OK);
+    std::thread dev_worker;
+    // host path, device-resident matrix: the dictionary comes down first (small), the matrix then follows row by row on a thread
+    // of its own and the chunk deflaters below start on a row as soon as it has arrived
+    const uint64_t *kmers = nullptr, *data = nullptr;
+    std::atomic<size_t> rows_ready(0);
+    std::atomic<int> copy_failed(0);
+    std::thread copier;
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } join_dev{dev_worker}, join_copy{copier};
+    if (on_device) {
+        dev_worker = std::thread([&]() {
+            int rc = grm_matrix_deflate_kmer_strings(m, 1 << 16, &seq_streams.buf, &seq_streams.starts, &seq_streams.lens, &seq_streams.n);
+            if (rc == GRM_OK && !parts)
+                rc = grm_matrix_deflate_rows(m, chunk_cols, &mat_streams.buf, &mat_streams.starts, &mat_streams.lens, &mat_streams.n);
+            dev_rc = rc;
+        });
+    } else {
+        kmers = grm_matrix_kmers(m);
+        if (!kmers) return GRM_ERR_HIP;
+        if (!parts) {
+            int already = 0;
+            data = grm_internal_matrix_download_begin(m, &already);
+            if (!data) return GRM_ERR_HIP;
+            rows_ready = already ? R : 0;
+            if (!already)
+                copier = std::thread([&]() {
+                    for (size_t r = 0; r < R; r++) {
+                        if (grm_internal_matrix_download_rows(m, r, r + 1) != GRM_OK) { copy_failed = 1; rows_ready = R; return; }
+                        rows_ready = r + 1;
+                    }
+                    grm_internal_matrix_download_end(m);
+                });
+        }
+        lap("k-mers device -> host");
+    }
 
     H.Eset_auto2(0, nullptr, nullptr);
     hid_t file = H.Fopen(existing_h5_path, 1u /* H5F_ACC_RDWR */, 0);
     if (file < 0) return grm_internal_fail(m, GRM_ERR_HDF5, (std::string("cannot open existing Kover HDF5 ") + existing_h5_path).c_str());
     std::string err;
     int rc = 0;
+    Fault fault;
+
+    // kmer_by_matrix_column: identity map in the minimum unsigned width (utils.py:117-130); small, deflated on the host
+    {
+        if (U <= 0xffu) { std::vector<uint8_t> v(U + 1); for (size_t i = 0; i < U; i++) v[i] = (uint8_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U8, 1, v.data(), U, gzip_level, nullptr, fault, err); }
+        else if (U <= 0xffffu) { std::vector<uint16_t> v(U); for (size_t i = 0; i < U; i++) v[i] = (uint16_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U16, 2, v.data(), U, gzip_level, nullptr, fault, err); }
+        else if (U <= 0xffffffffull) {
+            std::vector<uint32_t> v(U);
+            parallel_for(U, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) v[i] = (uint32_t)i; });
+            rc = write_1d(H, file, "kmer_by_matrix_column", H.U32, 4, v.data(), U, gzip_level, nullptr, fault, err);
+        }
+        else { std::vector<uint64_t> v(U); for (size_t i = 0; i < U; i++) v[i] = i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U64, 8, v.data(), U, gzip_level, nullptr, fault, err); }
+    }
+    lap("kmer_by_matrix_column");
+
+    if (on_device) {
+        dev_worker.join();
+        if (dev_rc != GRM_OK && !rc) { err = std::string("deflate on the device: ") + grm_matrix_last_error(m); rc = -1; }
+        lap("device deflate (waited for)");
+    }
 
     // kmer_sequences: fixed-length S<k> (what numpy 'S31' becomes in h5py), null padded
-    {
-        std::vector<char> seq(U * (size_t)k + 1);
-        const int words = grm_matrix_words(m);
-        parallel_for(U, [&](size_t c0, size_t c1) {
-            for (size_t c = c0; c < c1; c++) decode_kmer(kmers + c * (size_t)words, words, k, seq.data() + c * (size_t)k);
-        });
-        lap("decode k-mer strings");
+    if (!rc) {
         hid_t st = H.Tcopy(H.C_S1);
         H.Tset_size(st, (size_t)k);
         H.Tset_strpad(st, 1);   // H5T_STR_NULLPAD
-        rc = write_1d(H, file, "kmer_sequences", st, (size_t)k, seq.data(), U, gzip_level, err);
+        if (on_device) {
+            rc = write_1d(H, file, "kmer_sequences", st, (size_t)k, nullptr, U, gzip_level, &seq_streams, fault, err);
+        } else {
+            std::vector<char> seq(U * (size_t)k + 1);
+            const int words = grm_matrix_words(m);
+            parallel_for(U, [&](size_t c0, size_t c1) {
+                for (size_t c = c0; c < c1; c++) decode_kmer(kmers + c * (size_t)words, words, k, seq.data() + c * (size_t)k);
+            });
+            lap("decode k-mer strings");
+            rc = write_1d(H, file, "kmer_sequences", st, (size_t)k, seq.data(), U, gzip_level, nullptr, fault, err);
+        }
         H.Tclose(st);
         lap("kmer_sequences");
     }
-    // kmer_by_matrix_column: identity map in the minimum unsigned width (utils.py:117-130)
-    if (!rc) {
-        if (U <= 0xffu) { std::vector<uint8_t> v(U + 1); for (size_t i = 0; i < U; i++) v[i] = (uint8_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U8, 1, v.data(), U, gzip_level, err); }
-        else if (U <= 0xffffu) { std::vector<uint16_t> v(U); for (size_t i = 0; i < U; i++) v[i] = (uint16_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U16, 2, v.data(), U, gzip_level, err); }
-        else if (U <= 0xffffffffull) { std::vector<uint32_t> v(U); for (size_t i = 0; i < U; i++) v[i] = (uint32_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U32, 4, v.data(), U, gzip_level, err); }
-        else { std::vector<uint64_t> v(U); for (size_t i = 0; i < U; i++) v[i] = i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U64, 8, v.data(), U, gzip_level, err); }
-    }
-    lap("kmer_by_matrix_column");
-    // kmer_matrix: chunks (1, min(U, chunk_cols)) as from_tsv does (create.py:160,230)
+
+    // kmer_matrix
     if (!rc) {
         if (H.Lexists(file, "kmer_matrix", 0) > 0) H.Ldelete(file, "kmer_matrix", 0);
         hsize_t dims[2] = {R, U};
         hid_t space = H.Screate_simple(2, dims, nullptr);
-        const hsize_t cw = U ? (U < (size_t)chunk_cols ? U : (hsize_t)chunk_cols) : 1;
         hid_t dcpl = 0;
         if (U && R) {
             hsize_t chunk[2] = {1, cw};
@@ -305,11 +457,20 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
         hid_t ds = (dcpl < 0) ? -1 : H.Dcreate2(file, "kmer_matrix", H.U64, space, 0, dcpl, 0);
         if (ds < 0) { err = "H5Dcreate2 kmer_matrix"; rc = -1; }
         else if (U && R) {
-            const size_t chunks_per_row = (U + cw - 1) / cw;
             const size_t n_chunks = chunks_per_row * R;
-            if (gzip_level > 0 && H.Dwrite_chunk) {
-                // deflate every chunk on the host cores, then hand the raw chunks to HDF5 in order
-                std::vector<std::vector<unsigned char>> z;
+            auto put = [&](size_t i, const unsigned char *p, size_t len) {
+                hsize_t off[2] = {i / chunks_per_row, (i % chunks_per_row) * cw};
+                if (fault.hit() || H.Dwrite_chunk(ds, 0, 0, off, len, p) < 0) { err = "H5Dwrite_chunk kmer_matrix"; rc = -1; }
+            };
+            if (parts) {
+                for (int p = 0; p < n_parts && !rc; p++)
+                    for (size_t j = 0; j < (size_t)p_rows[p] * chunks_per_row && !rc; j++)
+                        put((size_t)p_row0[p] * chunks_per_row + j, p_streams[p] + p_starts[p][j], p_lens[p][j]);
+            } else if (on_device) {
+                if (mat_streams.n != n_chunks) { err = "kmer_matrix: chunk count of the device's streams"; rc = -1; }
+                for (size_t i = 0; i < n_chunks && !rc; i++) put(i, mat_streams.at(i), mat_streams.len(i));
+            } else if (gzip_level > 0 && H.Dwrite_chunk) {
+                // deflate every chunk on the host threads, then hand the streams to HDF5 in order
                 const bool ok = deflate_chunks(n_chunks, (size_t)cw * 8, gzip_level, [&](size_t i, unsigned char *buf) -> const unsigned char * {
                     const size_t r = i / chunks_per_row, c0 = (i % chunks_per_row) * cw;
                     while (rows_ready.load() <= r) std::this_thread::sleep_for(std::chrono::microseconds(200));     // this row is still on its way
@@ -319,18 +480,15 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
                     memcpy(buf, src, nc * 8);                         // edge chunk: HDF5 stores full chunks, pad with the fill value 0
                     memset(buf + nc * 8, 0, ((size_t)cw - nc) * 8);
                     return buf;
-                }, z);
-                if (!ok) { err = "zlib compress2 failed"; rc = -1; }
+                }, mat_streams);
+                if (!ok) { err = "deflate failed"; rc = -1; }
                 if (copy_failed) { err = "device -> host copy of the matrix failed"; rc = -1; }
                 lap("kmer_matrix download + deflate");
-                for (size_t i = 0; i < n_chunks && !rc; i++) {
-                    hsize_t off[2] = {i / chunks_per_row, (i % chunks_per_row) * cw};
-                    if (H.Dwrite_chunk(ds, 0, 0, off, z[i].size(), z[i].data()) < 0) { err = "H5Dwrite_chunk kmer_matrix"; rc = -1; }
-                }
+                for (size_t i = 0; i < n_chunks && !rc; i++) put(i, mat_streams.at(i), mat_streams.len(i));
             } else {
-                copier.join();
+                if (copier.joinable()) copier.join();
                 if (copy_failed) { err = "device -> host copy of the matrix failed"; rc = -1; }      // never write rows that did not arrive
-                else if (H.Dwrite(ds, H.U64, 0, 0, 0, data) < 0) { err = "H5Dwrite kmer_matrix"; rc = -1; }
+                else if (fault.hit() || H.Dwrite(ds, H.U64, 0, 0, 0, data) < 0) { err = "H5Dwrite kmer_matrix"; rc = -1; }
             }
         }
         if (ds >= 0) H.Dclose(ds);
@@ -338,8 +496,26 @@ extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, i
         H.Sclose(space);
     }
     lap("kmer_matrix write");
+    if (rc) {
+        // whatever exists of the three datasets is incomplete: a reader must not find it (unwritten chunks read back as zeros)
+        for (const char *name : {"kmer_sequences", "kmer_by_matrix_column", "kmer_matrix"})
+            if (H.Lexists(file, name, 0) > 0) H.Ldelete(file, name, 0);
+    }
     if (H.Fclose(file) < 0 && !rc) { err = "H5Fclose"; rc = -1; }
     lap("H5Fclose");
-    if (rc) return grm_internal_fail(m, GRM_ERR_HDF5, err.c_str());
+    if (rc) return grm_internal_fail(m, GRM_ERR_HDF5, (err + " (" + existing_h5_path + ": the partly written datasets were removed)").c_str());
     return GRM_OK;
+}
+
+extern "C" int grm_write_kover_h5(grm_matrix *m, const char *existing_h5_path, int gzip_level, int chunk_cols)
+{
+    return write_kover(m, existing_h5_path, gzip_level, chunk_cols, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int grm_write_kover_h5_parts(grm_matrix *dict, const char *existing_h5_path, int gzip_level, int chunk_cols, uint64_t n_rows_total, int n_parts,
+                                        const unsigned char *const *streams, const uint64_t *const *starts, const uint32_t *const *lens,
+                                        const uint64_t *row0, const uint64_t *rows)
+{
+    if (n_parts <= 0 || !streams || !starts || !lens || !row0 || !rows) return GRM_ERR_ARG;
+    return write_kover(dict, existing_h5_path, gzip_level, chunk_cols, n_rows_total, n_parts, streams, starts, lens, row0, rows);
 }

@@ -322,4 +322,15 @@ void launch_wh_entry_cols(hipStream_t s, const uint64_t *s_hi, const uint64_t *s
 void launch_wh_cols_from_order(hipStream_t s, const uint32_t *order, const uint32_t *keep, const uint32_t *pos, uint64_t n, uint32_t *entry_col);
 hipError_t wh_set_max_dynamic_lds();
 
+// ---- zlib encoder on the device (grm_deflate.hip): the HDF5 chunks of kmer_matrix / kmer_sequences as finished streams ----
+// one wave per chunk; out: deflate_chunk_cap(raw bytes of a chunk) bytes per chunk of the launch, sizes[c] = stream length;
+// tok: chunk_cols uint16 per chunk of the launch (scratch)
+uint64_t deflate_chunk_cap(uint64_t raw_bytes);
+hipError_t launch_deflate_rows(hipStream_t s, const uint64_t *matrix, uint64_t n_cols, uint32_t chunk_cols, uint32_t chunks_per_row,
+                               uint64_t first_chunk, uint32_t n_chunks, uint16_t *tok, uint8_t *out, uint64_t cap, uint32_t *sizes);
+hipError_t launch_deflate_kmer_strings(hipStream_t s, const uint64_t *kmers, uint64_t n, int words, int k, uint32_t chunk_elems,
+                                       uint64_t first_chunk, uint32_t n_chunks, uint8_t *out, uint64_t cap, uint32_t *sizes);
+// the streams of a launch moved next to each other: dst[off[c] ..), off[c] multiples of 16
+hipError_t launch_deflate_compact(hipStream_t s, const uint8_t *src, uint64_t cap, const uint32_t *sizes, uint32_t n_chunks, uint64_t *off, uint8_t *dst);
+
 }  // namespace grm

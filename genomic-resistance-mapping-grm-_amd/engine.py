@@ -45,7 +45,7 @@ class Context:
             for child in list(self._children):
                 try:
                     child.free()
-                except Exception:
+                except GrmError:        # (a free never fails in the library; anything else is a bug and must surface)
                     pass
             self.L.grm_destroy(self.h)
             self.h = None
@@ -136,7 +136,23 @@ class Context:
         return Batch(self, n_genomes)
 
 
-class KmerSet:
+class _Handle:
+    """A library handle.  Reading `.h` of a freed one raises instead of handing NULL to the C ABI (which would answer 0 / an empty
+    array): Context.close() frees the handles that are still alive, so a Matrix carried out of its `with Context` block is dead."""
+    _h = None
+
+    @property
+    def h(self):
+        if self._h is None:
+            raise GrmError(-7, "%s: the handle was freed (explicitly, or because its Context was closed)" % type(self).__name__)
+        return self._h
+
+    @h.setter
+    def h(self, value):
+        self._h = value
+
+
+class KmerSet(_Handle):
     def __init__(self, ctx, h):
         self.ctx, self.h = ctx, h
         ctx._adopt(self)
@@ -171,9 +187,9 @@ class KmerSet:
         return np.ctypeslib.as_array(p, shape=(n,)).copy()
 
     def free(self):
-        if self.h:
-            self.ctx.L.grm_kmer_set_free(self.h)
-            self.h = None
+        if self._h:
+            self.ctx.L.grm_kmer_set_free(self._h)
+            self._h = None
 
     def __del__(self):
         try:
@@ -182,7 +198,7 @@ class KmerSet:
             pass
 
 
-class Matrix:
+class Matrix(_Handle):
     """dictionary (ascending, A<C<T<G) + uint64 presence matrix [ceil(N/64)][U], MSB-first"""
 
     def __init__(self, ctx, h):
@@ -285,10 +301,43 @@ class Matrix:
     def write_kover_h5(self, path, gzip_level=4, chunk_cols=100000):
         self.ctx._chk(self.ctx.L.grm_write_kover_h5(self.h, path.encode(), gzip_level, chunk_cols))
 
+    def _streams(self, fn, chunk):
+        buf, starts, lens, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self.ctx._chk(fn(self.h, int(chunk), C.byref(buf), C.byref(starts), C.byref(lens), C.byref(n)))
+        try:
+            n = int(n.value)
+            if n == 0:
+                return ChunkStreams(np.zeros(0, np.uint8), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+            st = np.ctypeslib.as_array(C.cast(starts, C.POINTER(C.c_uint64)), shape=(n,)).copy()
+            ln = np.ctypeslib.as_array(C.cast(lens, C.POINTER(C.c_uint32)), shape=(n,)).copy()
+            total = int(st[-1]) + int(ln[-1])
+            return ChunkStreams(np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(total,)).copy(), st, ln)
+        finally:
+            for ptr in (buf, starts, lens):
+                self.ctx.L.grm_host_free(ptr)
+
+    def deflate_rows(self, chunk_cols=100000):
+        """the kmer_matrix HDF5 chunks of this matrix's word-rows as zlib streams made on the device -> ChunkStreams"""
+        return self._streams(self.ctx.L.grm_matrix_deflate_rows, chunk_cols)
+
+    def deflate_kmer_strings(self, chunk_elems=65536):
+        return self._streams(self.ctx.L.grm_matrix_deflate_kmer_strings, chunk_elems)
+
+    def write_kover_h5_parts(self, path, parts, n_rows_total, gzip_level=4, chunk_cols=100000):
+        """append the three datasets with kmer_matrix chunks made elsewhere: parts = [(first word-row, word-rows, ChunkStreams)]
+        covering rows 0 .. n_rows_total in order; this matrix gives the dictionary"""
+        n = len(parts)
+        bufs = (C.c_void_p * n)(*[p[2].buf.ctypes.data for p in parts])
+        starts = (C.c_void_p * n)(*[p[2].starts.ctypes.data for p in parts])
+        lens = (C.c_void_p * n)(*[p[2].lens.ctypes.data for p in parts])
+        row0 = (C.c_uint64 * n)(*[int(p[0]) for p in parts])
+        rows = (C.c_uint64 * n)(*[int(p[1]) for p in parts])
+        self.ctx._chk(self.ctx.L.grm_write_kover_h5_parts(self.h, path.encode(), gzip_level, chunk_cols, int(n_rows_total), n, bufs, starts, lens, row0, rows))
+
     def free(self):
-        if self.h:
-            self.ctx.L.grm_matrix_free(self.h)
-            self.h = None
+        if self._h:
+            self.ctx.L.grm_matrix_free(self._h)
+            self._h = None
 
     def __del__(self):
         try:
@@ -297,7 +346,40 @@ class Matrix:
             pass
 
 
-class DictAccum:
+class ChunkStreams:
+    """finished zlib streams of a dataset's HDF5 chunks: chunk i = buf[starts[i] : starts[i] + lens[i]]"""
+
+    def __init__(self, buf, starts, lens):
+        self.buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self.starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        self.lens = np.ascontiguousarray(lens, dtype=np.uint32)
+
+    def __len__(self):
+        return int(self.lens.shape[0])
+
+    def chunk(self, i):
+        a = int(self.starts[i])
+        return self.buf[a: a + int(self.lens[i])].tobytes()
+
+    def tofile(self, path):
+        """one spool file: n, starts, lens, bytes (a rank of a multi-GPU run hands its rows' chunks to the writing rank)"""
+        with open(path, "wb") as f:
+            np.array([len(self), self.buf.shape[0]], dtype=np.uint64).tofile(f)
+            self.starts.tofile(f)
+            self.lens.tofile(f)
+            self.buf.tofile(f)
+
+    @classmethod
+    def fromfile(cls, path):
+        with open(path, "rb") as f:
+            n, nb = (int(v) for v in np.fromfile(f, dtype=np.uint64, count=2))
+            starts = np.fromfile(f, dtype=np.uint64, count=n)
+            lens = np.fromfile(f, dtype=np.uint32, count=n)
+            buf = np.fromfile(f, dtype=np.uint8, count=nb)
+        return cls(buf, starts, lens)
+
+
+class DictAccum(_Handle):
     """(k-mer, flag) entries of the local dictionaries of a sequence of batches (pass 1 of the
     two-pass build for inputs that do not fit HBM at once)"""
 
@@ -312,9 +394,9 @@ class DictAccum:
         return int(self.ctx.L.grm_dict_accum_size(self.h))
 
     def free(self):
-        if self.h:
-            self.ctx.L.grm_dict_accum_free(self.h)
-            self.h = None
+        if self._h:
+            self.ctx.L.grm_dict_accum_free(self._h)
+            self._h = None
 
     def __del__(self):
         try:
@@ -323,7 +405,7 @@ class DictAccum:
             pass
 
 
-class Batch:
+class Batch(_Handle):
     """device-resident batch of genomes: parse -> partition -> dictionary -> presence bits"""
 
     def __init__(self, ctx, n_genomes):
@@ -440,9 +522,9 @@ class Batch:
         return {"records_held_mean": held / ends, "occurrences": asked, "found": found, "hit_rate": found / asked if asked else 0.0}
 
     def free(self):
-        if self.h:
-            self.ctx.L.grm_batch_free(self.h)
-            self.h = None
+        if self._h:
+            self.ctx.L.grm_batch_free(self._h)
+            self._h = None
 
     def __del__(self):
         try:

@@ -145,6 +145,26 @@ int  grm_write_tsv(grm_matrix *, const char *const *genome_ids, const char *path
 /* appends kmer_sequences / kmer_matrix / kmer_by_matrix_column to the EXISTING Kover HDF5
  * exactly as dsk2kover does (schema dataset/create.py:214-238); libhdf5 is dlopen()ed. */
 int  grm_write_kover_h5(grm_matrix *, const char *existing_h5_path, int gzip_level, int chunk_cols);
+/* On failure (GRM_ERR_HDF5) whatever exists of the three datasets is unlinked before the file is closed: the caller
+ * (kmer_pack.py:28) ignores the tool's return code, and unwritten chunks would read back as "absent everywhere".
+ * A matrix that lives on the device is deflated THERE (one wave per HDF5 chunk, zlib streams handed to H5Dwrite_chunk; any
+ * gzip_level >= 1 gives the same streams, the level only goes into the dataset's filter parameters); host-only matrices,
+ * GRM_DEFLATE=host and libhdf5 < 1.10.3 take host threads (GRM_WRITER_THREADS; default: the process's CPU share).
+ *
+ * The same streams for callers that write the file elsewhere -- the ranks of a multi-GPU run deflate the word-rows they
+ * filled and rank 0 appends them (replaces the gather of raw rows; create.py:365-390 seen from N GPUs):
+ * chunk i of kmer_matrix in row-major order (word-row i / chunks_per_row, columns (i % chunks_per_row) * cw .. + cw with
+ * cw = min(n_kmers, chunk_cols), zero-padded) is lens[i] bytes at streams + starts[i]; kmer_sequences likewise in chunks of
+ * min(n_kmers, chunk_elems) strings (the writer uses 65536).  The three arrays are malloc'ed: grm_host_free each. */
+int  grm_matrix_deflate_rows(grm_matrix *, int chunk_cols, unsigned char **streams, uint64_t **starts, uint32_t **lens, uint64_t *n_chunks);
+int  grm_matrix_deflate_kmer_strings(grm_matrix *, int chunk_elems, unsigned char **streams, uint64_t **starts, uint32_t **lens, uint64_t *n_chunks);
+void grm_host_free(void *);
+/* grm_write_kover_h5 with the kmer_matrix chunks made elsewhere: `dict` gives the dictionary (kmer_sequences,
+ * kmer_by_matrix_column; on the device or host-only); part p holds the chunks of word-rows [row0[p], row0[p] + rows[p]) as
+ * grm_matrix_deflate_rows returns them; the parts cover rows 0 .. n_rows_total in order.  gzip_level >= 1. */
+int  grm_write_kover_h5_parts(grm_matrix *dict, const char *existing_h5_path, int gzip_level, int chunk_cols, uint64_t n_rows_total, int n_parts,
+                              const unsigned char *const *streams, const uint64_t *const *starts, const uint32_t *const *lens,
+                              const uint64_t *row0, const uint64_t *rows);
 
 /* ---- fused device-resident batch path ------------------------------------------------- */
 int  grm_batch_create(grm_ctx *, int n_genomes, grm_batch **out);
