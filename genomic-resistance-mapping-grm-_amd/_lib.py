@@ -57,6 +57,7 @@ PROTOTYPES = [
     ("grm_matrix_last_error", C.c_char_p, [_P]),
     ("grm_matrix_free", None, [_P]),
     ("grm_write_tsv", C.c_int, [_P, C.POINTER(C.c_char_p), C.c_char_p]),
+    ("grm_write_tsv_slice", C.c_int, [_P, C.POINTER(C.c_char_p), C.c_char_p, C.c_uint64, C.c_uint64]),
     ("grm_write_kover_h5", C.c_int, [_P, C.c_char_p, C.c_int, C.c_int]),
     ("grm_matrix_deflate_rows", C.c_int, [_P, C.c_int, _PP, _PP, _PP, _U64P]),
     ("grm_matrix_deflate_kmer_strings", C.c_int, [_P, C.c_int, _PP, _PP, _PP, _U64P]),

@@ -3647,15 +3647,18 @@ static inline void decode_kmer(const uint64_t *w, int words, int k, char *out)
     }
 }
 
-extern "C" int grm_write_tsv(grm_matrix *m, const char *const *genome_ids, const char *path)
+// rows [col0, col1) of the TSV (a row = one k-mer = one matrix column) into `path` at their final offsets; the header when
+// col0 == 0.  whole = true: path is written as <path>.tmp and renamed (grm_write_tsv); false: the file is shared with other
+// writers (the ranks of a multi-GPU run each format a slice), opened without truncation, no rename
+static int write_tsv_rows(grm_matrix *m, const char *const *genome_ids, const char *path, size_t col0, size_t col1, bool whole)
 {
     if (!m || !path || (m->n_genomes && !genome_ids)) return GRM_ERR_ARG;
     grm_ctx *c = m->ctx;
     const uint64_t *kmers = grm_matrix_kmers(m);
     const uint64_t *data = grm_matrix_data(m);
     if (!kmers || !data) return GRM_ERR_HIP;
-    std::string tmp = std::string(path) + ".tmp";
-    int fd = open(tmp.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    std::string tmp = whole ? std::string(path) + ".tmp" : std::string(path);
+    int fd = open(tmp.c_str(), O_CREAT | (whole ? O_TRUNC : 0) | O_WRONLY, 0644);
     if (fd < 0) return fail(c, GRM_ERR_IO, "cannot create %s", tmp.c_str());
     std::string header = "kmers";                      // first header cell is forced by dataset/create.py:241
     for (int g = 0; g < m->n_genomes; g++) { header += '\t'; header += genome_ids[g]; }
@@ -3664,10 +3667,12 @@ extern "C" int grm_write_tsv(grm_matrix *m, const char *const *genome_ids, const
     // and written by all host cores at computed file offsets
     const size_t line_len = (size_t)m->k + 2 * (size_t)m->n_genomes + 1;
     const size_t U = m->n_kmers;
+    col1 = std::min(col1, U);
+    col0 = std::min(col0, col1);
     std::atomic<int> bad(0);
-    if (pwrite(fd, header.data(), header.size(), 0) != (ssize_t)header.size()) bad = 1;
+    if (col0 == 0 && pwrite(fd, header.data(), header.size(), 0) != (ssize_t)header.size()) bad = 1;
     const size_t rows_per_block = std::max<size_t>(1, ((size_t)8 << 20) / line_len);
-    const size_t n_blocks = (U + rows_per_block - 1) / rows_per_block;
+    const size_t n_blocks = (col1 - col0 + rows_per_block - 1) / rows_per_block;
     std::atomic<size_t> next(0);
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 4;
@@ -3678,7 +3683,7 @@ extern "C" int grm_write_tsv(grm_matrix *m, const char *const *genome_ids, const
         for (;;) {
             const size_t blk = next.fetch_add(1);
             if (blk >= n_blocks || bad) break;
-            const size_t c0 = blk * rows_per_block, c1 = std::min(U, c0 + rows_per_block);
+            const size_t c0 = col0 + blk * rows_per_block, c1 = std::min(col1, c0 + rows_per_block);
             char *p = buf.data();
             for (size_t col = c0; col < c1; col++) {
                 decode_kmer(kmers + col * (size_t)m->words, m->words, m->k, p);
@@ -3702,7 +3707,16 @@ extern "C" int grm_write_tsv(grm_matrix *m, const char *const *genome_ids, const
     for (unsigned t = 0; t < nt; t++) th.emplace_back(work);
     for (auto &t : th) t.join();
     if (close(fd) != 0) bad = 1;
-    if (bad) { remove(tmp.c_str()); return fail(c, GRM_ERR_IO, "write to %s failed", tmp.c_str()); }
-    if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return fail(c, GRM_ERR_IO, "rename to %s failed", path); }
+    if (bad) { if (whole) remove(tmp.c_str()); return fail(c, GRM_ERR_IO, "write to %s failed", tmp.c_str()); }
+    if (whole && rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return fail(c, GRM_ERR_IO, "rename to %s failed", path); }
     return GRM_OK;
+}
+
+extern "C" int grm_write_tsv(grm_matrix *m, const char *const *genome_ids, const char *path)
+{
+    return write_tsv_rows(m, genome_ids, path, 0, (size_t)-1, true);
+}
+extern "C" int grm_write_tsv_slice(grm_matrix *m, const char *const *genome_ids, const char *path, uint64_t first_kmer, uint64_t n_kmers)
+{
+    return write_tsv_rows(m, genome_ids, path, (size_t)first_kmer, (size_t)(first_kmer + n_kmers), false);
 }

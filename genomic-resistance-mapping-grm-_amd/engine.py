@@ -575,6 +575,13 @@ class HostMatrix(Matrix):
         if rc:
             raise GrmError(rc, self._err())
 
+    def write_tsv_slice(self, genome_ids, path, first_kmer, n_kmers):
+        """rows [first_kmer, first_kmer + n_kmers) in place (one of several writers of the file)"""
+        arr = (C.c_char_p * max(1, len(genome_ids)))(*[g.encode() for g in genome_ids])
+        rc = self.ctx.L.grm_write_tsv_slice(self.h, arr, path.encode(), int(first_kmer), int(n_kmers))
+        if rc:
+            raise GrmError(rc, self._err())
+
     def write_kover_h5(self, path, gzip_level=4, chunk_cols=100000):
         rc = self.ctx.L.grm_write_kover_h5(self.h, path.encode(), gzip_level, chunk_cols)
         if rc:

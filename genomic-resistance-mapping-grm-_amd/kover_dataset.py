@@ -296,12 +296,10 @@ def matrix_of_files(ctx, files_per_genome, kmer_size, abundance_min, filter_sing
     return m
 
 
-def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton, phenotype_description,
-                 phenotype_metadata_path, gzip, progress=None, abundance_min=1, source_type="contigs"):
-    """create.py:278-396 with the two tool calls replaced by one fused engine pass."""
-    _say = progress or (lambda m: None)
-    _t0 = time.time()
-    progress = lambda m: _say("[%6.2fs] %s" % (time.time() - _t0, m))
+def plan_dataset(contig_list_path, phenotype_description, phenotype_metadata_path, warn=None):
+    """what create.py:278-336 settles before the tools run: genome ids in ROW ORDER (argsorted by label when a phenotype is
+    given, create.py:334-336), labels, tags, classification type, and every genome's files (from-reads: the directory's
+    .fastq / .fastq.gz, create.py:402,484-487).  Deterministic: every rank of a multi-GPU run computes the same plan."""
     if (phenotype_description is None) != (phenotype_metadata_path is None):
         raise KoverError("If a phenotype is specified, it must have a description and a metadata file.")
     paths, order = parse_genome_list(contig_list_path)
@@ -311,12 +309,8 @@ def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton
     labels = tags = ctype = None
     ids = order
     if phenotype_description is not None:
-        ids, labels, tags, ctype = parse_metadata(phenotype_metadata_path, list(paths.keys()), warn=progress)
+        ids, labels, tags, ctype = parse_metadata(phenotype_metadata_path, list(paths.keys()), warn=warn)
         ids, labels = label_sorted(ids, labels)
-    tmp = output_path + ".tmp"
-    write_header(tmp, source_type, contig_list_path, phenotype_description, phenotype_metadata_path, gzip,
-                 ids, labels, tags, ctype, "singleton" if filter_singleton else "nothing")
-    progress("multidsk+dsk2kover (gfx950): %d genomes, k=%d" % (len(ids), kmer_size))
     files_per_genome = []
     for gid in ids:
         p = paths[gid]
@@ -325,6 +319,20 @@ def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton
         else:
             fl = [p]
         files_per_genome.append(fl)
+    return ids, labels, tags, ctype, files_per_genome
+
+
+def from_contigs(ctx, contig_list_path, output_path, kmer_size, filter_singleton, phenotype_description,
+                 phenotype_metadata_path, gzip, progress=None, abundance_min=1, source_type="contigs"):
+    """create.py:278-396 with the two tool calls replaced by one fused engine pass."""
+    _say = progress or (lambda m: None)
+    _t0 = time.time()
+    progress = lambda m: _say("[%6.2fs] %s" % (time.time() - _t0, m))
+    ids, labels, tags, ctype, files_per_genome = plan_dataset(contig_list_path, phenotype_description, phenotype_metadata_path, warn=progress)
+    tmp = output_path + ".tmp"
+    write_header(tmp, source_type, contig_list_path, phenotype_description, phenotype_metadata_path, gzip,
+                 ids, labels, tags, ctype, "singleton" if filter_singleton else "nothing")
+    progress("multidsk+dsk2kover (gfx950): %d genomes, k=%d" % (len(ids), kmer_size))
     m = matrix_of_files(ctx, files_per_genome, kmer_size, abundance_min, bool(filter_singleton), progress)
     progress("dictionary: %d k-mers; writing HDF5 (gzip %d)" % (m.n_kmers, gzip))
     m.write_kover_h5(tmp, gzip, BLOCK_SIZE)

@@ -142,6 +142,10 @@ void            grm_matrix_free(grm_matrix *);
 
 /* Ray-Surveyor-compatible TSV (layout read by dataset/create.py:121-137,241) */
 int  grm_write_tsv(grm_matrix *, const char *const *genome_ids, const char *path);
+/* rows [first_kmer, first_kmer + n_kmers) of the same file (a TSV row = one k-mer), written in place at their final offsets --
+ * every row has the same byte length (create.py:130-137) -- and the header when first_kmer == 0.  The file is opened without
+ * truncation and not renamed: several writers (the ranks Ray runs as under mpiexec, src/app.py:1310) fill one file. */
+int  grm_write_tsv_slice(grm_matrix *, const char *const *genome_ids, const char *path, uint64_t first_kmer, uint64_t n_kmers);
 /* appends kmer_sequences / kmer_matrix / kmer_by_matrix_column to the EXISTING Kover HDF5
  * exactly as dsk2kover does (schema dataset/create.py:214-238); libhdf5 is dlopen()ed. */
 int  grm_write_kover_h5(grm_matrix *, const char *existing_h5_path, int gzip_level, int chunk_cols);

@@ -165,3 +165,160 @@ def test_two_rank_gloo_matches_single_process_oracle(n_genomes, filt, k):
     want = orc.build_matrix(_genomes(n_genomes), k, 1, filt)
     assert kmers.shape == want["kmers"].shape and (kmers == want["kmers"]).all()
     assert rows.shape == want["matrix"].shape and (rows == want["matrix"]).all()
+
+
+# ---- the sharded spans of multi_gpu.py (N GPUs behind the command surface) on CPU: ranks over gloo, oracle-backed engine ----
+class StandInMatrix(FakeMatrix):
+    """what multi_gpu needs of engine.Matrix, on the host: the chunk streams come from zlib here (on the device: grm_deflate.hip),
+    the append goes through the library's own grm_write_kover_h5_parts on a host-only matrix"""
+
+    def __init__(self, kmers, data, n_genomes, k):
+        super().__init__(kmers, data)
+        self.n_genomes, self.k = n_genomes, k
+
+    @property
+    def n_kmers(self):
+        return self._k.shape[0]
+
+    def deflate_rows(self, chunk_cols):
+        import zlib
+        E = import_module(PKG + ".engine")
+        U = self.n_kmers
+        cw = min(U, chunk_cols) if U else 1
+        blobs = []
+        for r in range(self._d.shape[0]):
+            for c0 in range(0, U, cw):
+                raw = np.zeros(cw, np.uint64)
+                part = self._d[r, c0:c0 + cw]
+                raw[: part.shape[0]] = part
+                blobs.append(zlib.compress(raw.tobytes(), 4))
+        lens = np.array([len(b) for b in blobs], dtype=np.uint32)
+        starts = np.concatenate(([0], np.cumsum((lens.astype(np.uint64) + 15) // 16 * 16)))[:-1].astype(np.uint64)
+        buf = np.zeros(int(starts[-1] + lens[-1]) if len(blobs) else 0, np.uint8)
+        for s_, b in zip(starts, blobs):
+            buf[int(s_): int(s_) + len(b)] = np.frombuffer(b, np.uint8)
+        return E.ChunkStreams(buf, starts, lens)
+
+    def write_kover_h5_parts(self, path, parts, n_rows_total, gzip_level=4, chunk_cols=100000):
+        import grm_amd
+        hm = grm_amd.HostMatrix(self._k, self._d, self.n_genomes, self.k)
+        try:
+            grm_amd.Matrix.write_kover_h5_parts(hm, path, parts, n_rows_total, gzip_level, chunk_cols)
+        finally:
+            hm.free()
+
+
+class FileOracleBatch(OracleBatch):
+    def __init__(self, n):
+        super().__init__([[] for _ in range(n)])
+
+    def add_file(self, j, path):
+        self.genomes[j].append(open(path, "rb").read())
+
+    def upload(self):
+        pass
+
+    def free(self):
+        pass
+
+    def partition(self, k, abundance_min):
+        self.k = k
+        super().partition(k, abundance_min)
+
+    def fill(self):
+        m = super().fill()
+        return StandInMatrix(m.kmers(), m.data(), len(self.genomes), self.k)
+
+
+class StandInContext:
+    def batch(self, n):
+        return FileOracleBatch(n)
+
+
+def _sharded_worker(rank, world, port, d, k, filt, what):
+    import torch.distributed as dist
+    import grm_amd  # noqa: F401
+    mg = import_module(PKG + ".multi_gpu")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    R = mg.Ranks(rank, world, None, owns_group=True)
+    try:
+        if what == "kover":
+            mg.from_contigs_sharded(StandInContext(), R, os.path.join(d, "paths.tsv"), os.path.join(d, "sharded.kover"), k, filt, "pheno",
+                                    os.path.join(d, "md.tsv"), 4)
+        else:
+            samples = [l.split() for l in open(os.path.join(d, "paths.tsv"))]
+            mg.tsv_sharded(StandInContext(), R, [(a, b) for a, b in samples], k, os.path.join(d, "sharded.tsv"))
+    finally:
+        R.close()
+
+
+def _run_ranks(world, target, args):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=target, args=(r, world, port) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+
+
+@pytest.fixture(scope="module")
+def genome_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("sharded")
+    gs = _genomes(130)
+    with open(d / "paths.tsv", "w") as f:
+        for g, bufs in enumerate(gs):
+            p = d / ("g%03d.fna" % g)
+            p.write_bytes(bufs[0])
+            f.write("g%03d\t%s\n" % (g, p))
+    with open(d / "md.tsv", "w") as f:
+        for g in range(130):
+            f.write("g%03d\t%d\n" % (g, (g * 7) % 3 == 0))
+    return str(d), gs
+
+
+@pytest.mark.parametrize("world,filt", [(2, True), (4, False)])
+def test_kover_file_from_sharded_ranks(genome_files, world, filt):
+    """world 4: 130 genomes fill three blocks of 64 -- the fourth rank holds nothing and only keeps the collective calendar"""
+    import grm_amd  # noqa: F401
+    kd = import_module(PKG + ".kover_dataset")
+    d, gs = genome_files
+    out = os.path.join(d, "sharded.kover")
+    if os.path.exists(out):
+        os.remove(out)
+    _run_ranks(world, _sharded_worker, (d, 15, filt, "kover"))
+    r = kd.KoverDatasetReader(out)
+    ids = r.genome_identifiers
+    labels = [(int(g[1:]) * 7) % 3 == 0 for g in ids]
+    assert labels == sorted(labels) and sorted(ids) == ["g%03d" % g for g in range(130)]          # rows label-sorted (create.py:334-336)
+    want = orc.build_matrix([gs[int(g[1:])] for g in ids], 15, 1, filt)
+    assert r.kmer_sequences == orc.decode_kmers(want["kmers"], 15)
+    assert (r.kmer_matrix == want["matrix"]).all()
+    assert not [f for f in os.listdir(d) if f.endswith(".chunks") or f.endswith(".tmp")]           # spool files and temp output are gone
+
+
+def test_tsv_from_sharded_ranks(genome_files):
+    import grm_amd
+    d, gs = genome_files
+    _run_ranks(3, _sharded_worker, (d, 15, False, "tsv"))
+    want = orc.build_matrix(gs, 15, 1, False)
+    hm = grm_amd.HostMatrix(want["kmers"][:, 0], want["matrix"], 130, 15)
+    ref = os.path.join(d, "single.tsv")
+    hm.write_tsv(["g%03d" % g for g in range(130)], ref)
+    hm.free()
+    assert open(os.path.join(d, "sharded.tsv"), "rb").read() == open(ref, "rb").read()
+
+
+def test_rank_planning():
+    import grm_amd  # noqa: F401
+    mg = import_module(PKG + ".multi_gpu")
+    assert mg.ranks_worth_starting(10, 4) == 1 and mg.ranks_worth_starting(130, 4) == 3 and mg.ranks_worth_starting(1000, 8) == 8
+    assert mg.ranks_worth_starting(64, 2) == 1 and mg.ranks_worth_starting(65, 2) == 2
+    assert mg.shardable([["/dev/null"]] * 200, 2, 31, 1) is None
+    assert "k = 64" in mg.shardable([["/dev/null"]] * 200, 2, 65, 1)
+    assert mg.shardable([["/dev/null"]] * 200, 2, 47, 2) is not None

@@ -60,7 +60,20 @@ def test_close_frees_live_children_first():
         with grm_amd.Context(0) as ctx:
             b = filled(ctx)
             m = b.run(31, 1, True)
-        assert b.h is None and m.h is None                      # Context.close() freed them
+        assert b._h is None and m._h is None                    # Context.close() freed them
+        for dead in (b, m):                                     # ... and a freed handle says so instead of handing NULL to the C ABI
+            try:
+                dead.h
+            except grm_amd.GrmError as e:
+                assert e.code == -7
+            else:
+                raise SystemExit("a freed handle gave out a pointer")
+        try:
+            m.kmers()
+        except grm_amd.GrmError:
+            pass
+        else:
+            raise SystemExit("an accessor of a freed Matrix returned")
         del b, m
         print("ok")
     """)

@@ -1,0 +1,144 @@
+"""GPU: N ranks behind the command surface (multi_gpu.py) on a one-GPU box -- the ranks share cuda:0, the collective runs over
+gloo with host staging (the rehearsal of the RCCL path: same calls, same payloads).  What is compared: the file a run over
+several ranks leaves against the one-rank file of the same command."""
+import os
+import shutil
+import subprocess
+import sys
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_ctypes as orc
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "genomic-resistance-mapping-grm-_amd"
+CLI = os.path.join(ROOT, PKG, "cli")
+
+
+def _run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(args, capture_output=True, text=True, env=e, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-4000:] + r.stdout[-2000:]
+    return r
+
+
+@pytest.fixture(scope="module")
+def strains(tmp_path_factory):
+    """150 small related genomes (two contigs each): three blocks of 64"""
+    d = tmp_path_factory.mktemp("strains")
+    rng = np.random.RandomState(21)
+    core = cases.rand_seq(rng, 6000)
+    paths = []
+    for g in range(150):
+        s = list(core)
+        for p in rng.randint(0, len(core), size=12):
+            s[p] = "ACGT"[rng.randint(4)]
+        recs = [("c1", "".join(s[:3500])), ("c2", "".join(s[3500:]) + cases.rand_seq(rng, 120))]
+        path = str(d / ("s%03d.fna" % g))
+        open(path, "w").write(cases.fasta(recs, width=80))
+        paths.append(path)
+    with open(d / "paths.tsv", "w") as f:
+        f.writelines("s%03d\t%s\n" % (g, p) for g, p in enumerate(paths))
+    with open(d / "md.tsv", "w") as f:
+        f.writelines("s%03d\t%d\n" % (g, (g * 5) % 7 < 3) for g in range(150))
+    return str(d), paths
+
+
+def _datasets(path):
+    kd = import_module(PKG + ".kover_dataset")
+    r = kd.KoverDatasetReader(path)
+    return r.genome_identifiers, r.kmer_sequences, r.kmer_matrix, r.kmer_by_matrix_column
+
+
+@pytest.mark.parametrize("k,devices,singletons", [(31, "0,0", False), (31, "0,0,0,0", True), (63, "0,0,0", False)])
+def test_kover_create_over_ranks_equals_one_rank(strains, tmp_path, k, devices, singletons):
+    """`kover dataset create from-contigs` with GRM_DEVICES: a parent that touches no GPU, one child per device, each child reads its
+    own files, one dictionary exchange, every rank deflates the chunks of its own word-rows, rank 0 appends.  "0,0,0,0": 150
+    genomes fill three blocks -- three ranks are started, not four."""
+    import grm_amd  # noqa: F401
+    d, paths = strains
+    base = [sys.executable, os.path.join(CLI, "kover"), "dataset", "create", "from-contigs", "--genomic-data", os.path.join(d, "paths.tsv"),
+            "--phenotype-description", "resistant", "--phenotype-metadata", os.path.join(d, "md.tsv"), "--kmer-size", str(k), "--compression", "4",
+            "-x"] + (["--singleton-kmers"] if singletons else [])
+    one, many = str(tmp_path / "one.kover"), str(tmp_path / "many.kover")
+    _run(base + ["--output", one])
+    r = _run(base + ["--output", many, "--temp-dir", str(tmp_path)], env={"GRM_DEVICES": devices})
+    assert "x %d)" % min(3, len(devices.split(","))) in r.stdout, r.stdout
+    a, b = _datasets(one), _datasets(many)
+    assert a[0] == b[0] and a[1] == b[1] and (a[2] == b[2]).all() and (a[3] == b[3]).all()
+    assert os.path.getsize(one) == os.path.getsize(many)               # the same streams chunk for chunk (both files carry a uuid and a time stamp)
+    assert not [f for f in os.listdir(str(tmp_path)) if f.endswith((".chunks", ".tmp"))]
+    # and both are what the CPU restatement says
+    ids = a[0]
+    want = orc.build_matrix([[open(paths[int(g[1:])], "rb").read()] for g in ids], k, 1, not singletons)
+    assert a[1] == orc.decode_kmers(want["kmers"], k) and (a[2] == want["matrix"]).all()
+
+
+def _conf(tmp_path, paths, k):
+    conf = str(tmp_path / "survey.conf")
+    outdir = str(tmp_path / "survey.res")
+    with open(conf, "w") as f:      # src/app.py:3820-3833
+        f.write("-k %d\n-run-surveyor\n-output %s\n-write-kmer-matrix\n" % (k, outdir))
+        for p in paths:
+            f.write("-read-sample-assembly %s %s\n" % (os.path.basename(p)[:-4], p))
+    return conf, os.path.join(outdir, "Surveyor", "KmerMatrix.tsv")
+
+
+def test_ray_as_four_mpi_ranks(strains, tmp_path):
+    """`mpiexec -n 4 Ray survey.conf` (src/app.py:1310): the four copies find rank and size in the environment; 150 samples fill
+    three blocks, so ranks 0..2 form the group (gloo: they share the one device) and rank 3 leaves at once.  Every working rank
+    writes its slice of the k-mers into the one TSV."""
+    d, paths = strains
+    single = tmp_path / "single"
+    single.mkdir()
+    conf1, tsv1 = _conf(single, paths, 21)
+    _run([sys.executable, os.path.join(CLI, "Ray"), conf1])
+    ranked = tmp_path / "ranked"
+    ranked.mkdir()
+    conf4, tsv4 = _conf(ranked, paths, 21)
+    procs = [subprocess.Popen([sys.executable, os.path.join(CLI, "Ray"), conf4], env=dict(os.environ, PMI_RANK=str(r), PMI_SIZE="4"),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(4)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    assert "x 3)" in outs[0][0]
+    assert open(tsv4, "rb").read() == open(tsv1, "rb").read()
+    left = os.listdir(os.path.dirname(tsv4))
+    assert left == ["KmerMatrix.tsv"], left
+    mpiexec = shutil.which("mpiexec") or ("/opt/conda/bin/mpiexec" if os.path.exists("/opt/conda/bin/mpiexec") else None)
+    if mpiexec:
+        real = tmp_path / "real"
+        real.mkdir()
+        confm, tsvm = _conf(real, paths, 21)
+        _run([mpiexec, "-n", "4", sys.executable, os.path.join(CLI, "Ray"), confm])
+        assert open(tsvm, "rb").read() == open(tsv1, "rb").read()
+
+
+def test_multidsk_over_ranks_then_dsk2kover(strains, tmp_path):
+    """the pair as Kover drives it (kmer_count.py:28-37, kmer_pack.py:28-36), multidsk split over two ranks"""
+    import grm_amd  # noqa: F401
+    kd = import_module(PKG + ".kover_dataset")
+    d, paths = strains
+    paths = paths[:100]
+    tmp = str(tmp_path)
+    lst = os.path.join(tmp, "list_contigs_files")
+    open(lst, "w").writelines(p + "\n" for p in paths)
+    _run([sys.executable, os.path.join(CLI, "multidsk"), "-file", lst, "-out-dir", tmp, "-kmer-size", "31", "-abundance-min", "1", "-out-compress", "4",
+          "-nb-cores", "0", "-out-tmp", tmp, "-verbose", "0", "-progress", "True"], env={"GRM_DEVICES": "0,0"})
+    h5s = [os.path.join(tmp, os.path.basename(os.path.splitext(p + "\n")[0]) + ".h5") for p in paths]   # create.py:375
+    assert all(os.path.exists(p) for p in h5s)
+    ids = ["s%03d" % g for g in range(100)]
+    out = os.path.join(tmp, "d.kover")
+    kd.write_header(out, "contigs", lst, None, None, 4, ids, None, None, None, "singleton")
+    lh5 = os.path.join(tmp, "list_h5")
+    open(lh5, "w").writelines(p + "\n" for p in h5s)
+    _run([sys.executable, os.path.join(CLI, "dsk2kover"), "-file", lh5, "-out", out, "-filter", "singleton", "-kmer-length", "31", "-compression", "4",
+          "-chunk-size", "100000", "-nb-genomes", "100", "-verbose", "True"])
+    want = orc.build_matrix([[open(p, "rb").read()] for p in paths], 31, 1, True)
+    r = kd.KoverDatasetReader(out)
+    assert r.kmer_sequences == orc.decode_kmers(want["kmers"], 31) and (r.kmer_matrix == want["matrix"]).all()
