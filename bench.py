@@ -369,7 +369,7 @@ def rank_budget_leg(ctx, synth, Dm, args, n_ranks, device):
                 ctx.timing_reset()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            n_cols = b.set_global_dict_gathered(payload.data_ptr(), n_max, n_locals, bbs, filt)
+            n_cols = b.set_global_dict_gathered(payload.data_ptr(), n_max, n_locals, bbs, filt, my_rank=r)
             t1 = time.perf_counter()
             m = b.fill()
             torch.cuda.synchronize()

@@ -858,6 +858,8 @@ struct grm_batch {
     int filter_singleton = 0;
     // scratch that survives between steps (grow-only)
     DevBuf t_flag, t_ord_off;
+    DevBuf t_track, t_union_col;   // rank union with tracking: union entry of every position of the exported list; column of every union entry
+    bool exported_ordered = false; // t_ord_off describes the list grm_batch_export_dict_ordered wrote for the current local dictionary
     DevBuf t_u_off, t_u_len, t_u_foff, t_u_keys, t_u_flags, t_u_wg_base, t_u_wg_cnt;     // union of gathered rank dictionaries
     int sb_union_hint = 0;
     DevBuf t_sk, t_sf, t_keep, t_pos, t_tmp, t_bid, t_col, t_bid_sorted;
@@ -1812,6 +1814,7 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
     if (b->k > 32) return wide_stage_n_local(b, n_local);
     HIPCHK(c, hipSetDevice(c->device));
     b->have_local = b->have_global = false;
+    b->exported_ordered = false;
     b->have_bits = false;
     b->dict_launches = 0;
     const uint32_t G = (uint32_t)b->n_genomes;
@@ -1980,22 +1983,22 @@ static int dict_from_entries(grm_batch *b, const uint64_t *keys, const uint8_t *
     return GRM_OK;
 }
 
-// one GPU, the dictionary is the batch's own local one: its entries are distinct already, so they are sorted together
-// with their entry index and every entry's column falls out of the select step (no search afterwards)
-static int dict_from_own_entries(grm_batch *b, int filter_singleton)
+// DISTINCT entries (one GPU: the batch's own local dictionary; several ranks: their union out of the LDS tables): they are
+// sorted together with their entry index and every entry's column falls out of the select step -- col_of_entry[i] = column
+// of entry i, 0xffffffff when filtered out -- no search afterwards
+static int dict_from_distinct_entries(grm_batch *b, const uint64_t *keys, const uint8_t *flags, uint64_t n, int filter_singleton, uint32_t *col_of_entry)
 {
     grm_ctx *c = b->ctx;
     hipStream_t s = c->stream;
-    const uint64_t n = b->n_local;
     b->n_dict = 0;
     if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "dictionary of %llu k-mers exceeds 2^32-1 columns", (unsigned long long)n);
+    if (!n) return b->d_dict.ensure(16) == hipSuccess ? GRM_OK : fail(c, GRM_ERR_OOM, "alloc");
     DevBuf &d_sk = b->t_sk, &d_keep = b->t_keep, &d_pos = b->t_pos, &d_tmp = b->t_tmp, &d_i0 = b->t_bid, &d_i1 = b->t_col;
     HIPCHK(c, d_sk.ensure(n * 8));
     HIPCHK(c, d_keep.ensure((n + 1) * 4));
     HIPCHK(c, d_pos.ensure((n + 1) * 8));
     HIPCHK(c, d_i0.ensure(n * 4));
     HIPCHK(c, d_i1.ensure(n * 4));
-    HIPCHK(c, b->d_entry_col.ensure((n + 1) * 4));
     for (int attempt = 0; attempt < 2; attempt++) {
         // key-range sort (grm_dictsort.hip); the general radix sort when asked for, or when a key range did not fit LDS
         const bool by_ranges = attempt == 0 && c->opt_dict_sort_prim <= 0;
@@ -2005,16 +2008,16 @@ static int dict_from_own_entries(grm_batch *b, int filter_singleton)
         HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 4, s));
         if (by_ranges) {
             HIPCHK(c, d_tmp.ensure(dict_sort_scratch_bytes(n)));
-            HIPCHK(c, launch_dict_sort(s, b->d_local_keys.as<uint64_t>(), n, 2 * b->k, d_sk.as<uint64_t>(), d_i1.as<uint32_t>(), d_tmp.p, b->t_flag.as<int>()));
+            HIPCHK(c, launch_dict_sort(s, keys, n, 2 * b->k, d_sk.as<uint64_t>(), d_i1.as<uint32_t>(), d_tmp.p, b->t_flag.as<int>()));
         } else {
             launch_iota_u32(s, d_i0.as<uint32_t>(), n);
             size_t tmp_bytes = 0;
-            HIPCHK(c, sort_pairs_u64_u32(s, b->d_local_keys.as<uint64_t>(), d_sk.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, nullptr, tmp_bytes));
+            HIPCHK(c, sort_pairs_u64_u32(s, keys, d_sk.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, nullptr, tmp_bytes));
             HIPCHK(c, d_tmp.ensure(tmp_bytes));
-            HIPCHK(c, sort_pairs_u64_u32(s, b->d_local_keys.as<uint64_t>(), d_sk.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, d_tmp.p, tmp_bytes));
+            HIPCHK(c, sort_pairs_u64_u32(s, keys, d_sk.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, d_tmp.p, tmp_bytes));
         }
         HIPCHK(c, hipMemsetAsync(d_keep.as<uint32_t>() + n, 0, 4, s));
-        launch_dict_mark_idx(s, b->d_local_flags.as<uint8_t>(), d_i1.as<uint32_t>(), n, filter_singleton, d_keep.as<uint32_t>());
+        launch_dict_mark_idx(s, flags, d_i1.as<uint32_t>(), n, filter_singleton, d_keep.as<uint32_t>());
         size_t tmp2 = 0;
         HIPCHK(c, exclusive_scan_u32_u64(s, d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), n + 1, nullptr, tmp2));
         // (the scan's scratch must not be the sort's: d_tmp may be re-allocated here only after the sort has run -- same stream, in order)
@@ -2027,12 +2030,20 @@ static int dict_from_own_entries(grm_batch *b, int filter_singleton)
         if (by_ranges && too_big) continue;          // (keys crowding under one prefix: a degenerate input)
         HIPCHK(c, b->d_dict.ensure((b->n_dict + 2) * 8));
         launch_dict_select_idx(s, d_sk.as<uint64_t>(), d_keep.as<uint32_t>(), d_pos.as<uint64_t>(), d_i1.as<uint32_t>(), n, b->d_dict.as<uint64_t>(),
-                               b->d_entry_col.as<uint32_t>());
+                               col_of_entry);
         break;
     }
     HIPCHK(c, hipGetLastError());
-    b->entry_cols_ready = true;
     return GRM_OK;
+}
+
+static int dict_from_own_entries(grm_batch *b, int filter_singleton)
+{
+    HIPCHK(b->ctx, b->d_entry_col.ensure((b->n_local + 1) * 4));
+    int rc = dict_from_distinct_entries(b, b->d_local_keys.as<uint64_t>(), b->d_local_flags.as<uint8_t>(), b->n_local, filter_singleton,
+                                        b->d_entry_col.as<uint32_t>());
+    if (rc == GRM_OK) b->entry_cols_ready = true;
+    return rc;
 }
 
 // the batch's own structures against b->d_dict: columns of its entries (fused form) or the bucketised dictionary
@@ -2134,6 +2145,7 @@ extern "C" int grm_batch_export_dict_ordered(grm_batch *b, void *dev_record, uin
                                (uint32_t *)(rec + boff_off));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
+    b->exported_ordered = true;          // t_ord_off describes the list just written (tracked through the union by set_global_dict_gathered_from)
     return GRM_OK;
 }
 
@@ -2141,8 +2153,20 @@ extern "C" int grm_batch_export_dict_ordered(grm_batch *b, void *dev_record, uin
 // counts / bucket_bits: host arrays, one entry per rank.  When every rank used the same bucket geometry the gathered
 // lists are first united bucket by bucket in LDS tables (the ranks of a pan-genome hold nearly the same k-mers, so
 // what has to be sorted shrinks from the sum of the rank dictionaries to their union); otherwise they are sorted as a whole.
+static int set_global_dict_gathered(grm_batch *b, const void *dev_payload, int n_ranks, int my_rank, uint64_t n_max, const uint64_t *counts,
+                                    const int *bucket_bits, int filter_singleton, uint64_t *n_kmers);
 extern "C" int grm_batch_set_global_dict_gathered(grm_batch *b, const void *dev_payload, int n_ranks, uint64_t n_max,
                                                   const uint64_t *counts, const int *bucket_bits, int filter_singleton, uint64_t *n_kmers)
+{
+    return set_global_dict_gathered(b, dev_payload, n_ranks, -1, n_max, counts, bucket_bits, filter_singleton, n_kmers);
+}
+extern "C" int grm_batch_set_global_dict_gathered_from(grm_batch *b, const void *dev_payload, int n_ranks, int my_rank, uint64_t n_max,
+                                                       const uint64_t *counts, const int *bucket_bits, int filter_singleton, uint64_t *n_kmers)
+{
+    return set_global_dict_gathered(b, dev_payload, n_ranks, my_rank, n_max, counts, bucket_bits, filter_singleton, n_kmers);
+}
+static int set_global_dict_gathered(grm_batch *b, const void *dev_payload, int n_ranks, int my_rank, uint64_t n_max, const uint64_t *counts,
+                                    const int *bucket_bits, int filter_singleton, uint64_t *n_kmers)
 {
     if (!b || n_ranks < 1 || !counts || !bucket_bits) return GRM_ERR_ARG;
     grm_ctx *c = b->ctx;
@@ -2185,6 +2209,17 @@ extern "C" int grm_batch_set_global_dict_gathered(grm_batch *b, const void *dev_
         a.n_genomes = (uint32_t)n_ranks; a.bb = bb_min; a.cap_log2 = b->cap_log2;
         a.in_flags = payload; a.in_flag_off = b->t_u_foff.as<uint64_t>();
         const DictOut out = {&b->t_u_keys, &b->t_u_flags, &b->t_u_wg_base, &b->t_u_wg_cnt};
+        // The calling rank's own list inside the payload is TRACKED through the union when the caller says which one it is (and it is
+        // the list this batch exported): every local entry then learns its union entry in the union kernel and its column from the
+        // union's sort -- no search of the dictionary afterwards.
+        const bool track = my_rank >= 0 && my_rank < n_ranks && b->have_local && b->have_bits && b->total_keys && b->exported_ordered &&
+                           counts[my_rank] == b->n_local && (bucket_bits[my_rank] & 0xff) == b->bb && b->n_local;
+        if (track) {
+            HIPCHK(c, b->t_track.ensure((b->n_local + 1) * 4));
+            a.track = b->t_track.as<uint32_t>();
+            a.track_g = (uint32_t)my_rank;
+            a.track_flag_base = (uint64_t)my_rank * stride + flags_off;
+        }
         int sb = 0;
         uint64_t n_union = 0;
         bool bits = false;
@@ -2195,8 +2230,18 @@ extern "C" int grm_batch_set_global_dict_gathered(grm_batch *b, const void *dev_
             b->filter_singleton = filter_singleton;
             b->own_dict = false;
             b->entry_cols_ready = false;
-            rc = dict_from_entries(b, b->t_u_keys.as<uint64_t>(), b->t_u_flags.as<uint8_t>(), n_union, filter_singleton);
+            // the union's entries are distinct: sorted with their index, each learns its column in the select step
+            HIPCHK(c, b->t_union_col.ensure((n_union + 1) * 4));
+            rc = dict_from_distinct_entries(b, b->t_u_keys.as<uint64_t>(), b->t_u_flags.as<uint8_t>(), n_union, filter_singleton, b->t_union_col.as<uint32_t>());
             if (rc) return rc;
+            if (track) {
+                HIPCHK(c, b->d_entry_col.ensure((b->n_local + 1) * 4));
+                TimeScope t(c, "dict_entry_cols", b->n_local);
+                launch_entry_cols_from_union(s, b->d_wg_base.as<uint64_t>(), b->d_wg_cnt.as<uint32_t>(), b->t_ord_off.as<uint64_t>(), 1u << (b->bb + b->sb_dict),
+                                             b->t_track.as<uint32_t>(), b->t_union_col.as<uint32_t>(), b->d_entry_col.as<uint32_t>());
+                HIPCHK(c, hipGetLastError());
+                b->entry_cols_ready = true;
+            }
             return dict_attach(b, n_kmers);
         }
         if (rc != GRM_ERR_OVERFLOW) return rc;         // a union too large for the tables: sort everything instead

@@ -182,6 +182,12 @@ struct DictArgs {
     // rank) is marked as carried by several although only one rank holds it.  nullptr otherwise.
     const uint8_t *in_flags;
     const uint64_t *in_flag_off;
+    // rank union, optional: the calling rank's own list is "tracked" -- track[p] = index of the union entry (in out_keys) that
+    // holds the key at position p of rank track_g's list (p = in_flag_off[segment] - track_flag_base + i), so that the rank's
+    // local entries find their columns through the union's sort instead of a search.  nullptr: not wanted
+    uint32_t *track;
+    uint32_t track_g;
+    uint64_t track_flag_base;
 };
 void launch_dict_build(hipStream_t s, const DictArgs &a);
 // record memo of dict_build's record form: 13/32 * 2^memo_log2 records; LDS bytes: 72 per record (the record, the 24 table slots of
@@ -208,6 +214,8 @@ void launch_union_segments(hipStream_t s, const uint8_t *payload, uint32_t n_ran
 // (prefix_first: scratch of 2^22 + 2 uint32)
 void launch_dict_entry_cols(hipStream_t s, const uint64_t *dict, uint64_t n_dict, const uint64_t *entry_keys, uint64_t n_entries, int k,
                             uint32_t *prefix_first, uint32_t *entry_col);
+void launch_entry_cols_from_union(hipStream_t s, const uint64_t *wg_base, const uint32_t *wg_cnt, const uint64_t *ord_off, uint32_t n_wg,
+                                  const uint32_t *track, const uint32_t *union_col, uint32_t *entry_col);
 // matrix[r][entry_col[e]] = presence word of entry e in row r.  entry_major: scratch of n_cols * n_rows words for
 // the two-step form (zeroed by the caller where a column may have no local entry); nullptr: direct scattered form
 void launch_matrix_permute(hipStream_t s, const uint64_t *matrix_s, const uint16_t *birth, const uint64_t *wg_base,

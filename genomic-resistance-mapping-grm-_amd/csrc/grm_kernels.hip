@@ -2058,15 +2058,18 @@ struct DictWave {
     uint16_t *birth;
     uint32_t *need;
     uint16_t *sid;          // table slot of entry id (record form with the memo: the word-row's end goes by id); nullptr: not kept
+    uint32_t *track;        // rank union: table slot of every key of the tracked rank's list, by list position (DictArgs::track); nullptr: none
 };
 
 // J keys per lane (EMPTY_KEY = none) against the table: the table is consulted four keys at a time (the 16-byte reads
 // of more keys than that at once cost more registers than the LDS latency they would hide).
 // several (FLAGS): bit j = key j is carried by several genomes inside its rank
 // LIVE: the caller says which of the J keys exist (bit j of `live`) instead of marking the others with EMPTY_KEY
+// tpos (FLAGS, rank union): list position of key 0 of a lane of the TRACKED rank (key j: tpos + 64 j), 0xffffffff otherwise -- the
+// slot every such key ends in is noted, so that the rank's entries learn their union entry without a search afterwards
 template <int J, bool FLAGS, bool LIVE = false>
 __device__ __forceinline__ void dict_probe(const DictWave &w, const uint64_t (&kv)[J], uint32_t several, uint32_t g, uint32_t r,
-                                           unsigned long long bit, uint32_t live = 0)
+                                           unsigned long long bit, uint32_t live = 0, uint32_t tpos = 0xffffffffu)
 {
     uint32_t sl[J];
     uint32_t todo = 0;
@@ -2097,6 +2100,7 @@ __device__ __forceinline__ void dict_probe(const DictWave &w, const uint64_t (&k
             if (h3) at = (sl[j0 + q] + 3) & w.cap_mask;
             const bool done = h0 | h1 | h2 | h3;
             if (active && done) atomicOr(&w.words[at], (FLAGS && ((several >> (j0 + q)) & 1u)) ? (bit | 1ull) : bit);
+            if (FLAGS && active && done && tpos != 0xffffffffu) w.track[tpos + 64u * (uint32_t)(j0 + q)] = at;
             todo |= (uint32_t)(active && !done) << (j0 + q);
         }
     }
@@ -2119,6 +2123,7 @@ __device__ __forceinline__ void dict_probe(const DictWave &w, const uint64_t (&k
                 over = id >= w.max_fill;
             }
             atomicOr(&w.words[slot], (FLAGS && ((several >> j) & 1u)) ? (bit | 1ull) : bit);
+            if (FLAGS && tpos != 0xffffffffu) w.track[tpos + 64u * (uint32_t)j] = slot;
         }
         if (over) {
             w.full.set(1);       // (what the workgroup would have needed is counted after the word-row loop: dict_build_kernel)
@@ -2130,7 +2135,7 @@ __device__ __forceinline__ void dict_probe(const DictWave &w, const uint64_t (&k
 // J x 64 keys of one genome's segment: keys[i0 + 64 j] for j < J (i0 includes the lane), n = segment length
 template <int J, bool FLAGS>
 __device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__restrict__ keys, const uint8_t *__restrict__ flg, uint64_t i0,
-                                           uint64_t n, uint32_t g, uint32_t r, unsigned long long bit)
+                                           uint64_t n, uint32_t g, uint32_t r, unsigned long long bit, uint32_t tpos = 0xffffffffu)
 {
     uint64_t kv[J];
     uint32_t several = 0;
@@ -2141,7 +2146,7 @@ __device__ __forceinline__ void dict_chunk(const DictWave &w, const uint64_t *__
         if (FLAGS && i < n && flg[i] >= 2) several |= 1u << j;
     }
     // all J global loads are in flight
-    dict_probe<J, FLAGS>(w, kv, several, g, r, bit);
+    dict_probe<J, FLAGS>(w, kv, several, g, r, bit, 0u, tpos == 0xffffffffu ? tpos : tpos + (uint32_t)i0);
 }
 
 // ---- record memo (record form) --------------------------------------------------------------------------------------
@@ -2377,6 +2382,7 @@ __global__ __launch_bounds__(MAXT, 4) void dict_build_kernel(const DictArgs a)
     w.tkeys = tkeys; w.words = words; w.meta = meta; w.full = full; w.n_distinct = &n_distinct;
     w.cap_mask = cap_mask; w.max_fill = cap - (cap >> 3); w.cap_log2 = a.cap_log2;
     w.wg = wg; w.sub = wg & ((1u << sb) - 1); w.G = G; w.bb = a.bb; w.sb = sb; w.birth = a.birth; w.need = a.need; w.sid = nullptr;
+    w.track = FLAGS ? a.track : nullptr;
     // segment of the NEXT genome is fetched while the current one is processed (the two dependent
     // global round trips -- bounds, then keys -- would otherwise serialise per genome).  Wave w takes
     // genomes w, w + nw, ...: since nw divides 64 that sequence walks the word-rows in step with the
@@ -2547,14 +2553,16 @@ __global__ __launch_bounds__(MAXT, 4) void dict_build_kernel(const DictArgs a)
                     // wide: KIF keys per lane in flight, their hashes, two 16-byte table reads each; a key found there
                     // -- almost every key of a pan-genome after the first few genomes -- costs one more LDS OR.  The
                     // tail of the segment goes through a copy of the same code that is exactly as deep as it needs.
+                    // (rank union: the list position of this segment's first key when this is the tracked rank)
+                    const uint32_t tp = (FLAGS && a.track && g == a.track_g) ? (uint32_t)(f0 - a.track_flag_base) : 0xffffffffu;
                     uint64_t i0 = lane;
-                    for (; i0 + 64u * (KIF - 1) < n; i0 += 64 * KIF) dict_chunk<KIF, FLAGS>(w, seg, flg, i0, n, gr, r, bit);
+                    for (; i0 + 64u * (KIF - 1) < n; i0 += 64 * KIF) dict_chunk<KIF, FLAGS>(w, seg, flg, i0, n, gr, r, bit, tp);
                     if (i0 - lane < n && !full) {
                         const uint32_t nj = (uint32_t)((n - (i0 - lane) + 63) >> 6);        // wave-uniform: 1 .. KIF - 1
-                        if (KIF > 4 && nj > 4) dict_chunk<(KIF > 4 ? KIF : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
-                        else if (KIF > 2 && nj > 2) dict_chunk<(KIF > 2 ? 4 : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
-                        else if (KIF > 1 && nj == 2) dict_chunk<(KIF > 1 ? 2 : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit);
-                        else dict_chunk<1, FLAGS>(w, seg, flg, i0, n, gr, r, bit);
+                        if (KIF > 4 && nj > 4) dict_chunk<(KIF > 4 ? KIF : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit, tp);
+                        else if (KIF > 2 && nj > 2) dict_chunk<(KIF > 2 ? 4 : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit, tp);
+                        else if (KIF > 1 && nj == 2) dict_chunk<(KIF > 1 ? 2 : 1), FLAGS>(w, seg, flg, i0, n, gr, r, bit, tp);
+                        else dict_chunk<1, FLAGS>(w, seg, flg, i0, n, gr, r, bit, tp);
                     }
                 }
                 s0 = s0_next;
@@ -2688,6 +2696,17 @@ __global__ __launch_bounds__(MAXT, 4) void dict_build_kernel(const DictArgs a)
         a.out_keys[base + (m & META_ID)] = key;
         a.out_flags[base + (m & META_ID)] = (m & META_MULTI) ? 2 : 1;
     }
+    if (FLAGS && a.track && a.track_g < G) {
+        // the tracked rank's keys of this bucket: slot noted while probing -> index of the union entry (the slots' ids are final now)
+        uint64_t ts = 0, tn = 0;
+        seg_bounds(a.seg, (uint64_t)a.track_g * B + b, ts, tn);
+        const uint32_t tp = (uint32_t)(a.in_flag_off[(uint64_t)a.track_g * B + b] - a.track_flag_base);
+        for (uint64_t i = threadIdx.x; i < tn; i += blockDim.x) {
+            if (sb && hash_sub(mix64(a.keys[ts + i]), a.bb, sb) != w.sub) continue;          // a sibling sub-bucket workgroup's key
+            const uint32_t slot = a.track[tp + i];
+            a.track[tp + i] = (uint32_t)(base + (meta[slot & cap_mask] & META_ID));
+        }
+    }
 }
 
 // local dictionary in bucket order (multi-GPU exchange): entries of workgroup wg -> [ord_off[wg], ord_off[wg + 1])
@@ -2731,6 +2750,19 @@ __global__ void union_segments_kernel(const uint8_t *__restrict__ payload, uint3
 // PB-bit key prefix (2^22 prefixes: ~2.5 entries each at 10 M columns) narrows the search to one or two steps.  The table is filled from
 // one sweep of the sorted dictionary (entry i opens every prefix between its predecessor's and its own) -- a binary search per prefix, as
 // before, was 2^20 x 23 dependent loads: most of the 0.53 ms this step took.
+// rank union with tracking: local entry (workgroup wg, id) stands at position ord_off[wg] + id of the rank's exported list;
+// track[] gives that position's union entry, union_col[] the union entry's column (0xffffffff: filtered out)
+__global__ void entry_cols_from_union_kernel(const uint64_t *__restrict__ wg_base, const uint32_t *__restrict__ wg_cnt, const uint64_t *__restrict__ ord_off,
+                                             uint32_t n_wg, const uint32_t *__restrict__ track, const uint32_t *__restrict__ union_col,
+                                             uint32_t *__restrict__ entry_col)
+{
+    for (uint32_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
+        const uint64_t base = wg_base[wg], o = ord_off[wg];
+        const uint32_t n = wg_cnt[wg];
+        for (uint32_t id = threadIdx.x; id < n; id += blockDim.x) entry_col[base + id] = union_col[track[o + id]];
+    }
+}
+
 __global__ void dict_prefix_index_kernel(const uint64_t *__restrict__ dict, uint64_t n_dict, int shift, uint32_t n_prefix,
                                          uint32_t *__restrict__ first)
 {
@@ -3364,6 +3396,14 @@ void launch_union_segments(hipStream_t s, const uint8_t *payload, uint32_t n_ran
     hipLaunchKernelGGL(union_segments_kernel, dim3(grid_for((uint64_t)n_ranks * n_buckets, 256)), dim3(256), 0, s, payload, n_ranks, stride,
                        flags_off, boff_off, n_buckets, shifts, off, len, flag_off);
 }
+void launch_entry_cols_from_union(hipStream_t s, const uint64_t *wg_base, const uint32_t *wg_cnt, const uint64_t *ord_off, uint32_t n_wg,
+                                  const uint32_t *track, const uint32_t *union_col, uint32_t *entry_col)
+{
+    if (!n_wg) return;
+    hipLaunchKernelGGL(entry_cols_from_union_kernel, dim3(n_wg < (1u << 16) ? n_wg : (1u << 16)), dim3(64), 0, s, wg_base, wg_cnt, ord_off, n_wg, track,
+                       union_col, entry_col);
+}
+
 void launch_dict_entry_cols(hipStream_t s, const uint64_t *dict, uint64_t n_dict, const uint64_t *entry_keys, uint64_t n_entries, int k,
                             uint32_t *prefix_first /* 2^22 + 2 entries */, uint32_t *entry_col)
 {

@@ -116,7 +116,7 @@ def sharded_step(batch, k, abundance_min, filter_singleton, device, group=None, 
         batch.set_global_dict(keys.data_ptr(), flags.data_ptr(), n_local, filter_singleton)
         return batch.fill()
     payload, n_max, counts, bbs = exchange_dict(batch, n_local, device, group, words, stats)
-    batch.set_global_dict_gathered(payload.data_ptr(), n_max, counts, bbs, filter_singleton)
+    batch.set_global_dict_gathered(payload.data_ptr(), n_max, counts, bbs, filter_singleton, my_rank=dist.get_rank(group))
     return batch.fill()
 
 

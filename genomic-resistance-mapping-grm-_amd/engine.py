@@ -486,13 +486,15 @@ class Batch(_Handle):
     def export_dict_ordered(self, dev_record_ptr, flags_off, boff_off):
         self.ctx._chk(self.ctx.L.grm_batch_export_dict_ordered(self.h, dev_record_ptr, flags_off, boff_off))
 
-    def set_global_dict_gathered(self, dev_payload_ptr, n_max, counts, bucket_bits, filter_singleton):
+    def set_global_dict_gathered(self, dev_payload_ptr, n_max, counts, bucket_bits, filter_singleton, my_rank=-1):
+        """my_rank: which record of the payload this batch wrote (export_dict_ordered) -- its entries then take their columns
+        from the union's sort; -1: unknown (they are searched in the finished dictionary)"""
         n = len(counts)
         cnt = (C.c_uint64 * n)(*[int(v) for v in counts])
         bbs = (C.c_int * n)(*[int(v) for v in bucket_bits])
         u = C.c_uint64()
-        self.ctx._chk(self.ctx.L.grm_batch_set_global_dict_gathered(self.h, dev_payload_ptr, n, n_max, cnt, bbs,
-                                                                    1 if filter_singleton else 0, C.byref(u)))
+        self.ctx._chk(self.ctx.L.grm_batch_set_global_dict_gathered_from(self.h, dev_payload_ptr, n, int(my_rank), n_max, cnt, bbs,
+                                                                         1 if filter_singleton else 0, C.byref(u)))
         return int(u.value)
 
     @property

@@ -208,6 +208,11 @@ int  grm_batch_bucket_bits(const grm_batch *);
 int  grm_batch_export_dict_ordered(grm_batch *, void *dev_record, uint64_t flags_off, uint64_t boff_off);
 int  grm_batch_set_global_dict_gathered(grm_batch *, const void *dev_payload, int n_ranks, uint64_t n_max, const uint64_t *counts,
                                         const int *bucket_bits, int filter_singleton, uint64_t *n_kmers);
+/* the same when the caller knows which record of the payload is this batch's own (my_rank: its index; the record must be the one
+ * grm_batch_export_dict_ordered wrote last): the union then notes, for every entry of that list, the union entry it fell into,
+ * and the batch's entries take their columns from the union's sort instead of searching the finished dictionary */
+int  grm_batch_set_global_dict_gathered_from(grm_batch *, const void *dev_payload, int n_ranks, int my_rank, uint64_t n_max,
+                                             const uint64_t *counts, const int *bucket_bits, int filter_singleton, uint64_t *n_kmers);
 /* Inputs larger than one device batch (thousands of genomes): two passes over chunks of genomes.
  * Pass 1, per chunk: upload, grm_batch_partition, grm_batch_local_dict, grm_dict_accum_add, free.
  * Pass 2, per chunk: upload, partition, local_dict, grm_batch_set_global_dict_accum, grm_batch_fill.

@@ -83,7 +83,7 @@ class OracleBatch:
         boff[0] = 0
         C.memmove(rec_ptr + boff_off, boff.ctypes.data, boff.nbytes)
 
-    def set_global_dict_gathered(self, payload_ptr, n_max, counts, bucket_bits, filter_singleton):
+    def set_global_dict_gathered(self, payload_ptr, n_max, counts, bucket_bits, filter_singleton, my_rank=-1):
         flags_off, _, stride = self.exchange_layout(n_max, self.w, max(bucket_bits))
         raw = np.ctypeslib.as_array(C.cast(payload_ptr, C.POINTER(C.c_uint8)), shape=(stride * len(counts),))
         keys = [raw[r * stride: r * stride + n * 8 * self.w].view(np.uint64).reshape(n, self.w) for r, n in enumerate(counts)]

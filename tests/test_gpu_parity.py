@@ -1195,14 +1195,16 @@ def test_counted_sets_through_both_dedup_forms(ctx, opts):
             ctx.set_option(name, -1)
 
 
+@pytest.mark.parametrize("tracked", [False, True])
 @pytest.mark.parametrize("opts", [{}, {"no_union": 1}, {"cap_log2": 8}])
 @pytest.mark.parametrize("k", [31, 47])
-def test_gathered_exchange_in_one_process(ctx, k, opts):
+def test_gathered_exchange_in_one_process(ctx, k, opts, tracked):
     """the exchange records of three "ranks" (three batches of one context) laid out as an all-gather would leave
     them; every batch builds the global dictionary from the payload (rank union in LDS tables, or the sort of
     everything with no_union / k > 32; cap_log2 8 forces the union through its sizing ladder) and fills its rows:
     stacked, they are the oracle's matrix.  One rank uses another bucket count in a second round: its finer or coarser
-    buckets nest in the others', the union runs over the coarsest."""
+    buckets nest in the others', the union runs over the coarsest.  tracked: every batch says which record of the payload is its
+    own, and its entries take their columns from the union's sort (the union notes where each of them fell) instead of a search."""
     import torch
     dev = torch.device("cuda", 0)
     pg = synth.PanGenome(genome_len=150_000, n_snps=1500, n_accessory=8, accessory_len=1500, seed=77, n_contigs=2)
@@ -1241,8 +1243,8 @@ def test_gathered_exchange_in_one_process(ctx, k, opts):
                 boff = payload[boff_off: boff_off + 4 * ((1 << (bbs[0] & 0xff)) + 1)].cpu().numpy().view(np.uint32)
                 assert boff[0] == 0 and boff[-1] == n_locals[0] and (np.diff(boff.astype(np.int64)) >= 0).all()
                 rows = []
-                for b in batches:
-                    u = b.set_global_dict_gathered(payload.data_ptr(), n_max, n_locals, bbs, filt)
+                for r, b in enumerate(batches):
+                    u = b.set_global_dict_gathered(payload.data_ptr(), n_max, n_locals, bbs, filt, my_rank=r if tracked else -1)
                     assert u == want["kmers"].shape[0]
                     m = b.fill()
                     assert (m.kmers().reshape(-1) == want["kmers"].reshape(-1)).all()
