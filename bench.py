@@ -79,10 +79,10 @@ def parse_args():
     ap.add_argument("--no-realistic", action="store_true", help="skip the realistic-assemblies leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the reads leg (BASELINE configs[3])")
     ap.add_argument("--no-c5", action="store_true", help="skip the k=63 leg (BASELINE configs[4])")
-    ap.add_argument("--rank-budget", type=int, default=0, metavar="N",
+    ap.add_argument("--rank-budget", type=int, default=8, metavar="N",
                     help="N=1 only: the headline set cut into the N shards of an N-GPU run (BASELINE configs[2]), every rank's pass timed in this "
                          "one process on this one GPU: partition + local dictionary per shard, the exchange records, the union of the N real "
-                         "payloads, the fill -- what a rank of the N-GPU run spends, without the wire")
+                         "payloads, the fill -- what a rank of the N-GPU run spends, without the wire (default 8; 0: skip)")
     ap.add_argument("--only", default=None, choices=["headline", "realistic", "c4", "c5", "random"],
                     help="run ONE leg (profiling); for any leg but the headline, the headline shrinks to 16 genomes")
     ap.add_argument("--cpu-genomes", type=int, default=-1,
@@ -204,14 +204,14 @@ def kernel_table(ctx, n_cols, n_rows, n_local):
     return kernels
 
 
-def roofline_of(kernels, traffic_of=None, occurrences=None, words=1):
+def roofline_of(kernels, traffic_of=None, occurrences=None, words=1, leg=None):
     dom = max((n for n in kernels if "algo_GBps" in kernels[n]), key=lambda n: kernels[n]["avg_ms"] * kernels[n]["launches"], default=None)
     if not dom:
         return None
     a = kernels[dom]["algo_GBps"]
     traffic = traffic_of(dom) if traffic_of else None
     r = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
-         "traffic": traffic, "traffic_source": "committed PMC passes of this workload (profiles/hbm_traffic.json)" if traffic else None,
+         "traffic": traffic, "traffic_source": "committed PMC passes of this workload (profiles/hbm_traffic.json; rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE)" if traffic else None,
          "avg_launch_ms": kernels[dom]["avg_ms"]}
     # SURVEY.md 8(d) prices the stages of a straightforward extract / sort / fill pipeline per k-mer occurrence (W = 8 B per word):
     # 1 + W extract, 4W partition + sort, 2W + 1/8 fill.  The record form reaches the k-mers through ~3 bytes per occurrence of run
@@ -223,10 +223,15 @@ def roofline_of(kernels, traffic_of=None, occurrences=None, words=1):
              "dict_build": ("fill: key + dictionary probe + output bit", 16.0 * words + 0.125)}.get(dom)
     if stage and occurrences:
         g = stage[1] * occurrences / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        r["survey_stage"] = {"stage": stage[0], "bytes_per_occurrence": stage[1], "achieved": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4)}
+        r["survey_stage"] = {"stage": stage[0], "bytes_per_occurrence": stage[1], "model_GBps_equivalent": round(g, 1),
+                             "times_peak": round(g / HBM_PEAK_GBS, 3),
+                             "what": "SURVEY 8(d)'s bytes for the stage this kernel stands for over the kernel's duration: NOT a roofline fraction (the "
+                                     "record form moves fewer bytes than the model; `frac` above is the fraction)"}
     if traffic:           # (the committed profile is of this very workload): what bounds the kernel, as read from that profile
         try:
             lj = json.load(open(os.path.join(ROOT, "profiles", "limits.json")))
+            if leg is not None:
+                lj = lj.get("legs", {}).get(leg, {})
             if dom in lj.get("limited_by", {}):
                 r["limited_by"] = {"text": lj["limited_by"][dom], "profile_commit": lj.get("commit"), "source": lj.get("source")}
         except (OSError, ValueError):
@@ -244,6 +249,18 @@ def committed_traffic(args, genomes):
     except (OSError, ValueError, KeyError):
         pass
     return None
+
+
+def leg_traffic(leg, args, genomes):
+    """the same for the other legs (profiles/hbm_traffic.json -> legs, scripts/pmc_hbm_leg.sh): only at the leg's committed size"""
+    full = {"c5": 500, "c4": 8, "random_acgt": 1000, "realistic": 1000}.get(leg)
+    if genomes != full or args.genome_len != 5_000_000 or args.opt:
+        return None
+    try:
+        lj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["legs"][leg]
+        return lambda name: lj["bytes_per_launch"].get(name)
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def make_batch(ctx, synth, mode, base, n, genome_len, keep=None):
@@ -388,13 +405,16 @@ def rank_budget_leg(ctx, synth, Dm, args, n_ranks, device):
     stages = ["partition", "local_dict", "export_record", "global_dict_from_payload", "fill"]
     per_rank = [round(sum(best[s][r] for s in stages), 3) for r in range(n_ranks)]
     gather_bytes = n_ranks * stride
-    # every rank receives (n_ranks - 1) records, each over its own xGMI link (all-pairs): one record at ~153 GB/s nominal per link
+    # every rank receives (n_ranks - 1) records, each over its own xGMI link (all-pairs): one record at the link's NOMINAL 153 GB/s is a
+    # LOWER bound of the exchange (all seven links delivering at once into one receiver, no latency, no size exchange) -- no measured
+    # single-node RCCL all-gather figure exists yet (no multi-GPU node was available in any round)
     wire_ms = stride / 153e9 * 1e3
     return {"ranks": n_ranks, "shards": [b - a for a, b in shards], "columns": int(n_cols),
             "stage_ms_slowest_rank": {s: round(max(best[s].values()), 3) for s in stages},
             "stage_ms_mean": {s: round(sum(best[s].values()) / n_ranks, 3) for s in stages},
             "rank_ms": max(per_rank), "rank_ms_all": per_rank,
-            "exchange": {"record_bytes": int(stride), "payload_bytes": int(gather_bytes), "wire_ms_at_153GBps_per_link": round(wire_ms, 3)},
+            "exchange": {"record_bytes": int(stride), "payload_bytes": int(gather_bytes), "wire_ms_lower_bound": round(wire_ms, 3),
+                         "wire_priced_as": "one record per link at the nominal 153 GB/s of an xGMI link, all seven links at once: a lower bound, not a measurement"},
             "kernels_of_rank0_ms": {k: round(v, 3) for k, v in per_kernel.items()},
             "what": "host wall clock around the engine's staged calls, one GPU, best of %d repetitions; the all-gather itself is not run "
                     "(one process): priced from the record size" % reps}
@@ -417,7 +437,8 @@ def realistic_leg(D, Dm, ctx, synth, args):
                         "per genome cut at its own places, shuffled, random strands), k=%d, %s" % (
                             args.genomes, args.genome_len, args.k, "singleton filter" if not args.keep_singletons else "singletons kept"),
             "ms_per_step": round(1000 * el / args.steps, 3), "kmers_per_s": round(occ * args.steps / el, 1), "bases_per_s": round(syms * args.steps / el, 1),
-            "columns": int(n_cols), "record_memo": memo, "roofline": roofline_of(kernels, occurrences=occ), "kernels": kernels}
+            "columns": int(n_cols), "record_memo": memo, "roofline": roofline_of(kernels, leg_traffic("realistic", args, args.genomes), occurrences=occ, leg="realistic"),
+            "kernels": kernels}
 
 
 def c5_leg(D, Dm, ctx, synth, args, orc):
@@ -436,7 +457,7 @@ def c5_leg(D, Dm, ctx, synth, args, orc):
     occ = b.n_occurrences
     out = {"workload": "%d x %d bp pan-genome (mode P), k=63, singletons kept" % (n, args.genome_len),
            "ms_per_step": round(1000 * el / args.steps, 3), "kmers_per_s": round(occ * args.steps / el, 1), "columns": int(n_cols),
-           "roofline": roofline_of(kernels, occurrences=occ, words=2), "kernels": kernels}
+           "roofline": roofline_of(kernels, leg_traffic("c5", args, n), occurrences=occ, words=2, leg="c5"), "kernels": kernels}
     m = b.run(63, 1, False)
     # one genome's columns against the CPU restatement: with the singletons kept, exactly its own k-mers carry its bit
     g = 3
@@ -522,7 +543,7 @@ def c4_leg(D, ctx, synth, args, orc):
     out = {"workload": "%d genomes x %d bp, %d bp reads at %dx with 0.5 %% substitution errors (%.1f GB of FASTQ resident), k=%d, abundance-min %d: "
                        "counting stage" % (n_g, args.genome_len, rl, cov, in_bytes / 1e9, k, amin),
            "ms_per_step": round(1000 * el / steps, 3), "kmers_per_s": round(occ * steps / el, 1), "bases_per_s": round(syms * steps / el, 1),
-           "roofline": roofline_of(kernels), "kernels": kernels}
+           "roofline": roofline_of(kernels, leg_traffic("c4", args, n_g), leg="c4"), "kernels": kernels}
     # genome 0: solid k-mers and their counts
     s0 = b.genome_set(0)
     gk, gc = s0.kmers()[:, 0], s0.counts().astype(np.int64)
@@ -742,6 +763,71 @@ def e2e_leg(ctx, synth, args, orc, n_genomes, cpu_genomes):
             shutil.rmtree(d, ignore_errors=True)
 
 
+def e2e_sharded_leg(D, ctx, synth, args, n_genomes):
+    """N > 1: the e2e span over the ranks (multi_gpu.from_contigs_sharded, what `GRM_DEVICES=... kover dataset create` runs): every rank
+    writes, reads and uploads the files of ITS word-row block, one dictionary all-gather, every rank deflates the chunks of its rows
+    on its device, rank 0 appends.  Wall clock between two barriers; a sample of the file against the CPU restatement."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from importlib import import_module
+    mg = import_module("genomic-resistance-mapping-grm-_amd.multi_gpu")
+    kd = import_module("genomic-resistance-mapping-grm-_amd.kover_dataset")
+    Dm = import_module("genomic-resistance-mapping-grm-_amd.distributed")
+    d = args.tmp or os.path.join(tempfile.gettempdir(), "grm_e2e_ranks_%s" % os.environ.get("MASTER_PORT", "0"))
+    os.makedirs(d, exist_ok=True)
+    pg = synth.PanGenome(genome_len=args.genome_len, seed=1234)
+    # rows stand in label order (create.py:334-336): labels g % 2 -> the even genomes first; every rank writes the files of its block
+    order = [g for g in range(n_genomes) if g % 2 == 0] + [g for g in range(n_genomes) if g % 2 == 1]
+    a, b = Dm.shard_genomes(n_genomes, D.world)[D.rank]
+    for g in order[a:b]:
+        pg.genome(g).tofile(os.path.join(d, "g%05d.fna" % g))
+    data, md = os.path.join(d, "paths.tsv"), os.path.join(d, "md.tsv")
+    if D.rank == 0:
+        open(data, "w").writelines("g%05d\t%s\n" % (g, os.path.join(d, "g%05d.fna" % g)) for g in range(n_genomes))
+        open(md, "w").writelines("g%05d\t%d\n" % (g, g % 2) for g in range(n_genomes))
+    R = mg.Ranks.from_initialized(D.local_rank)
+    kover = os.path.join(d, "DATASET.kover")
+    out = None
+    try:
+        D.sync()
+        t0 = time.perf_counter()
+        n_cols = mg.from_contigs_sharded(ctx, R, data, kover, args.k, not args.keep_singletons, "synthetic phenotype", md, args.gzip, spool_dir=d)
+        D.sync()
+        wall = D.max_f(time.perf_counter() - t0)
+        if D.rank == 0:
+            out = {"seconds": round(wall, 3), "genomes": n_genomes, "ranks": D.world, "columns": int(n_cols), "genomes_per_min": round(n_genomes / wall * 60, 1),
+                   "kover_bytes": os.path.getsize(kover), "gzip": args.gzip,
+                   "span": "FASTA files (page cache, every rank its own block) -> label-sorted header -> sharded engine pass with ONE dictionary "
+                           "all-gather -> per-rank device deflate of the rank's word-rows -> rank 0 appends kmer_sequences / kmer_matrix / "
+                           "kmer_by_matrix_column (dataset/create.py:311-390 over %d ranks)" % D.world}
+            # sample: two genomes' columns of the written file against the CPU restatement's k-mer sets of those genomes
+            from oracle import oracle_ctypes as orc
+            rd = kd.KoverDatasetReader(kover)
+            ids = rd.genome_identifiers
+            seqs = None
+            ok = ids == ["g%05d" % g for g in order]
+            mat = rd.kmer_matrix
+            for row in (0, n_genomes - 1):
+                g = order[row]
+                km, _, _ = orc.count_genome([pg.genome(g).tobytes()], args.k, 1)
+                mine = (mat[row // 64] >> np.uint64(63 - row % 64)) & np.uint64(1) == 1
+                if seqs is None:
+                    seqs = np.array(rd.kmer_sequences)
+                got = set(seqs[mine].tolist())
+                want = set(orc.decode_kmers(km, args.k))
+                # with the singleton filter the file holds the genome's k-mers that another genome carries too: a subset, and every
+                # column the genome is marked in must be one of its k-mers
+                ok = ok and got <= want and (args.keep_singletons and got == want or not args.keep_singletons and len(got) > 0.9 * len(want))
+            out["bit_exact_sample"] = bool(ok)
+            out["bit_exact_what"] = "row order = label order; the columns carrying the first and the last row's bit are k-mers of those genomes (CPU restatement)"
+    finally:
+        D.sync()
+        if not args.tmp and D.rank == 0:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -814,8 +900,19 @@ def main():
             # (1 + 7W bytes per occurrence): the record form moves fewer bytes than that model, so this can pass 1
             bpk = SURVEY_BYTES_PER_KMER[1 if args.k <= 32 else 2]
             gbps = occ_total * bpk * args.steps / elapsed / 1e9 / world
-            out["survey_model"] = {"bytes_per_kmer": bpk, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
-                                   "frac": round(gbps / HBM_PEAK_GBS, 4)}
+            out["survey_model"] = {"bytes_per_kmer": bpk, "model_GBps_equivalent": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                                   "times_peak": round(gbps / HBM_PEAK_GBS, 3),
+                                   "what": "SURVEY 8(d)'s 1 + 7W bytes per occurrence over the pass's duration: above 1 because this design moves ~11 B per "
+                                           "occurrence, not 57 -- NOT a roofline fraction (roofline.frac and pass_traffic are)"}
+            tj = committed_traffic(args, n_mine) if world == 1 and args.mode == "P" else None
+            if tj is not None:
+                try:
+                    total = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["sum_over_all_kernels_per_pass"]
+                    out["pass_traffic"] = {"bytes_per_pass": total, "achieved": round(total / (elapsed / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "what": "counter traffic of ALL kernels of a pass (committed PMC passes of this workload) over this run's ms per pass"}
+                except (OSError, ValueError, KeyError):
+                    pass
         if world > 1:
             out["collective"] = {"backend": D.backend, "world_size_seen": D.dist.get_world_size(),
                                  "allgather_calls": xfer["calls"] if xfer else 0,
@@ -833,9 +930,19 @@ def main():
                            "genomes_per_gpu": args.genomes, "genomes_total": args.genomes * world, "columns": int(w_cols)}
 
     solo = world == 1 and rank == 0 and args.stage == "matrix" and args.mode == "P"
-    if solo and args.rank_budget > 1:
-        out["rank_budget"] = rank_budget_leg(ctx, synth, Dm, args, args.rank_budget, D.device)
-        out["rank_budget"]["speedup_bound_vs_1gpu"] = round(out["ms_per_step"] / (out["rank_budget"]["rank_ms"] + out["rank_budget"]["exchange"]["wire_ms_at_153GBps_per_link"]), 2)
+    if solo and args.rank_budget > 1 and args.only in (None, "headline") and args.genomes >= 64 * args.rank_budget and args.k <= 64:
+        rb = rank_budget_leg(ctx, synth, Dm, args, args.rank_budget, D.device)
+        wire = rb["exchange"]["wire_ms_lower_bound"]
+        rb["speedup_bound_vs_1gpu"] = round(out["ms_per_step"] / (rb["rank_ms"] + wire), 2)
+        # Amdahl: what of a rank's pass does not shrink with its shard.  Every rank needs a column for each of its local entries and
+        # ranks of a pan-genome hold nearly all k-mers, so union + sort + fill (and the insertions of the local dictionary) are
+        # dictionary-sized on every rank; only parse / partition / the record look-ups are genome-sized.
+        u_sized = sum(rb["kernels_of_rank0_ms"].get(k, 0.0) for k in ("dict_union", "dict_sort", "dict_entry_cols", "matrix_fill"))
+        rb["dictionary_sized_kernels_ms"] = round(u_sized, 3)
+        rb["note"] = ("an upper bound of the N-GPU speed-up over this run's one-GPU pass: slowest rank's pass + the wire's lower bound; %.2f ms of the "
+                      "rank pass are dictionary-sized kernels every rank repeats (union, sort, columns, fill) -- with ONE all-gather every rank "
+                      "builds the whole dictionary, so that part does not shrink with the shard" % u_sized)
+        out["rank_budget"] = rb
     # ---- the same strains as real assemblies ----
     if solo and not args.no_realistic and args.only in (None, "realistic"):
         out["realistic"] = realistic_leg(D, Dm, ctx, synth, args)
@@ -875,7 +982,13 @@ def main():
                 "bases_per_s": round(r_syms * args.steps / r_el, 1), "kmers_per_s": round(r_occ * args.steps / r_el, 1),
                 "ms_per_step": round(1000 * r_el / args.steps, 3), "bit_exact_sample": r_ok,
                 "bit_exact_what": "counted sets (k-mers and counts) of the first and the last genome of rank 0 = the CPU restatement's",
-                "roofline": roofline_of(r_kernels), "kernels": r_kernels}
+                "roofline": roofline_of(r_kernels, leg_traffic("random_acgt", args, args.genomes) if world == 1 else None, leg="random_acgt"), "kernels": r_kernels}
+
+    # ---- end to end over the ranks (N > 1) ----
+    if world > 1 and args.stage == "matrix" and args.mode == "P" and not args.no_e2e and args.only in (None, "headline") and args.k <= 64:
+        e2e_n = e2e_sharded_leg(D, ctx, synth, args, args.genomes)
+        if rank == 0:
+            out["e2e"] = e2e_n
 
     # ---- end to end + CPU restatement (N = 1) ----
     if world == 1 and rank == 0 and args.stage == "matrix" and args.only in (None, "headline"):
@@ -898,7 +1011,7 @@ def main():
     if rank == 0:
         out.setdefault("cpu_baseline", None)
         # "bit-exact" is part of the metric: any leg that compared its result with the CPU restatement and found a difference fails the run
-        checks = {"e2e": (out.get("e2e") or {}).get("bit_exact"), "c5": (out.get("c5") or {}).get("bit_exact_sample"),
+        checks = {"e2e": (out.get("e2e") or {}).get("bit_exact", (out.get("e2e") or {}).get("bit_exact_sample")), "c5": (out.get("c5") or {}).get("bit_exact_sample"),
                   "c4": (out.get("c4") or {}).get("bit_exact_sample"), "random_acgt": (out.get("random_acgt") or {}).get("bit_exact_sample")}
         out["bit_exact"] = {k: v for k, v in checks.items() if v is not None}
         failed = any(v is False for v in checks.values())

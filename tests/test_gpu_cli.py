@@ -311,3 +311,15 @@ def test_bench_starts_its_ranks_itself():
     assert b["collective"]["world_size_seen"] == 2 and b["collective"]["allgather_calls"] >= 1
     for line in (a, b):
         assert line["roofline"] and line["unit"] == "k-mers/s" and line["value"] > 0
+
+
+def test_bench_two_ranks_end_to_end_leg():
+    """`bench.py --gpus 2` with its e2e leg: files -> .kover over the two ranks (multi_gpu.from_contigs_sharded: every rank reads its own
+    block, one dictionary exchange, per-rank device deflate, rank 0 appends), a sample of the file checked against the CPU restatement"""
+    import json
+    two = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genomes", "160", "--genome-len", "150000", "--steps", "1", "--warmup", "1",
+                "--no-random", "--no-weak", "--cpu-genomes", "0"], env={"GRM_BENCH_REHEARSAL": "1"})
+    line = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][0])
+    e = line["e2e"]
+    assert e["ranks"] == 2 and e["genomes"] == 160 and e["columns"] == line["config"]["columns"] > 0
+    assert e["bit_exact_sample"] is True and line["bit_exact"]["e2e"] is True
