@@ -83,6 +83,16 @@ struct grm_ctx {
 };
 static void ctx_release(grm_ctx *c);
 static inline void ctx_retain(grm_ctx *c) { c->refs.fetch_add(1, std::memory_order_relaxed); }
+// The contexts that exist.  The owner's pointer dangles once grm_destroy has been called AND the last handle is gone; the calls
+// that take a bare grm_ctx* from the owner (grm_destroy, grm_ctx_live_handles, grm_last_error) look it up here first, so that a
+// second grm_destroy or a late query is a no-op instead of a read of freed memory.
+static std::mutex g_ctx_mu;
+static std::vector<grm_ctx *> g_ctx_live;
+static bool ctx_is_live(const grm_ctx *c)
+{
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    return std::find(g_ctx_live.begin(), g_ctx_live.end(), c) != g_ctx_live.end();
+}
 // a handle's reference to its context (NULL for host-only objects)
 struct CtxRef {
     grm_ctx *p = nullptr;
@@ -250,12 +260,20 @@ extern "C" grm_ctx *grm_create(int device_ordinal, int n_streams)
         delete c;
         return nullptr;
     }
+    {
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        g_ctx_live.push_back(c);
+    }
     return c;
 }
 
 static void ctx_release(grm_ctx *c)
 {
     if (c->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+    {
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        g_ctx_live.erase(std::remove(g_ctx_live.begin(), g_ctx_live.end(), c), g_ctx_live.end());
+    }
     (void)hipSetDevice(c->device);
     for (auto &r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -266,15 +284,19 @@ static void ctx_release(grm_ctx *c)
 
 extern "C" void grm_destroy(grm_ctx *c)
 {
-    if (!c) return;
+    if (!c || !ctx_is_live(c)) return;             // (a second grm_destroy after the last handle went: the context no longer exists)
     if (c->owner_gone.exchange(true)) return;      // (a second grm_destroy while handles keep the context alive)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     ctx_release(c);
 }
-extern "C" int grm_ctx_live_handles(const grm_ctx *c) { return c ? c->refs.load() - (c->owner_gone.load() ? 0 : 1) : 0; }
+extern "C" int grm_ctx_live_handles(const grm_ctx *c) { return c && ctx_is_live(c) ? c->refs.load() - (c->owner_gone.load() ? 0 : 1) : 0; }
 
-extern "C" const char *grm_last_error(grm_ctx *c) { return c ? c->err.c_str() : "no context (no HIP device?)"; }
+extern "C" const char *grm_last_error(grm_ctx *c)
+{
+    if (!c) return "no context (no HIP device?)";
+    return ctx_is_live(c) ? c->err.c_str() : "the context no longer exists (grm_destroy, and its last handle was freed)";
+}
 
 extern "C" int grm_set_option(grm_ctx *c, const char *name, int value)
 {
@@ -1341,6 +1363,9 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
             HIPCHK(c, hipStreamSynchronize(s));
             if (l2_idx >= 0 && l2_idx < (int)c->recs.size()) c->recs[l2_idx].units = h.records;
             bool merged_parts = false;
+            // (record_merge adds a genome's k-mer occurrences per coarse bucket over all its parts in 32 bits and compares the sum with the
+            // key capacity kstride << pbits: beyond 2^32 - 1 the sum could wrap and pass the test -- such a read set takes the key form)
+            if (!h.over && counting && pbits > 0 && (kstride << pbits) >= (1ull << 32)) h.over = 1;
             if (!h.over && counting && pbits > 0) {
                 // genomes in parts: a genome's bucket is counted over its parts' record segments (the table must hold its DISTINCT k-mers:
                 // 2^12 slots first, 2^13 if those overflow, the key form after that)
@@ -3144,7 +3169,13 @@ static int wide_hash_global(grm_batch *b, const uint64_t *hi, const uint64_t *lo
             HIPCHK(c, hipMemcpyAsync(&too_big, W.flag.p, 4, hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
             if (!too_big) {
-                launch_wh_ties(s, W.t_b.as<uint64_t>(), W.idx2.as<uint32_t>(), lo, n);
+                // (W.flag is zero here; a tie group too long for the one-thread ordering raises it: the radix sort below then)
+                launch_wh_ties(s, W.t_b.as<uint64_t>(), W.idx2.as<uint32_t>(), lo, n, W.flag.as<int>());
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, hipMemcpyAsync(&too_big, W.flag.p, 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipStreamSynchronize(s));
+            }
+            if (!too_big) {
                 launch_gather_u64(s, hi, W.idx2.as<uint32_t>(), n, W.t_b.as<uint64_t>());
                 launch_gather_u64(s, lo, W.idx2.as<uint32_t>(), n, W.t_a.as<uint64_t>());     // sorted: hi = t_b, lo = t_a
                 HIPCHK(c, hipGetLastError());

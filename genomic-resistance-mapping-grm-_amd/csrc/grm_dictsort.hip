@@ -195,12 +195,10 @@ hipError_t launch_dict_sort(hipStream_t s, const uint64_t *keys, uint64_t n, int
     hipLaunchKernelGGL(ds_offsets_kernel, dim3((a.n_ranges + 63) / 64), dim3(64), 0, s, counts, a.n_chunks, a.n_ranges, total);
     hipLaunchKernelGGL(ds_starts_kernel, dim3(1), dim3(1024), 0, s, total, a.n_ranges, start, too_big);
     hipLaunchKernelGGL(ds_scatter_kernel, dim3(a.n_chunks), dim3(DS_THREADS), (size_t)a.n_ranges * 4, s, a, counts, start, okeys, oidx);
-    static bool attr_set = false;
+    static std::atomic<uint64_t> lds_set{0};
     const size_t lds = (size_t)DS_RANGE_CAP * 12 + ((size_t)2 << DS_SUB_BITS) * 4 + 16;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ds_sort_ranges_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    const hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void *>(ds_sort_ranges_kernel), (int)lds, lds_set);
+    if (ea != hipSuccess) return ea;
     const uint32_t grid = a.n_ranges < 2048u ? a.n_ranges : 2048u;
     hipLaunchKernelGGL(ds_sort_ranges_kernel, dim3(grid), dim3(DS_SORT_THREADS), lds, s, okeys, oidx, start, a.n_ranges, a.shift);
     return hipGetLastError();

@@ -3,7 +3,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace grm {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) holds per DEVICE: a kernel that asks for more than 64 KiB of dynamic LDS registers
+// itself once per device it is launched on (`done`: one bit per device ordinal, a function-local static of the launcher).  A failure
+// is returned; a launcher that cannot return it launches anyway and the launch itself fails loudly (hipGetLastError at the call site).
+inline hipError_t ensure_dynamic_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // ---- parse geometry ----
 constexpr int PARSE_THREADS = 256;
@@ -314,7 +331,8 @@ void launch_wh_l2(hipStream_t s, const KmerLaunch &L, const uint64_t *off, const
                   uint32_t fine_cap, const uint32_t *cursor1, uint32_t *len_out, int *overflow);
 // entries leave staged at wg * cap in entry-id order; presence words at matrix_s[wg][row][entry id] (nullptr: no bits)
 void launch_wh_top64(hipStream_t s, const uint64_t *hi, const uint64_t *lo, uint64_t n, int k, uint64_t *top);
-void launch_wh_ties(hipStream_t s, const uint64_t *top_sorted, uint32_t *order, const uint64_t *lo, uint64_t n);
+// *too_long (device, zeroed by the caller) = 1: a group of equal top words was longer than the kernel orders; the output is then NOT sorted
+void launch_wh_ties(hipStream_t s, const uint64_t *top_sorted, uint32_t *order, const uint64_t *lo, uint64_t n, int *too_long);
 void launch_wh_dict_build(hipStream_t s, const void *keys, const SegLayout &seg, uint32_t n_genomes, int bb, int sb, uint32_t cap_log2,
                           uint64_t *stage_lo, uint64_t *stage_hi, uint8_t *stage_flags, uint32_t *stage_cnt, uint64_t *matrix_s,
                           uint16_t *birth, int *overflow, uint32_t *need, int recs_k = 0, int part_bits = 0);

@@ -3323,13 +3323,10 @@ hipError_t launch_record_merge(hipStream_t s, const void *recs, uint32_t rstride
     if (!n_regions) return hipSuccess;
     const ulonglong2 *r = reinterpret_cast<const ulonglong2 *>(recs);
     const int b2 = bb - b1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(record_merge_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(record_merge_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_set12{0}, lds_set13{0};
+    hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void *>(record_merge_kernel<12>), 150 * 1024, lds_set12);
+    if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void *>(record_merge_kernel<13>), 150 * 1024, lds_set13);
+    if (ea != hipSuccess) return ea;
     const size_t lds = ((size_t)14 << (big_log2 >= 13 ? 13 : 12)) + 8 * 1360;
     const uint32_t grid = (uint32_t)(n_regions < 256u * 8u ? n_regions : 256u * 8u);
     if (big_log2 >= 13)

@@ -579,11 +579,8 @@ __global__ void minimizer_bucket_ids_kernel(const uint64_t *__restrict__ dict, u
 template <int W, bool WIDE = false>
 static void launch_sk1(hipStream_t s, const SkArgs &a, ulonglong2 *recs1, uint32_t rstride, uint32_t *rcount1, uint32_t *part_kmers, int *overflow)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(superkmer_l1_kernel<W, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_L1_LDS);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    (void)ensure_dynamic_lds(reinterpret_cast<const void *>(superkmer_l1_kernel<W, WIDE>), (int)SK_L1_LDS, lds_set);
     hipLaunchKernelGGL((superkmer_l1_kernel<W, WIDE>), dim3(a.n_genomes << a.part_bits), dim3(SK_THREADS), SK_L1_LDS, s, a, recs1, rstride, rcount1,
                        part_kmers, overflow);
 }
@@ -634,12 +631,8 @@ template <int MAXR>
 static void launch_l2r_staged(hipStream_t s, uint32_t grid, const ulonglong2 *r1, uint32_t rstride, const uint32_t *rcount1, uint64_t n_regions, int k,
                               int bb, int b1, ulonglong2 *r2, uint64_t *off, uint32_t *len, int *overflow)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(superkmer_l2_records_kernel<true, MAXR>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  96 * 1024);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    (void)ensure_dynamic_lds(reinterpret_cast<const void *>(superkmer_l2_records_kernel<true, MAXR>), 96 * 1024, lds_set);
     // the records and, beside them, their 16-bit ranks
     hipLaunchKernelGGL((superkmer_l2_records_kernel<true, MAXR>), dim3(grid), dim3(SK2R_THREADS), (size_t)rstride * 18, s, r1, rstride, rcount1,
                        n_regions, k, bb, b1, r2, off, len, overflow);
@@ -672,11 +665,8 @@ void launch_superkmer_l2_wide(hipStream_t s, const void *recs1, uint32_t rstride
     if (!n_regions) return;
     const uint32_t cap = rstride < (uint32_t)(SKW_THREADS * SKW_MAXR) ? rstride : (uint32_t)(SKW_THREADS * SKW_MAXR);
     const size_t lds = (size_t)cap * 24;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(superkmer_l2_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SKW_THREADS * SKW_MAXR * 24);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    (void)ensure_dynamic_lds(reinterpret_cast<const void *>(superkmer_l2_wide_kernel), SKW_THREADS * SKW_MAXR * 24, lds_set);
     const uint32_t grid = (uint32_t)(n_regions < 256u * 16u ? n_regions : 256u * 16u);
     hipLaunchKernelGGL(superkmer_l2_wide_kernel, dim3(grid), dim3(SKW_THREADS), lds, s, reinterpret_cast<const uint64_t *>(recs1), rstride, rcount1,
                        n_regions, k, bb, b1, reinterpret_cast<uint64_t *>(recs2), off, len_out, overflow);

@@ -926,13 +926,20 @@ __global__ void wide_top64_kernel(const uint64_t *__restrict__ hi, const uint64_
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         top[i] = up ? (hi[i] << up) | (lo[i] >> (64 - up)) : hi[i];
 }
-__global__ void wide_ties_kernel(const uint64_t *__restrict__ top_sorted, uint32_t *__restrict__ order, const uint64_t *__restrict__ lo, uint64_t n)
+// A group of entries that agree in their top 64 bits is put in order by ONE thread (an insertion sort through global memory): fine for
+// the pairs and triples a dictionary holds (the two alleles of a SNP in a k-mer's second half; one copy per rank in the multi-rank
+// merge), quadratic for long groups -- k = 64 repeats that share their first 32 bases, low-complexity flanks.  A group longer than
+// WIDE_TIE_MAX raises *too_long and is left alone: the host then takes the two-pass radix sort.
+constexpr uint32_t WIDE_TIE_MAX = 32;
+__global__ void wide_ties_kernel(const uint64_t *__restrict__ top_sorted, uint32_t *__restrict__ order, const uint64_t *__restrict__ lo, uint64_t n,
+                                 int *__restrict__ too_long)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t t = top_sorted[i];
         if ((i && top_sorted[i - 1] == t) || i + 1 >= n || top_sorted[i + 1] != t) continue;       // not the first of a group of two or more
         uint64_t e = i + 2;
-        while (e < n && top_sorted[e] == t) e++;
+        while (e < n && e - i <= WIDE_TIE_MAX && top_sorted[e] == t) e++;
+        if (e - i > WIDE_TIE_MAX) { atomicExch(too_long, 1); continue; }
         for (uint64_t a = i + 1; a < e; a++) {           // insertion sort of the group's indices by the low word
             const uint32_t ia = order[a];
             const uint64_t la = lo[ia];
@@ -948,11 +955,11 @@ void launch_wh_top64(hipStream_t s, const uint64_t *hi, const uint64_t *lo, uint
     const uint64_t g = (n + 255) / 256;
     hipLaunchKernelGGL(wide_top64_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, hi, lo, n, k, top);
 }
-void launch_wh_ties(hipStream_t s, const uint64_t *top_sorted, uint32_t *order, const uint64_t *lo, uint64_t n)
+void launch_wh_ties(hipStream_t s, const uint64_t *top_sorted, uint32_t *order, const uint64_t *lo, uint64_t n, int *too_long)
 {
     if (!n) return;
     const uint64_t g = (n + 255) / 256;
-    hipLaunchKernelGGL(wide_ties_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, top_sorted, order, lo, n);
+    hipLaunchKernelGGL(wide_ties_kernel, dim3((uint32_t)(g > 8192 ? 8192 : g)), dim3(256), 0, s, top_sorted, order, lo, n, too_long);
 }
 void launch_wh_mark(hipStream_t s, const uint64_t *s_hi, const uint64_t *s_lo, const uint8_t *flags, const uint32_t *order, uint64_t n,
                     int filter_singleton, uint32_t *keep)

@@ -25,6 +25,8 @@
  *   - lifetime: every handle made from a context (grm_batch, grm_matrix, grm_kmer_set, grm_dict_accum) holds a
  *     reference to it.  grm_destroy drops the owner's reference; the device streams are released when the last
  *     handle has been freed, so handles may be freed after grm_destroy (a caller that unwinds on an error does).
+ *     After grm_destroy the grm_ctx pointer is the owner's no longer: do not pass it to anything but grm_destroy,
+ *     grm_ctx_live_handles and grm_last_error, which recognise a context that has ceased to exist (no-op / 0 / a fixed text).
  *   - plain pointers and sizes only: no Python / torch types cross this boundary.
  *     Arguments named dev_* are HIP device pointers on the ctx's device.
  */

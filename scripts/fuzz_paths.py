@@ -13,12 +13,17 @@ import grm_amd                                          # noqa: E402
 from oracle import oracle_ctypes as orc                 # noqa: E402
 
 synth = import_module("genomic-resistance-mapping-grm-_amd.synth")
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.RandomState(seed)
-t0 = time.time()
-n_cases = 0
-with grm_amd.Context(0) as ctx:
+
+
+class Mismatch(AssertionError):
+    pass
+
+
+def run(ctx, budget, seed, say=print):
+    """cases until `budget` seconds have passed; -> number of cases.  Raises Mismatch with the case's description."""
+    rng = np.random.RandomState(seed)
+    t0 = time.time()
+    n_cases = 0
     while time.time() - t0 < budget:
         k = int(rng.choice([19, 21, 25, 31, 32, 33, 34, 47, 63, 64]))
         n = int(rng.choice([1, 2, 3, 7, 40, 70, 129, 150]))
@@ -68,15 +73,29 @@ with grm_amd.Context(0) as ctx:
                     s.free()
             b.free()
             if not ok:
-                print("MISMATCH", desc, flush=True)
-                sys.exit(1)
+                raise Mismatch("result differs from the oracle: " + desc)
+        except Mismatch:
+            raise
         except Exception:
-            print("ERROR in case", desc, flush=True)
+            say("ERROR in case " + desc)
             raise
         finally:
             for name in opts:
                 ctx.set_option(name, -1)
         n_cases += 1
         if n_cases % 10 == 0:
-            print("%d cases ok (%.0f s) last: %s" % (n_cases, time.time() - t0, desc), flush=True)
-print("fuzz ok: %d cases in %.0f s (seed %d)" % (n_cases, time.time() - t0, seed))
+            say("%d cases ok (%.0f s) last: %s" % (n_cases, time.time() - t0, desc))
+    return n_cases
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    with grm_amd.Context(0) as ctx:
+        try:
+            n_cases = run(ctx, budget, seed, say=lambda m: print(m, flush=True))
+        except Mismatch as e:
+            print("MISMATCH", e, flush=True)
+            sys.exit(1)
+    print("fuzz ok: %d cases in %.0f s (seed %d)" % (n_cases, time.time() - t0, seed))

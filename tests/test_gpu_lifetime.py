@@ -103,3 +103,24 @@ def test_error_return_keeps_the_process_alive():
     """)
     assert rc == 1, (rc, err[-2000:])
     assert "GRM_ERR" in err and "terminate called" not in err
+
+
+def test_double_destroy_and_late_queries_are_harmless():
+    """after grm_destroy AND the last handle's free the context no longer exists: a second grm_destroy, grm_ctx_live_handles and
+    grm_last_error on the stale pointer recognise that instead of reading freed memory"""
+    rc, out, err = _child("""
+        ctx = grm_amd.Context(0)
+        b = filled(ctx)
+        h = ctx.h
+        ctx.L.grm_destroy(h)
+        ctx.L.grm_destroy(h)                                    # twice while a handle keeps it alive
+        assert ctx.L.grm_ctx_live_handles(h) == 1
+        b.free()                                                # the context goes with its last handle
+        ctx.L.grm_destroy(h)                                    # and once more: no-op
+        assert ctx.L.grm_ctx_live_handles(h) == 0
+        assert b"no longer exists" in ctx.L.grm_last_error(h)
+        ctx.h = None
+        print("ok")
+    """)
+    assert rc == 0, (rc, err[-2000:])
+    assert out.startswith("ok")

@@ -1324,3 +1324,24 @@ def test_three_and_four_word_kmers(ctx, k, tmp_path):
     assert r.kmer_sequences == strs and (r.kmer_matrix == want["matrix"]).all()
     for o in sets + sets2 + [m, m2]:
         o.free()
+
+
+def test_many_64mers_sharing_their_first_32_bases(ctx):
+    """two-word dictionaries are sorted by the top 64 bits first and ties are put in order by one thread per group: a group longer
+    than the kernel takes (repeats that share their first 32 bases at k = 64) must fall back to the radix sort, not crawl or misorder"""
+    rng = np.random.RandomState(64)
+    prefix = "A" * 20 + cases.rand_seq(rng, 12)
+    recs = [("c%d" % i, prefix + cases.rand_seq(rng, 32)) for i in range(150)]
+    recs += [("r%d" % i, cases.rand_seq(rng, 200)) for i in range(20)]
+    genomes = [[cases.fasta(recs[: 100 + 10 * g], width=70).encode()] for g in range(5)]
+    want = orc.build_matrix(genomes, 64, 1, False)
+    b = ctx.batch(len(genomes))
+    for g, files in enumerate(genomes):
+        b.add(g, files[0])
+    b.upload()
+    m = b.run(64, 1, False)
+    hi = m.kmers()[:, 0]
+    assert np.max(np.unique(hi, return_counts=True)[1]) > 32          # the case is what it claims to be
+    assert m.kmers().shape == want["kmers"].shape and (m.kmers() == want["kmers"]).all() and (m.data() == want["matrix"]).all()
+    m.free()
+    b.free()
