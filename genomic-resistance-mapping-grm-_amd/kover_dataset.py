@@ -289,7 +289,9 @@ def matrix_of_files(ctx, files_per_genome, kmer_size, abundance_min, filter_sing
         progress("%d genomes in %d chunks, two passes" % (len(files_per_genome), len(rows_chunks)))
         return two_pass_matrix(ctx, files_per_genome, rows_chunks, kmer_size, abundance_min, filter_singleton, progress)[0]
     # deep read sets: the reference's own two steps, multidsk then dsk2kover
+    progress("%d genomes (%.1f GB) in device batches of at most %.1f GB: counted sets, then their merge" % (len(files_per_genome), total / 1e9, DEFAULT_BATCH_BYTES / 1e9))
     sets = counted_sets(ctx, files_per_genome, kmer_size, abundance_min, DEFAULT_BATCH_BYTES, progress)
+    progress("all genomes counted; merging %d solid sets" % len(sets))
     m = ctx.build_matrix(sets, filter_singleton)
     for s_ in sets:
         s_.free()
