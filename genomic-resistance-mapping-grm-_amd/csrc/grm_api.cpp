@@ -18,7 +18,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -622,10 +625,56 @@ extern "C" int grm_matrix_risk_index(grm_matrix *m, const uint32_t *lut_presence
 }
 
 // The HDF5 chunks of kmer_matrix (what = 0: chunk_elems columns of one word-row each, row-major) or of kmer_sequences
-// (what = 1: chunk_elems strings each) as zlib streams made on the device (grm_deflate.hip).  Host result (malloc): the
-// streams at starts[i] (multiples of 16), lens[i] bytes each.  The chunks go through the device in slabs of a few GB.
+// (what = 1: chunk_elems strings each) as zlib streams made on the device (grm_deflate.hip).  The chunks go through the
+// device in slabs (a few GB of scratch at most; `max_slab` chunks when the caller wants them sooner than that).
+//   sink == nullptr: host result (malloc) = ALL streams at starts[i] (multiples of 16), lens[i] bytes each;
+//   sink != nullptr: every slab is handed over as soon as it has arrived on the host -- sink(user, first chunk, n, block, starts
+//     relative to the block, lens); the block (malloc) is the sink's to free.  The HDF5 writer appends slab k while slab k + 1
+//     is encoded and copied (grm_h5.cpp).
+// Two pinned buffers between the encoder and a sink that consumes on another thread: a piece (whole chunks, <= cap bytes) is copied
+// into a free buffer at PCIe speed (a pageable copy runs at a fifth of it and faults its pages in first), the sink gives the buffer
+// back with grm_internal_deflate_release when it has written the piece.
+struct DeflateRing {
+    unsigned char *buf[2] = {nullptr, nullptr};
+    size_t cap = 0;
+    bool busy[2] = {false, false};
+    std::mutex mu;
+    std::condition_variable cv;
+    int acquire()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return !busy[0] || !busy[1]; });
+        const int i = busy[0] ? 1 : 0;
+        busy[i] = true;
+        return i;
+    }
+    void release(int i)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        busy[i] = false;
+        cv.notify_all();
+    }
+    void wait_idle()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return !busy[0] && !busy[1]; });
+    }
+    ~DeflateRing()
+    {
+        for (auto *b : buf)
+            if (b) (void)hipHostFree(b);
+    }
+};
+extern "C" void grm_internal_deflate_release(void *ring, int slot)
+{
+    if (ring && slot >= 0) static_cast<DeflateRing *>(ring)->release(slot);
+}
+// sink: block holds the piece's streams at starts[i] (relative), lens[i]; slot >= 0: a buffer of `ring`, to be given back with
+// grm_internal_deflate_release(ring, slot) -- also when the sink fails or has lost interest; slot < 0: a malloc block, the sink's to free
+typedef int (*grm_deflate_sink)(void *user, uint64_t first_chunk, uint64_t n, unsigned char *block, const uint64_t *starts, const uint32_t *lens, void *ring,
+                                int slot);
 static int matrix_deflate_device(grm_matrix *m, int what, uint64_t chunk_elems, unsigned char **streams, uint64_t **starts_out, uint32_t **lens_out,
-                                 uint64_t *n_chunks_out)
+                                 uint64_t *n_chunks_out, grm_deflate_sink sink = nullptr, void *sink_user = nullptr, uint64_t max_slab = 0)
 {
     grm_ctx *c = m->ctx;
     if (!c) return GRM_ERR_NO_DEVICE;
@@ -637,25 +686,40 @@ static int matrix_deflate_device(grm_matrix *m, int what, uint64_t chunk_elems, 
     const uint64_t n_chunks = what == 0 ? per_row * R : per_row;
     const uint64_t raw = chunk_elems * (what == 0 ? 8ull : (uint64_t)m->k);
     if (raw >= ((uint64_t)1 << 32) - 4096) return fail(c, GRM_ERR_ARG, "deflate: a chunk of %llu bytes is beyond the encoder's 4 GiB", (unsigned long long)raw);
-    *streams = nullptr; *starts_out = nullptr; *lens_out = nullptr; *n_chunks_out = n_chunks;
+    if (streams) { *streams = nullptr; *starts_out = nullptr; *lens_out = nullptr; }
+    *n_chunks_out = n_chunks;
     if (!n_chunks) return GRM_OK;
     const uint64_t cap = deflate_chunk_cap(raw);
     const uint64_t per_chunk = cap + (what == 0 ? 2 * chunk_elems : 0);
-    const uint64_t slab = std::max<uint64_t>(1, std::min<uint64_t>(n_chunks, ((uint64_t)4 << 30) / per_chunk));
+    uint64_t slab = std::max<uint64_t>(1, std::min<uint64_t>(n_chunks, ((uint64_t)4 << 30) / per_chunk));
+    if (max_slab) slab = std::min(slab, max_slab);
     DevBuf d_out, d_tok, d_sizes, d_off, d_packed;
     HIPCHK(c, d_out.alloc(slab * cap));
     if (what == 0) HIPCHK(c, d_tok.alloc(slab * chunk_elems * 2));
     HIPCHK(c, d_sizes.alloc(slab * 4));
     HIPCHK(c, d_off.alloc((slab + 1) * 8));
-    uint64_t *starts = static_cast<uint64_t *>(malloc(n_chunks * 8));
-    uint32_t *lens = static_cast<uint32_t *>(malloc(n_chunks * 4));
+    uint64_t *starts = static_cast<uint64_t *>(malloc((sink ? slab : n_chunks) * 8));
+    uint32_t *lens = static_cast<uint32_t *>(malloc((sink ? slab : n_chunks) * 4));
     unsigned char *host = nullptr;
     uint64_t host_used = 0, host_cap = 0;
-    auto bail = [&](int rc) { free(starts); free(lens); free(host); return rc; };
+    DeflateRing ring;
+    // (sink mode: the ring's buffers die with this frame -- whatever the sink still holds must have come back first)
+    auto bail = [&](int rc) { if (sink) ring.wait_idle(); free(starts); free(lens); free(host); return rc; };
     if (!starts || !lens) return bail(fail(c, GRM_ERR_OOM, "deflate: host allocation failed"));
-    std::vector<uint64_t> off(slab + 1);
+    std::vector<uint64_t> off(slab + 2), rel(slab + 1);
+    if (sink) {
+        ring.cap = (size_t)64 << 20;
+        for (auto *&bp : ring.buf) {
+            const hipError_t e = hipHostMalloc((void **)&bp, ring.cap, hipHostMallocDefault);
+            if (e != hipSuccess) { bp = nullptr; return bail(fail(c, GRM_ERR_HIP, "deflate: pinned buffers: %s", hipGetErrorString(e))); }
+        }
+    }
+    const bool trace = getenv("GRM_TRACE") && atoi(getenv("GRM_TRACE")) > 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = now();
     for (uint64_t c0 = 0; c0 < n_chunks; c0 += slab) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(slab, n_chunks - c0);
+        uint32_t *ln = sink ? lens : lens + c0;
         hipError_t e;
         {
             TimeScope t(c, what == 0 ? "deflate_rows" : "deflate_kmer_strings", (uint64_t)n * raw);
@@ -664,16 +728,17 @@ static int matrix_deflate_device(grm_matrix *m, int what, uint64_t chunk_elems, 
                           : launch_deflate_kmer_strings(s, m->d_kmers.as<uint64_t>(), U, m->words, m->k, (uint32_t)chunk_elems, c0, n, d_out.as<uint8_t>(), cap,
                                                         d_sizes.as<uint32_t>());
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(lens + c0, d_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(ln, d_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "deflate on the device: %s", hipGetErrorString(e)));
+        if (trace) fprintf(stderr, "[deflate %s] %u chunks encoded               %8.1f ms\n", what == 0 ? "rows" : "strings", n, (now() - t_last) * 1e3), t_last = now();
         uint64_t total = 0;
         for (uint32_t i = 0; i < n; i++) {
-            if (lens[c0 + i] == 0 || lens[c0 + i] > cap) return bail(fail(c, GRM_ERR_STATE, "deflate: chunk %llu came back with %u bytes", (unsigned long long)(c0 + i), lens[c0 + i]));
+            if (ln[i] == 0 || ln[i] > cap) return bail(fail(c, GRM_ERR_STATE, "deflate: chunk %llu came back with %u bytes", (unsigned long long)(c0 + i), ln[i]));
             off[i] = total;
-            total += ((uint64_t)lens[c0 + i] + 15) & ~15ull;
+            total += ((uint64_t)ln[i] + 15) & ~15ull;
         }
-        if (host_used + total > host_cap) {
+        if (!sink && host_used + total > host_cap) {
             // first slab: the whole result at this slab's ratio; later: what is missing
             host_cap = host_used + std::max<uint64_t>(total, c0 == 0 ? total * ((n_chunks + n - 1) / n) + (total >> 4) : total * 2);
             unsigned char *p = static_cast<unsigned char *>(realloc(host, host_cap));
@@ -683,14 +748,50 @@ static int matrix_deflate_device(grm_matrix *m, int what, uint64_t chunk_elems, 
         if ((e = d_packed.ensure(total)) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "deflate: %s", hipGetErrorString(e)));
         e = hipMemcpyAsync(d_off.p, off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = launch_deflate_compact(s, d_out.as<uint8_t>(), cap, d_sizes.as<uint32_t>(), n, d_off.as<uint64_t>(), d_packed.as<uint8_t>());
+        if (sink) {
+            // pieces of whole chunks through the pinned ring (a chunk larger than a buffer: a malloc block of its own)
+            if (e != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "deflate: gathering the streams: %s", hipGetErrorString(e)));
+            off[n] = total;
+            for (uint32_t i0 = 0; i0 < n;) {
+                uint32_t i1 = i0 + 1;
+                while (i1 < n && off[i1 + 1] - off[i0] <= ring.cap) i1++;
+                const uint64_t bytes = off[i1] - off[i0];
+                int slot = -1;
+                unsigned char *block;
+                if (bytes <= ring.cap) { slot = ring.acquire(); block = ring.buf[slot]; }
+                else if (!(block = static_cast<unsigned char *>(malloc(bytes)))) return bail(fail(c, GRM_ERR_OOM, "deflate: host allocation failed"));
+                e = hipMemcpyAsync(block, d_packed.as<uint8_t>() + off[i0], bytes, hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipStreamSynchronize(s);
+                if (e != hipSuccess) {
+                    if (slot >= 0) ring.release(slot); else free(block);
+                    return bail(fail(c, GRM_ERR_HIP, "deflate: copying the streams: %s", hipGetErrorString(e)));
+                }
+                for (uint32_t i = i0; i < i1; i++) rel[i - i0] = off[i] - off[i0];
+                const int rc = sink(sink_user, c0 + i0, i1 - i0, block, rel.data(), ln + i0, &ring, slot);
+                if (rc != GRM_OK) return bail(rc);
+                i0 = i1;
+            }
+            if (trace) fprintf(stderr, "[deflate %s] %.1f MB handed to the writer                %6.1f ms\n", what == 0 ? "rows" : "strings", total / 1e6, (now() - t_last) * 1e3), t_last = now();
+            continue;
+        }
         if (e == hipSuccess) e = hipMemcpyAsync(host + host_used, d_packed.p, total, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "deflate: gathering the streams: %s", hipGetErrorString(e)));
+        if (trace) fprintf(stderr, "[deflate %s] %.1f MB gathered and copied to the host %6.1f ms\n", what == 0 ? "rows" : "strings", total / 1e6, (now() - t_last) * 1e3), t_last = now();
         for (uint32_t i = 0; i < n; i++) starts[c0 + i] = host_used + off[i];
         host_used += total;
     }
+    if (sink) ring.wait_idle();                 // (the ring's buffers die with this frame: the sink must be through with them)
+    if (sink) { free(starts); free(lens); return GRM_OK; }
     *streams = host; *starts_out = starts; *lens_out = lens;
     return GRM_OK;
+}
+// the slab-wise form for the HDF5 writer (grm_h5.cpp): what = 0 rows / 1 k-mer strings
+extern "C" int grm_internal_deflate_stream(grm_matrix *m, int what, uint64_t chunk_elems, uint64_t max_slab, grm_deflate_sink sink, void *user, uint64_t *n_chunks)
+{
+    if (!m || !sink || !n_chunks) return GRM_ERR_ARG;
+    const uint64_t ce = m->n_kmers ? std::min<uint64_t>(m->n_kmers, chunk_elems) : 1;
+    return matrix_deflate_device(m, what, ce, nullptr, nullptr, nullptr, n_chunks, sink, user, max_slab);
 }
 extern "C" int grm_matrix_deflate_rows(grm_matrix *m, int chunk_cols, unsigned char **streams, uint64_t **starts, uint32_t **lens, uint64_t *n_chunks)
 {
@@ -1023,7 +1124,9 @@ extern "C" int grm_batch_upload(grm_batch *b)
     // plain files by pread from the page cache) while the other is on its way over PCIe.
     {
         const uint64_t total = RAW_FRONT_PAD + pos + 64;
-        const uint64_t slab_want = c->opt_upload_slab_kb > 0 ? (uint64_t)c->opt_upload_slab_kb << 10 : (uint64_t)128 << 20;
+        // 32 MiB: a filler's piece of it (2 MiB at 16 threads) stays in its core's L2 between the newline fill and the read; measured
+        // at 1000 x 5.6 MB files: 0.165 s for 5.6 GB against 0.222 s with 128 MiB slabs (and 0.33 s with 8 MiB: too little work per hand-over)
+        const uint64_t slab_want = c->opt_upload_slab_kb > 0 ? (uint64_t)c->opt_upload_slab_kb << 10 : (uint64_t)32 << 20;
         const size_t slab_bytes = (size_t)std::min<uint64_t>(slab_want, total);
         uint8_t *pinned[2] = {nullptr, nullptr};
         hipEvent_t done[2] = {nullptr, nullptr};
@@ -1043,8 +1146,14 @@ extern "C" int grm_batch_upload(grm_batch *b)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
             if (e != hipSuccess) { cleanup(); return fail(c, GRM_ERR_HIP, "upload: pinned slab: %s", hipGetErrorString(e)); }
         }
+        // host threads that fill a slab (page cache -> pinned memory): GRM_UPLOAD_THREADS, else 16 (what a one-GPU share of a
+        // box gives; more only take turns there)
         const unsigned hw = std::thread::hardware_concurrency();
-        const int n_thr = (int)std::min<unsigned>(16u, std::max(1u, hw));
+        int n_thr = (int)std::min<unsigned>(16u, std::max(1u, hw));
+        if (const char *e = getenv("GRM_UPLOAD_THREADS")) {
+            const int v = atoi(e);
+            if (v > 0 && v <= 256) n_thr = v;
+        }
         // fills image bytes [a, b) (absolute image offsets) into dst (which maps offset a)
         auto fill_range = [&](uint8_t *dst, uint64_t a, uint64_t bnd) {
             memset(dst, '\n', (size_t)(bnd - a));
@@ -1087,6 +1196,55 @@ extern "C" int grm_batch_upload(grm_batch *b)
                 }
             }
         };
+        // the fillers live for the whole upload (a slab is a few milliseconds of work: starting threads per slab cost a fifth of it)
+        struct FillPool {
+            std::vector<std::thread> th;
+            std::mutex mu;
+            std::condition_variable go, done;
+            uint64_t gen = 0;
+            int pending = 0;
+            bool stop = false;
+            std::function<void(int)> job;
+            explicit FillPool(int n)
+            {
+                for (int t = 0; t < n; t++)
+                    th.emplace_back([this, t]() {
+                        uint64_t seen = 0;
+                        for (;;) {
+                            std::function<void(int)> j;
+                            {
+                                std::unique_lock<std::mutex> lk(mu);
+                                go.wait(lk, [&]() { return stop || gen != seen; });
+                                if (stop) return;
+                                seen = gen;
+                                j = job;
+                            }
+                            j(t);
+                            std::lock_guard<std::mutex> lk(mu);
+                            if (--pending == 0) done.notify_one();
+                        }
+                    });
+            }
+            void run(std::function<void(int)> j)
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                job = std::move(j);
+                pending = (int)th.size();
+                gen++;
+                go.notify_all();
+                done.wait(lk, [&]() { return pending == 0; });
+            }
+            ~FillPool()
+            {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    stop = true;
+                }
+                go.notify_all();
+                for (auto &t : th) t.join();
+            }
+        };
+        FillPool pool(n_thr);
         int which = 0;
         for (uint64_t s0 = 0; s0 < total; s0 += slab_bytes, which ^= 1) {
             const uint64_t s1 = std::min<uint64_t>(s0 + slab_bytes, total);
@@ -1097,13 +1255,10 @@ extern "C" int grm_batch_upload(grm_batch *b)
             }
             uint8_t *slab = pinned[which];
             const uint64_t len = s1 - s0, piece = round_up((len + n_thr - 1) / n_thr, 4096);
-            std::vector<std::thread> pool;
-            for (int t = 1; t < n_thr; t++) {
+            pool.run([&](int t) {
                 const uint64_t a = s0 + (uint64_t)t * piece, bnd = std::min(s1, a + piece);
-                if (a < bnd) pool.emplace_back(fill_range, slab + (a - s0), a, bnd);
-            }
-            fill_range(slab, s0, std::min(s1, s0 + piece));
-            for (auto &t : pool) t.join();
+                if (a < bnd) fill_range(slab + (a - s0), a, bnd);
+            });
             if (!io_err.empty()) { cleanup(); return fail(c, GRM_ERR_IO, "%s", io_err.c_str()); }
             hipError_t e = hipMemcpyAsync(d_raw + s0, slab, (size_t)len, hipMemcpyHostToDevice, c->copy_stream);
             if (e == hipSuccess) e = hipEventRecord(done[which], c->copy_stream);

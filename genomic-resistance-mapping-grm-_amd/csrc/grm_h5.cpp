@@ -30,11 +30,17 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/grm_kmer.h"
+
+extern "C" void grm_internal_deflate_release(void *ring, int slot);
 
 typedef int64_t hid_t;
 typedef int herr_t;
@@ -264,16 +270,91 @@ struct Fault {
     bool hit() { return at >= 0 && seen++ == at; }
 };
 
-// 1-D dataset with `ce` elements per chunk.  streams != nullptr: its finished chunks; else raw `data` (deflated here when gzip > 0
-// and H5Dwrite_chunk exists, plain H5Dwrite otherwise)
-int write_1d(H5 &H, hid_t file, const char *name, hid_t type, size_t elem_bytes, const void *data, hsize_t n, int gzip, const Streams *streams,
-             Fault &fault, std::string &err)
+// slabs of finished chunks on their way from the device (grm_internal_deflate_stream, a thread of its own) to the HDF5 calls of the
+// writing thread: the k-mer strings' slabs first, then the matrix rows', each in chunk order
+struct SlabQueue {
+    struct Slab {
+        int what = 0;
+        uint64_t first = 0, n = 0;
+        unsigned char *block = nullptr;
+        void *ring = nullptr;        // block is buffer `slot` of the producer's pinned ring (given back when done), or a malloc block (slot < 0)
+        int slot = -1;
+        std::vector<uint64_t> starts;
+        std::vector<uint32_t> lens;
+        void done()
+        {
+            if (block) { if (slot >= 0) grm_internal_deflate_release(ring, slot); else free(block); }
+            block = nullptr;
+        }
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Slab> q;
+    bool finished = false, abandoned = false;
+    int producing = 0;           // dataset the producer is on (sink calls carry no tag of their own)
+    Slab cur;
+    ~SlabQueue() { drop_all(); }
+    void drop_all()
+    {
+        cur.done();
+        for (auto &sl : q) sl.done();
+        q.clear();
+    }
+    static int sink(void *user, uint64_t first, uint64_t n, unsigned char *block, const uint64_t *starts, const uint32_t *lens, void *ring, int slot)
+    {
+        SlabQueue *Q = static_cast<SlabQueue *>(user);
+        Slab sl;
+        sl.what = Q->producing; sl.first = first; sl.n = n; sl.block = block; sl.ring = ring; sl.slot = slot;
+        sl.starts.assign(starts, starts + n);
+        sl.lens.assign(lens, lens + n);
+        std::lock_guard<std::mutex> g(Q->mu);
+        if (Q->abandoned) { sl.done(); return GRM_ERR_STATE; }       // the writer gave up: stop producing
+        Q->q.push_back(std::move(sl));
+        Q->cv.notify_all();
+        return GRM_OK;
+    }
+    void finish()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        finished = true;
+        cv.notify_all();
+    }
+    // the writer is through (done, or failed): nothing more is wanted, and the producer gets its buffers back at once
+    void abandon()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        abandoned = true;
+        drop_all();
+    }
+    // chunk i of dataset `what` (asked for in order); false: the producer ended without delivering it
+    bool get(int what, uint64_t i, const unsigned char *&p, size_t &len)
+    {
+        while (!(cur.block && cur.what == what && i >= cur.first && i < cur.first + cur.n)) {
+            cur.done();
+            cur = Slab();
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&]() { return !q.empty() || finished; });
+            if (q.empty()) return false;
+            cur = std::move(q.front());
+            q.pop_front();
+        }
+        p = cur.block + cur.starts[i - cur.first];
+        len = cur.lens[i - cur.first];
+        return true;
+    }
+};
+
+// 1-D dataset with `ce_want` elements per chunk.  chunk_at != nullptr: its finished chunks come from there; else raw `data`
+// (deflated here when gzip > 0 and H5Dwrite_chunk exists, plain H5Dwrite otherwise)
+typedef std::function<bool(size_t, const unsigned char *&, size_t &)> ChunkAt;
+int write_1d(H5 &H, hid_t file, const char *name, hid_t type, size_t elem_bytes, const void *data, hsize_t n, int gzip, hsize_t ce_want,
+             const ChunkAt *chunk_at, Fault &fault, std::string &err)
 {
     if (H.Lexists(file, name, 0) > 0) H.Ldelete(file, name, 0);
     hsize_t dims[1] = {n};
     hid_t space = H.Screate_simple(1, dims, nullptr);
     hid_t dcpl = 0;
-    const hsize_t ce = n < (1u << 16) ? (n ? n : 1) : (1u << 16);      // elements per chunk
+    const hsize_t ce = n < ce_want ? (n ? n : 1) : ce_want;      // elements per chunk
     if (n > 0) {
         hsize_t chunk[1] = {ce};
         dcpl = make_dcpl(H, 1, chunk, gzip);
@@ -286,7 +367,7 @@ int write_1d(H5 &H, hid_t file, const char *name, hid_t type, size_t elem_bytes,
         if (n > 0 && gzip > 0 && H.Dwrite_chunk) {
             const size_t n_chunks = (size_t)((n + ce - 1) / ce), cb = (size_t)ce * elem_bytes;
             Streams own;
-            if (!streams) {
+            if (!chunk_at) {
                 const unsigned char *base = static_cast<const unsigned char *>(data);
                 const bool ok = deflate_chunks(n_chunks, cb, gzip, [&](size_t i, unsigned char *buf) -> const unsigned char * {
                     const size_t e0 = i * (size_t)ce, ne = (size_t)std::min<hsize_t>(ce, n - e0);
@@ -296,11 +377,15 @@ int write_1d(H5 &H, hid_t file, const char *name, hid_t type, size_t elem_bytes,
                     return buf;
                 }, own);
                 if (!ok) { err = "deflate failed"; rc = -1; }
-                streams = &own;
-            } else if (streams->n != n_chunks) { err = std::string(name) + ": chunk count of the prepared streams"; rc = -1; }
+            }
             for (size_t i = 0; i < n_chunks && !rc; i++) {
                 hsize_t off[1] = {i * ce};
-                if (fault.hit() || H.Dwrite_chunk(ds, 0, 0, off, streams->len(i), streams->at(i)) < 0) { err = std::string("H5Dwrite_chunk ") + name; rc = -1; }
+                const unsigned char *p = nullptr;
+                size_t len = 0;
+                if (chunk_at) {
+                    if (!(*chunk_at)(i, p, len)) { err = std::string(name) + ": the chunk producer stopped early"; rc = -1; break; }
+                } else { p = own.at(i); len = own.len(i); }
+                if (fault.hit() || H.Dwrite_chunk(ds, 0, 0, off, len, p) < 0) { err = std::string("H5Dwrite_chunk ") + name; rc = -1; }
             }
         } else if (n > 0 && (fault.hit() || H.Dwrite(ds, type, 0, 0, 0, data) < 0)) { err = std::string("H5Dwrite ") + name; rc = -1; }
         H.Dclose(ds);
@@ -318,6 +403,10 @@ extern "C" uint64_t *grm_internal_matrix_download_begin(grm_matrix *m, int *alre
 extern "C" int grm_internal_matrix_download_rows(grm_matrix *m, size_t r0, size_t r1);
 extern "C" void grm_internal_matrix_download_end(grm_matrix *m);
 extern "C" int grm_internal_matrix_on_device(const grm_matrix *m);
+typedef int (*grm_deflate_sink)(void *user, uint64_t first_chunk, uint64_t n, unsigned char *block, const uint64_t *starts, const uint32_t *lens, void *ring,
+                                int slot);
+extern "C" void grm_internal_deflate_release(void *ring, int slot);
+extern "C" int grm_internal_deflate_stream(grm_matrix *m, int what, uint64_t chunk_elems, uint64_t max_slab, grm_deflate_sink sink, void *user, uint64_t *n_chunks);
 
 // The append itself.  parts == nullptr: kmer_matrix holds m's own rows.  Otherwise kmer_matrix has n_rows_total word-rows whose
 // chunks come finished from n_parts producers (ranks of a multi-GPU run, each having deflated the rows it filled): part p covers
@@ -361,7 +450,11 @@ static int write_kover(grm_matrix *m, const char *existing_h5_path, int gzip_lev
     const bool on_device = grm_internal_matrix_on_device(m) && gzip_level > 0 && H.Dwrite_chunk && !(mode && !strcmp(mode, "host"));
 
     // ---- the producers of the two large datasets start first: they run beside the HDF5 calls of this thread ----
-    Streams seq_streams, mat_streams;
+    // device path: a thread drives the encoder slab by slab (k-mer strings, then the matrix rows) and this thread appends slab k
+    // while slab k + 1 is encoded and copied
+    constexpr hsize_t SEQ_CHUNK = 1 << 14;         // strings per chunk of kmer_sequences on the device path: 600 waves for 10 M k-mers (65536: 150)
+    SlabQueue slabs;
+    Streams mat_streams;
     std::atomic<int> dev_rc(GRM_OK);
     std::thread dev_worker;
     // host path, device-resident matrix: the dictionary comes down first (small), the matrix then follows row by row on a thread
@@ -370,13 +463,21 @@ static int write_kover(grm_matrix *m, const char *existing_h5_path, int gzip_lev
     std::atomic<size_t> rows_ready(0);
     std::atomic<int> copy_failed(0);
     std::thread copier;
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } join_dev{dev_worker}, join_copy{copier};
+    struct Joiner { std::thread &t; SlabQueue *q; ~Joiner() { if (q) q->abandon(); if (t.joinable()) t.join(); } } join_dev{dev_worker, &slabs}, join_copy{copier, nullptr};
     if (on_device) {
         dev_worker = std::thread([&]() {
-            int rc = grm_matrix_deflate_kmer_strings(m, 1 << 16, &seq_streams.buf, &seq_streams.starts, &seq_streams.lens, &seq_streams.n);
-            if (rc == GRM_OK && !parts)
-                rc = grm_matrix_deflate_rows(m, chunk_cols, &mat_streams.buf, &mat_streams.starts, &mat_streams.lens, &mat_streams.n);
+            uint64_t n = 0;
+            slabs.producing = 1;
+            int rc = grm_internal_deflate_stream(m, 1, SEQ_CHUNK, 1024, SlabQueue::sink, &slabs, &n);
+            if (rc == GRM_OK && !parts) {
+                {
+                    std::lock_guard<std::mutex> g(slabs.mu);
+                    slabs.producing = 0;
+                }
+                rc = grm_internal_deflate_stream(m, 0, (uint64_t)chunk_cols, 512, SlabQueue::sink, &slabs, &n);
+            }
             dev_rc = rc;
+            slabs.finish();
         });
     } else {
         kmers = grm_matrix_kmers(m);
@@ -407,22 +508,16 @@ static int write_kover(grm_matrix *m, const char *existing_h5_path, int gzip_lev
 
     // kmer_by_matrix_column: identity map in the minimum unsigned width (utils.py:117-130); small, deflated on the host
     {
-        if (U <= 0xffu) { std::vector<uint8_t> v(U + 1); for (size_t i = 0; i < U; i++) v[i] = (uint8_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U8, 1, v.data(), U, gzip_level, nullptr, fault, err); }
-        else if (U <= 0xffffu) { std::vector<uint16_t> v(U); for (size_t i = 0; i < U; i++) v[i] = (uint16_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U16, 2, v.data(), U, gzip_level, nullptr, fault, err); }
+        if (U <= 0xffu) { std::vector<uint8_t> v(U + 1); for (size_t i = 0; i < U; i++) v[i] = (uint8_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U8, 1, v.data(), U, gzip_level, 1 << 16, nullptr, fault, err); }
+        else if (U <= 0xffffu) { std::vector<uint16_t> v(U); for (size_t i = 0; i < U; i++) v[i] = (uint16_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U16, 2, v.data(), U, gzip_level, 1 << 16, nullptr, fault, err); }
         else if (U <= 0xffffffffull) {
             std::vector<uint32_t> v(U);
             parallel_for(U, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) v[i] = (uint32_t)i; });
-            rc = write_1d(H, file, "kmer_by_matrix_column", H.U32, 4, v.data(), U, gzip_level, nullptr, fault, err);
+            rc = write_1d(H, file, "kmer_by_matrix_column", H.U32, 4, v.data(), U, gzip_level, 1 << 16, nullptr, fault, err);
         }
-        else { std::vector<uint64_t> v(U); for (size_t i = 0; i < U; i++) v[i] = i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U64, 8, v.data(), U, gzip_level, nullptr, fault, err); }
+        else { std::vector<uint64_t> v(U); for (size_t i = 0; i < U; i++) v[i] = i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U64, 8, v.data(), U, gzip_level, 1 << 16, nullptr, fault, err); }
     }
     lap("kmer_by_matrix_column");
-
-    if (on_device) {
-        dev_worker.join();
-        if (dev_rc != GRM_OK && !rc) { err = std::string("deflate on the device: ") + grm_matrix_last_error(m); rc = -1; }
-        lap("device deflate (waited for)");
-    }
 
     // kmer_sequences: fixed-length S<k> (what numpy 'S31' becomes in h5py), null padded
     if (!rc) {
@@ -430,7 +525,8 @@ static int write_kover(grm_matrix *m, const char *existing_h5_path, int gzip_lev
         H.Tset_size(st, (size_t)k);
         H.Tset_strpad(st, 1);   // H5T_STR_NULLPAD
         if (on_device) {
-            rc = write_1d(H, file, "kmer_sequences", st, (size_t)k, nullptr, U, gzip_level, &seq_streams, fault, err);
+            const ChunkAt from_device = [&](size_t i, const unsigned char *&p, size_t &len) { return slabs.get(1, i, p, len); };
+            rc = write_1d(H, file, "kmer_sequences", st, (size_t)k, nullptr, U, gzip_level, SEQ_CHUNK, &from_device, fault, err);
         } else {
             std::vector<char> seq(U * (size_t)k + 1);
             const int words = grm_matrix_words(m);
@@ -438,7 +534,7 @@ static int write_kover(grm_matrix *m, const char *existing_h5_path, int gzip_lev
                 for (size_t c = c0; c < c1; c++) decode_kmer(kmers + c * (size_t)words, words, k, seq.data() + c * (size_t)k);
             });
             lap("decode k-mer strings");
-            rc = write_1d(H, file, "kmer_sequences", st, (size_t)k, seq.data(), U, gzip_level, nullptr, fault, err);
+            rc = write_1d(H, file, "kmer_sequences", st, (size_t)k, seq.data(), U, gzip_level, 1 << 16, nullptr, fault, err);
         }
         H.Tclose(st);
         lap("kmer_sequences");
@@ -467,8 +563,12 @@ static int write_kover(grm_matrix *m, const char *existing_h5_path, int gzip_lev
                     for (size_t j = 0; j < (size_t)p_rows[p] * chunks_per_row && !rc; j++)
                         put((size_t)p_row0[p] * chunks_per_row + j, p_streams[p] + p_starts[p][j], p_lens[p][j]);
             } else if (on_device) {
-                if (mat_streams.n != n_chunks) { err = "kmer_matrix: chunk count of the device's streams"; rc = -1; }
-                for (size_t i = 0; i < n_chunks && !rc; i++) put(i, mat_streams.at(i), mat_streams.len(i));
+                for (size_t i = 0; i < n_chunks && !rc; i++) {
+                    const unsigned char *p = nullptr;
+                    size_t len = 0;
+                    if (!slabs.get(0, i, p, len)) { err = "kmer_matrix: the device stopped before chunk " + std::to_string(i); rc = -1; break; }
+                    put(i, p, len);
+                }
             } else if (gzip_level > 0 && H.Dwrite_chunk) {
                 // deflate every chunk on the host threads, then hand the streams to HDF5 in order
                 const bool ok = deflate_chunks(n_chunks, (size_t)cw * 8, gzip_level, [&](size_t i, unsigned char *buf) -> const unsigned char * {
@@ -496,6 +596,11 @@ static int write_kover(grm_matrix *m, const char *existing_h5_path, int gzip_lev
         H.Sclose(space);
     }
     lap("kmer_matrix write");
+    if (on_device) {
+        slabs.abandon();             // (nothing more is wanted; a producer that is still at work stops at its next hand-over)
+        dev_worker.join();
+        if (dev_rc != GRM_OK && (!rc || err.find("stopped") != std::string::npos)) { err = std::string("deflate on the device: ") + grm_matrix_last_error(m); rc = -1; }
+    }
     if (rc) {
         // whatever exists of the three datasets is incomplete: a reader must not find it (unwritten chunks read back as zeros)
         for (const char *name : {"kmer_sequences", "kmer_by_matrix_column", "kmer_matrix"})

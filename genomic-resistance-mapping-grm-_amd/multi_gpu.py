@@ -7,8 +7,8 @@ The reference's one parallel entry point is `mpiexec -n 4 Ray survey.conf` (src/
                         form a torch.distributed group (RCCL = backend "nccl" over xGMI; gloo with host staging when two
                         ranks share a device: the one-GPU rehearsal of the path) and split the genomes in blocks of whole
                         word-rows (distributed.shard_genomes);
-  mpiexec -n 4 Ray      the ranks mpiexec starts ARE the ranks (PMI_RANK / PMI_SIZE; rendezvous through a file next to the
-                        output): rank r works on device GRM_DEVICES[r mod len] (default: all on GRM_DEVICE).
+  mpiexec -n 4 Ray      the ranks mpiexec starts ARE the ranks (PMI_RANK / PMI_SIZE; rendezvous through a loopback TCP store whose port
+                        follows from the launch): rank r works on device GRM_DEVICES[r mod len] (default: all on GRM_DEVICE).
 
 Per rank: read + upload ITS files (N file readers, N PCIe links), distributed.sharded_step (ONE dictionary all-gather), then
   .kover   the rank deflates the chunks of ITS word-rows on its device (chunks are (1, 100000): rows are independent), leaves the
@@ -117,7 +117,7 @@ class Ranks:
 
     @classmethod
     def from_mpi(cls, rendezvous_dir):
-        """ranks started by mpiexec (src/app.py:1310): rendezvous through a file store in a directory all of them see"""
+        """ranks started by mpiexec (src/app.py:1310); rendezvous_dir: the output directory all of them were given"""
         import torch
         import torch.distributed as dist
         rank, world = mpi_world()
@@ -127,18 +127,19 @@ class Ranks:
         shared = world > len(set(devices))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev)
-        os.makedirs(rendezvous_dir, exist_ok=True)
-        # the ranks of one launch share a parent (mpiexec's proxy): its pid names the store, a stale file of another launch does not
-        path = os.path.join(rendezvous_dir, ".grm_rendezvous_%d" % os.getppid())
-        store = dist.FileStore(path, world)
+        # Rendezvous without a launcher-provided address: a TCP store on the loopback interface whose port every rank derives from what
+        # the ranks of ONE launch share and other launches do not -- their parent (mpiexec's proxy) and the output directory.  (A
+        # file store next to the output left its file behind whenever a slow rank closed after rank 0 had removed it.)
+        import zlib
+        port = int(os.environ.get("GRM_RENDEZVOUS_PORT", 20000 + zlib.crc32(("%d:%s" % (os.getppid(), os.path.abspath(rendezvous_dir))).encode()) % 30000))
+        from datetime import timedelta
+        store = dist.TCPStore("127.0.0.1", port, world, is_master=(rank == 0), timeout=timedelta(seconds=120))
         backend = os.environ.get("GRM_DIST_BACKEND", "gloo" if shared else "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", store=store, rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend, store=store, rank=rank, world_size=world)
-        me = cls(rank, world, dev)
-        me._rendezvous_file = path
-        return me
+        return cls(rank, world, dev)
 
     @classmethod
     def from_initialized(cls, device_ordinal):
@@ -176,12 +177,6 @@ class Ranks:
                 self.barrier()
             finally:
                 dist.destroy_process_group()
-        f = getattr(self, "_rendezvous_file", None)
-        if f and self.rank == 0:
-            try:
-                os.remove(f)
-            except OSError:
-                pass
 
 
 def ranks_worth_starting(n_genomes, n_ranks):
