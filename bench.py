@@ -189,7 +189,7 @@ def kernel_table(ctx, n_cols, n_rows, n_local):
             byts = 24.0 * n_records + 8.0 * n_local * n_rows + 17.0 * n_local       # the same for two-word k-mers
         elif name == "superkmer_l2" and n_records is not None:
             byts = 2.0 * rec_bytes * n_records                                      # read and write every record
-        elif name == "record_dedup" and n_records is not None:
+        elif name == "record_count" and n_records is not None:
             byts = 16.0 * n_records + 12.0 * d["units"] / d["launches"]             # read the records; write <= a key + a 4-byte count per k-mer
         elif name == "record_merge" and n_records is not None:
             byts = 16.0 * n_records                                                 # read the records (what it writes: the distinct k-mers, few at 100x)

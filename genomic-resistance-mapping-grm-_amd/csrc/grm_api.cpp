@@ -1555,7 +1555,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
                 HIPCHK(c, b->d_marks.ensure(n_regions + 16));
                 HIPCHK(c, hipMemsetAsync(b->t_flag.p, 0, 8, s));
                 {
-                    TimeScope t(c, "record_dedup", h.total);
+                    TimeScope t(c, "record_count", h.total);
                     launch_record_count(s, b->d_recs2.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, k, bbr, b1r, kstride, cap_w, abundance_min,
                                         b->d_keys.as<uint64_t>(), want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, b->d_koff.as<uint64_t>(),
                                         b->d_klen.as<uint32_t>(), b->t_flag.as<int>(), b->d_marks.as<uint8_t>(), b->t_flag.as<int>() + 1);
@@ -1566,7 +1566,7 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
                 HIPCHK(c, hipStreamSynchronize(s));
                 if (!fl[0] && fl[1]) {
                     // segments with more k-mers or records than a wave takes: the workgroup form over the regions that hold one
-                    TimeScope t(c, "record_dedup_rest", h.total);
+                    TimeScope t(c, "record_dedup", h.total);
                     launch_record_dedup_rest(s, b->d_recs2.p, rstride, b->d_counts1.as<uint32_t>(), n_regions, k, bbr, b1r, kstride, cap_w, abundance_min,
                                              b->d_keys.as<uint64_t>(), want_counts ? b->d_kcnt.as<uint32_t>() : nullptr, b->d_koff.as<uint64_t>(),
                                              b->d_klen.as<uint32_t>(), b->t_flag.as<int>(), b->d_marks.as<uint8_t>());
