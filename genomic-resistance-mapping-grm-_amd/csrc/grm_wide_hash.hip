@@ -542,9 +542,10 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                     __asm__ volatile("" ::: "memory");
                 }
                 const uint32_t total = st.seg_end[WREC_SEGS - 1];
-                for (uint32_t f0 = 0; f0 < total && !is_full(); f0 += 64) {
-                    const uint32_t f = f0 + (uint32_t)lane;
-                    const bool have = f < total;
+                // a batch of 64 records is asked for while the batch before it is worked on (the loads are unconditional -- index clamped,
+                // validity applied at use -- so that nothing but the wait for THIS batch stands between them and the work)
+                auto fetch = [&](uint32_t f0, uint64_t &q0, uint64_t &q1, uint64_t &q2, uint32_t &qgb) {
+                    const uint32_t f = min(f0 + (uint32_t)lane, total ? total - 1u : 0u);
                     uint32_t lo = 0, hi = WREC_SEGS - 1;            // first segment whose running count exceeds f
 #pragma unroll
                     for (int it = 0; it < 4; it++) {
@@ -553,10 +554,20 @@ __global__ __launch_bounds__(TABLE_THREADS) void wide_dict_build_kernel(
                         hi = below ? mid : hi;
                         lo = below ? lo : min(mid + 1, WREC_SEGS - 1);
                     }
-                    const uint64_t at = st.seg_base[lo] + f;
-                    const uint32_t gb = st.seg_gb[lo];
-                    uint64_t r0 = 0, r1 = 0, r2 = 0;
-                    if (have) { r0 = recs[3 * at]; r1 = recs[3 * at + 1]; r2 = recs[3 * at + 2]; }
+                    const uint64_t at = total ? st.seg_base[lo] + f : 0;
+                    qgb = st.seg_gb[lo];
+                    q0 = recs[3 * at]; q1 = recs[3 * at + 1]; q2 = recs[3 * at + 2];
+                };
+                uint64_t n0 = 0, n1 = 0, n2 = 0;
+                uint32_t ngb = 0;
+                if (total) fetch(0, n0, n1, n2, ngb);
+                for (uint32_t f0 = 0; f0 < total && !is_full(); f0 += 64) {
+                    const bool have = f0 + (uint32_t)lane < total;
+                    uint64_t r0 = n0, r1 = n1, r2 = n2;
+                    const uint32_t gb = ngb;
+                    __asm__ volatile("" ::"v"(r0), "v"(r1), "v"(r2));          // (the wait for this batch stands here, before the next one is asked for)
+                    if (f0 + 64 < total) fetch(f0 + 64, n0, n1, n2, ngb);
+                    if (!have) { r0 = 0; r1 = 0; r2 = 0; }
                     const uint64_t n_keys = wide_rec_stage(have, r0, r1, r2, gb, st, M);
                     constexpr int KJ = 2;
                     for (uint64_t i0 = lane; i0 < n_keys + (uint64_t)lane && !is_full(); i0 += 64 * KJ) {        // (uniform trip count)
