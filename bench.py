@@ -805,20 +805,27 @@ def e2e_sharded_leg(D, ctx, synth, args, n_genomes):
             from oracle import oracle_ctypes as orc
             rd = kd.KoverDatasetReader(kover)
             ids = rd.genome_identifiers
-            seqs = None
             ok = ids == ["g%05d" % g for g in order]
-            mat = rd.kmer_matrix
+            with rd._open() as f:
+                seqs = f.read("kmer_sequences")                     # fixed-width byte strings, one per column
+                mat = f.read("kmer_matrix")
             for row in (0, n_genomes - 1):
                 g = order[row]
                 km, _, _ = orc.count_genome([pg.genome(g).tobytes()], args.k, 1)
                 mine = (mat[row // 64] >> np.uint64(63 - row % 64)) & np.uint64(1) == 1
-                if seqs is None:
-                    seqs = np.array(rd.kmer_sequences)
-                got = set(seqs[mine].tolist())
-                want = set(orc.decode_kmers(km, args.k))
+                # the letters of the marked columns -> 2-bit words (A=0 C=1 T=2 G=3, first base most significant, most significant word first)
+                letters = np.frombuffer(seqs[mine].tobytes(), dtype=np.uint8).reshape(-1, args.k)
+                words = km.shape[1]
+                got = np.zeros((letters.shape[0], words), dtype=np.uint64)
+                for j in range(args.k):
+                    w = words - 1 - (args.k - 1 - j) // 32
+                    got[:, w] = (got[:, w] << np.uint64(2)) | ((letters[:, j] >> np.uint8(1)) & np.uint8(3)).astype(np.uint64)
+                void = np.dtype((np.void, 8 * words))
+                gv, wv = np.ascontiguousarray(got).view(void).reshape(-1), np.ascontiguousarray(km).view(void).reshape(-1)
                 # with the singleton filter the file holds the genome's k-mers that another genome carries too: a subset, and every
                 # column the genome is marked in must be one of its k-mers
-                ok = ok and got <= want and (args.keep_singletons and got == want or not args.keep_singletons and len(got) > 0.9 * len(want))
+                sub = bool(np.isin(gv, wv).all())
+                ok = ok and sub and (gv.shape[0] == wv.shape[0] if args.keep_singletons else gv.shape[0] > 0.9 * wv.shape[0])
             out["bit_exact_sample"] = bool(ok)
             out["bit_exact_what"] = "row order = label order; the columns carrying the first and the last row's bit are k-mers of those genomes (CPU restatement)"
     finally:
