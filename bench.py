@@ -83,6 +83,7 @@ def parse_args():
                     help="N=1 only: the headline set cut into the N shards of an N-GPU run (BASELINE configs[2]), every rank's pass timed in this "
                          "one process on this one GPU: partition + local dictionary per shard, the exchange records, the union of the N real "
                          "payloads, the fill -- what a rank of the N-GPU run spends, without the wire (default 8; 0: skip)")
+    ap.add_argument("--rank-budget-curve", action="store_true", help="also run the rank budget for 2 and 4 ranks (an upper bound of the 1 / 2 / 4 / 8-GPU curve)")
     ap.add_argument("--only", default=None, choices=["headline", "realistic", "c4", "c5", "random"],
                     help="run ONE leg (profiling); for any leg but the headline, the headline shrinks to 16 genomes")
     ap.add_argument("--cpu-genomes", type=int, default=-1,
@@ -950,6 +951,13 @@ def main():
                       "rank pass are dictionary-sized kernels every rank repeats (union, sort, columns, fill) -- with ONE all-gather every rank "
                       "builds the whole dictionary, so that part does not shrink with the shard" % u_sized)
         out["rank_budget"] = rb
+        if args.rank_budget_curve:
+            curve = {"1": 1.0}
+            for nr in (2, 4, args.rank_budget):
+                r2 = rb if nr == args.rank_budget else rank_budget_leg(ctx, synth, Dm, args, nr, D.device)
+                curve[str(nr)] = {"rank_ms": r2["rank_ms"], "wire_ms_lower_bound": r2["exchange"]["wire_ms_lower_bound"],
+                                  "speedup_bound": round(out["ms_per_step"] / (r2["rank_ms"] + r2["exchange"]["wire_ms_lower_bound"]), 2)}
+            out["rank_budget_curve"] = curve
     # ---- the same strains as real assemblies ----
     if solo and not args.no_realistic and args.only in (None, "realistic"):
         out["realistic"] = realistic_leg(D, Dm, ctx, synth, args)
