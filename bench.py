@@ -453,22 +453,27 @@ def c5_leg(D, Dm, ctx, synth, args, orc):
     a5.k, a5.keep_singletons, a5.abundance_min = 63, True, 1
     n = min(500, args.genomes)
     kept = {}
-    b = make_batch(ctx, synth, "P", 0, n, args.genome_len, keep=lambda i, g: kept.__setitem__(i, g) if i == 3 else None)
+    check = sorted(set(g for g in (3, n // 5, n // 2 + 7, n - 1) if 0 <= g < n))
+    b = make_batch(ctx, synth, "P", 0, n, args.genome_len, keep=lambda i, g: kept.__setitem__(i, g) if i in check else None)
     el, n_cols, n_rows, kernels, _ = matrix_leg(D, Dm, ctx, a5, b, args.steps, 1)
     occ = b.n_occurrences
     out = {"workload": "%d x %d bp pan-genome (mode P), k=63, singletons kept" % (n, args.genome_len),
            "ms_per_step": round(1000 * el / args.steps, 3), "kmers_per_s": round(occ * args.steps / el, 1), "columns": int(n_cols),
            "roofline": roofline_of(kernels, leg_traffic("c5", args, n), occurrences=occ, words=2, leg="c5"), "kernels": kernels}
     m = b.run(63, 1, False)
-    # one genome's columns against the CPU restatement: with the singletons kept, exactly its own k-mers carry its bit
-    g = 3
-    km, _, _ = orc.count_genome([kept[g].tobytes()], 63, 1)
-    row = m.data()[g // 64]
-    mine = (row >> np.uint64(63 - g % 64)) & np.uint64(1) == 1
-    got = m.kmers()[mine]
-    out["bit_exact_sample"] = bool(got.shape == km.shape and np.array_equal(got, km))
-    out["bit_exact_what"] = "the columns that carry genome %d's bit = the CPU restatement's k-mer set of that genome (%d 63-mers)" % (g, km.shape[0])
-    del row, mine, got
+    # some genomes' columns against the CPU restatement: with the singletons kept, exactly a genome's own k-mers carry its bit
+    ok, n_checked = True, 0
+    mk = m.kmers()
+    md = m.data()
+    for g in check:
+        km, _, _ = orc.count_genome([kept[g].tobytes()], 63, 1)
+        mine = (md[g // 64] >> np.uint64(63 - g % 64)) & np.uint64(1) == 1
+        got = mk[mine]
+        ok = ok and bool(got.shape == km.shape and np.array_equal(got, km))
+        n_checked += km.shape[0]
+    out["bit_exact_sample"] = ok
+    out["bit_exact_what"] = "for genomes %s: the columns that carry the genome's bit = the CPU restatement's k-mer set of that genome (%d 63-mers in all)" % (check, n_checked)
+    del mk
     d = tempfile.mkdtemp(prefix="grm_c5_")
     try:
         path = os.path.join(d, "C5.kover")
@@ -477,6 +482,11 @@ def c5_leg(D, Dm, ctx, synth, args, orc):
         kd.write_header(path, "contigs", "synthetic", None, None, 5, ids, None, None, None, "nothing")
         m.write_kover_h5(path, 5, 100000)
         out["kover_gzip5"] = {"seconds": round(time.perf_counter() - t0, 3), "bytes": os.path.getsize(path)}
+        # the file back through libhdf5's own inflate: the matrix the device deflated chunk by chunk
+        back = kd.KoverDatasetReader(path).kmer_matrix
+        out["kover_gzip5"]["read_back_equal"] = bool(back.shape == md.shape and np.array_equal(back, md))
+        out["bit_exact_sample"] = bool(out["bit_exact_sample"] and out["kover_gzip5"]["read_back_equal"])
+        del back, md
     finally:
         import shutil
         shutil.rmtree(d, ignore_errors=True)
@@ -728,6 +738,10 @@ def e2e_leg(ctx, synth, args, orc, n_genomes, cpu_genomes):
             # GPU-written file names them, so that the two matrices can be compared word for word
             rd = kd.KoverDatasetReader(kover)
             row_ids = rd.genome_identifiers
+            # ... and that order must be the label order Kover prescribes (argsort of the labels, create.py:334-336), worked out HERE
+            # from the metadata, not taken from the file: label g % 2 -> the even genomes, then the odd ones, each in list order
+            expected_ids = ["g%05d" % g for g in range(n_genomes) if g % 2 == 0] + ["g%05d" % g for g in range(n_genomes) if g % 2 == 1]
+            out["row_order_ok"] = bool(row_ids == expected_ids)
             row_paths = [paths[int(g[1:])] for g in row_ids]
             t0 = time.perf_counter()
             bufs = [open(p, "rb").read() for p in row_paths[:n]]
@@ -735,9 +749,9 @@ def e2e_leg(ctx, synth, args, orc, n_genomes, cpu_genomes):
             res, count_s, merge_s, occ_cpu = orc.pipeline(bufs, args.k, args.abundance_min, not args.keep_singletons, cores)
             del bufs
             if n == n_genomes:
-                out["bit_exact"] = kover_equals(rd, res, args.k)
+                out["bit_exact"] = bool(kover_equals(rd, res, args.k) and out["row_order_ok"])
                 out["bit_exact_what"] = ("kmer_sequences, kmer_matrix and kmer_by_matrix_column READ BACK from the GPU-written .kover against the "
-                                         "CPU restatement's dictionary and packed rows for all %d genomes (rows in the file's label order)" % n)
+                                         "CPU restatement's dictionary and packed rows for all %d genomes; the rows' order = the label order worked out from the metadata" % n)
             t1 = time.perf_counter()
             cpu_kover = os.path.join(d, "CPU.kover")
             ids = row_ids[:n]
