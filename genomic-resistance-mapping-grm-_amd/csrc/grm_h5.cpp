@@ -506,18 +506,47 @@ static int write_kover(grm_matrix *m, const char *existing_h5_path, int gzip_lev
     int rc = 0;
     Fault fault;
 
-    // kmer_by_matrix_column: identity map in the minimum unsigned width (utils.py:117-130); small, deflated on the host
-    {
-        if (U <= 0xffu) { std::vector<uint8_t> v(U + 1); for (size_t i = 0; i < U; i++) v[i] = (uint8_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U8, 1, v.data(), U, gzip_level, 1 << 16, nullptr, fault, err); }
-        else if (U <= 0xffffu) { std::vector<uint16_t> v(U); for (size_t i = 0; i < U; i++) v[i] = (uint16_t)i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U16, 2, v.data(), U, gzip_level, 1 << 16, nullptr, fault, err); }
-        else if (U <= 0xffffffffull) {
-            std::vector<uint32_t> v(U);
-            parallel_for(U, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) v[i] = (uint32_t)i; });
-            rc = write_1d(H, file, "kmer_by_matrix_column", H.U32, 4, v.data(), U, gzip_level, 1 << 16, nullptr, fault, err);
-        }
-        else { std::vector<uint64_t> v(U); for (size_t i = 0; i < U; i++) v[i] = i; rc = write_1d(H, file, "kmer_by_matrix_column", H.U64, 8, v.data(), U, gzip_level, 1 << 16, nullptr, fault, err); }
+    // kmer_by_matrix_column: identity map in the minimum unsigned width (utils.py:117-130); small, deflated on the host.  On the device
+    // path a thread of its own prepares its chunks while this one appends the two large datasets, and they are appended last.
+    const size_t col_bytes = U <= 0xffu ? 1 : U <= 0xffffu ? 2 : U <= 0xffffffffull ? 4 : 8;
+    const hid_t col_type = col_bytes == 1 ? H.U8 : col_bytes == 2 ? H.U16 : col_bytes == 4 ? H.U32 : H.U64;
+    std::vector<unsigned char> col_raw;
+    auto fill_col = [&]() {
+        col_raw.resize((U + 1) * col_bytes);
+        parallel_for(U, [&](size_t c0, size_t c1) {
+            for (size_t i = c0; i < c1; i++) {
+                if (col_bytes == 1) col_raw[i] = (uint8_t)i;
+                else if (col_bytes == 2) reinterpret_cast<uint16_t *>(col_raw.data())[i] = (uint16_t)i;
+                else if (col_bytes == 4) reinterpret_cast<uint32_t *>(col_raw.data())[i] = (uint32_t)i;
+                else reinterpret_cast<uint64_t *>(col_raw.data())[i] = (uint64_t)i;
+            }
+        });
+    };
+    constexpr hsize_t COL_CHUNK = 1 << 16;
+    Streams col_streams;
+    std::atomic<int> col_ok(1);
+    std::thread col_worker;
+    struct ColJoin { std::thread &t; ~ColJoin() { if (t.joinable()) t.join(); } } join_col{col_worker};
+    const bool col_aside = on_device && U > 0 && gzip_level > 0 && H.Dwrite_chunk;
+    if (col_aside) {
+        col_worker = std::thread([&]() {
+            fill_col();
+            const hsize_t ce = U < COL_CHUNK ? U : COL_CHUNK;
+            const size_t n_chunks = (size_t)((U + ce - 1) / ce), cb = (size_t)ce * col_bytes;
+            const bool ok = deflate_chunks(n_chunks, cb, gzip_level, [&](size_t i, unsigned char *buf) -> const unsigned char * {
+                const size_t e0 = i * (size_t)ce, ne = std::min<size_t>((size_t)ce, U - e0);
+                if (ne == (size_t)ce) return col_raw.data() + e0 * col_bytes;
+                memcpy(buf, col_raw.data() + e0 * col_bytes, ne * col_bytes);
+                memset(buf + ne * col_bytes, 0, cb - ne * col_bytes);
+                return buf;
+            }, col_streams);
+            if (!ok) col_ok = 0;
+        });
+    } else {
+        fill_col();
+        rc = write_1d(H, file, "kmer_by_matrix_column", col_type, col_bytes, col_raw.data(), U, gzip_level, COL_CHUNK, nullptr, fault, err);
+        lap("kmer_by_matrix_column");
     }
-    lap("kmer_by_matrix_column");
 
     // kmer_sequences: fixed-length S<k> (what numpy 'S31' becomes in h5py), null padded
     if (!rc) {
@@ -600,6 +629,17 @@ static int write_kover(grm_matrix *m, const char *existing_h5_path, int gzip_lev
         slabs.abandon();             // (nothing more is wanted; a producer that is still at work stops at its next hand-over)
         dev_worker.join();
         if (dev_rc != GRM_OK && (!rc || err.find("stopped") != std::string::npos)) { err = std::string("deflate on the device: ") + grm_matrix_last_error(m); rc = -1; }
+    }
+    if (col_aside) {
+        col_worker.join();
+        if (!rc) {
+            if (!col_ok) { err = "deflate failed (kmer_by_matrix_column)"; rc = -1; }
+            else {
+                const ChunkAt from_worker = [&](size_t i, const unsigned char *&p, size_t &len) { p = col_streams.at(i); len = col_streams.len(i); return i < col_streams.n; };
+                rc = write_1d(H, file, "kmer_by_matrix_column", col_type, col_bytes, nullptr, U, gzip_level, COL_CHUNK, &from_worker, fault, err);
+            }
+        }
+        lap("kmer_by_matrix_column");
     }
     if (rc) {
         // whatever exists of the three datasets is incomplete: a reader must not find it (unwritten chunks read back as zeros)
