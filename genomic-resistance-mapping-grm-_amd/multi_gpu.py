@@ -244,8 +244,12 @@ def from_contigs_sharded(ctx, R, contig_list_path, output_path, kmer_size, filte
         R.barrier()
         return n
     tmp = output_path + ".tmp"
-    spool_dir = spool_dir or (os.path.dirname(os.path.abspath(output_path)) or ".")
-    spool = lambda r: os.path.join(spool_dir, ".%s.rank%d.chunks" % (os.path.basename(output_path), r))
+    # the ranks' streams wait for rank 0 in memory-backed files when the node has them (the ranks share a node), else next to the output
+    if not spool_dir:
+        spool_dir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else (os.path.dirname(os.path.abspath(output_path)) or ".")
+    import zlib
+    tag = "%s.%08x" % (os.path.basename(output_path), zlib.crc32(os.path.abspath(output_path).encode()))
+    spool = lambda r: os.path.join(spool_dir, ".grm_%s.rank%d.chunks" % (tag, r))
     if R.rank == 0:
         kd.write_header(tmp, source_type, contig_list_path, phenotype_description, phenotype_metadata_path, gzip, ids, labels, tags, ctype,
                         "singleton" if filter_singleton else "nothing")

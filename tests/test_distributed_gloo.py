@@ -300,6 +300,8 @@ def test_kover_file_from_sharded_ranks(genome_files, world, filt):
     assert r.kmer_sequences == orc.decode_kmers(want["kmers"], 15)
     assert (r.kmer_matrix == want["matrix"]).all()
     assert not [f for f in os.listdir(d) if f.endswith(".chunks") or f.endswith(".tmp")]           # spool files and temp output are gone
+    if os.path.isdir("/dev/shm"):
+        assert not [f for f in os.listdir("/dev/shm") if f.startswith(".grm_sharded.kover.")]
 
 
 def test_tsv_from_sharded_ranks(genome_files):
