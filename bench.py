@@ -83,6 +83,9 @@ def parse_args():
                     help="N=1 only: the headline set cut into the N shards of an N-GPU run (BASELINE configs[2]), every rank's pass timed in this "
                          "one process on this one GPU: partition + local dictionary per shard, the exchange records, the union of the N real "
                          "payloads, the fill -- what a rank of the N-GPU run spends, without the wire (default 8; 0: skip)")
+    ap.add_argument("--weak-budget", type=int, default=0, metavar="N",
+                    help="N=1 only: the WEAK form of the rank budget -- N shards of --genomes genomes each (N x the headline set), rank 0's pass timed against "
+                         "the payload of all N real records (the shards are made and counted one after the other: N x the set-up time)")
     ap.add_argument("--rank-budget-curve", action="store_true", help="also run the rank budget for 2 and 4 ranks (an upper bound of the 1 / 2 / 4 / 8-GPU curve)")
     ap.add_argument("--only", default=None, choices=["headline", "realistic", "c4", "c5", "random"],
                     help="run ONE leg (profiling); for any leg but the headline, the headline shrinks to 16 genomes")
@@ -419,6 +422,66 @@ def rank_budget_leg(ctx, synth, Dm, args, n_ranks, device):
             "kernels_of_rank0_ms": {k: round(v, 3) for k, v in per_kernel.items()},
             "what": "host wall clock around the engine's staged calls, one GPU, best of %d repetitions; the all-gather itself is not run "
                     "(one process): priced from the record size" % reps}
+
+
+def weak_budget_leg(ctx, synth, Dm, args, n_ranks, device):
+    """weak scaling on one GPU: n_ranks shards of args.genomes genomes each (genomes r * G .. of the same pan-genome); every shard is counted
+    and leaves its exchange record in ONE payload; rank 0's pass -- partition, local dictionary, export, global dictionary from the
+    payload of all ranks, fill -- is timed with its batch kept resident.  Best of the repetitions; the all-gather itself is priced."""
+    import torch
+    filt = not args.keep_singletons
+    words = 1 if args.k <= 32 else 2
+    G = args.genomes
+    n_locals, bbs = [], []
+    b0, payload = None, None
+    # The records need ONE layout (the largest dictionary of any rank): it is fixed after the first shard with 10 % of head room (the
+    # shards are equally large samples of one pan-genome) -- every later shard is counted, writes its record and is freed at once:
+    # eight resident 1000-genome batches would not fit HBM.
+    for r in range(n_ranks):
+        b = make_batch(ctx, synth, "P", r * G, G, args.genome_len)
+        b.partition(args.k, args.abundance_min)
+        n_locals.append(b.local_dict())
+        bbs.append(b.bucket_bits)
+        if r == 0:
+            b0 = b
+            n_max = int(n_locals[0] * 1.1) + 1024
+            flags_off, boff_off, stride = b0.exchange_layout(n_max, words, bbs[0] & 0xff)
+            payload = torch.empty(n_ranks * stride, dtype=torch.uint8, device=device)
+        if n_locals[r] > n_max or bbs[r] != bbs[0]:
+            raise RuntimeError("weak budget: shard %d needs another record layout (%d entries, bucket code %#x)" % (r, n_locals[r], bbs[r]))
+        b.export_dict_ordered(payload.data_ptr() + r * stride, flags_off, boff_off)
+        if r:
+            b.free()
+    best = {}
+    n_cols = 0
+    for rep in range(max(2, args.steps) + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        b0.partition(args.k, args.abundance_min)
+        t1 = time.perf_counter()
+        b0.local_dict()
+        t2 = time.perf_counter()
+        b0.export_dict_ordered(payload.data_ptr(), flags_off, boff_off)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        n_cols = b0.set_global_dict_gathered(payload.data_ptr(), n_max, n_locals, bbs, filt, my_rank=0)
+        t4 = time.perf_counter()
+        m = b0.fill()
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        m.free()
+        if rep:
+            for key, v in (("partition", t1 - t0), ("local_dict", t2 - t1), ("export_record", t3 - t2), ("global_dict_from_payload", t4 - t3), ("fill", t5 - t4)):
+                best[key] = min(best.get(key, 1e30), v * 1e3)
+    b0.free()
+    del payload
+    rank_ms = sum(best.values())
+    wire_ms = stride / 153e9 * 1e3
+    return {"ranks": n_ranks, "genomes_per_rank": G, "genomes_total": G * n_ranks, "columns": int(n_cols), "stage_ms_rank0": {k: round(v, 3) for k, v in best.items()},
+            "rank_ms": round(rank_ms, 3), "exchange": {"record_bytes": int(stride), "wire_ms_lower_bound": round(wire_ms, 3)},
+            "genomes_per_s_bound": round(G * n_ranks / ((rank_ms + wire_ms) * 1e-3), 1),
+            "what": "rank 0's pass of a weak-scaling run (every rank its own %d genomes of one pan-genome), one GPU, best of the repetitions; the all-gather is priced, "
+                    "not run" % G}
 
 
 def realistic_leg(D, Dm, ctx, synth, args):
@@ -972,6 +1035,10 @@ def main():
                 curve[str(nr)] = {"rank_ms": r2["rank_ms"], "wire_ms_lower_bound": r2["exchange"]["wire_ms_lower_bound"],
                                   "speedup_bound": round(out["ms_per_step"] / (r2["rank_ms"] + r2["exchange"]["wire_ms_lower_bound"]), 2)}
             out["rank_budget_curve"] = curve
+    if solo and args.weak_budget > 1 and args.only in (None, "headline") and args.k <= 64:
+        wb = weak_budget_leg(ctx, synth, Dm, args, args.weak_budget, D.device)
+        wb["throughput_bound_vs_1gpu"] = round(wb["genomes_per_s_bound"] / (args.genomes / (out["ms_per_step"] * 1e-3)), 2)
+        out["weak_budget"] = wb
     # ---- the same strains as real assemblies ----
     if solo and not args.no_realistic and args.only in (None, "realistic"):
         out["realistic"] = realistic_leg(D, Dm, ctx, synth, args)
