@@ -3104,7 +3104,10 @@ static int wide_hash_local(grm_batch *b, int k, bool *fallback)
     bool by_recs = false;
     int rec_pbits = 0;
     if (c->opt_records != 0 && c->opt_dense_layout <= 0 && !W.rec_failed && k <= 64) {
-        int bbr = c->opt_bucket_bits >= 0 ? bb : bb + 1;           // (minimizer buckets are less even than hashed k-mers: one more bit)
+        // minimizer buckets are less even than hashed k-mers, and a bucket's DISTINCT records must fit wh_dict_build's memo (96 records of up
+        // to 22 k-mers): two more bits than the key form -- at 2^14 buckets a third of them held more records than the memo (78 on
+        // average at 500 x 5 Mbp) and every occurrence of the rest went the direct way: 7.85 ms against 6.55 ms at 2^15
+        int bbr = c->opt_bucket_bits >= 0 ? bb : bb + (c->opt_rec_bucket_shift >= 0 ? c->opt_rec_bucket_shift : 2);
         bbr = std::min(bbr, superkmer_coarse_bits(bbr) + 7);
         const int b1r = superkmer_coarse_bits(bbr);
         // one workgroup of level 1 per genome part: enough parts to fill the device when genomes are few (as batch_partition_impl)
