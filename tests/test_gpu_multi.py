@@ -142,3 +142,49 @@ def test_multidsk_over_ranks_then_dsk2kover(strains, tmp_path):
     want = orc.build_matrix([[open(p, "rb").read()] for p in paths], 31, 1, True)
     r = kd.KoverDatasetReader(out)
     assert r.kmer_sequences == orc.decode_kmers(want["kmers"], 31) and (r.kmer_matrix == want["matrix"]).all()
+
+
+def test_kover_from_reads_over_ranks_with_an_abundance_filter(tmp_path):
+    """`kover dataset create from-reads --kmer-min-abundance 2` over two ranks: every rank counts its own read sets (the filter acts on
+    the per-genome counts), the ranks exchange their dictionaries of SOLID k-mers; the file equals the one-rank file and the oracle"""
+    import grm_amd  # noqa: F401
+    rng = np.random.RandomState(5)
+    core = cases.rand_seq(rng, 2500)
+    dirs, bufs = [], []
+    for g in range(70):
+        s = list(core)
+        for p in rng.randint(0, len(core), size=6):
+            s[p] = "ACGT"[rng.randint(4)]
+        s = "".join(s)
+        reads = []
+        for r in range(160):                       # ~8x coverage, 120 bp reads, a few with an error (k-mers seen once: filtered out)
+            a = rng.randint(0, len(s) - 120)
+            rd = list(s[a:a + 120])
+            if rng.rand() < 0.2:
+                rd[rng.randint(120)] = "ACGT"[rng.randint(4)]
+            reads.append("".join(rd))
+        d = tmp_path / ("reads_%03d" % g)
+        d.mkdir()
+        half = len(reads) // 2
+        texts = []
+        for name, part in (("r_1.fastq", reads[:half]), ("r_2.fastq", reads[half:])):
+            t = "".join("@r%d\n%s\n+\n%s\n" % (i, x, "I" * len(x)) for i, x in enumerate(part))
+            (d / name).write_text(t)
+            texts.append(t.encode())
+        dirs.append(str(d))
+        bufs.append(texts)
+    with open(tmp_path / "paths.tsv", "w") as f:
+        f.writelines("s%03d\t%s\n" % (g, p) for g, p in enumerate(dirs))
+    with open(tmp_path / "md.tsv", "w") as f:
+        f.writelines("s%03d\t%d\n" % (g, g % 2) for g in range(70))
+    base = [sys.executable, os.path.join(CLI, "kover"), "dataset", "create", "from-reads", "--genomic-data", str(tmp_path / "paths.tsv"),
+            "--phenotype-description", "p", "--phenotype-metadata", str(tmp_path / "md.tsv"), "--kmer-size", "21", "--kmer-min-abundance", "2",
+            "--compression", "4", "-x"]
+    one, many = str(tmp_path / "one.kover"), str(tmp_path / "many.kover")
+    _run(base + ["--output", one])
+    r = _run(base + ["--output", many], env={"GRM_DEVICES": "0,0"})
+    assert "x 2)" in r.stdout, r.stdout
+    a, b = _datasets(one), _datasets(many)
+    assert a[0] == b[0] and a[1] == b[1] and (a[2] == b[2]).all()
+    want = orc.build_matrix([bufs[int(g[1:])] for g in a[0]], 21, 2, True)
+    assert a[1] == orc.decode_kmers(want["kmers"], 21) and (a[2] == want["matrix"]).all()
