@@ -739,7 +739,13 @@ def host_floors(paths, kover, gzip):
         z = zlib.compress(sample, gzip)
         mbps = len(sample) / (time.perf_counter() - t0) / 1e6
         cores = os.cpu_count() or 1
-        out["deflate"] = {"MBps_per_core_incompressible": round(mbps, 1), "cores": cores, "kover_bytes": raw,
+        quota = None
+        try:                    # what the job may actually use: the cgroup's CPU quota (a 256-thread box gives a one-GPU job 16 CPUs)
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else round(int(q) / int(per), 1)
+        except (OSError, ValueError):
+            pass
+        out["deflate"] = {"MBps_per_core_incompressible": round(mbps, 1), "cores": cores, "cpu_quota": quota, "kover_bytes": raw,
                           "how": "zlib level %d on 4 MiB of random bits (an upper bound on the work per byte; real rows compress faster)" % gzip}
         del z
     except Exception as e:          # noqa: BLE001
