@@ -839,6 +839,7 @@ def e2e_leg(ctx, synth, args, orc, n_genomes, cpu_genomes):
             if n == n_genomes:
                 out["speedup_vs_cpu"] = round(cpu_total / wall, 2)
             cpu_baseline = {"value": round(occ_cpu / (count_s + merge_s), 1), "unit": "k-mers/s", "cores": cores, "kind": "port",
+                            "cpu_quota": (out.get("floors", {}).get("deflate") or {}).get("cpu_quota"),
                             "sample": "%d of the %d genomes of the headline set (same generator): count %.2fs + merge %.2fs on %d threads; CPU "
                                       "restatement of DSK+dsk2kover semantics (the reference binaries are absent)" % (n, n_genomes, count_s, merge_s, cores)}
         return out, cpu_baseline
