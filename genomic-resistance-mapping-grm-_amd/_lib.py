@@ -77,6 +77,7 @@ PROTOTYPES = [
     ("grm_exchange_layout", None, [C.c_uint64, C.c_int, C.c_int, _U64P, _U64P, _U64P]),
     ("grm_batch_bucket_bits", C.c_int, [_P]),
     ("grm_batch_export_dict_ordered", C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
+    ("grm_batch_export_dict_record", C.c_int, [_P, _P, C.c_uint64, C.c_int, C.POINTER(C.c_int)]),
     ("grm_batch_set_global_dict_gathered", C.c_int, [_P, _P, C.c_int, C.c_uint64, _U64P, C.POINTER(C.c_int), C.c_int, _U64P]),
     ("grm_batch_set_global_dict_gathered_from", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint64, _U64P, C.POINTER(C.c_int), C.c_int, _U64P]),
     ("grm_dict_accum_create", C.c_int, [_P, _PP]),

@@ -2285,11 +2285,14 @@ extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, con
 //   [0, n_max * 8 * words)            keys, grouped by hash bucket (ascending), (hi, lo) pairs for words = 2
 //   [flags_off, flags_off + n_max)    flags
 //   [boff_off, boff_off + 4 (B + 1))  first entry of every hash bucket (uint32), boff[B] = n_local
+//   [stride - 16, stride)             header, written by grm_batch_export_dict_record: n_local (uint64), bucket-bits code (uint32,
+//                                     grm_batch_bucket_bits), GRM_EXCHANGE_MAGIC (uint32) -- what the ranks used to tell each other in
+//                                     a collective of its own before the layout could be fixed
 extern "C" void grm_exchange_layout(uint64_t n_max, int words, int bucket_bits, uint64_t *flags_off, uint64_t *boff_off, uint64_t *stride)
 {
     const uint64_t fo = n_max * 8 * (uint64_t)(words < 1 ? 1 : words);
     const uint64_t bo = (fo + n_max + 15) / 16 * 16;
-    const uint64_t st = (bo + (((uint64_t)1 << (bucket_bits & 0xff)) + 1) * 4 + 15) / 16 * 16;
+    const uint64_t st = (bo + (((uint64_t)1 << (bucket_bits & 0xff)) + 1) * 4 + 15) / 16 * 16 + GRM_EXCHANGE_HEADER_BYTES;
     if (flags_off) *flags_off = fo;
     if (boff_off) *boff_off = bo;
     if (stride) *stride = st;
@@ -2327,6 +2330,27 @@ extern "C" int grm_batch_export_dict_ordered(grm_batch *b, void *dev_record, uin
     HIPCHK(c, hipStreamSynchronize(s));
     b->exported_ordered = true;          // t_ord_off describes the list just written (tracked through the union by set_global_dict_gathered_from)
     return GRM_OK;
+}
+
+// The record of a step whose layout was fixed BEFORE the ranks knew each other's sizes (n_cap, bucket_bits: what the previous step
+// saw, with some slack): the header always goes out; the lists only when they fit -- a rank that overflows says so through its header,
+// every rank reads every header after the all-gather, and all of them repeat the step with the larger layout.
+extern "C" int grm_batch_export_dict_record(grm_batch *b, void *dev_record, uint64_t n_cap, int bucket_bits, int *fits)
+{
+    if (!b || !dev_record) return GRM_ERR_ARG;
+    grm_ctx *c = b->ctx;
+    if (!b->have_local) return fail(c, GRM_ERR_STATE, "grm_batch_export_dict_record before grm_batch_local_dict");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t flags_off, boff_off, stride;
+    grm_exchange_layout(n_cap, b->k > 32 ? 2 : 1, bucket_bits, &flags_off, &boff_off, &stride);
+    const bool ok = b->n_local <= n_cap && b->bb <= (bucket_bits & 0xff);
+    if (fits) *fits = ok ? 1 : 0;
+    struct { uint64_t n_local; uint32_t code, magic; } head = {b->n_local, (uint32_t)grm_batch_bucket_bits(b), GRM_EXCHANGE_MAGIC};
+    static_assert(sizeof head == GRM_EXCHANGE_HEADER_BYTES, "exchange header");
+    HIPCHK(c, hipMemcpyAsync((uint8_t *)dev_record + stride - GRM_EXCHANGE_HEADER_BYTES, &head, sizeof head, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // (head is a stack variable; the export below ends with a synchronize of its own)
+    if (!ok) return GRM_OK;
+    return grm_batch_export_dict_ordered(b, dev_record, flags_off, boff_off);
 }
 
 // dev_payload: the records of all ranks (rank r at r * stride, grm_exchange_layout(n_max, words, max bucket_bits)).

@@ -585,6 +585,123 @@ GRM_HD void stream_insert(uint32_t pos, int cnt, uint32_t sym, uint32_t inv, OS 
     if (oi + (uint32_t)cnt > 64u) or_inv(wi + 1, (uint64_t)inv >> (64 - oi));
 }
 
+// ---- "clean" chunks: nothing but bytes of sequence lines and newlines ---------------------------------------------------
+// Nearly every 1 KiB of a FASTA holds no '>' and no CR, and then a byte is a symbol unless it is a newline, every line that starts is a
+// sequence line, and what a chunk adds to the tile's scan follows from the COUNT of its newlines and the place of the first one -- no
+// 16-bit masks, no flood of line types.  The test is conservative: letters have bit 6 set, '\n', '\r', '>' and whatever else a parser
+// must look at have not; a chunk with a byte below 0x40 that is not '\n' (or a byte >= 0x80 without bit 6) goes the general way.
+GRM_HD uint32_t nl_bytes4(uint32_t x)                    // 0x80 in every byte of x that is '\n' (exact)
+{
+    const uint32_t y = x ^ 0x0a0a0a0au;
+    return ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);
+}
+// z[i] = nl_bytes4(w[i]); returns nonzero iff the chunk holds a byte that is neither a newline nor has bit 6 set
+GRM_HD uint32_t clean_scan(const uint32_t w[4], uint32_t z[4])
+{
+    uint32_t odd = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 4; i++) {
+        z[i] = nl_bytes4(w[i]);
+        odd |= ((~w[i] & 0x40404040u) << 1) ^ z[i];
+    }
+    return odd;
+}
+GRM_HD uint32_t clean_nl_count(const uint32_t z[4])
+{
+    return (uint32_t)(__builtin_popcount(z[0]) + __builtin_popcount(z[1]) + __builtin_popcount(z[2]) + __builtin_popcount(z[3]));
+}
+GRM_HD uint32_t clean_first_nl(const uint32_t z[4])      // byte index of the chunk's first newline, 16: none
+{
+    const uint64_t zl = (uint64_t)z[0] | ((uint64_t)z[1] << 32), zh = (uint64_t)z[2] | ((uint64_t)z[3] << 32);
+    if (zl) return (uint32_t)__builtin_ctzll(zl) >> 3;
+    if (zh) return 8u + ((uint32_t)__builtin_ctzll(zh) >> 3);
+    return 16u;
+}
+GRM_HD uint32_t clean_nl_mask16(const uint32_t z[4])     // bit j <=> byte j is a newline (what chunk_masks calls nl)
+{
+    auto g = [](uint32_t zz) { return (((zz >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xfu; };
+    return g(z[0]) | (g(z[1]) << 4) | (g(z[2]) << 8) | (g(z[3]) << 12);
+}
+// the scan element (pelem32) of a clean chunk == what chunk_classify(.., T_NONE, ..) + chunk_last_event give for it:
+// the first line start is byte 0 when the byte before the chunk is a newline, else the byte after the first newline (if that is still
+// inside); bytes before it count only if a sequence line runs in (extra), the other non-newline bytes always (ch)
+GRM_HD uint32_t clean_elem(const uint32_t z[4], uint32_t prev_nl)
+{
+    const uint32_t nlc = clean_nl_count(z), f = clean_first_nl(z);
+    const uint32_t extra = prev_nl ? 0u : f;             // (f == 15: the line starts in the next chunk; 15 plain bytes before it)
+    const uint32_t ch = 16u - nlc - extra;
+    return pelem32_make((prev_nl || f < 15u) ? T_SEQ : T_NONE, ch + extra, ch);
+}
+// the 2-bit codes of all 16 bytes, first byte on top (what chunk_pack's SWAR path builds word by word): on the device a 4 x 4 byte
+// transpose (8 v_perm_b32) puts byte k of every word side by side, so that ONE shift and mask per k serves the four words
+GRM_HD uint32_t chunk_codes16(const uint32_t w[4])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t a01 = __builtin_amdgcn_perm(w[0], w[1], 0x04000501u), a23 = __builtin_amdgcn_perm(w[0], w[1], 0x06020703u);
+    const uint32_t c01 = __builtin_amdgcn_perm(w[2], w[3], 0x04000501u), c23 = __builtin_amdgcn_perm(w[2], w[3], 0x06020703u);
+    const uint32_t t0 = __builtin_amdgcn_perm(a01, c01, 0x07060302u), t1 = __builtin_amdgcn_perm(a01, c01, 0x05040100u);
+    const uint32_t t2 = __builtin_amdgcn_perm(a23, c23, 0x07060302u), t3 = __builtin_amdgcn_perm(a23, c23, 0x05040100u);
+    return ((t0 << 5) & 0xc0c0c0c0u) | ((t1 << 3) & 0x30303030u) | ((t2 << 1) & 0x0c0c0c0cu) | ((t3 >> 1) & 0x03030303u);
+#else
+    return (codes_of_word(w[0]) << 24) | (codes_of_word(w[1]) << 16) | (codes_of_word(w[2]) << 8) | codes_of_word(w[3]);
+#endif
+}
+// nonzero iff a byte of the chunk that is not a newline has the bad-base bit ('\n' = 0x0a has it too: nlc of the bytes counted are those)
+GRM_HD uint32_t clean_bad_any(const uint32_t w[4], uint32_t nlc)
+{
+    const uint32_t n = (uint32_t)(__builtin_popcount(w[0] & 0x08080808u) + __builtin_popcount(w[1] & 0x08080808u) +
+                                  __builtin_popcount(w[2] & 0x08080808u) + __builtin_popcount(w[3] & 0x08080808u));
+    return n ^ nlc;
+}
+// 16 two-bit symbols, first on top; symbol j (0..15) is taken out and the ones after it move up: 15 symbols in the top 30 bits, zeros
+// below.  j == 16: nothing is taken out.
+GRM_HD uint32_t close_hole_top(uint32_t s16, uint32_t j)
+{
+    const uint32_t keep = ~(uint32_t)(0xffffffffull >> (2u * j));     // the 2 j bits of the symbols before j
+    return (s16 & keep) | ((s16 << 2) & ~keep);
+}
+// OR up to 16 symbols (top-aligned in v, ZEROS below the last one) into the stream at symbol position pos -- the count is not needed
+template <typename OS>
+GRM_HD void stream_insert_top(uint32_t pos, uint32_t v, OS &&or_sym)
+{
+    const uint32_t w = pos >> 5, o = pos & 31u;
+    const uint64_t v64 = (uint64_t)v << 32;
+    or_sym(w, v64 >> (2u * o));
+    if (o > 16u) {
+        const uint64_t lo = v64 << (64u - 2u * o);
+        if (lo) or_sym(w + 1, lo);
+    }
+}
+template <typename OI>
+GRM_HD void stream_insert_inv(uint32_t pos, uint32_t cnt, uint32_t inv, OI &&or_inv)
+{
+    if (!inv) return;
+    const uint32_t wi = pos >> 6, oi = pos & 63u;
+    or_inv(wi, (uint64_t)inv << oi);
+    if (oi + cnt > 64u) or_inv(wi + 1, (uint64_t)inv >> (64u - oi));
+}
+// a clean chunk whose incoming line is a sequence line, packed and inserted: every byte but the newlines is a symbol.  with_inv: some
+// chunk of the wave holds a bad base (else the inv words stay as they are: zero)
+template <typename OS, typename OI>
+GRM_HD void clean_chunk_insert(const uint32_t w[4], const uint32_t z[4], uint32_t nlc, uint32_t pos, bool with_inv, OS &&or_sym, OI &&or_inv)
+{
+    if (nlc >= 2u) {                                      // blank lines, padding, lines shorter than a chunk: the general packer
+        uint32_t cs, ci;
+        const int cnt = chunk_pack(w, ~clean_nl_mask16(z) & 0xffffu, 0u, cs, ci);
+        stream_insert(pos, cnt, cs, ci, or_sym, or_inv);
+        return;
+    }
+    const uint32_t j = clean_first_nl(z);
+    stream_insert_top(pos, close_hole_top(chunk_codes16(w), j), or_sym);
+    if (with_inv) {
+        uint32_t b16 = bad_of_word(w[0]) | (bad_of_word(w[1]) << 4) | (bad_of_word(w[2]) << 8) | (bad_of_word(w[3]) << 12);
+        b16 = (b16 & ((1u << j) - 1u)) | ((b16 >> (j + 1u)) << j);        // (j == 16: all 16 stay)
+        stream_insert_inv(pos, 16u - nlc, b16, or_inv);
+    }
+}
+
 // ---- k-mer windows of one 64-symbol group ------------------------------------------
 // valid-start mask for the 64 positions of a group: position p is valid iff none of the
 // k symbols p..p+k-1 is flagged in the 128-bit window (i1:i0).  k in 1..64.

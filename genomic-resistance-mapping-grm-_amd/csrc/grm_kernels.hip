@@ -56,6 +56,28 @@ __device__ __forceinline__ void tile_round(const uint4 &v, uint32_t edge, int la
     elem = pelem32_make(chunk_last_event(ls, gt), __popc(ek) + __popc(unk), __popc(ek));
 }
 
+// the same element for parse_summarize, which needs nothing else of the chunk: a wave whose 1 KiB is clean (clean_scan: letters and
+// newlines only -- nearly every wave of a FASTA) gets it from the count and the place of its newlines, ~60 instructions per chunk
+// against ~150 through the masks and the flood of line types; the kernel is bound by instruction issue
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x)          // lane i <- lane i - 1; lane 0 <- 0
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);
+}
+template <int R>
+__device__ __forceinline__ void tile_round_sum(const uint4 &v, uint32_t edge, int lane, uint32_t &elem)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t z[4];
+    const uint32_t odd = clean_scan(w, z);
+    if (!__any(odd != 0u)) {
+        const uint32_t up = wave_shr1(z[3] >> 31);
+        elem = clean_elem(z, lane == 0 ? edge : up);
+    } else {
+        TileChunks unused;
+        tile_round<R>(v, edge, lane, unused, elem);
+    }
+}
+
 // The scan of a FASTA tile's 1024 chunks (order: round, thread), giving every chunk its exclusive prefix element (ev, cs, ch) and the
 // tile its total.  The element's combine is associative, but a log-step scan of it costs ~14 instructions and a cross-lane move per
 // step and round (138 of parse_summarize's 313 instructions per chunk).  The element has more structure than that:
@@ -65,6 +87,8 @@ __device__ __forceinline__ void tile_round(const uint4 &v, uint32_t edge, int la
 //   cs   = the same if a sequence line does = ch + sum of pend_i = (ev_i == NONE ? extra_i : 0), extra = the chunk's bytes before
 //          its own first line start;
 // i.e. ONE integer prefix sum of the packed pair (known | pend << 16; a tile holds 16384 bytes): six DPP adds per round.
+// SUM_ONLY: the caller wants tc.pre[] and tc.total only (parse_summarize), not the chunks' words and masks
+template <bool SUM_ONLY = false>
 __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint32_t tile, uint64_t *partial64 /* LDS [16] */,
                                           TileChunks &tc)
 {
@@ -81,10 +105,17 @@ __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint3
     }
     if (threadIdx.x == 0) partial[16] = 0;
     uint32_t el[ROUNDS_PER_TILE];
-    tile_round<0>(v[0], edge[0], lane, tc, el[0]);
-    tile_round<1>(v[1], edge[1], lane, tc, el[1]);
-    tile_round<2>(v[2], edge[2], lane, tc, el[2]);
-    tile_round<3>(v[3], edge[3], lane, tc, el[3]);
+    if (SUM_ONLY) {
+        tile_round_sum<0>(v[0], edge[0], lane, el[0]);
+        tile_round_sum<1>(v[1], edge[1], lane, el[1]);
+        tile_round_sum<2>(v[2], edge[2], lane, el[2]);
+        tile_round_sum<3>(v[3], edge[3], lane, el[3]);
+    } else {
+        tile_round<0>(v[0], edge[0], lane, tc, el[0]);
+        tile_round<1>(v[1], edge[1], lane, tc, el[1]);
+        tile_round<2>(v[2], edge[2], lane, tc, el[2]);
+        tile_round<3>(v[3], edge[3], lane, tc, el[3]);
+    }
     __syncthreads();                                     // (partial[16] zeroed; also orders a caller's LDS writes before its use of them)
     // nearest line start before the chunk inside its group, and the group's last one
     uint32_t t_in[ROUNDS_PER_TILE];                      // 0: no line start before the chunk inside its group
@@ -321,7 +352,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_summarize_kernel(
         s.tag = 4u | fq_elem_nl(tc.total);
     } else {
         TileChunks tc;
-        tile_scan(raw, tile, partial, tc);
+        tile_scan<true>(raw, tile, partial, tc);
         // the exclusive prefix element of every 16-byte chunk: parse_pack needs exactly these and would otherwise repeat the
         // whole scan (4 bytes per 16 of input, against ~240 of its ~450 instructions per chunk)
         if (chunk_pre) {
@@ -578,25 +609,56 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
         TileChunks tc;
         const int st = state == T_NONE ? T_SEQ : state;   // only before the first line start of a file
         if (chunk_pre) {
-            // the scan of this tile was done by parse_summarize: its per-chunk prefixes and the tile's totals are read back
-            tile_rounds(raw, tile, tc);
+            // the scan of this tile was done by parse_summarize: its per-chunk prefixes and the tile's totals are read back.  A wave
+            // whose 1 KiB is clean and inside sequence lines -- nearly every one -- packs its chunks without masks or line types
+            // (clean_chunk_insert: ~110 instructions per chunk against ~240)
+            const int lane = lane_id();
+            uint4 v[ROUNDS_PER_TILE];
+            uint32_t edge[ROUNDS_PER_TILE], pre[ROUNDS_PER_TILE];
 #pragma unroll
-            for (int r = 0; r < ROUNDS_PER_TILE; r++) tc.pre[r] = chunk_pre[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x];
+            for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+                const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
+                v[r] = *reinterpret_cast<const uint4 *>(raw + base);
+                edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;
+                pre[r] = chunk_pre[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x];
+            }
             const TileSummary ts = sums[tile];
             n_tile = st == T_SEQ ? ts.v[0] + ts.v[1] : ts.v[0];
             __syncthreads();                              // (orders the zeroing above, as the scan's barrier does)
+#pragma unroll
+            for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+                const uint32_t w[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+                uint32_t z[4];
+                const uint32_t odd = clean_scan(w, z);
+                const int ev = pelem32_ev(pre[r]);
+                const int cin = ev ? ev : st;
+                const uint32_t pos = lead + (st == T_SEQ ? pelem32_cs(pre[r]) : pelem32_ch(pre[r]));
+                if (!__any(odd != 0u || cin != T_SEQ)) {
+                    const uint32_t nlc = clean_nl_count(z);
+                    const bool with_inv = __any(clean_bad_any(w, nlc) != 0u);
+                    clean_chunk_insert(w, z, nlc, pos, with_inv, or_sym, or_inv);
+                } else {
+                    uint32_t nl, gt, cr, ek, sep, unk, cs, ci;
+                    chunk_masks(w, nl, gt, cr);
+                    const uint32_t up = wave_shr1((nl >> 15) & 1u);
+                    const uint32_t ls = ((nl << 1) | (lane == 0 ? edge[r] : up)) & 0xffffu;
+                    chunk_classify(nl, gt, cr, ls, T_NONE, ek, sep, unk);
+                    const int cnt = chunk_pack(w, ek | (cin == T_SEQ ? unk : 0u), sep, cs, ci);
+                    stream_insert(pos, cnt, cs, ci, or_sym, or_inv);
+                }
+            }
         } else {
             tile_scan(raw, tile, partial, tc);
             n_tile = st == T_SEQ ? pelem32_cs(tc.total) : pelem32_ch(tc.total);
-        }
 #pragma unroll
-        for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-            const int ev = pelem32_ev(tc.pre[r]);
-            const int cin = ev ? ev : st;
-            const uint32_t emit = tc.ek[r] | (cin == T_SEQ ? tc.unk[r] : 0u);
-            uint32_t cs, ci;
-            const int cnt = chunk_pack(tc.w[r], emit, tc.sep[r], cs, ci);
-            stream_insert(lead + (st == T_SEQ ? pelem32_cs(tc.pre[r]) : pelem32_ch(tc.pre[r])), cnt, cs, ci, or_sym, or_inv);
+            for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+                const int ev = pelem32_ev(tc.pre[r]);
+                const int cin = ev ? ev : st;
+                const uint32_t emit = tc.ek[r] | (cin == T_SEQ ? tc.unk[r] : 0u);
+                uint32_t cs, ci;
+                const int cnt = chunk_pack(tc.w[r], emit, tc.sep[r], cs, ci);
+                stream_insert(lead + (st == T_SEQ ? pelem32_cs(tc.pre[r]) : pelem32_ch(tc.pre[r])), cnt, cs, ci, or_sym, or_inv);
+            }
         }
     }
     __syncthreads();

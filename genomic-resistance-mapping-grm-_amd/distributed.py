@@ -6,8 +6,9 @@ the presence-bit fill; the ONE exchange step is the union of the per-rank dictio
 
     rank r:  local distinct k-mers (uint64; (hi, lo) pairs for 33 <= k <= 64), grouped by hash
              bucket, + flag (1 = carried by one local genome, 2 = by several)  n_r entries
-    sizes (n_r, bucket geometry): host integers over gloo  ->  ONE all-gather over RCCL of one
-             fixed-stride record per rank (keys | flags | bucket offsets)
+    ONE all-gather over RCCL of one fixed-stride record per rank (keys | flags | bucket offsets | header with n_r and the
+             bucket geometry); the stride comes from the previous step's sizes, a rank that outgrew it says so in its header
+             and all ranks repeat (exchange_dict)
     every rank: the gathered lists are united bucket by bucket in LDS tables (ranks of a pan-genome
              hold nearly the same k-mers: what is left to sort is the union, not the sum), then the
              same deterministic sort / singleton filter  ->  identical global dictionary and
@@ -65,39 +66,69 @@ def _host_group(group):
     return _host_groups[key]
 
 
-def exchange_dict(batch, n_local, device, group=None, words=1, stats=None):
-    """the exchange step: every rank learns every rank's local dictionary.
+HEADER_BYTES = 16          # include/grm_kmer.h: GRM_EXCHANGE_HEADER_BYTES -- n_local u64 | bucket-bits code u32 | magic u32
+MAGIC = 0x584d5247
+_plans = {}                # per group: (n_cap, bucket bits) the next step lays its record out with
 
-    1. sizes: (n_local, bucket_bits) of every rank -- host integers over a gloo group, no device
-       round trip (n_local is on the host already);
-    2. ONE data-path collective: all-gather of one fixed-stride byte record per rank
-       (keys grouped by hash bucket | flags | bucket offsets; layout: grm_exchange_layout).
-    -> (payload uint8 tensor [world * stride], n_max, counts, bucket_bits)"""
+
+def _grow(n):
+    """capacity for a list of n entries: 1/16 of slack, whole KiB of flags"""
+    return max(1024, (n + n // 16 + 1023) // 1024 * 1024)
+
+
+def forget_plans():
+    """drop what earlier steps learnt about list sizes (tests; a group that is destroyed)"""
+    _plans.clear()
+
+
+def exchange_dict(batch, n_local, device, group=None, words=1, stats=None):
+    """the exchange step: every rank learns every rank's local dictionary in ONE collective -- an all-gather of one fixed-stride
+    byte record per rank (keys grouped by hash bucket | flags | bucket offsets | header; layout: grm_exchange_layout).
+
+    The stride must be the same on every rank before any of them knows the others' sizes: it comes from what the PREVIOUS step of
+    this group saw (largest list + 1/16, largest bucket count).  Every record ends in a header with its rank's n_local and bucket
+    geometry, so after the all-gather every rank knows the same world sizes: if a list did not fit its rank sent the header alone,
+    all ranks see that, and all repeat the step with the layout that fits -- no vote, no extra collective otherwise.  Only the very
+    first step of a group has nothing to go by and asks for the sizes over the host (gloo) group first.
+    -> (payload uint8 tensor [world * stride], n_cap, counts, bucket-bits codes)"""
     import time
     import torch
     import torch.distributed as dist
     t0 = time.perf_counter()
     world = dist.get_world_size(group)
-    mine = torch.tensor([n_local, batch.bucket_bits], dtype=torch.int64)
-    sizes = torch.empty(2 * world, dtype=torch.int64)
-    dist.all_gather_into_tensor(sizes, mine, group=_host_group(group))
-    counts = sizes[0::2].tolist()
-    bbs = sizes[1::2].tolist()
-    n_max = max(1, max(counts))
-    flags_off, boff_off, stride = batch.exchange_layout(n_max, words, max(v & 0xff for v in bbs))      # low byte: the bits; 0x100: minimizer buckets
-    rec = torch.empty(stride, dtype=torch.uint8, device=device)       # padding is never read
-    batch.export_dict_ordered(rec.data_ptr(), flags_off, boff_off)
-    payload = torch.empty(world * stride, dtype=torch.uint8, device=device)
-    _all_gather(payload, rec, group)
-    if payload.is_cuda:
-        # the engine launches on ITS OWN stream: the collective was only enqueued on torch's stream and
-        # must have finished before the raw pointer is handed over
-        torch.cuda.current_stream(payload.device).synchronize()
+    key = (id(group), words, world)
+    plan = _plans.get(key)
+    if plan is None:
+        mine = torch.tensor([n_local, batch.bucket_bits], dtype=torch.int64)
+        sizes = torch.empty(2 * world, dtype=torch.int64)
+        dist.all_gather_into_tensor(sizes, mine, group=_host_group(group))
+        plan = (_grow(max(sizes[0::2].tolist())), max(v & 0xff for v in sizes[1::2].tolist()))
+    while True:
+        n_cap, bits = plan
+        _, _, stride = batch.exchange_layout(n_cap, words, bits)
+        rec = torch.empty(stride, dtype=torch.uint8, device=device)       # padding is never read
+        batch.export_dict_record(rec.data_ptr(), n_cap, bits)
+        payload = torch.empty(world * stride, dtype=torch.uint8, device=device)
+        _all_gather(payload, rec, group)
+        # the headers, on the host: the copy is ordered behind the collective on torch's stream and the host waits for it -- the
+        # engine (which launches on ITS OWN stream) may take the raw pointer afterwards without another synchronize
+        heads = payload.view(world, stride)[:, stride - HEADER_BYTES:].contiguous().cpu().numpy()
+        counts = [int(v) for v in heads[:, :8].copy().view(np.uint64).reshape(-1)]
+        codes = heads[:, 8:].copy().view(np.uint32).reshape(world, 2)
+        if not (codes[:, 1] == MAGIC).all():
+            raise RuntimeError("exchange_dict: a record without a header (ranks of different versions?)")
+        bbs = [int(v) for v in codes[:, 0]]
+        if stats is not None:
+            stats["bytes"] += world * stride
+            stats["calls"] += 1
+        need = (max(counts), max(v & 0xff for v in bbs))
+        if need[0] <= n_cap and need[1] <= bits:
+            break
+        plan = (_grow(need[0]), max(bits, need[1]))
+    _plans[key] = (_grow(need[0]), need[1])
     if stats is not None:
-        stats["bytes"] += world * stride
         stats["ms"] += (time.perf_counter() - t0) * 1e3
-        stats["calls"] += 1
-    return payload, n_max, counts, bbs
+    return payload, n_cap, counts, bbs
 
 
 def sharded_step(batch, k, abundance_min, filter_singleton, device, group=None, stats=None):

@@ -486,6 +486,13 @@ class Batch(_Handle):
     def export_dict_ordered(self, dev_record_ptr, flags_off, boff_off):
         self.ctx._chk(self.ctx.L.grm_batch_export_dict_ordered(self.h, dev_record_ptr, flags_off, boff_off))
 
+    def export_dict_record(self, dev_record_ptr, n_cap, bucket_bits):
+        """the record of a layout fixed in advance (exchange_layout(n_cap, words, bucket_bits)): header always, lists if they fit
+        -> True when they did"""
+        fits = C.c_int()
+        self.ctx._chk(self.ctx.L.grm_batch_export_dict_record(self.h, dev_record_ptr, int(n_cap), int(bucket_bits), C.byref(fits)))
+        return bool(fits.value)
+
     def set_global_dict_gathered(self, dev_payload_ptr, n_max, counts, bucket_bits, filter_singleton, my_rank=-1):
         """my_rank: which record of the payload this batch wrote (export_dict_ordered) -- its entries then take their columns
         from the union's sort; -1: unknown (they are searched in the finished dictionary)"""

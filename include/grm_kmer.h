@@ -206,6 +206,14 @@ int  grm_batch_fill(grm_batch *, grm_matrix **out);
  * of the partition); grm_exchange_layout reads the low byte only, so pass the largest low byte of any rank.  Replaces
  * the k-mer delivery between Ray's MPI ranks (src/app.py:1310). */
 void grm_exchange_layout(uint64_t n_max, int words, int bucket_bits, uint64_t *flags_off, uint64_t *boff_off, uint64_t *stride);
+/* The last GRM_EXCHANGE_HEADER_BYTES of every record: { uint64 n_local; uint32 bucket-bits code (grm_batch_bucket_bits);
+ * uint32 GRM_EXCHANGE_MAGIC }.  With it a step needs ONE collective: the layout (n_cap, bucket_bits) is fixed from what the
+ * previous step saw, grm_batch_export_dict_record writes the header always and the lists when they fit (*fits), the host
+ * all-gathers, reads the n_ranks headers, and -- only if some rank did not fit -- repeats with the larger layout every rank now
+ * knows.  The reference has no such step (Ray's ranks exchange k-mers in many small MPI messages, src/app.py:1310). */
+#define GRM_EXCHANGE_HEADER_BYTES 16
+#define GRM_EXCHANGE_MAGIC 0x584d5247u /* "GRMX" */
+int  grm_batch_export_dict_record(grm_batch *, void *dev_record, uint64_t n_cap, int bucket_bits, int *fits);
 int  grm_batch_bucket_bits(const grm_batch *);
 int  grm_batch_export_dict_ordered(grm_batch *, void *dev_record, uint64_t flags_off, uint64_t boff_off);
 int  grm_batch_set_global_dict_gathered(grm_batch *, const void *dev_payload, int n_ranks, uint64_t n_max, const uint64_t *counts,

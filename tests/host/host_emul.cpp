@@ -150,6 +150,54 @@ uint64_t emul_parse2(const uint8_t *raw, uint64_t n_bytes, uint64_t tile_bytes, 
     return off;
 }
 
+// The clean-chunk route of parse_summarize / parse_pack beside the general one (grm_device_fns.h "clean chunks"): a chunk the kernels
+// would treat as clean (clean_scan says nothing odd; the kernels ask that of the whole wave) must get the SAME scan element from
+// clean_elem as from the masks, and -- when a sequence line runs into it -- the same symbols in the stream from clean_chunk_insert as
+// from chunk_pack + stream_insert.  Returns the number of symbols, ~0 on an element mismatch; *n_clean = chunks that took the route.
+uint64_t emul_parse3(const uint8_t *raw, uint64_t n_bytes, uint64_t tile_bytes, uint64_t *sym2, uint64_t *inv, uint64_t n_groups_cap, uint64_t *n_clean)
+{
+    std::memset(sym2, 0, n_groups_cap * 16);
+    std::memset(inv, 0, n_groups_cap * 8);
+    const uint64_t n_tiles = n_bytes / tile_bytes;
+    *n_clean = 0;
+    int state = T_SEQ;
+    uint64_t off = 0;
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        uint32_t pre = pelem32_make(0, 0, 0);
+        for (uint64_t base = t * tile_bytes; base < (t + 1) * tile_bytes; base += 16) {
+            uint32_t w[4], z[4], nl, gt, cr, ek, sep, unk;
+            std::memcpy(w, raw + base, 16);
+            chunk_masks(w, nl, gt, cr);
+            const uint32_t prev_nl = base == 0 ? 1u : (raw[base - 1] == '\n');
+            const uint32_t ls = ((nl << 1) | prev_nl) & 0xffffu;
+            chunk_classify(nl, gt, cr, ls, T_NONE, ek, sep, unk);
+            const uint32_t e = pelem32_make(chunk_last_event(ls, gt), __builtin_popcount(ek) + __builtin_popcount(unk), __builtin_popcount(ek));
+            const bool clean = clean_scan(w, z) == 0;
+            if (clean) {
+                if (clean_elem(z, prev_nl) != e || clean_nl_mask16(z) != nl) return ~0ull;
+            } else if ((gt | cr) == 0 && clean_nl_mask16(z) != nl) return ~0ull;
+            const int cin = pelem32_ev(pre) ? pelem32_ev(pre) : state;
+            const uint64_t pos = off + (state == T_SEQ ? pelem32_cs(pre) : pelem32_ch(pre));
+            const uint64_t wbase = (pos >> 6) << 6;
+            auto or_sym = [&](uint32_t wi, uint64_t v) { if ((wbase >> 5) + wi < n_groups_cap * 2) sym2[(wbase >> 5) + wi] |= v; };
+            auto or_inv = [&](uint32_t wi, uint64_t v) { if ((wbase >> 6) + wi < n_groups_cap) inv[(wbase >> 6) + wi] |= v; };
+            if (clean && cin == T_SEQ) {
+                const uint32_t nlc = clean_nl_count(z);
+                clean_chunk_insert(w, z, nlc, (uint32_t)(pos - wbase), clean_bad_any(w, nlc) != 0, or_sym, or_inv);
+                ++*n_clean;
+            } else {
+                uint32_t cs, ci;
+                const int cnt = chunk_pack(w, ek | (cin == T_SEQ ? unk : 0u), sep, cs, ci);
+                stream_insert((uint32_t)(pos - wbase), cnt, cs, ci, or_sym, or_inv);
+            }
+            pre = pelem32_combine(pre, e);
+        }
+        off += state == T_SEQ ? pelem32_cs(pre) : pelem32_ch(pre);
+        if (pelem32_ev(pre)) state = pelem32_ev(pre);
+    }
+    return off;
+}
+
 // FASTQ through the device primitives: per-chunk phase masks + associative elements.  Layout as
 // the batch builds it for FASTQ files: bytes + '\n', padded with '\n' (no synthetic header).
 uint64_t emul_parse_fastq(const uint8_t *raw, uint64_t n_bytes, uint64_t tile_bytes, uint64_t *sym2, uint64_t *inv, uint64_t n_groups_cap)

@@ -83,6 +83,16 @@ class OracleBatch:
         boff[0] = 0
         C.memmove(rec_ptr + boff_off, boff.ctypes.data, boff.nbytes)
 
+    def export_dict_record(self, rec_ptr, n_cap, bucket_bits):
+        flags_off, boff_off, stride = self.exchange_layout(n_cap, self.w, bucket_bits)
+        head = np.zeros(1, dtype=[("n", "<u8"), ("code", "<u4"), ("magic", "<u4")])
+        head["n"], head["code"], head["magic"] = len(self.lk), self.bucket_bits, 0x584d5247
+        C.memmove(rec_ptr + stride - 16, head.ctypes.data, 16)
+        fits = len(self.lk) <= n_cap and self.bucket_bits <= (bucket_bits & 0xff)
+        if fits:
+            self.export_dict_ordered(rec_ptr, flags_off, boff_off)
+        return fits
+
     def set_global_dict_gathered(self, payload_ptr, n_max, counts, bucket_bits, filter_singleton, my_rank=-1):
         flags_off, _, stride = self.exchange_layout(n_max, self.w, max(bucket_bits))
         raw = np.ctypeslib.as_array(C.cast(payload_ptr, C.POINTER(C.c_uint8)), shape=(stride * len(counts),))
@@ -168,6 +178,58 @@ def test_two_rank_gloo_matches_single_process_oracle(n_genomes, filt, k):
 
 
 # ---- the sharded spans of multi_gpu.py (N GPUs behind the command surface) on CPU: ranks over gloo, oracle-backed engine ----
+def _steps_worker(rank, world, port, sizes, q):
+    import torch
+    import torch.distributed as dist
+    import grm_amd  # noqa: F401
+    D = import_module(PKG + ".distributed")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        out = []
+        for step, n_genomes in enumerate(sizes):
+            genomes = _genomes(n_genomes)
+            a, b = D.shard_genomes(n_genomes, world)[rank]
+            batch = OracleBatch(genomes[a:b])
+            if step == len(sizes) - 1:
+                batch.bucket_bits = 5                        # and a rank geometry the layout did not plan for
+            stats = {"bytes": 0, "ms": 0.0, "calls": 0}
+            m = D.sharded_step(batch, 15, 1, True, torch.device("cpu"), stats=stats)
+            rows = D.gather_rows(m.data(), torch.device("cpu"))
+            out.append((m.kmers().copy(), rows, stats["calls"], stats["bytes"]))
+        if rank == 0:
+            q.put(out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_step_is_one_collective_and_a_list_that_outgrows_the_layout_is_sent_again():
+    """the record's stride comes from the previous step (distributed.exchange_dict): same sizes -> one all-gather and nothing else;
+    a dictionary more than 1/16 larger, or more buckets, than the layout allows -> every rank reads that in the headers and all repeat
+    the step once with the layout that fits; a smaller one -> one all-gather, and the layout shrinks for the step after"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    sizes = [70, 70, 200, 200, 70, 70, 70]
+    procs = [ctx.Process(target=_steps_worker, args=(r, 2, port, sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    calls = [o[2] for o in out]
+    assert calls == [1, 1, 2, 1, 1, 1, 2], calls                 # the last: the bucket geometry of that step did not fit
+    assert out[5][3] < out[4][3] == out[3][3]                    # the stride follows the sizes down again, one step behind
+    for n_genomes, (kmers, rows, _, _) in zip(sizes, out):
+        want = orc.build_matrix(_genomes(n_genomes), 15, 1, True)
+        assert (kmers == want["kmers"]).all() and (rows == want["matrix"]).all()
+
+
 class StandInMatrix(FakeMatrix):
     """what multi_gpu needs of engine.Matrix, on the host: the chunk streams come from zlib here (on the device: grm_deflate.hip),
     the append goes through the library's own grm_write_kover_h5_parts on a host-only matrix"""

@@ -33,6 +33,8 @@ def emul():
     L.emul_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
     L.emul_parse2.restype = C.c_uint64
     L.emul_parse2.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.emul_parse3.restype = C.c_uint64
+    L.emul_parse3.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.emul_parse_fastq.restype = C.c_uint64
     L.emul_parse_fastq.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     L.emul_kmers_wide.restype = C.c_uint64
@@ -83,6 +85,10 @@ def extract(emul, files, k):
         i2 = np.zeros(ng, dtype=np.uint64)
         n2 = emul.emul_parse2(raw.ctypes.data, len(raw), tile_bytes, s2.ctypes.data, i2.ctypes.data, ng)
         assert n2 == nsym and (s2 == sym2).all() and (i2 == inv).all()
+        # and with the chunks of letters and newlines only taking the kernels' short route
+        nc = C.c_uint64(0)
+        n3 = emul.emul_parse3(raw.ctypes.data, len(raw), tile_bytes, s2.ctypes.data, i2.ctypes.data, ng, C.byref(nc))
+        assert n3 == nsym and (s2 == sym2).all() and (i2 == inv).all()
     cap = max(1, int(nsym))
     out = np.zeros(cap, dtype=np.uint64)
     n = emul.emul_kmers(sym2.ctypes.data, inv.ctypes.data, nsym, k, out.ctypes.data, cap)
@@ -133,6 +139,33 @@ def test_long_lines_and_tile_straddling(emul):
                 if le.value:
                     state = le.value
             assert total == nsym
+
+
+def test_clean_chunks_take_the_short_route_to_the_same_stream(emul):
+    """letters-and-newlines chunks (what nearly every wave of a FASTA holds) through clean_elem / clean_chunk_insert: blank lines, lines
+    shorter than a chunk, a newline as the chunk's first or last byte, N runs, lower case, high bytes -- same stream as the masks give;
+    chunks with '>' or CR or a digit keep to the general route"""
+    rng = np.random.RandomState(77)
+    files = []
+    for width in (1, 2, 7, 15, 16, 17, 31, 60, 80, 333):
+        seq = "".join(rng.choice(list("ACGTNacgtnRYKM"), p=[.2, .2, .2, .2, .03, .03, .03, .03, .03, .01, .01, .01, .01, .01]) for _ in range(3000))
+        body = "\n".join(seq[i:i + width] for i in range(0, len(seq), width))
+        files.append((">c1 x\n" + body + "\n\n\n>c2\n" + body[:500] + "\n").encode())
+    files.append(b">h\nACGT\r\nAC9GT\nAC>GT\n" + bytes([65, 200, 67, 0xff, 71, 10]) * 40)
+    files.append(b"ACGT" * 5000)                                    # no header of its own, no newline for 20 000 bytes
+    for f in files:
+        raw = layout([f])
+        ng = len(raw) // 64 + 8
+        sym2 = np.zeros(2 * ng, dtype=np.uint64)
+        inv = np.zeros(ng, dtype=np.uint64)
+        nsym = emul.emul_parse(raw.ctypes.data, len(raw), sym2.ctypes.data, inv.ctypes.data, ng)
+        for tile_bytes in (TILE, 64):
+            s2 = np.zeros(2 * ng, dtype=np.uint64)
+            i2 = np.zeros(ng, dtype=np.uint64)
+            nc = C.c_uint64(0)
+            n3 = emul.emul_parse3(raw.ctypes.data, len(raw), tile_bytes, s2.ctypes.data, i2.ctypes.data, ng, C.byref(nc))
+            assert n3 == nsym and (s2 == sym2).all() and (i2 == inv).all()
+            assert nc.value > 0
 
 
 def test_valid_starts_bruteforce(emul):
