@@ -612,12 +612,13 @@ GRM_HD uint32_t clean_nl_count(const uint32_t z[4])
 {
     return (uint32_t)(__builtin_popcount(z[0]) + __builtin_popcount(z[1]) + __builtin_popcount(z[2]) + __builtin_popcount(z[3]));
 }
-GRM_HD uint32_t clean_first_nl(const uint32_t z[4])      // byte index of the chunk's first newline, 16: none
+GRM_HD uint32_t first_bit_or_max(uint32_t x) { return x ? (uint32_t)__builtin_ctz(x) : 0xffffffffu; }      // (v_ffbl_b32 as it is)
+GRM_HD uint32_t clean_first_nl(const uint32_t z[4])      // byte index of the chunk's first newline, 16: none -- no branches
 {
-    const uint64_t zl = (uint64_t)z[0] | ((uint64_t)z[1] << 32), zh = (uint64_t)z[2] | ((uint64_t)z[3] << 32);
-    if (zl) return (uint32_t)__builtin_ctzll(zl) >> 3;
-    if (zh) return 8u + ((uint32_t)__builtin_ctzll(zh) >> 3);
-    return 16u;
+    const uint32_t a = first_bit_or_max(z[0]), b = first_bit_or_max(z[1]) | 32u, c = first_bit_or_max(z[2]) | 64u, d = first_bit_or_max(z[3]) | 96u;
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    const uint32_t f = (ab < cd ? ab : cd) >> 3;
+    return f < 16u ? f : 16u;
 }
 GRM_HD uint32_t clean_nl_mask16(const uint32_t z[4])     // bit j <=> byte j is a newline (what chunk_masks calls nl)
 {

@@ -63,6 +63,27 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x)          // lane i <- 
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);
 }
+// exclusive prefixes of the tile's 16 (round, wave) group totals for this wave's four groups, and the sum of all 16: every row of 16
+// lanes scans the same 16 words with four DPP adds and the wave reads its four out with v_readlane -- the loop over 16 LDS words with
+// four selects each that this replaces was ~100 instructions per thread
+template <int STRIDE = 1>
+__device__ __forceinline__ void group_prefixes(const uint32_t *partial /* LDS [16 * STRIDE] */, int lane, int wave, uint32_t (&wp)[4], uint32_t &total)
+{
+    const uint32_t pv = partial[(lane & 15) * STRIDE];
+    uint32_t s = pv;
+    s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, false);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, false);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, false);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, false);
+    const uint32_t ex = s - pv;
+    const int w = __builtin_amdgcn_readfirstlane(wave);
+    wp[0] = (uint32_t)__builtin_amdgcn_readlane((int)ex, w);
+    wp[1] = (uint32_t)__builtin_amdgcn_readlane((int)ex, 4 + w);
+    wp[2] = (uint32_t)__builtin_amdgcn_readlane((int)ex, 8 + w);
+    wp[3] = (uint32_t)__builtin_amdgcn_readlane((int)ex, 12 + w);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)s, 15);
+}
+
 template <int R>
 __device__ __forceinline__ void tile_round_sum(const uint4 &v, uint32_t edge, int lane, uint32_t &elem)
 {
@@ -87,22 +108,33 @@ __device__ __forceinline__ void tile_round_sum(const uint4 &v, uint32_t edge, in
 //   cs   = the same if a sequence line does = ch + sum of pend_i = (ev_i == NONE ? extra_i : 0), extra = the chunk's bytes before
 //          its own first line start;
 // i.e. ONE integer prefix sum of the packed pair (known | pend << 16; a tile holds 16384 bytes): six DPP adds per round.
+// a thread's four chunks of a tile, and for lane 0 whether the byte before each is a newline (lanes > 0 ask their neighbour).  The
+// parse kernels issue these loads FIRST, before they read what kind of tile it is: a workgroup lives for one tile, and every dependent
+// load in front of these is time it holds its registers with nothing in flight
+struct TileLoad {
+    uint4 v[ROUNDS_PER_TILE];
+    uint32_t edge[ROUNDS_PER_TILE];
+};
+__device__ __forceinline__ void tile_load(const uint8_t *__restrict__ raw, uint32_t tile, TileLoad &tl)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
+        const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
+        tl.v[r] = *reinterpret_cast<const uint4 *>(raw + base);
+        tl.edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;
+    }
+}
+
 // SUM_ONLY: the caller wants tc.pre[] and tc.total only (parse_summarize), not the chunks' words and masks
 template <bool SUM_ONLY = false>
-__device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint32_t tile, uint64_t *partial64 /* LDS [16] */,
-                                          TileChunks &tc)
+__device__ __forceinline__ void tile_scan(const TileLoad &tl, uint64_t *partial64 /* LDS [16] */, TileChunks &tc)
 {
     uint32_t *partial = reinterpret_cast<uint32_t *>(partial64);        // [0..15]: group totals, [16]: last line-start type of every group, 2 bits each
     const int lane = lane_id(), wave = wave_id();
     static_assert(ROUNDS_PER_TILE == 4 && PARSE_THREADS == 256, "tile_scan assumes 4 rounds x 4 waves");
-    uint4 v[ROUNDS_PER_TILE];
-    uint32_t edge[ROUNDS_PER_TILE];
-#pragma unroll
-    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-        const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
-        v[r] = *reinterpret_cast<const uint4 *>(raw + base);
-        edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;   // lanes > 0 ask their neighbour
-    }
+    const uint4 (&v)[ROUNDS_PER_TILE] = tl.v;
+    const uint32_t (&edge)[ROUNDS_PER_TILE] = tl.edge;
     if (threadIdx.x == 0) partial[16] = 0;
     uint32_t el[ROUNDS_PER_TILE];
     if (SUM_ONLY) {
@@ -124,6 +156,12 @@ __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint3
     for (int r = 0; r < ROUNDS_PER_TILE; r++) {
         const uint32_t ev = (uint32_t)pelem32_ev(el[r]);
         const unsigned long long any = __ballot(ev != 0), hdr = __ballot(ev == (uint32_t)T_HDR);
+        if (hdr == 0ull) {                               // (a scalar branch) no header line starts in these 1 KiB: any line start is a sequence line's
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+            t_in[r] = before ? (uint32_t)T_SEQ : 0u;
+            if (lane == 0 && any) atomicOr(&partial[16], (uint32_t)T_SEQ << (2 * (r * (PARSE_THREADS / 64) + wave)));
+            continue;
+        }
         const unsigned long long m = any & below;
         const int src = 63 - (int)__builtin_clzll(m | 1ull);
         t_in[r] = m ? (((hdr >> src) & 1ull) ? (uint32_t)T_HDR : (uint32_t)T_SEQ) : 0u;
@@ -133,11 +171,11 @@ __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint3
         }
     }
     __syncthreads();
-    const uint32_t groups = partial[16];
+    const uint32_t groups = (uint32_t)__builtin_amdgcn_readfirstlane((int)partial[16]);          // (scalar: what follows of it is SALU work)
     uint32_t inc[ROUNDS_PER_TILE], own[ROUNDS_PER_TILE];
 #pragma unroll
     for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-        const int g = r * (PARSE_THREADS / 64) + wave;
+        const int g = r * (PARSE_THREADS / 64) + __builtin_amdgcn_readfirstlane(wave);
         const uint32_t lower = groups & ((1u << (2 * g)) - 1u);
         const uint32_t t_prev = lower ? (groups >> (2 * ((31 - (int)__builtin_clz(lower)) >> 1))) & 3u : 0u;
         const uint32_t t = t_in[r] ? t_in[r] : t_prev;          // type of the nearest line start before the chunk, 0 = none in this tile
@@ -151,43 +189,16 @@ __device__ __forceinline__ void tile_scan(const uint8_t *__restrict__ raw, uint3
         for (int r = 0; r < ROUNDS_PER_TILE; r++) partial[r * (PARSE_THREADS / 64) + wave] = inc[r];
     }
     __syncthreads();
-    // prefix of this (round, wave) over the 16 group totals, kept in scalars (no indexed array)
-    uint32_t acc = 0, wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (i == wave) wp0 = acc;
-        if (i == 4 + wave) wp1 = acc;
-        if (i == 8 + wave) wp2 = acc;
-        if (i == 12 + wave) wp3 = acc;
-        acc += partial[i];
-    }
+    // prefix of this (round, wave) over the 16 group totals
+    uint32_t wp[4], acc;
+    group_prefixes(partial, lane, wave, wp, acc);
     auto elem = [](uint32_t type, uint32_t packed) { return pelem32_make((int)type, (packed & 0xffffu) + (packed >> 16), packed & 0xffffu); };
     // the tile's total: its last line start is the last group's with one
     tc.total = elem(groups ? (groups >> (2 * ((31 - (int)__builtin_clz(groups)) >> 1))) & 3u : 0u, acc);
-    tc.pre[0] = elem(t_in[0], wp0 + inc[0] - own[0]);
-    tc.pre[1] = elem(t_in[1], wp1 + inc[1] - own[1]);
-    tc.pre[2] = elem(t_in[2], wp2 + inc[2] - own[2]);
-    tc.pre[3] = elem(t_in[3], wp3 + inc[3] - own[3]);
-}
-
-// the tile's chunks classified, WITHOUT the scan: the exclusive prefix element of every chunk comes from the caller (parse_pack reads
-// what parse_summarize's scan of the same tile left in chunk_pre)
-__device__ __forceinline__ void tile_rounds(const uint8_t *__restrict__ raw, uint32_t tile, TileChunks &tc)
-{
-    const int lane = lane_id();
-    uint4 v[ROUNDS_PER_TILE];
-    uint32_t edge[ROUNDS_PER_TILE];
-#pragma unroll
-    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-        const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
-        v[r] = *reinterpret_cast<const uint4 *>(raw + base);
-        edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;
-    }
-    uint32_t unused;
-    tile_round<0>(v[0], edge[0], lane, tc, unused);
-    tile_round<1>(v[1], edge[1], lane, tc, unused);
-    tile_round<2>(v[2], edge[2], lane, tc, unused);
-    tile_round<3>(v[3], edge[3], lane, tc, unused);
+    tc.pre[0] = elem(t_in[0], wp[0] + inc[0] - own[0]);
+    tc.pre[1] = elem(t_in[1], wp[1] + inc[1] - own[1]);
+    tc.pre[2] = elem(t_in[2], wp[2] + inc[2] - own[2]);
+    tc.pre[3] = elem(t_in[3], wp[3] + inc[3] - own[3]);
 }
 
 // FASTQ variant of the tile scan: the element carries the newline count mod 4 and the symbol
@@ -233,18 +244,11 @@ __device__ __forceinline__ uint64_t fq_elem_from16(uint32_t nl_mod4, uint64_t c1
 {
     return ((uint64_t)(nl_mod4 & 3u) << 60) | (c16 & 0x7fffull) | (((c16 >> 16) & 0x7fffull) << 15) | (((c16 >> 32) & 0x7fffull) << 30) | (((c16 >> 48) & 0x7fffull) << 45);
 }
-__device__ __forceinline__ void tile_scan_fq(const uint8_t *__restrict__ raw, uint32_t tile, uint64_t *partial /* LDS [16] */,
-                                             TileChunksFq &tc)
+__device__ __forceinline__ void tile_scan_fq(const TileLoad &tl, uint64_t *partial /* LDS [16] */, TileChunksFq &tc)
 {
     const int lane = lane_id(), wave = wave_id();
-    uint4 v[ROUNDS_PER_TILE];
-    uint32_t edge[ROUNDS_PER_TILE];
-#pragma unroll
-    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-        const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
-        v[r] = *reinterpret_cast<const uint4 *>(raw + base);
-        edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;
-    }
+    const uint4 (&v)[ROUNDS_PER_TILE] = tl.v;
+    const uint32_t (&edge)[ROUNDS_PER_TILE] = tl.edge;
     uint64_t el[ROUNDS_PER_TILE];
     tile_round_fq<0>(v[0], edge[0], lane, tc, el[0]);
     tile_round_fq<1>(v[1], edge[1], lane, tc, el[1]);
@@ -264,17 +268,9 @@ __device__ __forceinline__ void tile_scan_fq(const uint8_t *__restrict__ raw, ui
         for (int r = 0; r < ROUNDS_PER_TILE; r++) p32[r * (PARSE_THREADS / 64) + wave] = nl_inc[r];
     }
     __syncthreads();
-    uint32_t acc = 0, np0 = 0, np1 = 0, np2 = 0, np3 = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (i == wave) np0 = acc;
-        if (i == 4 + wave) np1 = acc;
-        if (i == 8 + wave) np2 = acc;
-        if (i == 12 + wave) np3 = acc;
-        acc += p32[i];
-    }
-    const uint32_t nl_total = acc;
-    const uint32_t nl_pre[ROUNDS_PER_TILE] = {np0 + nl_inc[0] - nl_own[0], np1 + nl_inc[1] - nl_own[1], np2 + nl_inc[2] - nl_own[2], np3 + nl_inc[3] - nl_own[3]};
+    uint32_t np[4], nl_total;
+    group_prefixes(p32, lane, wave, np, nl_total);
+    const uint32_t nl_pre[ROUNDS_PER_TILE] = {np[0] + nl_inc[0] - nl_own[0], np[1] + nl_inc[1] - nl_own[1], np[2] + nl_inc[2] - nl_own[2], np[3] + nl_inc[3] - nl_own[3]};
     // the chunks' counts, rotated to the tile's phases, summed
     uint64_t own[ROUNDS_PER_TILE], inc[ROUNDS_PER_TILE];
 #pragma unroll
@@ -290,15 +286,13 @@ __device__ __forceinline__ void tile_scan_fq(const uint8_t *__restrict__ raw, ui
         for (int r = 0; r < ROUNDS_PER_TILE; r++) partial[r * (PARSE_THREADS / 64) + wave] = inc[r];
     }
     __syncthreads();
-    uint64_t acc64 = 0, wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (i == wave) wp0 = acc64;
-        if (i == 4 + wave) wp1 = acc64;
-        if (i == 8 + wave) wp2 = acc64;
-        if (i == 12 + wave) wp3 = acc64;
-        acc64 += partial[i];
-    }
+    // (four 16-bit counts per word, none above 16384 in a whole tile: the two halves add up on their own)
+    uint32_t wlo[4], whi[4], tlo, thi;
+    group_prefixes<2>(p32, lane, wave, wlo, tlo);
+    group_prefixes<2>(p32 + 1, lane, wave, whi, thi);
+    const uint64_t acc64 = (uint64_t)tlo | ((uint64_t)thi << 32);
+    const uint64_t wp0 = (uint64_t)wlo[0] | ((uint64_t)whi[0] << 32), wp1 = (uint64_t)wlo[1] | ((uint64_t)whi[1] << 32);
+    const uint64_t wp2 = (uint64_t)wlo[2] | ((uint64_t)whi[2] << 32), wp3 = (uint64_t)wlo[3] | ((uint64_t)whi[3] << 32);
     tc.total = fq_elem_from16(nl_total, acc64);
     tc.pre[0] = fq_elem_from16(nl_pre[0], wp0 + inc[0] - own[0]);
     tc.pre[1] = fq_elem_from16(nl_pre[1], wp1 + inc[1] - own[1]);
@@ -307,17 +301,11 @@ __device__ __forceinline__ void tile_scan_fq(const uint8_t *__restrict__ raw, ui
 }
 
 // the FASTQ tile's chunks classified, without the scan (parse_pack: the prefix elements come from parse_summarize's chunk_pre64)
-__device__ __forceinline__ void tile_rounds_fq(const uint8_t *__restrict__ raw, uint32_t tile, TileChunksFq &tc)
+__device__ __forceinline__ void tile_rounds_fq(const TileLoad &tl, TileChunksFq &tc)
 {
     const int lane = lane_id();
-    uint4 v[ROUNDS_PER_TILE];
-    uint32_t edge[ROUNDS_PER_TILE];
-#pragma unroll
-    for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-        const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
-        v[r] = *reinterpret_cast<const uint4 *>(raw + base);
-        edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;
-    }
+    const uint4 (&v)[ROUNDS_PER_TILE] = tl.v;
+    const uint32_t (&edge)[ROUNDS_PER_TILE] = tl.edge;
 #pragma unroll
     for (int r = 0; r < ROUNDS_PER_TILE; r++) {
         tc.w[r][0] = v[r].x; tc.w[r][1] = v[r].y; tc.w[r][2] = v[r].z; tc.w[r][3] = v[r].w;
@@ -339,10 +327,12 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_summarize_kernel(
     __shared__ uint64_t partial[ROUNDS_PER_TILE * (PARSE_THREADS / 64)];
     const uint32_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
+    TileLoad tl;
+    tile_load(raw, tile, tl);
     TileSummary s;
     if (tile_meta[tile] & TILE_META_FASTQ) {
         TileChunksFq tc;
-        tile_scan_fq(raw, tile, partial, tc);
+        tile_scan_fq(tl, partial, tc);
         if (chunk_pre64) {
 #pragma unroll
             for (int r = 0; r < ROUNDS_PER_TILE; r++) chunk_pre64[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x] = tc.pre[r];
@@ -352,12 +342,17 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_summarize_kernel(
         s.tag = 4u | fq_elem_nl(tc.total);
     } else {
         TileChunks tc;
-        tile_scan<true>(raw, tile, partial, tc);
+        tile_scan<true>(tl, partial, tc);
         // the exclusive prefix element of every 16-byte chunk: parse_pack needs exactly these and would otherwise repeat the
         // whole scan (4 bytes per 16 of input, against ~240 of its ~450 instructions per chunk)
+        // In 16 bits: the type of the last line start before the chunk and cs, the symbols before it when a sequence line runs into
+        // the tile (< 16384).  ch, the count when a header line does, follows: nothing before the tile's first line start counts then,
+        // everything after it does, so ch = (a line start before the chunk ? cs - v[1] : 0) with the tile's v[1] (tests/host: emul_parse3).
         if (chunk_pre) {
+            uint16_t *pre16 = reinterpret_cast<uint16_t *>(chunk_pre);
 #pragma unroll
-            for (int r = 0; r < ROUNDS_PER_TILE; r++) chunk_pre[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x] = tc.pre[r];
+            for (int r = 0; r < ROUNDS_PER_TILE; r++)
+                pre16[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x] = (uint16_t)(((uint32_t)pelem32_ev(tc.pre[r]) << 14) | pelem32_cs(tc.pre[r]));
         }
         s.v[0] = pelem32_ch(tc.total);
         s.v[1] = pelem32_cs(tc.total) - pelem32_ch(tc.total);
@@ -566,7 +561,7 @@ __global__ void parse_prezero_kernel(const uint64_t *__restrict__ tile_off, uint
 // Every chunk packs its symbols into two small bit strings and ORs them into the tile's
 // LDS image of the packed stream (ds_or_b64); the image is then stored with coalesced writes.
 // Groups shared with a neighbouring tile go out through global atomicOr (buffers pre-zeroed).
-__global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
+__global__ __launch_bounds__(PARSE_THREADS, 6) void parse_pack_kernel(
     const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint8_t *__restrict__ tile_meta,
     const uint64_t *__restrict__ tile_off, const uint8_t *__restrict__ tile_state, uint64_t *__restrict__ sym2,
     uint64_t *__restrict__ inv, const TileSummary *__restrict__ sums, const uint32_t *__restrict__ chunk_pre, const uint64_t *__restrict__ chunk_pre64)
@@ -577,6 +572,8 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
     __shared__ uint64_t wi[MAX_GROUPS];
     const uint32_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
+    TileLoad tl;
+    tile_load(raw, tile, tl);
     for (int i = threadIdx.x; i < 2 * MAX_GROUPS; i += PARSE_THREADS) w2[i] = 0;
     for (int i = threadIdx.x; i < MAX_GROUPS; i += PARSE_THREADS) wi[i] = 0;
     const uint64_t sym_base = tile_off[tile];
@@ -588,13 +585,13 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
     if (tile_meta[tile] & TILE_META_FASTQ) {
         TileChunksFq tc;
         if (chunk_pre64) {
-            tile_rounds_fq(raw, tile, tc);
+            tile_rounds_fq(tl, tc);
 #pragma unroll
             for (int r = 0; r < ROUNDS_PER_TILE; r++) tc.pre[r] = chunk_pre64[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x];
             n_tile = sums[tile].v[state];
             __syncthreads();                              // (orders the zeroing above, as the scan's barriers do)
         } else {
-            tile_scan_fq(raw, tile, partial, tc);           // its barriers also order the zeroing above
+            tile_scan_fq(tl, partial, tc);                  // its barriers also order the zeroing above
             n_tile = fq_elem_cnt(tc.total, state);
         }
 #pragma unroll
@@ -613,14 +610,12 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
             // whose 1 KiB is clean and inside sequence lines -- nearly every one -- packs its chunks without masks or line types
             // (clean_chunk_insert: ~110 instructions per chunk against ~240)
             const int lane = lane_id();
-            uint4 v[ROUNDS_PER_TILE];
-            uint32_t edge[ROUNDS_PER_TILE], pre[ROUNDS_PER_TILE];
+            const uint4 (&v)[ROUNDS_PER_TILE] = tl.v;
+            const uint32_t (&edge)[ROUNDS_PER_TILE] = tl.edge;
+            uint32_t pre[ROUNDS_PER_TILE];
 #pragma unroll
             for (int r = 0; r < ROUNDS_PER_TILE; r++) {
-                const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
-                v[r] = *reinterpret_cast<const uint4 *>(raw + base);
-                edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;
-                pre[r] = chunk_pre[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x];
+                pre[r] = reinterpret_cast<const uint16_t *>(chunk_pre)[((uint64_t)tile * ROUNDS_PER_TILE + r) * PARSE_THREADS + threadIdx.x];
             }
             const TileSummary ts = sums[tile];
             n_tile = st == T_SEQ ? ts.v[0] + ts.v[1] : ts.v[0];
@@ -630,9 +625,10 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
                 const uint32_t w[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
                 uint32_t z[4];
                 const uint32_t odd = clean_scan(w, z);
-                const int ev = pelem32_ev(pre[r]);
+                const int ev = (int)(pre[r] >> 14);
                 const int cin = ev ? ev : st;
-                const uint32_t pos = lead + (st == T_SEQ ? pelem32_cs(pre[r]) : pelem32_ch(pre[r]));
+                const uint32_t cs_before = pre[r] & 0x3fffu;
+                const uint32_t pos = lead + (st == T_SEQ ? cs_before : (ev ? cs_before - ts.v[1] : 0u));
                 if (!__any(odd != 0u || cin != T_SEQ)) {
                     const uint32_t nlc = clean_nl_count(z);
                     const bool with_inv = __any(clean_bad_any(w, nlc) != 0u);
@@ -648,7 +644,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_pack_kernel(
                 }
             }
         } else {
-            tile_scan(raw, tile, partial, tc);
+            tile_scan(tl, partial, tc);
             n_tile = st == T_SEQ ? pelem32_cs(tc.total) : pelem32_ch(tc.total);
 #pragma unroll
             for (int r = 0; r < ROUNDS_PER_TILE; r++) {
@@ -801,13 +797,15 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_fused_kernel(
     TileChunks tc;
     TileChunksFq tq;
     TileSummary sum;
+    TileLoad tl;
+    tile_load(raw, tile, tl);
     if (fastq) {
-        tile_scan_fq(raw, tile, partial, tq);
+        tile_scan_fq(tl, partial, tq);
         sum.v[0] = fq_elem_cnt(tq.total, 0); sum.v[1] = fq_elem_cnt(tq.total, 1);
         sum.v[2] = fq_elem_cnt(tq.total, 2); sum.v[3] = fq_elem_cnt(tq.total, 3);
         sum.tag = 4u | fq_elem_nl(tq.total);
     } else {
-        tile_scan(raw, tile, partial, tc);
+        tile_scan(tl, partial, tc);
         sum.v[0] = pelem32_ch(tc.total);
         sum.v[1] = pelem32_cs(tc.total) - pelem32_ch(tc.total);
         sum.v[2] = sum.v[3] = 0;
@@ -3192,7 +3190,7 @@ void launch_parse_summarize(hipStream_t s, const uint8_t *raw, uint32_t n_tiles,
 {
     hipLaunchKernelGGL(parse_summarize_kernel, dim3(n_tiles), dim3(PARSE_THREADS), 0, s, raw, n_tiles, tile_meta, sums, chunk_pre, chunk_pre64);
 }
-// 4 bytes per 16-byte chunk (FASTA tiles); with FASTQ tiles in the batch 8 more per chunk behind them (chunk_pre64 = chunk_pre + the 4-byte part)
+// 2 bytes per 16-byte chunk (FASTA tiles; the buffer keeps 4); with FASTQ tiles in the batch 8 more per chunk behind them (chunk_pre64 = chunk_pre + the 4-byte part)
 size_t parse_chunk_pre_bytes(uint32_t n_tiles, bool with_fastq) { return (size_t)n_tiles * ROUNDS_PER_TILE * PARSE_THREADS * (with_fastq ? 12 : 4); }
 // scratch: n_tiles * 20 B (tile prefixes) + n_blocks * (20 + 1 + 8) B + 8 B
 size_t parse_scan_scratch_bytes(uint32_t n_tiles)

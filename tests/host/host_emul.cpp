@@ -162,10 +162,13 @@ uint64_t emul_parse3(const uint8_t *raw, uint64_t n_bytes, uint64_t tile_bytes, 
     *n_clean = 0;
     int state = T_SEQ;
     uint64_t off = 0;
+    std::vector<uint32_t> pres;
     for (uint64_t t = 0; t < n_tiles; t++) {
         uint32_t pre = pelem32_make(0, 0, 0);
+        pres.clear();
         for (uint64_t base = t * tile_bytes; base < (t + 1) * tile_bytes; base += 16) {
             uint32_t w[4], z[4], nl, gt, cr, ek, sep, unk;
+            pres.push_back(pre);
             std::memcpy(w, raw + base, 16);
             chunk_masks(w, nl, gt, cr);
             const uint32_t prev_nl = base == 0 ? 1u : (raw[base - 1] == '\n');
@@ -192,6 +195,10 @@ uint64_t emul_parse3(const uint8_t *raw, uint64_t n_bytes, uint64_t tile_bytes, 
             }
             pre = pelem32_combine(pre, e);
         }
+        // what parse_summarize keeps of a chunk's prefix is 16 bits (line-start type, cs); parse_pack takes ch from the tile's summary
+        const uint32_t v1 = pelem32_cs(pre) - pelem32_ch(pre);
+        for (uint32_t q : pres)
+            if (pelem32_ch(q) != (pelem32_ev(q) ? pelem32_cs(q) - v1 : 0u) || pelem32_cs(q) >= (1u << 14)) return ~0ull - 1;
         off += state == T_SEQ ? pelem32_cs(pre) : pelem32_ch(pre);
         if (pelem32_ev(pre)) state = pelem32_ev(pre);
     }
