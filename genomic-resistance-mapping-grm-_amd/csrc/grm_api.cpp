@@ -912,13 +912,23 @@ static int wide_stage_export(grm_batch *b, void *dev_keys_out, void *dev_flags_o
 static int wide_stage_export_ordered(grm_batch *b, uint8_t *rec, uint64_t flags_off, uint64_t boff_off);
 static int wide_stage_global(grm_batch *b, const void *dev_keys, const void *dev_flags, uint64_t n, int filter_singleton, uint64_t *n_kmers);
 static int wide_stage_fill(grm_batch *b, grm_matrix **out);
+// the same calls over the SORT path (grm_multi.hip): k > 64, and 33 <= k <= 64 with abundance-min > 1 -- what grm_batch_run does for
+// those in one go (multi_matrix / wide_matrix), cut into the stages the multi-GPU and chunked routes need
+struct SortedStage;
+static void sorted_stage_free(SortedStage *);
+static int sorted_stage_local(grm_batch *b, int k, uint32_t abundance_min);
+static int sorted_stage_export(grm_batch *b, void *dev_keys_out, void *dev_flags_out);
+static int sorted_stage_global(grm_batch *b, const void *dev_keys, const void *dev_flags, uint64_t n, int filter_singleton, uint64_t *n_kmers);
+static int sorted_stage_fill(grm_batch *b, grm_matrix **out);
 
 struct grm_batch {
     CtxRef ctx;
     WideSorted *wide = nullptr;      // two-word (k > 32) sort path buffers, created on first use
     MultiSorted *multi = nullptr;    // three- / four-word (k > 64) sort path buffers
     WideHash *whash = nullptr;       // two-word hash-partition path buffers
-    ~grm_batch() { wide_free(wide); multi_free(multi); wide_hash_free(whash); }
+    SortedStage *sorted = nullptr;   // staged calls over the sort path: the batch's own matrix and the global dictionary
+    bool sorted_stage = false;       // the current partition went that way
+    ~grm_batch() { wide_free(wide); multi_free(multi); wide_hash_free(whash); sorted_stage_free(sorted); }
     int n_genomes = 0;
     std::vector<HostFile> files;
     bool uploaded = false, partitioned = false, have_local = false, have_global = false;
@@ -1782,10 +1792,16 @@ static int batch_partition_impl(grm_batch *b, int k, uint32_t abundance_min, boo
 extern "C" int grm_batch_partition(grm_batch *b, int k, uint32_t abundance_min)
 {
     if (!b) return GRM_ERR_ARG;
-    if (k > 64) return fail(b->ctx, GRM_ERR_UNSUPPORTED, "k=%d: the staged (multi-GPU / chunked) API handles k <= 64; use grm_batch_run or counted sets", k);
+    b->sorted_stage = false;
+    if (k > 64 || (k > 32 && abundance_min > 1)) {
+        // three- / four-word k-mers, and two-word ones with an abundance filter: the sort path, which leaves the batch's own
+        // dictionary AND its presence bits behind
+        int rc = batch_partition_impl(b, k, abundance_min, false);
+        if (rc) return rc;
+        return sorted_stage_local(b, k, abundance_min < 1 ? 1 : abundance_min);
+    }
     if (k > 32 && k <= 64) {
         // two-word k-mers: the hash-partition pipeline, which also leaves the local dictionary behind
-        if (abundance_min > 1) return fail(b->ctx, GRM_ERR_UNSUPPORTED, "k=%d: the staged (multi-GPU) API takes abundance-min 1 for k > 32", k);
         int rc = batch_partition_impl(b, k, abundance_min, false);
         if (rc) return rc;
         return wide_stage_local(b, k);
@@ -1991,6 +2007,10 @@ extern "C" int grm_batch_local_dict(grm_batch *b, uint64_t *n_local)
     if (!b) return GRM_ERR_ARG;
     grm_ctx *c = b->ctx;
     if (!b->partitioned) return fail(c, GRM_ERR_STATE, "grm_batch_local_dict before grm_batch_partition");
+    if (b->sorted_stage) {
+        if (n_local) *n_local = b->n_local;
+        return GRM_OK;
+    }
     if (b->k > 32) return wide_stage_n_local(b, n_local);
     HIPCHK(c, hipSetDevice(c->device));
     b->have_local = b->have_global = false;
@@ -2066,6 +2086,7 @@ extern "C" int grm_batch_export_dict(grm_batch *b, void *dev_keys_out, void *dev
     grm_ctx *c = b->ctx;
     if (!b->have_local) return fail(c, GRM_ERR_STATE, "grm_batch_export_dict before grm_batch_local_dict");
     HIPCHK(c, hipSetDevice(c->device));
+    if (b->sorted_stage) return sorted_stage_export(b, dev_keys_out, dev_flags_out);
     if (b->k > 32) return wide_stage_export(b, dev_keys_out, dev_flags_out);
     if (b->n_local) {
         HIPCHK(c, hipMemcpyAsync(dev_keys_out, b->d_local_keys.p, b->n_local * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -2268,6 +2289,7 @@ extern "C" int grm_batch_set_global_dict(grm_batch *b, const void *dev_keys, con
     if (n && (!dev_keys || !dev_flags)) return fail(c, GRM_ERR_ARG, "grm_batch_set_global_dict: NULL buffers");
     if (n >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "dictionary of %llu k-mers exceeds 2^32-1 columns", (unsigned long long)n);
     HIPCHK(c, hipSetDevice(c->device));
+    if (b->sorted_stage) return sorted_stage_global(b, dev_keys, dev_flags, n, filter_singleton, n_kmers);
     if (b->k > 32) return wide_stage_global(b, dev_keys, dev_flags, n, filter_singleton, n_kmers);
     b->have_global = false;
     b->filter_singleton = filter_singleton;
@@ -2299,7 +2321,7 @@ extern "C" void grm_exchange_layout(uint64_t n_max, int words, int bucket_bits, 
 }
 // bucket geometry of the batch as ranks compare it: bucket bits, + 0x100 when the buckets are minimizer buckets
 // (record form) -- lists of ranks with different codes cannot be united bucket by bucket
-extern "C" int grm_batch_bucket_bits(const grm_batch *b) { return b ? (b->bb | (b->rec_mode ? 0x100 : 0)) : 0; }
+extern "C" int grm_batch_bucket_bits(const grm_batch *b) { return !b || b->sorted_stage ? 0 : (b->bb | (b->rec_mode ? 0x100 : 0)); }
 
 extern "C" int grm_batch_export_dict_ordered(grm_batch *b, void *dev_record, uint64_t flags_off, uint64_t boff_off)
 {
@@ -2309,6 +2331,14 @@ extern "C" int grm_batch_export_dict_ordered(grm_batch *b, void *dev_record, uin
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     uint8_t *rec = (uint8_t *)dev_record;
+    if (b->sorted_stage) {
+        // a sorted list has no hash buckets: one bucket holds it all (bucket bits 0; lists of several words are never united bucket by bucket)
+        const uint32_t boff[2] = {0u, (uint32_t)b->n_local};
+        int rc = sorted_stage_export(b, rec, rec + flags_off);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpy(rec + boff_off, boff, sizeof boff, hipMemcpyHostToDevice));
+        return GRM_OK;
+    }
     if (b->k > 32) return wide_stage_export_ordered(b, rec, flags_off, boff_off);
     const uint32_t B = 1u << b->bb;
     if (b->total_keys == 0 || b->n_local == 0) {
@@ -2342,8 +2372,8 @@ extern "C" int grm_batch_export_dict_record(grm_batch *b, void *dev_record, uint
     if (!b->have_local) return fail(c, GRM_ERR_STATE, "grm_batch_export_dict_record before grm_batch_local_dict");
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t flags_off, boff_off, stride;
-    grm_exchange_layout(n_cap, b->k > 32 ? 2 : 1, bucket_bits, &flags_off, &boff_off, &stride);
-    const bool ok = b->n_local <= n_cap && b->bb <= (bucket_bits & 0xff);
+    grm_exchange_layout(n_cap, words_of(b->k), bucket_bits, &flags_off, &boff_off, &stride);
+    const bool ok = b->n_local <= n_cap && (grm_batch_bucket_bits(b) & 0xff) <= (bucket_bits & 0xff);
     if (fits) *fits = ok ? 1 : 0;
     struct { uint64_t n_local; uint32_t code, magic; } head = {b->n_local, (uint32_t)grm_batch_bucket_bits(b), GRM_EXCHANGE_MAGIC};
     static_assert(sizeof head == GRM_EXCHANGE_HEADER_BYTES, "exchange header");
@@ -2378,7 +2408,7 @@ static int set_global_dict_gathered(grm_batch *b, const void *dev_payload, int n
     if (!dev_payload) return fail(c, GRM_ERR_ARG, "grm_batch_set_global_dict_gathered: NULL payload");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const int words = b->k > 32 ? 2 : 1;
+    const int words = words_of(b->k);
     int bb_max = 0, bb_min = 255;
     bool same_kind = true;                 // hashed buckets or minimizer buckets, the same on every rank
     uint64_t total = 0;
@@ -2471,6 +2501,7 @@ extern "C" int grm_batch_fill(grm_batch *b, grm_matrix **out)
     grm_ctx *c = b->ctx;
     if (!b->have_global) return fail(c, GRM_ERR_STATE, "grm_batch_fill before grm_batch_set_global_dict");
     HIPCHK(c, hipSetDevice(c->device));
+    if (b->sorted_stage) return sorted_stage_fill(b, out);
     if (b->k > 32) return wide_stage_fill(b, out);
     hipStream_t s = c->stream;
     grm_matrix *m = new grm_matrix();
@@ -2652,7 +2683,7 @@ extern "C" int grm_dict_accum_add(grm_dict_accum *a, grm_batch *b)
     if (b->ctx != c) return fail(c, GRM_ERR_ARG, "grm_dict_accum_add: batch of another context");
     if (!b->have_local) return fail(c, GRM_ERR_STATE, "grm_dict_accum_add before grm_batch_local_dict");
     HIPCHK(c, hipSetDevice(c->device));
-    const int words = b->k > 32 ? 2 : 1;
+    const int words = words_of(b->k);
     if (a->words && a->words != words) return fail(c, GRM_ERR_ARG, "grm_dict_accum_add: batches with different k");
     a->words = words;
     const uint64_t add = b->n_local, need = a->n + add;
@@ -2684,7 +2715,7 @@ extern "C" int grm_batch_set_global_dict_accum(grm_batch *b, const grm_dict_accu
     if (!b || !a_) return GRM_ERR_ARG;
     grm_dict_accum *a = const_cast<grm_dict_accum *>(a_);      // the cached dictionary is not part of its visible state
     grm_ctx *c = b->ctx;
-    if (a->words && a->words != (b->k > 32 ? 2 : 1)) return fail(c, GRM_ERR_ARG, "accumulator holds k-mers of another width");
+    if (a->words && a->words != words_of(b->k)) return fail(c, GRM_ERR_ARG, "accumulator holds k-mers of another width");
     if (b->k > 32 || !a->n) return grm_batch_set_global_dict(b, a->keys.p, a->flags.p, a->n, filter_singleton, n_kmers);
     if (!b->partitioned) return fail(c, GRM_ERR_STATE, "grm_batch_set_global_dict_accum before grm_batch_partition");
     HIPCHK(c, hipSetDevice(c->device));
@@ -2864,12 +2895,21 @@ struct MultiSorted {
 static void multi_free(MultiSorted *w) { delete w; }
 
 // parse must have run (batch_partition_impl with k > 64), or K[] is preloaded with total_syms valid keys
-static int multi_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, MultiSorted &M, bool preloaded = false)
+// lists: the preloaded keys are not the batch's genomes but lists of their own (the staged calls' gathered dictionaries): n_lists
+// of them, bounds in the device array list_off, n_keys keys in all
+struct MultiLists {
+    const uint64_t *list_off = nullptr;
+    uint32_t n_lists = 0;
+    uint64_t n_keys = 0;
+};
+static int multi_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, MultiSorted &M, bool preloaded = false, const MultiLists *lists = nullptr)
 {
     grm_ctx *c = b->ctx;
     hipStream_t s = c->stream;
     const int W = words_of(k);
-    const uint64_t N = b->total_syms;
+    const uint64_t N = lists ? lists->n_keys : b->total_syms;
+    const uint64_t *gso = lists ? lists->list_off : b->d_genome_sym_off.as<uint64_t>();
+    const uint32_t n_gen = lists ? lists->n_lists : (uint32_t)b->n_genomes;
     if (N >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "k > 64 path is limited to 2^32-1 symbols per batch (got %llu)", (unsigned long long)N);
     M.n = M.n_sub = 0;
     M.words = W;
@@ -2919,8 +2959,7 @@ static int multi_sort_and_mark(grm_batch *b, int k, uint32_t abundance_min, Mult
     if (n == 0) return GRM_OK;
     TimeScope t(c, "multi_mark", n);
     HIPCHK(c, M.key_head.ensure((size_t)n * 4)); HIPCHK(c, M.kg_head.ensure((size_t)n * 4)); HIPCHK(c, M.sub_id.ensure((size_t)n * 4));
-    launch_multi_mark(s, W, M.sorted(), M.pos(), b->d_genome_sym_off.as<uint64_t>(), (uint32_t)b->n_genomes, n, M.key_head.as<uint32_t>(),
-                      M.kg_head.as<uint32_t>());
+    launch_multi_mark(s, W, M.sorted(), M.pos(), gso, n_gen, n, M.key_head.as<uint32_t>(), M.kg_head.as<uint32_t>());
     int rc = wide_scan(c, M.tmp, false, M.kg_head.as<uint32_t>(), M.sub_id.as<uint32_t>(), n);
     if (rc) return rc;
     uint32_t last_id = 0, last_flag = 0;
@@ -2991,13 +3030,13 @@ static int multi_matrix(grm_batch *b, int k, uint32_t abundance_min, int filter_
 }
 
 // single-genome batch -> sorted counted set (W words per k-mer)
-static int multi_set(grm_batch *b, int k, uint32_t abundance_min, grm_kmer_set **out)
+static int multi_set(grm_batch *b, int k, uint32_t abundance_min, grm_kmer_set **out, const MultiLists *lists = nullptr)
 {
     grm_ctx *c = b->ctx;
     hipStream_t s = c->stream;
     if (!b->multi) b->multi = new MultiSorted();
     MultiSorted &M = *b->multi;
-    int rc = multi_sort_and_mark(b, k, abundance_min, M);
+    int rc = multi_sort_and_mark(b, k, abundance_min, M, lists != nullptr, lists);
     if (rc) return rc;
     const int W = words_of(k);
     grm_kmer_set *set = new grm_kmer_set();
@@ -3070,6 +3109,139 @@ static int build_matrix_multi(grm_ctx *c, grm_kmer_set *const *sets, int n_genom
     rc = body();
     grm_batch_free(b);
     return rc;
+}
+
+// ---- the staged calls over the sort path -----------------------------------------------------------------------
+// grm_batch_partition    parse, then multi_matrix WITHOUT the singleton filter: the batch's own matrix = its sorted dictionary
+//                        (n_local x W words) and its presence bits; flag of a column = 1 / 2 for one / several carriers
+// export_dict            copies of the two
+// set_global_dict        the gathered lists (each holds distinct keys), with the entries flagged 2 laid out twice: sorted as ONE list
+//                        (multi_set, the counted set of a single-genome batch) a key that is "in two lists, or flagged in one" is a
+//                        run of length >= 2 -- the singleton filter is that call's abundance filter
+// fill                   every own column looks its key up in the global dictionary (binary search) and moves there
+struct SortedStage {
+    grm_matrix *own = nullptr;
+    DevBuf flags, gkeys, col, list_off, mark, pos;
+    uint64_t n_global = 0;
+    int words = 0;
+};
+static void sorted_stage_free(SortedStage *s)
+{
+    if (!s) return;
+    delete s->own;
+    delete s;
+}
+static int sorted_stage_local(grm_batch *b, int k, uint32_t abundance_min)
+{
+    grm_ctx *c = b->ctx;
+    if (!b->sorted) b->sorted = new SortedStage();
+    SortedStage &S = *b->sorted;
+    delete S.own;
+    S.own = nullptr;
+    b->have_local = b->have_global = false;
+    b->exported_ordered = false;
+    grm_matrix *m = nullptr;
+    int rc = multi_matrix(b, k, abundance_min, 0, &m);
+    if (rc) return rc;
+    S.own = m;
+    S.words = m->words;
+    b->n_local = m->n_kmers;
+    HIPCHK(c, S.flags.ensure(m->n_kmers + 16));
+    launch_multi_flags(c->stream, m->d_data.as<uint64_t>(), m->n_rows, m->n_kmers, S.flags.as<uint8_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    b->sorted_stage = true;
+    b->partitioned = true;
+    b->have_local = true;
+    return GRM_OK;
+}
+static int sorted_stage_export(grm_batch *b, void *dev_keys_out, void *dev_flags_out)
+{
+    grm_ctx *c = b->ctx;
+    SortedStage &S = *b->sorted;
+    if (b->n_local) {
+        HIPCHK(c, hipMemcpyAsync(dev_keys_out, S.own->d_kmers.p, b->n_local * 8 * (size_t)S.words, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dev_flags_out, S.flags.p, b->n_local, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GRM_OK;
+}
+static int sorted_stage_global(grm_batch *b, const void *dev_keys, const void *dev_flags, uint64_t n, int filter_singleton, uint64_t *n_kmers)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    if (!b->sorted || !b->sorted->own) return fail(c, GRM_ERR_STATE, "grm_batch_set_global_dict before grm_batch_partition");
+    SortedStage &S = *b->sorted;
+    const int W = S.words;
+    b->have_global = false;
+    b->filter_singleton = filter_singleton;
+    S.n_global = 0;
+    if (n) {
+        MultiSorted &M = *b->multi;
+        HIPCHK(c, S.mark.ensure((n + 1) * 4));
+        HIPCHK(c, S.pos.ensure((n + 1) * 4));
+        launch_multi_flag_mark(s, (const uint8_t *)dev_flags, n, S.mark.as<uint32_t>());
+        int rc = wide_scan(c, M.tmp, false, S.mark.as<uint32_t>(), S.pos.as<uint32_t>(), n);
+        if (rc) return rc;
+        uint32_t last_pos = 0, last_mark = 0;
+        HIPCHK(c, hipMemcpyAsync(&last_pos, S.pos.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&last_mark, S.mark.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        const uint64_t total = n + last_pos + last_mark;
+        if (total >= 0xffffffffull) return fail(c, GRM_ERR_UNSUPPORTED, "gathered dictionaries of %llu entries exceed 2^32-1", (unsigned long long)total);
+        MultiWordsOut dst;
+        for (int j = 0; j < 4; j++) dst.w[j] = nullptr;
+        for (int j = 0; j < W; j++) { HIPCHK(c, M.K[j].ensure((total + 2) * 8)); dst.w[j] = M.K[j].as<uint64_t>(); }
+        launch_multi_split(s, W, (const uint64_t *)dev_keys, n, dst, 0);
+        launch_multi_split_marked(s, W, (const uint64_t *)dev_keys, S.mark.as<uint32_t>(), S.pos.as<uint32_t>(), n, dst, n);
+        HIPCHK(c, hipGetLastError());
+        const uint64_t bounds[2] = {0, total};
+        HIPCHK(c, S.list_off.ensure(sizeof bounds));
+        HIPCHK(c, hipMemcpyAsync(S.list_off.p, bounds, sizeof bounds, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        MultiLists lists;
+        lists.list_off = S.list_off.as<uint64_t>(); lists.n_lists = 1; lists.n_keys = total;
+        const uint64_t keys_before = b->total_keys;
+        grm_kmer_set *set = nullptr;
+        rc = multi_set(b, b->k, filter_singleton ? 2u : 1u, &set, &lists);
+        b->total_keys = keys_before;
+        if (rc) { delete set; return rc; }
+        S.n_global = set->n;
+        hipError_t e = S.gkeys.ensure((set->n + 1) * 8 * (size_t)W);
+        if (e == hipSuccess && set->n) e = hipMemcpyAsync(S.gkeys.p, set->d_kmers.p, set->n * 8 * (size_t)W, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        delete set;
+        if (e != hipSuccess) return fail(c, GRM_ERR_HIP, "global dictionary copy: %s", hipGetErrorString(e));
+    }
+    b->have_global = true;
+    if (n_kmers) *n_kmers = S.n_global;
+    return GRM_OK;
+}
+static int sorted_stage_fill(grm_batch *b, grm_matrix **out)
+{
+    grm_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    SortedStage &S = *b->sorted;
+    const int W = S.words;
+    grm_matrix *m = new grm_matrix();
+    m->ctx = c; m->k = b->k; m->words = W; m->n_genomes = b->n_genomes;
+    m->n_rows = ((size_t)b->n_genomes + 63) / 64;
+    m->n_kmers = S.n_global;
+    const size_t cells = m->n_rows * m->n_kmers;
+    auto bail = [&](int code) { delete m; return code; };
+    if (m->d_data.alloc(cells * 8) != hipSuccess || m->d_kmers.alloc((m->n_kmers + 1) * 8 * (size_t)W) != hipSuccess)
+        return bail(fail(c, GRM_ERR_OOM, "matrix allocation failed (%zu cells)", cells));
+    if (S.col.ensure(((size_t)b->n_local + 1) * 4) != hipSuccess) return bail(fail(c, GRM_ERR_OOM, "alloc"));
+    if (cells) (void)hipMemsetAsync(m->d_data.p, 0, cells * 8, s);
+    if (m->n_kmers) (void)hipMemcpyAsync(m->d_kmers.p, S.gkeys.p, m->n_kmers * 8 * (size_t)W, hipMemcpyDeviceToDevice, s);
+    if (cells && b->n_local) {
+        TimeScope t(c, "multi_fill", (uint64_t)b->n_local * m->n_rows);
+        launch_multi_lookup(s, W, S.own->d_kmers.as<uint64_t>(), b->n_local, S.gkeys.as<uint64_t>(), S.n_global, S.col.as<uint32_t>());
+        launch_multi_scatter_cols(s, S.own->d_data.as<uint64_t>(), b->n_local, S.col.as<uint32_t>(), m->n_rows, m->d_data.as<uint64_t>(), m->n_kmers);
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return bail(fail(c, GRM_ERR_HIP, "multi_fill failed"));
+    *out = m;
+    return GRM_OK;
 }
 
 // ---- two-word k-mers: hash-partition pipeline (grm_wide_hash.hip) ------------------------------

@@ -323,6 +323,13 @@ void launch_multi_emit(hipStream_t s, int words, const MultiWords &S, const uint
 void launch_multi_set(hipStream_t s, int words, const MultiWords &S, const uint32_t *sub_start, const uint32_t *sub_ok, const uint32_t *out_pos,
                       uint32_t n_sub, uint64_t *kmers, uint32_t *counts);
 void launch_multi_split(hipStream_t s, int words, const uint64_t *keys, uint64_t n, const MultiWordsOut &out, uint64_t at);
+// the staged calls over the sort path (k > 64; 33..64 with abundance-min > 1)
+void launch_multi_flags(hipStream_t s, const uint64_t *matrix, uint64_t n_rows, uint64_t n_cols, uint8_t *flags);
+void launch_multi_flag_mark(hipStream_t s, const uint8_t *flags, uint64_t n, uint32_t *mark);
+void launch_multi_split_marked(hipStream_t s, int words, const uint64_t *keys, const uint32_t *mark, const uint32_t *pos, uint64_t n,
+                               const MultiWordsOut &out, uint64_t at);
+void launch_multi_lookup(hipStream_t s, int words, const uint64_t *mine, uint64_t n, const uint64_t *dict, uint64_t n_dict, uint32_t *col);
+void launch_multi_scatter_cols(hipStream_t s, const uint64_t *own, uint64_t n_own, const uint32_t *col, uint64_t n_rows, uint64_t *out, uint64_t n_cols);
 
 // ---- two-word k-mers, hash-partition pipeline (grm_wide_hash.hip) ----
 void launch_wh_hist(hipStream_t s, const KmerLaunch &L, uint32_t *counts);

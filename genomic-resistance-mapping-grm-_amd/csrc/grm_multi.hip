@@ -167,10 +167,12 @@ static inline uint32_t mgrid(uint64_t n)
     return (uint32_t)(g < 1 ? 1 : (g > 256u * 32u ? 256u * 32u : g));
 }
 
-#define GRM_MULTI_DISPATCH(W_, CALL3, CALL4) \
-    do {                                     \
-        if ((W_) == 3) { CALL3; }            \
-        else { CALL4; }                      \
+// (W = 2: two-word k-mers take this path only where the hash-partition pipeline does not apply in the staged calls -- abundance-min > 1)
+#define GRM_MULTI_KERNEL(W_, KERNEL, GRID, ...)                                                             \
+    do {                                                                                                    \
+        if ((W_) == 2) hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(256), 0, s, __VA_ARGS__);                   \
+        else if ((W_) == 3) hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(256), 0, s, __VA_ARGS__);              \
+        else hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), 0, s, __VA_ARGS__);                             \
     } while (0)
 
 void launch_multi_extract(hipStream_t s, int words, const uint64_t *sym2, const uint64_t *inv, uint64_t total_syms, int k,
@@ -179,39 +181,121 @@ void launch_multi_extract(hipStream_t s, int words, const uint64_t *sym2, const 
     if (!total_syms) return;
     const uint64_t n_threads = (total_syms + MULTI_PPT - 1) / MULTI_PPT;
     const dim3 grid((uint32_t)((n_threads + 255) / 256));
-    GRM_MULTI_DISPATCH(words, hipLaunchKernelGGL(multi_extract_kernel<3>, grid, dim3(256), 0, s, sym2, inv, total_syms, k, out, n_valid),
-                       hipLaunchKernelGGL(multi_extract_kernel<4>, grid, dim3(256), 0, s, sym2, inv, total_syms, k, out, n_valid));
+    GRM_MULTI_KERNEL(words, multi_extract_kernel, grid, sym2, inv, total_syms, k, out, n_valid);
 }
 void launch_multi_mark(hipStream_t s, int words, const MultiWords &S, const uint32_t *pos, const uint64_t *gso, uint32_t n_genomes, uint32_t n,
                        uint32_t *key_head, uint32_t *kg_head)
 {
     if (!n) return;
-    GRM_MULTI_DISPATCH(words, hipLaunchKernelGGL(multi_mark_kernel<3>, dim3(mgrid(n)), dim3(256), 0, s, S, pos, gso, n_genomes, n, key_head, kg_head),
-                       hipLaunchKernelGGL(multi_mark_kernel<4>, dim3(mgrid(n)), dim3(256), 0, s, S, pos, gso, n_genomes, n, key_head, kg_head));
+    GRM_MULTI_KERNEL(words, multi_mark_kernel, dim3(mgrid(n)), S, pos, gso, n_genomes, n, key_head, kg_head);
 }
 void launch_multi_emit(hipStream_t s, int words, const MultiWords &S, const uint32_t *pos, const uint64_t *gso, uint32_t n_genomes,
                        const uint32_t *sub_start, const uint32_t *sub_key_head, const uint32_t *sub_ok, const uint32_t *key_incl,
                        const uint32_t *keep, const uint32_t *col, uint32_t n_sub, uint64_t *dict, uint64_t *matrix, uint64_t n_cols)
 {
     if (!n_sub) return;
-    GRM_MULTI_DISPATCH(words,
-                       hipLaunchKernelGGL(multi_emit_kernel<3>, dim3(mgrid(n_sub)), dim3(256), 0, s, S, pos, gso, n_genomes, sub_start, sub_key_head,
-                                          sub_ok, key_incl, keep, col, n_sub, dict, matrix, n_cols),
-                       hipLaunchKernelGGL(multi_emit_kernel<4>, dim3(mgrid(n_sub)), dim3(256), 0, s, S, pos, gso, n_genomes, sub_start, sub_key_head,
-                                          sub_ok, key_incl, keep, col, n_sub, dict, matrix, n_cols));
+    GRM_MULTI_KERNEL(words, multi_emit_kernel, dim3(mgrid(n_sub)), S, pos, gso, n_genomes, sub_start, sub_key_head, sub_ok, key_incl, keep, col, n_sub,
+                     dict, matrix, n_cols);
 }
 void launch_multi_set(hipStream_t s, int words, const MultiWords &S, const uint32_t *sub_start, const uint32_t *sub_ok, const uint32_t *out_pos,
                       uint32_t n_sub, uint64_t *kmers, uint32_t *counts)
 {
     if (!n_sub) return;
-    GRM_MULTI_DISPATCH(words, hipLaunchKernelGGL(multi_set_kernel<3>, dim3(mgrid(n_sub)), dim3(256), 0, s, S, sub_start, sub_ok, out_pos, n_sub, kmers, counts),
-                       hipLaunchKernelGGL(multi_set_kernel<4>, dim3(mgrid(n_sub)), dim3(256), 0, s, S, sub_start, sub_ok, out_pos, n_sub, kmers, counts));
+    GRM_MULTI_KERNEL(words, multi_set_kernel, dim3(mgrid(n_sub)), S, sub_start, sub_ok, out_pos, n_sub, kmers, counts);
 }
 void launch_multi_split(hipStream_t s, int words, const uint64_t *keys, uint64_t n, const MultiWordsOut &out, uint64_t at)
 {
     if (!n) return;
-    GRM_MULTI_DISPATCH(words, hipLaunchKernelGGL(multi_split_kernel<3>, dim3(mgrid(n)), dim3(256), 0, s, keys, n, out, at),
-                       hipLaunchKernelGGL(multi_split_kernel<4>, dim3(mgrid(n)), dim3(256), 0, s, keys, n, out, at));
+    GRM_MULTI_KERNEL(words, multi_split_kernel, dim3(mgrid(n)), keys, n, out, at);
+}
+
+// ---- the staged calls (partition / local_dict / export / set_global_dict / fill) over this path -------------------------------
+// flag of every column of a batch's own matrix: 1 = carried by one of its genomes, 2 = by several
+__global__ void multi_flags_kernel(const uint64_t *__restrict__ matrix, uint64_t n_rows, uint64_t n_cols, uint8_t *__restrict__ flags)
+{
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t n = 0;
+        for (uint64_t r = 0; r < n_rows && n < 2; r++) n += (uint32_t)__popcll(matrix[r * n_cols + c]);
+        flags[c] = (uint8_t)(n < 2 ? n : 2);
+    }
+}
+void launch_multi_flags(hipStream_t s, const uint64_t *matrix, uint64_t n_rows, uint64_t n_cols, uint8_t *flags)
+{
+    if (!n_cols) return;
+    hipLaunchKernelGGL(multi_flags_kernel, dim3(mgrid(n_cols)), dim3(256), 0, s, matrix, n_rows, n_cols, flags);
+}
+// mark[i] = entry i of a gathered list says "several carriers" (flag 2): those entries are laid out a second time behind the n
+// others (at n + pos[i], pos = exclusive scan of mark), so that "in two lists, or flagged in one" becomes "twice in the sorted whole"
+__global__ void multi_flag_mark_kernel(const uint8_t *__restrict__ flags, uint64_t n, uint32_t *__restrict__ mark)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mark[i] = flags[i] >= 2 ? 1u : 0u;
+}
+void launch_multi_flag_mark(hipStream_t s, const uint8_t *flags, uint64_t n, uint32_t *mark)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(multi_flag_mark_kernel, dim3(mgrid(n)), dim3(256), 0, s, flags, n, mark);
+}
+template <int W>
+__global__ void multi_split_marked_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ mark, const uint32_t *__restrict__ pos,
+                                          uint64_t n, MultiWordsOut out, uint64_t at)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (!mark[i]) continue;
+#pragma unroll
+        for (int j = 0; j < W; j++) out.w[j][at + pos[i]] = keys[(uint64_t)W * i + j];
+    }
+}
+void launch_multi_split_marked(hipStream_t s, int words, const uint64_t *keys, const uint32_t *mark, const uint32_t *pos, uint64_t n,
+                               const MultiWordsOut &out, uint64_t at)
+{
+    if (!n) return;
+    GRM_MULTI_KERNEL(words, multi_split_marked_kernel, dim3(mgrid(n)), keys, mark, pos, n, out, at);
+}
+// column of every key of a sorted list `mine` (n x W words) in the sorted dictionary `dict` (n_dict x W): binary search; ~0 = not there
+template <int W>
+__global__ void multi_lookup_kernel(const uint64_t *__restrict__ mine, uint64_t n, const uint64_t *__restrict__ dict, uint64_t n_dict,
+                                    uint32_t *__restrict__ col)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        KeyW<W> key;
+#pragma unroll
+        for (int j = 0; j < W; j++) key.w[j] = mine[(uint64_t)W * i + j];
+        uint64_t lo = 0, hi = n_dict;                  // first entry >= key
+        while (lo < hi) {
+            const uint64_t m = (lo + hi) >> 1;
+            KeyW<W> d;
+#pragma unroll
+            for (int j = 0; j < W; j++) d.w[j] = dict[(uint64_t)W * m + j];
+            if (key_less<W>(d, key)) lo = m + 1; else hi = m;
+        }
+        bool same = lo < n_dict;
+        if (same) {
+#pragma unroll
+            for (int j = 0; j < W; j++) same = same && dict[(uint64_t)W * lo + j] == key.w[j];
+        }
+        col[i] = same ? (uint32_t)lo : ~0u;
+    }
+}
+void launch_multi_lookup(hipStream_t s, int words, const uint64_t *mine, uint64_t n, const uint64_t *dict, uint64_t n_dict, uint32_t *col)
+{
+    if (!n) return;
+    GRM_MULTI_KERNEL(words, multi_lookup_kernel, dim3(mgrid(n)), mine, n, dict, n_dict, col);
+}
+// the batch's own columns moved to their places in the global matrix (zeroed by the caller): out[r][col[c]] = own[r][c]
+__global__ void multi_scatter_cols_kernel(const uint64_t *__restrict__ own, uint64_t n_own, const uint32_t *__restrict__ col, uint64_t n_rows,
+                                          uint64_t *__restrict__ out, uint64_t n_cols)
+{
+    const uint64_t total = n_rows * n_own;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = t / n_own, c = t - r * n_own;
+        const uint32_t g = col[c];
+        if (g != ~0u) out[r * n_cols + g] = own[t];
+    }
+}
+void launch_multi_scatter_cols(hipStream_t s, const uint64_t *own, uint64_t n_own, const uint32_t *col, uint64_t n_rows, uint64_t *out, uint64_t n_cols)
+{
+    if (!n_own || !n_rows) return;
+    hipLaunchKernelGGL(multi_scatter_cols_kernel, dim3(mgrid(n_rows * n_own)), dim3(256), 0, s, own, n_own, col, n_rows, out, n_cols);
 }
 
 }  // namespace grm

@@ -138,7 +138,7 @@ def sharded_step(batch, k, abundance_min, filter_singleton, device, group=None, 
     import torch.distributed as dist
     batch.partition(k, abundance_min)
     n_local = batch.local_dict()
-    words = 2 if k > 32 else 1
+    words = (k + 31) // 32
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         import torch
         keys = torch.empty((max(1, n_local), words), dtype=torch.int64, device=device)

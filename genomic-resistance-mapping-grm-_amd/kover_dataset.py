@@ -284,7 +284,7 @@ def matrix_of_files(ctx, files_per_genome, kmer_size, abundance_min, filter_sing
         batch.free()
         return m
     rows_chunks = plan_chunks(files_per_genome, DEFAULT_BATCH_BYTES, multiple=KMER_MATRIX_PACKING_SIZE)
-    if rows_chunks is not None and kmer_size <= 64 and (abundance_min <= 1 or kmer_size <= 32):
+    if rows_chunks is not None:
         # contig sets beyond one device batch: two passes over chunks of whole word-rows
         progress("%d genomes in %d chunks, two passes" % (len(files_per_genome), len(rows_chunks)))
         return two_pass_matrix(ctx, files_per_genome, rows_chunks, kmer_size, abundance_min, filter_singleton, progress)[0]

@@ -187,10 +187,6 @@ def ranks_worth_starting(n_genomes, n_ranks):
 # ---- the sharded spans -------------------------------------------------------------------------
 def shardable(files_per_genome, world, kmer_size, abundance_min):
     """None when the genomes can be split over `world` ranks, else why not (the caller then runs on one device)"""
-    if kmer_size > 64:
-        return "the staged (multi-GPU) calls stop at k = 64"
-    if kmer_size > 32 and abundance_min > 1:
-        return "abundance-min > 1 at k > 32 goes through the counted-set path"
     shards = Dm.shard_genomes(len(files_per_genome), world)
     for a, b in shards:
         if sum(kd._input_bytes(f) for fl in files_per_genome[a:b] for f in fl) > kd.DEFAULT_BATCH_BYTES:

@@ -165,10 +165,11 @@ def test_kover_create_from_contig_tree(genomes, tmp_path):
     os.remove(tsv)
 
 
-@pytest.mark.parametrize("k,filt", [(31, True), (47, False)])
+@pytest.mark.parametrize("k,filt", [(31, True), (47, False), (90, True)])
 def test_kover_create_two_pass_chunks(tmp_path, k, filt):
     """contig sets beyond the device budget: two passes over chunks of 64 genomes (dictionary
-    accumulator, row stacking); 150 genomes with a budget of ~70 genome files -> chunks 64, 64, 22"""
+    accumulator, row stacking); 150 genomes with a budget of ~70 genome files -> chunks 64, 64, 22.  k = 90: three-word k-mers, the
+    staged calls over the sort path"""
     import grm_amd  # noqa: F401
     kd = import_module(PKG + ".kover_dataset")
     synth = import_module(PKG + ".synth")

@@ -56,7 +56,7 @@ def _datasets(path):
     return r.genome_identifiers, r.kmer_sequences, r.kmer_matrix, r.kmer_by_matrix_column
 
 
-@pytest.mark.parametrize("k,devices,singletons", [(31, "0,0", False), (31, "0,0,0,0", True), (63, "0,0,0", False)])
+@pytest.mark.parametrize("k,devices,singletons", [(31, "0,0", False), (31, "0,0,0,0", True), (63, "0,0,0", False), (80, "0,0", False)])
 def test_kover_create_over_ranks_equals_one_rank(strains, tmp_path, k, devices, singletons):
     """`kover dataset create from-contigs` with GRM_DEVICES: a parent that touches no GPU, one child per device, each child reads its
     own files, one dictionary exchange, every rank deflates the chunks of its own word-rows, rank 0 appends.  "0,0,0,0": 150

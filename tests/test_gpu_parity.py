@@ -429,38 +429,72 @@ def test_deep_read_set_counts(ctx):
         ctx.timing(False)
 
 
-@pytest.mark.parametrize("k", [31, 63])
-def test_staged_equals_fused(ctx, k):
-    """the staged (multi-GPU) API on one device; k = 63: keys travel as (hi, lo) pairs"""
+@pytest.mark.parametrize("k,amin", [(31, 1), (63, 1), (40, 2), (70, 1), (100, 2), (128, 1)])
+def test_staged_equals_fused(ctx, k, amin):
+    """the staged (multi-GPU) API on one device; k = 63: keys travel as (hi, lo) pairs; k > 64, or an abundance filter at k > 32: the
+    sort path in stages -- rows of three / four words, most significant first (grm_batch_run covers those in one call)"""
     import torch
-    w = 2 if k > 32 else 1
+    w = (k + 31) // 32
     genomes = _medium_genomes(n=4, length=100_000, seed=3)
-    want = orc.build_matrix(genomes, k, 1, True)
+    if amin > 1:          # every genome twice over, the second copy with its own SNPs: most k-mers are seen twice, some once
+        other = _medium_genomes(n=4, length=100_000, seed=4)
+        genomes = [[a[0] + b[0]] for a, b in zip(genomes, [other[0]] + genomes[:3])]
+    want = orc.build_matrix(genomes, k, amin, True)
     b = ctx.batch(len(genomes))
     for g, files in enumerate(genomes):
         b.add(g, files[0])
     b.upload()
-    b.partition(k, 1)
+    b.partition(k, amin)
     n_local = b.local_dict()
     keys = torch.empty((max(1, n_local), w), dtype=torch.int64, device="cuda:0")
     flags = torch.empty(max(1, n_local), dtype=torch.uint8, device="cuda:0")
     b.export_dict(keys.data_ptr(), flags.data_ptr())
     torch.cuda.synchronize()
     # local dictionary = every distinct k-mer of the union, flag 2 where >1 genome carries it
-    allm = orc.build_matrix(genomes, k, 1, False)
+    allm = orc.build_matrix(genomes, k, amin, False)
     k_host = keys.cpu().numpy().view(np.uint64)[:n_local]
     order = np.lexsort(tuple(k_host[:, j] for j in reversed(range(w))))
-    assert (k_host[order] == allm["kmers"]).all()
+    assert n_local == allm["kmers"].shape[0] and (k_host[order].reshape(allm["kmers"].shape) == allm["kmers"]).all()
     assert ((flags.cpu().numpy()[:n_local][order] == 2) == (allm["n_genomes_with"] > 1)).all()
     u = b.set_global_dict(keys.data_ptr(), flags.data_ptr(), n_local, True)
     assert u == want["kmers"].shape[0]
     m = b.fill()
     assert (m.kmers() == want["kmers"]).all() and (m.data() == want["matrix"]).all()
     m.free()
+    # and as two "ranks" on the one device: the genomes in two batches, their dictionaries handed to both
+    halves = [genomes[:1], genomes[1:]]
+    bs, ks, fs, ns = [], [], [], []
+    for part in halves:
+        bb = ctx.batch(len(part))
+        for g, files in enumerate(part):
+            bb.add(g, files[0])
+        bb.upload()
+        bb.partition(k, amin)
+        n = bb.local_dict()
+        kk = torch.empty((max(1, n), w), dtype=torch.int64, device="cuda:0")
+        ff = torch.empty(max(1, n), dtype=torch.uint8, device="cuda:0")
+        bb.export_dict(kk.data_ptr(), ff.data_ptr())
+        bs.append(bb); ks.append(kk[:n]); fs.append(ff[:n]); ns.append(n)
+    torch.cuda.synchronize()
+    allk, allf = torch.cat(ks).contiguous(), torch.cat(fs).contiguous()
+    for filt in (True, False):
+        wantf = orc.build_matrix(genomes, k, amin, filt)
+        got = np.zeros_like(wantf["matrix"])
+        for i, bb in enumerate(bs):
+            assert bb.set_global_dict(allk.data_ptr(), allf.data_ptr(), sum(ns), filt) == wantf["kmers"].shape[0]
+            mm = bb.fill()
+            assert (mm.kmers() == wantf["kmers"]).all()
+            d = mm.data()                      # one word-row per batch here: OR the rows together, each batch's genomes at its own bits
+            shift = sum(len(h) for h in halves[:i])
+            got[0] |= d[0] >> np.uint64(shift)
+            mm.free()
+        assert (got == wantf["matrix"]).all()
+    for bb in bs:
+        bb.free()
     b.free()
 
 
-def _rank_worker(rank, world, port, n_genomes, k, genome_len, q):
+def _rank_worker(rank, world, port, n_genomes, k, genome_len, q, amin=1):
     """one rank of the sharded path with the REAL engine; both ranks share cuda:0 (gloo, host-staged)"""
     import torch
     import torch.distributed as dist
@@ -477,7 +511,7 @@ def _rank_worker(rank, world, port, n_genomes, k, genome_len, q):
                 batch.add_array(g - a, pg.genome(g))
             batch.upload()
             dev = torch.device("cuda", 0)
-            m = D.sharded_step(batch, k, 1, True, dev)
+            m = D.sharded_step(batch, k, amin, True, dev)
             rows = D.gather_rows(m.data(), dev)
             if rank == 0:
                 q.put((m.kmers().copy(), rows))
@@ -489,7 +523,7 @@ def _rank_worker(rank, world, port, n_genomes, k, genome_len, q):
 
 
 @pytest.mark.parametrize("k,genome_len,n_genomes", [(31, 60_000, 100), (47, 60_000, 100), (31, 1_500_000, 100), (63, 1_500_000, 100),
-                                                     (47, 30_000, 400), (63, 30_000, 300)])
+                                                     (47, 30_000, 400), (63, 30_000, 300), (95, 60_000, 100)])
 def test_two_ranks_real_engine_one_gpu(ctx, k, genome_len, n_genomes):
     """N>1 path end to end with the HIP engine: 2 processes, genomes sharded 64 + 36, dictionary
     all-gather, identical global dictionary, rows stacked == single-process oracle matrix
@@ -534,7 +568,7 @@ def _nccl_worker(port, q):
             # record all-gather over RCCL, the rank union on the gathered payload
             n_local = (batch.partition(31, 1), batch.local_dict())[1]
             payload, n_max, counts, bbs = D.exchange_dict(batch, n_local, dev, None, 1)
-            assert counts == [n_local] and n_max == max(1, n_local) and payload.is_cuda
+            assert counts == [n_local] and n_max >= max(1, n_local) and payload.is_cuda
             batch.set_global_dict_gathered(payload.data_ptr(), n_max, counts, bbs, True)
             m = batch.fill()
             rows = D.gather_rows(m.data(), dev)
@@ -647,8 +681,8 @@ def test_two_word_kmers(ctx, k, tmp_path):
         tsv = str(tmp_path / "m.tsv")
         m.write_tsv(ids, tsv)
         assert [l.split("\t")[0] for l in open(tsv).read().split("\n")[1:] if l] == orc.decode_kmers(want["kmers"], k)
-        with pytest.raises(grm.GrmError):
-            b.partition(k, 2)                      # staged multi-GPU API at k > 32: abundance-min 1 only, and says so
+        b.partition(k, 2)                          # the staged calls at k > 32 with an abundance filter: the sort path (test_staged_equals_fused)
+        assert b.local_dict() == orc.build_matrix(genomes, k, 2, False)["kmers"].shape[0]
         m.free(); b.free()
 
 
@@ -848,8 +882,10 @@ def test_errors_are_loud(ctx):
         b.run(129, 1, False)        # the reference's range ends at 128 (bin/kover/kover:114)
     assert e.value.code == -1
     with pytest.raises(grm.GrmError) as e:
-        b.partition(65, 1)          # staged (multi-GPU / chunked) API: k <= 64
-    assert e.value.code == -6
+        b.partition(129, 1)         # the staged calls: the same range
+    assert e.value.code == -1
+    b.partition(65, 1)              # (k > 64 in stages: the sort path; a 4-base input holds no 65-mer)
+    assert b.local_dict() == 0
     b.free()
 
 
