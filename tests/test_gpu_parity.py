@@ -547,6 +547,60 @@ def test_two_ranks_real_engine_one_gpu(ctx, k, genome_len, n_genomes):
     assert rows.shape == want["matrix"].shape and (rows == want["matrix"]).all()
 
 
+def _growing_worker(rank, world, port, q):
+    """two steps of one process group with the REAL engine: the second step's dictionaries are ten times the first's, so the layout the
+    first step left behind does not hold them -- every rank sends its header alone, reads the others', and the step is repeated"""
+    import torch
+    import torch.distributed as dist
+    import grm_amd
+    D = import_module("genomic-resistance-mapping-grm-_amd.distributed")
+    S = import_module("genomic-resistance-mapping-grm-_amd.synth")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        out = []
+        with grm_amd.Context(0) as c:
+            dev = torch.device("cuda", 0)
+            for genome_len in (20_000, 200_000, 200_000):
+                pg = S.PanGenome(genome_len=genome_len, n_snps=genome_len // 100, n_accessory=6, accessory_len=1500, seed=21, n_contigs=2)
+                a, b_ = D.shard_genomes(100, world)[rank]
+                batch = c.batch(b_ - a)
+                for g in range(a, b_):
+                    batch.add_array(g - a, pg.genome(g))
+                batch.upload()
+                stats = {"bytes": 0, "ms": 0.0, "calls": 0}
+                m = D.sharded_step(batch, 31, 1, True, dev, stats=stats)
+                rows = D.gather_rows(m.data(), dev)
+                out.append((m.kmers().copy(), rows, stats["calls"]))
+                m.free()
+                batch.free()
+        if rank == 0:
+            q.put(out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_a_dictionary_that_outgrows_the_exchange_layout(ctx):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_growing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [o[2] for o in out] == [1, 2, 1]          # collectives per step: the second step twice, the third fits what the second learnt
+    for genome_len, (kmers, rows, _) in zip((20_000, 200_000, 200_000), out):
+        pg = synth.PanGenome(genome_len=genome_len, n_snps=genome_len // 100, n_accessory=6, accessory_len=1500, seed=21, n_contigs=2)
+        want = orc.pipeline([pg.genome(g).tobytes() for g in range(100)], 31, 1, True, min(os.cpu_count() or 1, 32))[0]
+        assert kmers.shape == want["kmers"].shape and (kmers == want["kmers"]).all()
+        assert rows.shape == want["matrix"].shape and (rows == want["matrix"]).all()
+
+
 def _nccl_worker(port, q):
     import torch
     import torch.distributed as dist
