@@ -25,7 +25,7 @@ def run(ctx, budget, seed, say=print):
     t0 = time.time()
     n_cases = 0
     while time.time() - t0 < budget:
-        k = int(rng.choice([19, 21, 25, 31, 32, 33, 34, 47, 63, 64]))
+        k = int(rng.choice([19, 21, 25, 31, 32, 33, 34, 47, 63, 64, 65, 96, 128]))
         n = int(rng.choice([1, 2, 3, 7, 40, 70, 129, 150]))
         L = int(rng.choice([2_000, 20_000, 150_000])) if n <= 7 else int(rng.choice([1_500, 8_000, 25_000]))
         pg = synth.realistic(genome_len=L, seed=int(rng.randint(1 << 30)), contigs=(1, 6), indel_sites=max(1, L // 3000), n_snps=max(1, L // 80),
@@ -78,6 +78,37 @@ def run(ctx, budget, seed, say=print):
                     if not ok:
                         desc += " [through the .kover writer, chunk_cols=%d gzip=%d]" % (cw, gz)
             m.free()
+            if ok and n >= 2 and rng.rand() < 0.35:
+                # the staged calls, as the chunked and multi-GPU routes use them: the genomes in two batches (the second starts a new
+                # word-row block only if the cut is a multiple of 64: the rows are compared genome by genome instead), both local
+                # dictionaries in an accumulator, each batch filled against the merged dictionary
+                cut = int(rng.randint(1, n))
+                acc = ctx.dict_accum()
+                parts = []
+                for lo, hi in ((0, cut), (cut, n)):
+                    bb = ctx.batch(hi - lo)
+                    for gi in range(lo, hi):
+                        for f in genomes[gi]:
+                            bb.add(gi - lo, f)
+                    bb.upload()
+                    bb.partition(k, amin)
+                    bb.local_dict()
+                    acc.add(bb)
+                    parts.append((lo, hi, bb))
+                for lo, hi, bb in parts:
+                    u = bb.set_global_dict_accum(acc, filt)
+                    mm = bb.fill()
+                    ok = ok and u == want["kmers"].shape[0] and (mm.kmers() == want["kmers"]).all()
+                    d = mm.data()
+                    for gi in range(lo, hi):
+                        mine = (d[(gi - lo) // 64] >> np.uint64(63 - (gi - lo) % 64)) & np.uint64(1)
+                        theirs = (want["matrix"][gi // 64] >> np.uint64(63 - gi % 64)) & np.uint64(1)
+                        ok = ok and bool((mine == theirs).all())
+                    mm.free()
+                    bb.free()
+                acc.free()
+                if not ok:
+                    desc += " [staged: two batches cut at %d, through the accumulator]" % cut
             if ok and k <= 32:
                 b.partition_counts(k, amin)
                 for gi in sorted(set([0, n // 2, n - 1])):
