@@ -47,8 +47,7 @@ __device__ __forceinline__ void tile_round(const uint4 &v, uint32_t edge, int la
     tc.w[R][0] = v.x; tc.w[R][1] = v.y; tc.w[R][2] = v.z; tc.w[R][3] = v.w;
     uint32_t nl, gt, cr;
     chunk_masks(tc.w[R], nl, gt, cr);
-    const uint32_t up = __shfl_up((nl >> 15) & 1u, 1);
-    const uint32_t prev_nl = lane == 0 ? edge : up;
+    const uint32_t prev_nl = edge;                       // (every lane holds the byte before its chunk: TileLoad)
     const uint32_t ls = ((nl << 1) | prev_nl) & 0xffffu;
     uint32_t ek, sep, unk;
     chunk_classify(nl, gt, cr, ls, T_NONE, ek, sep, unk);
@@ -59,10 +58,6 @@ __device__ __forceinline__ void tile_round(const uint4 &v, uint32_t edge, int la
 // the same element for parse_summarize, which needs nothing else of the chunk: a wave whose 1 KiB is clean (clean_scan: letters and
 // newlines only -- nearly every wave of a FASTA) gets it from the count and the place of its newlines, ~60 instructions per chunk
 // against ~150 through the masks and the flood of line types; the kernel is bound by instruction issue
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t x)          // lane i <- lane i - 1; lane 0 <- 0
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);
-}
 // exclusive prefixes of the tile's 16 (round, wave) group totals for this wave's four groups, and the sum of all 16: every row of 16
 // lanes scans the same 16 words with four DPP adds and the wave reads its four out with v_readlane -- the loop over 16 LDS words with
 // four selects each that this replaces was ~100 instructions per thread
@@ -91,8 +86,7 @@ __device__ __forceinline__ void tile_round_sum(const uint4 &v, uint32_t edge, in
     uint32_t z[4];
     const uint32_t odd = clean_scan(w, z);
     if (!__any(odd != 0u)) {
-        const uint32_t up = wave_shr1(z[3] >> 31);
-        elem = clean_elem(z, lane == 0 ? edge : up);
+        elem = clean_elem(z, edge);
     } else {
         TileChunks unused;
         tile_round<R>(v, edge, lane, unused, elem);
@@ -108,7 +102,7 @@ __device__ __forceinline__ void tile_round_sum(const uint4 &v, uint32_t edge, in
 //   cs   = the same if a sequence line does = ch + sum of pend_i = (ev_i == NONE ? extra_i : 0), extra = the chunk's bytes before
 //          its own first line start;
 // i.e. ONE integer prefix sum of the packed pair (known | pend << 16; a tile holds 16384 bytes): six DPP adds per round.
-// a thread's four chunks of a tile, and for lane 0 whether the byte before each is a newline (lanes > 0 ask their neighbour).  The
+// a thread's four chunks of a tile, and the byte before each (is it a newline?).  The
 // parse kernels issue these loads FIRST, before they read what kind of tile it is: a workgroup lives for one tile, and every dependent
 // load in front of these is time it holds its registers with nothing in flight
 struct TileLoad {
@@ -117,12 +111,14 @@ struct TileLoad {
 };
 __device__ __forceinline__ void tile_load(const uint8_t *__restrict__ raw, uint32_t tile, TileLoad &tl)
 {
-    const int lane = lane_id();
 #pragma unroll
     for (int r = 0; r < ROUNDS_PER_TILE; r++) {
         const uint64_t base = (uint64_t)tile * TILE_BYTES + (uint64_t)r * ROUND_BYTES + threadIdx.x * 16u;
         tl.v[r] = *reinterpret_cast<const uint4 *>(raw + base);
-        tl.edge[r] = lane == 0 ? (uint32_t)(raw[(int64_t)base - 1] == '\n') : 0u;
+        // (EVERY lane its own byte, and the byte as it is: a load under `lane == 0` needs a move or a compare behind it, which makes the
+        // wave wait for the load -- and, loads returning in order, for the 64 bytes asked for before it -- in front of the next round's
+        // request: until round 4's second half the four requests of a tile went out one round trip after the other)
+        tl.edge[r] = raw[(int64_t)base - 1];
     }
 }
 
@@ -138,15 +134,15 @@ __device__ __forceinline__ void tile_scan(const TileLoad &tl, uint64_t *partial6
     if (threadIdx.x == 0) partial[16] = 0;
     uint32_t el[ROUNDS_PER_TILE];
     if (SUM_ONLY) {
-        tile_round_sum<0>(v[0], edge[0], lane, el[0]);
-        tile_round_sum<1>(v[1], edge[1], lane, el[1]);
-        tile_round_sum<2>(v[2], edge[2], lane, el[2]);
-        tile_round_sum<3>(v[3], edge[3], lane, el[3]);
+        tile_round_sum<0>(v[0], (uint32_t)(edge[0] == '\n'), lane, el[0]);
+        tile_round_sum<1>(v[1], (uint32_t)(edge[1] == '\n'), lane, el[1]);
+        tile_round_sum<2>(v[2], (uint32_t)(edge[2] == '\n'), lane, el[2]);
+        tile_round_sum<3>(v[3], (uint32_t)(edge[3] == '\n'), lane, el[3]);
     } else {
-        tile_round<0>(v[0], edge[0], lane, tc, el[0]);
-        tile_round<1>(v[1], edge[1], lane, tc, el[1]);
-        tile_round<2>(v[2], edge[2], lane, tc, el[2]);
-        tile_round<3>(v[3], edge[3], lane, tc, el[3]);
+        tile_round<0>(v[0], (uint32_t)(edge[0] == '\n'), lane, tc, el[0]);
+        tile_round<1>(v[1], (uint32_t)(edge[1] == '\n'), lane, tc, el[1]);
+        tile_round<2>(v[2], (uint32_t)(edge[2] == '\n'), lane, tc, el[2]);
+        tile_round<3>(v[3], (uint32_t)(edge[3] == '\n'), lane, tc, el[3]);
     }
     __syncthreads();                                     // (partial[16] zeroed; also orders a caller's LDS writes before its use of them)
     // nearest line start before the chunk inside its group, and the group's last one
@@ -216,8 +212,7 @@ __device__ __forceinline__ void tile_round_fq(const uint4 &v, uint32_t edge, int
     tc.w[R][0] = v.x; tc.w[R][1] = v.y; tc.w[R][2] = v.z; tc.w[R][3] = v.w;
     uint32_t nl, gt, cr;
     chunk_masks(tc.w[R], nl, gt, cr, false);
-    const uint32_t up = __shfl_up((nl >> 15) & 1u, 1);
-    const uint32_t prev_nl = lane == 0 ? edge : up;
+    const uint32_t prev_nl = edge;                       // (every lane holds the byte before its chunk: TileLoad)
     const uint32_t ls = ((nl << 1) | prev_nl) & 0xffffu;
     tc.nl[R] = nl; tc.cr[R] = cr; tc.ls[R] = ls;
     uint32_t m[4];
@@ -250,10 +245,10 @@ __device__ __forceinline__ void tile_scan_fq(const TileLoad &tl, uint64_t *parti
     const uint4 (&v)[ROUNDS_PER_TILE] = tl.v;
     const uint32_t (&edge)[ROUNDS_PER_TILE] = tl.edge;
     uint64_t el[ROUNDS_PER_TILE];
-    tile_round_fq<0>(v[0], edge[0], lane, tc, el[0]);
-    tile_round_fq<1>(v[1], edge[1], lane, tc, el[1]);
-    tile_round_fq<2>(v[2], edge[2], lane, tc, el[2]);
-    tile_round_fq<3>(v[3], edge[3], lane, tc, el[3]);
+    tile_round_fq<0>(v[0], (uint32_t)(edge[0] == '\n'), lane, tc, el[0]);
+    tile_round_fq<1>(v[1], (uint32_t)(edge[1] == '\n'), lane, tc, el[1]);
+    tile_round_fq<2>(v[2], (uint32_t)(edge[2] == '\n'), lane, tc, el[2]);
+    tile_round_fq<3>(v[3], (uint32_t)(edge[3] == '\n'), lane, tc, el[3]);
     // newlines before every chunk
     uint32_t nl_own[ROUNDS_PER_TILE], nl_inc[ROUNDS_PER_TILE];
 #pragma unroll
@@ -303,7 +298,6 @@ __device__ __forceinline__ void tile_scan_fq(const TileLoad &tl, uint64_t *parti
 // the FASTQ tile's chunks classified, without the scan (parse_pack: the prefix elements come from parse_summarize's chunk_pre64)
 __device__ __forceinline__ void tile_rounds_fq(const TileLoad &tl, TileChunksFq &tc)
 {
-    const int lane = lane_id();
     const uint4 (&v)[ROUNDS_PER_TILE] = tl.v;
     const uint32_t (&edge)[ROUNDS_PER_TILE] = tl.edge;
 #pragma unroll
@@ -311,8 +305,7 @@ __device__ __forceinline__ void tile_rounds_fq(const TileLoad &tl, TileChunksFq 
         tc.w[r][0] = v[r].x; tc.w[r][1] = v[r].y; tc.w[r][2] = v[r].z; tc.w[r][3] = v[r].w;
         uint32_t nl, gt, cr;
         chunk_masks(tc.w[r], nl, gt, cr, false);
-        const uint32_t up = __shfl_up((nl >> 15) & 1u, 1);
-        const uint32_t prev_nl = lane == 0 ? edge[r] : up;
+        const uint32_t prev_nl = (uint32_t)(edge[r] == '\n');
         tc.nl[r] = nl; tc.cr[r] = cr; tc.ls[r] = ((nl << 1) | prev_nl) & 0xffffu;
     }
 }
@@ -561,6 +554,11 @@ __global__ void parse_prezero_kernel(const uint64_t *__restrict__ tile_off, uint
 // Every chunk packs its symbols into two small bit strings and ORs them into the tile's
 // LDS image of the packed stream (ds_or_b64); the image is then stored with coalesced writes.
 // Groups shared with a neighbouring tile go out through global atomicOr (buffers pre-zeroed).
+// (One tile per workgroup, on purpose: a STREAMING form -- as many workgroups as the device holds, each asking for its next tile's bytes,
+// chunk prefixes and totals while it packs the one it holds; two register sets taking turns, unconditional requests, LDS-only barriers;
+// 92 VGPRs, counted waits as intended in the ISA -- was built and measured on the same box: 1.89-1.94 ms against 1.68-1.69 for this
+// kernel.  Four waves per SIMD that each go through load / pack / store in turn use the vector unit worse than seven that are at
+// different points of it.)
 __global__ __launch_bounds__(PARSE_THREADS, 6) void parse_pack_kernel(
     const uint8_t *__restrict__ raw, uint32_t n_tiles, const uint8_t *__restrict__ tile_meta,
     const uint64_t *__restrict__ tile_off, const uint8_t *__restrict__ tile_state, uint64_t *__restrict__ sym2,
@@ -609,7 +607,6 @@ __global__ __launch_bounds__(PARSE_THREADS, 6) void parse_pack_kernel(
             // the scan of this tile was done by parse_summarize: its per-chunk prefixes and the tile's totals are read back.  A wave
             // whose 1 KiB is clean and inside sequence lines -- nearly every one -- packs its chunks without masks or line types
             // (clean_chunk_insert: ~110 instructions per chunk against ~240)
-            const int lane = lane_id();
             const uint4 (&v)[ROUNDS_PER_TILE] = tl.v;
             const uint32_t (&edge)[ROUNDS_PER_TILE] = tl.edge;
             uint32_t pre[ROUNDS_PER_TILE];
@@ -636,8 +633,7 @@ __global__ __launch_bounds__(PARSE_THREADS, 6) void parse_pack_kernel(
                 } else {
                     uint32_t nl, gt, cr, ek, sep, unk, cs, ci;
                     chunk_masks(w, nl, gt, cr);
-                    const uint32_t up = wave_shr1((nl >> 15) & 1u);
-                    const uint32_t ls = ((nl << 1) | (lane == 0 ? edge[r] : up)) & 0xffffu;
+                    const uint32_t ls = ((nl << 1) | (uint32_t)(edge[r] == '\n')) & 0xffffu;
                     chunk_classify(nl, gt, cr, ls, T_NONE, ek, sep, unk);
                     const int cnt = chunk_pack(w, ek | (cin == T_SEQ ? unk : 0u), sep, cs, ci);
                     stream_insert(pos, cnt, cs, ci, or_sym, or_inv);

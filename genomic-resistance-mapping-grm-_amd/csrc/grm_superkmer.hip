@@ -123,24 +123,25 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
         return j_a + (uint64_t)st * SK_STEP_WINDOWS + (uint32_t)(wave * SK_WAVE_WINDOWS + lane);
     };
     auto fetch = [&](uint32_t it, StepWords &f) {
-        f.w0 = f.w1 = f.w2 = f.w3 = f.pw = f.i0 = f.i1 = f.i2 = 0;
-        if (it >= n_steps) return;
-        const uint64_t j = step_window(it);
+        // EVERY lane asks, at every call, for the same number of words: a window past the part's last ones (or a step past the last step)
+        // asks for the last window's again, and what is valid is decided where the words are used.  A request under a condition makes
+        // the compiler lose count of the loads in flight at the loop's back edge, and it then waits for ALL of them -- the two steps'
+        // worth just asked for included -- at the first use: until round 4's second half the "two steps ahead" above was none.
         // (j_b: only for the run that crosses into it; j_b + 1: only its hashes; WIDE: j_b + 2 for its word -- a run of 85 bases that starts late
         // in the part's last window reaches the fourth word; the stream buffers end with slack words)
-        if (j <= j_b + (WIDE ? 2 : 1)) {
-            // (streamed once: loads marked non-temporal, so that the packed stream does not push the workgroups' half-filled record
-            // lines out of L2)
-            f.w0 = __builtin_nontemporal_load(&a.sym2[j]);
-            f.w1 = __builtin_nontemporal_load(&a.sym2[j + 1]);
-            f.w2 = __builtin_nontemporal_load(&a.sym2[j + 2]);
-            if (WIDE) f.w3 = __builtin_nontemporal_load(&a.sym2[j + 3]);
-            f.pw = j ? __builtin_nontemporal_load(&a.sym2[j - 1]) : 0ull;
-            const uint64_t q = j ? (j << 5) - 1 : 0;
-            f.i0 = __builtin_nontemporal_load(&a.inv[q >> 6]);
-            f.i1 = __builtin_nontemporal_load(&a.inv[(q >> 6) + 1]);
-            if (WIDE) f.i2 = __builtin_nontemporal_load(&a.inv[(q >> 6) + 2]);
-        }
+        const uint64_t j = min(step_window(it), j_b + (WIDE ? 2 : 1));
+        f.w3 = f.i2 = 0;
+        // (streamed once: loads marked non-temporal, so that the packed stream does not push the workgroups' half-filled record
+        // lines out of L2)
+        f.w0 = __builtin_nontemporal_load(&a.sym2[j]);
+        f.w1 = __builtin_nontemporal_load(&a.sym2[j + 1]);
+        f.w2 = __builtin_nontemporal_load(&a.sym2[j + 2]);
+        if (WIDE) f.w3 = __builtin_nontemporal_load(&a.sym2[j + 3]);
+        f.pw = __builtin_nontemporal_load(&a.sym2[j ? j - 1 : 0]);             // (j == 0: not used)
+        const uint64_t q = j ? (j << 5) - 1 : 0;
+        f.i0 = __builtin_nontemporal_load(&a.inv[q >> 6]);
+        f.i1 = __builtin_nontemporal_load(&a.inv[(q >> 6) + 1]);
+        if (WIDE) f.i2 = __builtin_nontemporal_load(&a.inv[(q >> 6) + 2]);
     };
     StepWords nxt, nxt2;
     fetch(0, nxt);
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(SK_THREADS) void superkmer_l1_kernel(SkArgs a, ulon
         if (j <= j_b + (WIDE ? 2 : 1)) {
             const uint64_t p0 = j << 5;
             w0 = cur.w0; w1 = cur.w1; w2 = cur.w2; w3 = cur.w3;
-            prev2 = (uint32_t)cur.pw & 3u;
+            prev2 = j ? (uint32_t)cur.pw & 3u : 0u;
             // bit t of vs: position p0 - 1 + t starts a k-mer (t = 0 .. 32; k <= 32 keeps all 33 inside the 64 flags read)
             const int qo = p0 ? (int)((p0 - 1) & 63) : 0;
             if (WIDE) vs = valid_starts_wide(cur.i0, cur.i1, cur.i2, qo, a.k);
