@@ -2896,10 +2896,18 @@ __global__ __launch_bounds__(ER_IDS) void matrix_entry_rows_kernel(
             for (uint32_t r0 = 0; r0 < n_rows; r0 += ER_ROWS) {
                 __syncthreads();            // the previous tile has been written out
                 if (r0 == 0) cols[threadIdx.x] = c;
+                // all sixteen words asked for before the first goes to LDS, from an address that is valid whatever the word's condition says
+                // (the condition picks the word or zero afterwards): a load under a condition, stored at once, is a round trip of its own
+                uint64_t got[ER_ROWS];
+#pragma unroll
+                for (int rr = 0; rr < ER_ROWS; rr++) {
+                    const uint32_t r = min(r0 + (uint32_t)rr, n_rows - 1u);
+                    got[rr] = matrix_s[(((uint64_t)wg * n_rows + r) << cap_log2) + (have ? id : 0u)];
+                }
 #pragma unroll
                 for (int rr = 0; rr < ER_ROWS; rr++) {
                     const uint32_t r = r0 + rr;
-                    tile[threadIdx.x][rr] = (have && r < n_rows && r >= b0) ? matrix_s[(((uint64_t)wg * n_rows + r) << cap_log2) + id] : 0ull;
+                    tile[threadIdx.x][rr] = (have && r < n_rows && r >= b0) ? got[rr] : 0ull;
                 }
                 __syncthreads();
                 const uint32_t rows_here = min((uint32_t)ER_ROWS, n_rows - r0);
@@ -2926,12 +2934,19 @@ __global__ __launch_bounds__(256) void matrix_transpose_kernel(const uint64_t *_
         const uint32_t r0 = (uint32_t)(t % n_rt) * TR_ROWS;
         __syncthreads();
         // read: 16 consecutive threads take the 16 rows (128 B) of one column
+        uint64_t got[TR_COLS * TR_ROWS / 256];               // (asked for together, from clamped addresses: see matrix_entry_rows)
+#pragma unroll
+        for (int pass = 0; pass < TR_COLS * TR_ROWS / 256; pass++) {
+            const uint32_t j = pass * 256 + threadIdx.x;
+            const uint32_t cl = j / TR_ROWS, rr = j % TR_ROWS;
+            got[pass] = me[min(c0 + cl, n_cols - 1) * n_rows + min(r0 + rr, n_rows - 1u)];
+        }
 #pragma unroll
         for (int pass = 0; pass < TR_COLS * TR_ROWS / 256; pass++) {
             const uint32_t j = pass * 256 + threadIdx.x;
             const uint32_t cl = j / TR_ROWS, rr = j % TR_ROWS;
             const uint64_t c = c0 + cl;
-            tile[rr][cl] = (c < n_cols && r0 + rr < n_rows) ? me[c * n_rows + r0 + rr] : 0ull;
+            tile[rr][cl] = (c < n_cols && r0 + rr < n_rows) ? got[pass] : 0ull;
         }
         __syncthreads();
         // write: 64 consecutive threads take 64 consecutive columns (512 B) of one row
