@@ -431,7 +431,16 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
                 }
             }
         } else {
-            for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) atomicAdd(&hist[rec_bin(rr[i].y, b2)], 1u);
+            // (four records per thread asked for before the first is used, from clamped indices: one load per trip of the loop is one
+            // round trip per trip)
+            for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 4u * SK2R_THREADS) {
+                uint64_t y[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) y[u] = rr[min(i0 + (uint32_t)u * SK2R_THREADS, n - 1u)].y;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (i0 + (uint32_t)u * SK2R_THREADS < n) atomicAdd(&hist[rec_bin(y[u], b2)], 1u);
+            }
         }
         __syncthreads();
         const uint32_t cnt = threadIdx.x < 2 * B2 ? hist[threadIdx.x] : 0u;
@@ -470,11 +479,17 @@ __global__ __launch_bounds__(SK2R_THREADS) void superkmer_l2_records_kernel(cons
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) out[i] = srec[i];
         } else {
-            for (uint32_t i = threadIdx.x; i < n; i += SK2R_THREADS) {
-                ulonglong2 rec = rr[i];
-                rec_flip(rec, k);
-                const uint32_t f = rec_bin(rec.y, b2);
-                out[start[f] + atomicAdd(&hist[f], 1u)] = rec;
+            for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 4u * SK2R_THREADS) {
+                ulonglong2 rec[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) rec[u] = rr[min(i0 + (uint32_t)u * SK2R_THREADS, n - 1u)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (i0 + (uint32_t)u * SK2R_THREADS >= n) continue;
+                    rec_flip(rec[u], k);
+                    const uint32_t f = rec_bin(rec[u].y, b2);
+                    out[start[f] + atomicAdd(&hist[f], 1u)] = rec[u];
+                }
             }
         }
         __syncthreads();
