@@ -1806,26 +1806,40 @@ __global__ __launch_bounds__(512) void record_merge_kernel(
             if (!kcount[f]) continue;                              // uniform
             uint32_t nd = 0;
             bool ok = true;
-            // a wave takes whole parts: their record segments (level 2's bounds; the next part's are asked for ahead)
+            // a wave takes whole parts: their record segments (level 2's bounds).  The bounds of the wave's part AFTER the next one are asked
+            // for when a part is begun and not touched until the part before theirs is (an `& 0xffff` on the spot would wait for the load)
             uint32_t p = (uint32_t)wave;
-            uint64_t r0 = 0;
-            uint32_t nr = 0;
-            if (p < P) {
-                const uint64_t sp = ((((uint64_t)g << part_bits) + p) << bb) + ((uint64_t)c << b2) + f;
-                r0 = roff[sp];
-                nr = rlen[sp] & 0xffffu;
-            }
+            auto bounds_at = [&](uint32_t pp, uint64_t &ro, uint32_t &rl) {
+                const uint64_t sp = ((((uint64_t)g << part_bits) + min(pp, P - 1u)) << bb) + ((uint64_t)c << b2) + f;      // (clamped: every wave asks)
+                ro = roff[sp];
+                rl = rlen[sp];
+            };
+            uint64_t r0, r0_n, r0_f;
+            uint32_t rl, rl_n, rl_f;
+            bounds_at(p, r0, rl);
+            bounds_at(p + WAVES, r0_n, rl_n);
+            uint32_t nr = p < P ? rl & 0xffffu : 0u;
+            // A segment is one or two chunks of 64 records, and a chunk asked for where it is needed is a round trip in front of ~1 us of
+            // work: the NEXT chunk -- of this part, or the first of the wave's next part -- is asked for before the current one is staged.
+            // The request is unconditional (index clamped; which lanes hold a record is decided at use): a load under `lane < nc` is
+            // followed by a select, and the select by a wait for the load it has just issued.
+            ulonglong2 ahead = recs[r0 + min((uint32_t)lane, nr ? nr - 1u : 0u)];
+            uint32_t ahead_p = p, ahead_c0 = 0;                    // what `ahead` holds: chunk ahead_c0 of part ahead_p
             while (p < P) {
-                uint64_t r0_n = 0;
-                uint32_t nr_n = 0;
-                if (p + WAVES < P) {
-                    const uint64_t sp = ((((uint64_t)g << part_bits) + p + WAVES) << bb) + ((uint64_t)c << b2) + f;
-                    r0_n = roff[sp];
-                    nr_n = rlen[sp] & 0xffffu;
-                }
+                bounds_at(p + 2 * WAVES, r0_f, rl_f);
+                const uint32_t nr_n = p + WAVES < P ? rl_n & 0xffffu : 0u;
                 for (uint32_t c0 = 0; c0 < nr; c0 += CH) {
                     const uint32_t nc = min(CH, nr - c0);
-                    const ulonglong2 rec = (uint32_t)lane < nc ? recs[r0 + c0 + lane] : make_ulonglong2(0, 0);
+                    ulonglong2 rec = ahead;
+                    if (ahead_p != p || ahead_c0 != c0) rec = recs[r0 + c0 + min((uint32_t)lane, nc - 1u)];      // (not asked for ahead: after an empty part)
+                    if (c0 + CH < nr) {
+                        ahead = recs[r0 + c0 + CH + min((uint32_t)lane, nr - c0 - CH - 1u)];
+                        ahead_p = p; ahead_c0 = c0 + CH;
+                    } else {
+                        ahead = recs[r0_n + min((uint32_t)lane, nr_n ? nr_n - 1u : 0u)];
+                        ahead_p = p + WAVES; ahead_c0 = 0;
+                    }
+                    if ((uint32_t)lane >= nc) rec = make_ulonglong2(0, 0);
                     const uint32_t tot = record_chunk_stage(rec, nc, srec, sstart, starts, firstrec);
                     for (uint32_t q0 = 0; q0 < tot; q0 += 256) {
                         uint64_t kv[4];
@@ -1840,7 +1854,7 @@ __global__ __launch_bounds__(512) void record_merge_kernel(
                     }
                     wave_lds_fence();
                 }
-                p += WAVES; r0 = r0_n; nr = nr_n;
+                p += WAVES; r0 = r0_n; nr = nr_n; r0_n = r0_f; rl_n = rl_f;
             }
             if (!ok && lane == 0) atomicExch(&big_fail, 1u);
             __syncthreads();
