@@ -46,7 +46,7 @@ typedef enum {
     GRM_ERR_HIP = -3,          /* HIP runtime error, text in grm_last_error */
     GRM_ERR_IO = -4,
     GRM_ERR_OOM = -5,
-    GRM_ERR_UNSUPPORTED = -6,  /* e.g. k > 32 with abundance-min > 1 through the staged multi-GPU calls */
+    GRM_ERR_UNSUPPORTED = -6,  /* e.g. per-k-mer counts of a whole batch (grm_batch_partition_counts) at k > 32 */
     GRM_ERR_STATE = -7,        /* calls out of order */
     GRM_ERR_OVERFLOW = -8,     /* LDS table overflow that retries could not cure */
     GRM_ERR_HDF5 = -9
@@ -182,9 +182,10 @@ int  grm_batch_upload(grm_batch *);
 /* whole hot path on the resident inputs: == partition + local_dict + set_global_dict(own) + fill */
 int  grm_batch_run(grm_batch *, int k, uint32_t abundance_min, int filter_singleton, grm_matrix **out);
 /* the same path in stages, so that the host can put ONE collective between them when the
- * genomes are sharded over several GPUs.  Dictionary entries are 8-byte keys for
- * k <= 32 and 16-byte (hi, lo) pairs for 33 <= k <= 64 (abundance-min 1 there; the staged calls stop at k = 64, grm_batch_run goes to 128); flags are one
- * byte each (1 = carried by one local genome, 2 = by several); n counts k-mers, not words. */
+ * genomes are sharded over several GPUs.  Dictionary entries are rows of ceil(k / 32) 64-bit words, most significant
+ * first: 8-byte keys for k <= 32, (hi, lo) pairs for 33 <= k <= 64, three or four words up to k = 128 (the whole range of
+ * grm_batch_run; k > 64, and k > 32 with abundance-min > 1, go through the sort path in stages: the lists they export are sorted, not
+ * grouped by hash bucket); flags are one byte each (1 = carried by one local genome, 2 = by several); n counts k-mers, not words. */
 int  grm_batch_partition(grm_batch *, int k, uint32_t abundance_min);
 /* same, but keeps per-k-mer occurrence counts so that grm_batch_genome_set can return them
  * (multidsk: one batch, one sorted counted set per genome) */
